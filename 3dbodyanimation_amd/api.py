@@ -1,0 +1,319 @@
+"""ctypes binding of libbodyfit.so (include/bodyfit.h) and a thin host-side mirror of the reference types.
+
+There is no CPU fallback: if the HIP library is missing, or no GPU is visible when a model is
+created, the calls raise BodyfitError.  Names follow the reference: PixelKP (include/Sim3BA.h:9),
+Sim3Params (:11-19), FramePoseParams (include/MultiFrameBA.h:9-14).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import re
+from dataclasses import dataclass, field
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libbodyfit.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "bodyfit.h")
+N_FRAME_PARAMS = 76
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int)
+_fp = C.POINTER(C.c_float)
+
+
+class BodyfitError(RuntimeError):
+    pass
+
+
+class _ModelDesc(C.Structure):
+    _fields_ = [("n_verts", C.c_int), ("n_joints", C.c_int), ("n_shape", C.c_int), ("n_pose_feat", C.c_int),
+                ("v_template", _dp), ("shapedirs", _dp), ("posedirs", _dp), ("j_regressor", _dp),
+                ("weights", _dp), ("parent", _ip), ("n_landmarks", C.c_int), ("landmark_vid", _ip)]
+
+
+class _ProblemDesc(C.Structure):
+    _fields_ = [("n_frames", C.c_int), ("kp_offset", _ip), ("kp_id", _ip), ("kp_uv", _dp),
+                ("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double),
+                ("R0", _dp), ("n_cols", C.c_int), ("use_shape", C.c_int), ("beta_per_frame", C.c_int),
+                ("pose_blend", C.c_int), ("beta_pose", C.c_double), ("gmm", C.c_void_p),
+                ("beta_shape", C.c_double), ("lambda_temporal", C.c_double), ("temporal_halo", C.c_int),
+                ("huber_delta", C.c_double), ("want_mesh", C.c_int)]
+
+
+class Layout(C.Structure):
+    _fields_ = [("n_keypoints", C.c_int), ("n_cols", C.c_int), ("reproj_rows", C.c_int),
+                ("prior_rows_per_frame", C.c_int), ("shape_rows", C.c_int), ("temporal_rows", C.c_int),
+                ("total_rows", C.c_int)]
+
+
+class DeviceViews(C.Structure):
+    _fields_ = [("residuals", C.c_void_p), ("jacobian", C.c_void_p), ("gmm_comp", C.c_void_p),
+                ("cloud", C.c_void_p), ("joints", C.c_void_p), ("normal_eq", C.c_void_p)]
+
+
+_lib = None
+
+
+def declared_symbols() -> list[str]:
+    """Every function include/bodyfit.h declares (used by the ABI test)."""
+    txt = open(HEADER_PATH).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(bodyfit_[a-z0-9_]+)\s*\(", txt)))
+
+
+def load_library():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise BodyfitError(f"{LIB_PATH} is missing: build it with `make -C 3dbodyanimation_amd/csrc` "
+                           "(__graft_entry__.build()). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    lib.bodyfit_last_error.restype = C.c_char_p
+    lib.bodyfit_mean_pixel_error.restype = C.c_double
+    lib.bodyfit_mean_pixel_error.argtypes = [C.c_int, _ip, _dp, _dp, C.c_double, C.c_double, C.c_double, C.c_double]
+    lib.bodyfit_model_create.argtypes = [C.POINTER(_ModelDesc), C.c_int, C.POINTER(C.c_void_p)]
+    lib.bodyfit_model_destroy.argtypes = [C.c_void_p]
+    lib.bodyfit_model_get_derived.argtypes = [C.c_void_p, _dp, _dp, _dp]
+    lib.bodyfit_gmm_create.argtypes = [C.c_int, C.c_int, _dp, _dp, _dp, C.c_double, C.c_int, C.POINTER(C.c_void_p)]
+    lib.bodyfit_gmm_destroy.argtypes = [C.c_void_p]
+    lib.bodyfit_gmm_get.argtypes = [C.c_void_p, _dp, _dp]
+    lib.bodyfit_problem_create.argtypes = [C.c_void_p, C.POINTER(_ProblemDesc), C.POINTER(C.c_void_p)]
+    lib.bodyfit_problem_destroy.argtypes = [C.c_void_p]
+    lib.bodyfit_problem_layout.argtypes = [C.c_void_p, C.POINTER(Layout)]
+    lib.bodyfit_problem_views.argtypes = [C.c_void_p, C.POINTER(DeviceViews)]
+    lib.bodyfit_evaluate_batch.argtypes = [C.c_void_p, _dp, _dp, _dp, _dp, _ip, C.c_int]
+    lib.bodyfit_evaluate_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    lib.bodyfit_reduce_shared_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.bodyfit_profile_sweep.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, _dp]
+    lib.bodyfit_forward.argtypes = [C.c_void_p, _dp, _dp, _dp, _fp]
+    lib.bodyfit_evaluate_block.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(_dp), _dp, C.POINTER(_dp)]
+    _lib = lib
+    return lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise BodyfitError(f"bodyfit status {rc}: {load_library().bodyfit_last_error().decode()}")
+
+
+def _c64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _c32i(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _d(a):
+    return None if a is None else a.ctypes.data_as(_dp)
+
+
+def _i(a):
+    return None if a is None else a.ctypes.data_as(_ip)
+
+
+def device_count() -> int:
+    return load_library().bodyfit_device_count()
+
+
+# ------------------------------------------------------------------------------------------------
+# reference-side value types
+# ------------------------------------------------------------------------------------------------
+@dataclass
+class PixelKP:  # include/Sim3BA.h:9
+    jid: int
+    u: float
+    v: float
+
+
+@dataclass
+class Sim3Params:  # include/Sim3BA.h:11-19   data = [s, aa(3), t(3)]
+    data: np.ndarray = field(default_factory=lambda: np.array([1.0, 0, 0, 0, 0, 0, 3.0]))
+
+    @property
+    def scale(self):
+        return self.data[0]
+
+    @property
+    def aa_root(self):
+        return self.data[1:4]
+
+    @property
+    def trans(self):
+        return self.data[4:7]
+
+
+@dataclass
+class FramePoseParams:  # include/MultiFrameBA.h:9-14
+    scale: float = 1.0
+    rootAA: np.ndarray = field(default_factory=lambda: np.zeros(3))
+    rootT: np.ndarray = field(default_factory=lambda: np.array([0.0, 0.0, 3.0]))
+    jointAA: np.ndarray = field(default_factory=lambda: np.zeros((24, 3)))  # index 0 unused
+
+    def pack(self) -> np.ndarray:
+        return np.concatenate([[self.scale], self.rootAA, self.rootT, self.jointAA[1:].reshape(-1)])
+
+    @staticmethod
+    def unpack(x) -> "FramePoseParams":
+        j = np.zeros((24, 3))
+        j[1:] = np.asarray(x[7:]).reshape(-1, 3)
+        return FramePoseParams(float(x[0]), np.array(x[1:4]), np.array(x[4:7]), j)
+
+
+class Model:
+    """Device-resident SMPL model (ark::AvatarModel stand-in)."""
+
+    def __init__(self, m, device: int = 0, pose_blend_data: bool = True):
+        lib = load_library()
+        self._keep = [_c64(m.v_template), _c64(m.shapedirs), _c64(m.posedirs) if pose_blend_data else None,
+                      _c64(m.j_regressor), _c64(m.weights), _c32i(m.parent), _c32i(m.landmark_vid)]
+        k = self._keep
+        self.n_verts, self.n_joints, self.n_shape = m.v_template.shape[0], len(m.parent), m.shapedirs.shape[2]
+        self.n_landmarks = len(m.landmark_vid)
+        desc = _ModelDesc(self.n_verts, self.n_joints, self.n_shape, m.posedirs.shape[2] if pose_blend_data else 0,
+                          _d(k[0]), _d(k[1]), _d(k[2]), _d(k[3]), _d(k[4]), _i(k[5]), self.n_landmarks, _i(k[6]))
+        h = C.c_void_p()
+        _check(lib.bodyfit_model_create(C.byref(desc), device, C.byref(h)))
+        self.h = h
+        self.device = device
+
+    def derived(self):
+        J0 = np.empty((self.n_joints, 3)); S = np.empty((3 * self.n_joints, self.n_shape))
+        off = np.empty((self.n_joints, 3))
+        _check(load_library().bodyfit_model_get_derived(self.h, _d(J0), _d(S), _d(off)))
+        return J0, S, off
+
+    def close(self):
+        if getattr(self, "h", None):
+            load_library().bodyfit_model_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Gmm:
+    """Device-resident max-mixture pose prior (ark::GaussianMixture stand-in)."""
+
+    def __init__(self, weights, means, covs, resid_scale=np.sqrt(0.5), device: int = 0):
+        self.K, self.D = means.shape
+        w, mu, cv = _c64(weights), _c64(means), _c64(covs)
+        h = C.c_void_p()
+        _check(load_library().bodyfit_gmm_create(self.K, self.D, _d(w), _d(mu), _d(cv), resid_scale, device, C.byref(h)))
+        self.h = h
+
+    def get(self):
+        L = np.empty((self.K, self.D, self.D)); nlw = np.empty(self.K)
+        _check(load_library().bodyfit_gmm_get(self.h, _d(L), _d(nlw)))
+        return L, nlw
+
+    def close(self):
+        if getattr(self, "h", None):
+            load_library().bodyfit_gmm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Problem:
+    """The residual blocks of one solve (what the reference adds to its ceres::Problem)."""
+
+    def __init__(self, model: Model, kp_offset, kp_id, kp_uv, intr, R0, n_cols=86, use_shape=True,
+                 beta_per_frame=False, pose_blend=True, beta_pose=0.0, gmm: Gmm | None = None, beta_shape=0.0,
+                 lambda_temporal=0.0, temporal_halo=False, huber_delta=3.0, want_mesh=False):
+        lib = load_library()
+        self.model = model
+        self.gmm = gmm
+        ko, ki, ku, r0 = _c32i(kp_offset), _c32i(kp_id), _c64(kp_uv), _c64(R0)
+        self.n_frames = len(ko) - 1
+        desc = _ProblemDesc(self.n_frames, _i(ko), _i(ki), _d(ku), float(intr[0]), float(intr[1]), float(intr[2]),
+                            float(intr[3]), _d(r0), int(n_cols), int(use_shape), int(beta_per_frame),
+                            int(pose_blend), float(beta_pose), gmm.h if gmm is not None else None,
+                            float(beta_shape), float(lambda_temporal), int(temporal_halo), float(huber_delta),
+                            int(want_mesh))
+        h = C.c_void_p()
+        _check(lib.bodyfit_problem_create(model.h, C.byref(desc), C.byref(h)))
+        self.h = h
+        self.layout = Layout()
+        _check(lib.bodyfit_problem_layout(self.h, C.byref(self.layout)))
+        self.n_cols = n_cols
+        self.want_mesh = want_mesh
+        self.n_param_rows = self.n_frames + (1 if temporal_halo else 0)
+
+    @classmethod
+    def from_sequence(cls, model: Model, seq, **kw):
+        return cls(model, seq.kp_offset, seq.kp_id, seq.kp_uv, seq.intr, seq.R0, **kw)
+
+    def evaluate(self, frame_params, beta=None, want_jacobian=True):
+        L = self.layout
+        x = _c64(frame_params); b = _c64(beta) if beta is not None else None
+        assert x.size == self.n_param_rows * N_FRAME_PARAMS, "frame_params must be [F(+1), 76]"
+        r = np.empty(L.total_rows); comp = np.zeros(self.n_frames, np.int32)
+        J = np.empty((L.reproj_rows, L.n_cols)) if want_jacobian else None
+        _check(load_library().bodyfit_evaluate_batch(self.h, _d(x), _d(b), _d(r), _d(J), _i(comp), int(want_jacobian)))
+        return r, J, comp
+
+    def evaluate_device(self, d_params_ptr: int, d_beta_ptr: int | None, want_jacobian=True, stream: int | None = None):
+        _check(load_library().bodyfit_evaluate_device(self.h, d_params_ptr, d_beta_ptr, int(want_jacobian), stream))
+
+    def reduce_shared_device(self, d_out_ptr: int | None = None, stream: int | None = None):
+        _check(load_library().bodyfit_reduce_shared_device(self.h, d_out_ptr, stream))
+
+    def profile_sweep(self, d_params_ptr, d_beta_ptr, want_jacobian=True, with_reduce=False, iters=50, stream=None):
+        ms = np.zeros(4)
+        _check(load_library().bodyfit_profile_sweep(self.h, d_params_ptr, d_beta_ptr, int(want_jacobian),
+                                                    int(with_reduce), int(iters), stream, _d(ms)))
+        return dict(frame_resjac=ms[0], priors=ms[1], mesh_blend_lbs=ms[2], reduce_shared=ms[3])
+
+    def views(self) -> DeviceViews:
+        v = DeviceViews()
+        _check(load_library().bodyfit_problem_views(self.h, C.byref(v)))
+        return v
+
+    def forward(self, frame_params, beta=None, want_cloud=True):
+        x = _c64(frame_params); b = _c64(beta) if beta is not None else None
+        joints = np.empty((self.n_frames, self.model.n_joints, 3))
+        cloud = np.empty((self.n_frames, self.model.n_verts, 3), np.float32) if want_cloud else None
+        _check(load_library().bodyfit_forward(self.h, _d(x), _d(b), _d(joints),
+                                              cloud.ctypes.data_as(_fp) if cloud is not None else None))
+        return joints, cloud
+
+    def evaluate_block(self, kind: int, index: int, blocks: list[np.ndarray], n_res: int, want=None):
+        """ceres::CostFunction::Evaluate on one block.  `want[b]` False -> jacobians[b] = NULL."""
+        blocks = [_c64(b) for b in blocks]
+        nb = len(blocks)
+        params = (_dp * nb)(*[_d(b) for b in blocks])
+        r = np.empty(n_res)
+        jacs = [np.full((n_res, len(b)), np.nan) for b in blocks]
+        if want is None:
+            want = [True] * nb
+        jp = (_dp * nb)(*[(_d(j) if w else None) for j, w in zip(jacs, want)])
+        _check(load_library().bodyfit_evaluate_block(self.h, kind, index, params, _d(r), jp))
+        return r, jacs
+
+    def close(self):
+        if getattr(self, "h", None):
+            load_library().bodyfit_problem_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def mean_pixel_error(jid, uv, joints, intr) -> float:
+    jid = _c32i(jid); uv = _c64(uv); joints = _c64(joints)
+    return load_library().bodyfit_mean_pixel_error(len(jid), _i(jid), _d(uv), _d(joints), float(intr[0]), float(intr[1]),
+                                                   float(intr[2]), float(intr[3]))

@@ -1,0 +1,784 @@
+// bodyfit_api.hip — host side of the C ABI in include/bodyfit.h: model upload (operand packing for the
+// MFMA kernel), GMM precompute, problem buffers, evaluation sweeps, Ceres-style per-block access.
+#include "../../include/bodyfit.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "bodyfit_device.h"
+
+using namespace bodyfit;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                         \
+  do {                                                                                        \
+    hipError_t e_ = (expr);                                                                   \
+    if (e_ != hipSuccess)                                                                     \
+      return fail(BODYFIT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));        \
+  } while (0)
+
+struct Allocs {
+  std::vector<void*> ptrs;
+  ~Allocs() {
+    for (void* p : ptrs) (void)hipFree(p);
+  }
+  template <typename T>
+  hipError_t alloc(T** out, size_t n) {
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, std::max<size_t>(n, 1) * sizeof(T));
+    if (e == hipSuccess) {
+      ptrs.push_back(p);
+      *out = static_cast<T*>(p);
+    }
+    return e;
+  }
+  template <typename T>
+  hipError_t upload(const T** out, const std::vector<T>& h) {
+    T* p = nullptr;
+    hipError_t e = alloc(&p, h.size());
+    if (e != hipSuccess) return e;
+    if (!h.empty()) e = hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice);
+    *out = p;
+    return e;
+  }
+};
+
+}  // namespace
+
+struct bodyfit_model {
+  int device = 0;
+  int V = 0, nJ = 0, nS = 0, P = 0, nL = 0;
+  bool mesh_ok = true;
+  DevModel d{};
+  std::vector<int> parent;
+  std::vector<double> J0, S, offset;
+  Allocs mem;
+};
+
+struct bodyfit_gmm {
+  int device = 0;
+  DevGmm d{};
+  std::vector<double> prec_cho, neg_log_w, mean;
+  Allocs mem;
+};
+
+struct bodyfit_problem {
+  const bodyfit_model* m = nullptr;
+  bodyfit_problem_desc desc{};
+  bodyfit_layout lay{};
+  DevProblem d{};
+  MeshCoef mc{};
+  DevGmm gmm{};
+  bool has_gmm = false;
+  int n_param_rows = 0, n_pairs = 0;
+  int row_prior = 0, row_shape = 0, row_temporal = 0;
+  // device buffers
+  double* d_params = nullptr;
+  double* d_beta = nullptr;
+  double* d_r = nullptr;
+  double* d_J = nullptr;
+  double* d_joints = nullptr;
+  double* d_partials = nullptr;
+  double* d_normal = nullptr;
+  int* d_comp = nullptr;
+  float* d_cloud = nullptr;
+  // host copies
+  std::vector<int> kp_offset, kp_id, kp_frame;
+  std::vector<double> kp_uv;
+  // host cache of the last batched evaluation (serves bodyfit_evaluate_block)
+  std::mutex mu;
+  bool cache_valid = false, cache_has_jac = false;
+  std::vector<double> c_params, c_beta, c_r, c_J;
+  std::vector<int> c_comp;
+  Allocs mem;
+};
+
+namespace {
+
+bool chol_lower(std::vector<double>& A, int n) {
+  for (int j = 0; j < n; ++j) {
+    double d = A[(size_t)j * n + j];
+    for (int k = 0; k < j; ++k) d -= A[(size_t)j * n + k] * A[(size_t)j * n + k];
+    if (!(d > 0.0)) return false;
+    d = std::sqrt(d);
+    A[(size_t)j * n + j] = d;
+    for (int i = j + 1; i < n; ++i) {
+      double s = A[(size_t)i * n + j];
+      for (int k = 0; k < j; ++k) s -= A[(size_t)i * n + k] * A[(size_t)j * n + k];
+      A[(size_t)i * n + j] = s / d;
+    }
+    for (int i = 0; i < j; ++i) A[(size_t)i * n + j] = 0.0;
+  }
+  return true;
+}
+
+int sweep(bodyfit_problem* p, const double* d_params, const double* d_beta, int want_jac, bool mesh,
+          hipStream_t st, hipEvent_t* ev = nullptr) {
+  const bodyfit_model* m = p->m;
+  MeshCoef mc = p->mc;
+  if (!mesh) mc = MeshCoef{};
+  if (ev) (void)hipEventRecord(ev[0], st);
+  launch_frame_resjac(m->d, p->d, d_params, d_beta, p->d_r, want_jac ? p->d_J : nullptr, p->d_joints, mc,
+                      want_jac, st);
+  if (ev) (void)hipEventRecord(ev[1], st);
+  const bodyfit_problem_desc& D = p->desc;
+  if (D.beta_pose > 0.0 || D.beta_shape > 0.0 || D.lambda_temporal > 0.0) {
+    launch_priors(p->d, m->nJ, m->nS, d_params, d_beta, D.beta_pose, p->has_gmm ? &p->gmm : nullptr,
+                  p->lay.shape_rows > 0 ? D.beta_shape : 0.0, D.lambda_temporal, p->n_pairs,
+                  p->d_r + p->row_prior, p->d_r + p->row_shape, p->d_r + p->row_temporal, p->d_comp, st);
+  }
+  if (ev) (void)hipEventRecord(ev[2], st);
+  if (mesh) launch_mesh(m->d, p->d, p->mc, p->d_cloud, st);
+  if (ev) (void)hipEventRecord(ev[3], st);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(BODYFIT_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
+  return BODYFIT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* bodyfit_last_error(void) { return g_err.c_str(); }
+
+int bodyfit_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+// ------------------------------------------------------------------------------------------------
+// model
+// ------------------------------------------------------------------------------------------------
+int bodyfit_model_create(const bodyfit_model_desc* desc, int device, bodyfit_model** out) {
+  if (!desc || !out) return fail(BODYFIT_ERR_INVALID, "null argument");
+  *out = nullptr;
+  const int V = desc->n_verts, nJ = desc->n_joints, nS = desc->n_shape;
+  const int P = desc->posedirs ? desc->n_pose_feat : 0;
+  const int nL = desc->n_landmarks;
+  if (V <= 0 || nJ <= 0 || nJ > kMaxJoints || nS < 0 || nS > kMaxShape)
+    return fail(BODYFIT_ERR_INVALID, "unsupported model size (n_joints <= 24, n_shape <= 10)");
+  if (P != 0 && P != 9 * (nJ - 1)) return fail(BODYFIT_ERR_INVALID, "n_pose_feat must be 9 (n_joints - 1)");
+  if (nL < 0 || nL > kMaxLandmarks) return fail(BODYFIT_ERR_INVALID, "too many landmarks (<= 32)");
+  if (!desc->v_template || !desc->shapedirs || !desc->j_regressor || !desc->weights || !desc->parent)
+    return fail(BODYFIT_ERR_INVALID, "missing model tensor");
+  if (desc->parent[0] != -1) return fail(BODYFIT_ERR_INVALID, "parent[0] must be -1 (npz_fixer convention)");
+  for (int j = 1; j < nJ; ++j)
+    if (desc->parent[j] < 0 || desc->parent[j] >= j)
+      return fail(BODYFIT_ERR_INVALID, "kintree must be topologically ordered with a single root");
+  for (int l = 0; l < nL; ++l)
+    if (desc->landmark_vid[l] < 0 || desc->landmark_vid[l] >= V) return fail(BODYFIT_ERR_INVALID, "landmark vertex id");
+
+  HIP_TRY(hipSetDevice(device));
+  bodyfit_model* m = new bodyfit_model();
+  std::unique_ptr<bodyfit_model> guard(m);
+  m->device = device;
+  m->V = V; m->nJ = nJ; m->nS = nS; m->P = P; m->nL = nL;
+  m->parent.assign(desc->parent, desc->parent + nJ);
+
+  // joint regression on the device: J0 = Jreg . v_template, S = Jreg . shapedirs
+  m->J0.assign((size_t)nJ * 3, 0.0);
+  m->S.assign((size_t)nJ * 3 * std::max(nS, 1), 0.0);
+  {
+    Allocs tmp;
+    double *d_reg, *d_vt, *d_sd, *d_j0, *d_s;
+    HIP_TRY(tmp.alloc(&d_reg, (size_t)nJ * V));
+    HIP_TRY(tmp.alloc(&d_vt, (size_t)V * 3));
+    HIP_TRY(tmp.alloc(&d_sd, (size_t)V * 3 * std::max(nS, 1)));
+    HIP_TRY(tmp.alloc(&d_j0, (size_t)nJ * 3));
+    HIP_TRY(tmp.alloc(&d_s, (size_t)nJ * 3 * std::max(nS, 1)));
+    HIP_TRY(hipMemcpy(d_reg, desc->j_regressor, (size_t)nJ * V * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_vt, desc->v_template, (size_t)V * 3 * sizeof(double), hipMemcpyHostToDevice));
+    launch_regress(nJ, V, 3, d_reg, d_vt, d_j0, nullptr);
+    if (nS > 0) {
+      HIP_TRY(hipMemcpy(d_sd, desc->shapedirs, (size_t)V * 3 * nS * sizeof(double), hipMemcpyHostToDevice));
+      launch_regress(nJ, V, 3 * nS, d_reg, d_sd, d_s, nullptr);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(m->J0.data(), d_j0, (size_t)nJ * 3 * sizeof(double), hipMemcpyDeviceToHost));
+    if (nS > 0)
+      HIP_TRY(hipMemcpy(m->S.data(), d_s, (size_t)nJ * 3 * nS * sizeof(double), hipMemcpyDeviceToHost));
+  }
+  const std::vector<double>& J0 = m->J0;
+  const std::vector<double>& S = m->S;
+
+  // rest offsets (include/Sim3BA.h:372-392) and the shape-difference tables
+  m->offset.assign((size_t)nJ * 3, 0.0);
+  std::vector<double> Jc0((size_t)nJ * 3), dS((size_t)nJ * 3 * std::max(nS, 1), 0.0), Sc(dS.size(), 0.0);
+  for (int j = 0; j < nJ; ++j)
+    for (int a = 0; a < 3; ++a) Jc0[j * 3 + a] = J0[j * 3 + a] - J0[a];
+  for (int j = 1; j < nJ; ++j)
+    for (int a = 0; a < 3; ++a) m->offset[j * 3 + a] = Jc0[j * 3 + a] - Jc0[m->parent[j] * 3 + a];
+  for (int j = 0; j < nJ; ++j)
+    for (int a = 0; a < 3; ++a)
+      for (int k = 0; k < nS; ++k) {
+        const double sj = S[(size_t)(j * 3 + a) * nS + k];
+        const int pj = m->parent[j];
+        dS[(size_t)(j * 3 + a) * nS + k] = sj - (pj >= 0 ? S[(size_t)(pj * 3 + a) * nS + k] : 0.0);
+        Sc[(size_t)(j * 3 + a) * nS + k] = sj - S[(size_t)a * nS + k];
+      }
+  // depth levels and ancestor masks
+  std::vector<int> depth(nJ, 0);
+  int maxd = 0;
+  for (int j = 1; j < nJ; ++j) { depth[j] = depth[m->parent[j]] + 1; maxd = std::max(maxd, depth[j]); }
+  std::vector<int> level_off(maxd + 1, 0), level_joint;
+  for (int d = 1; d <= maxd; ++d) {
+    level_off[d - 1] = (int)level_joint.size();
+    for (int j = 1; j < nJ; ++j)
+      if (depth[j] == d) level_joint.push_back(j);
+  }
+  level_off[maxd] = (int)level_joint.size();
+  std::vector<unsigned> anc(nJ, 0u);
+  for (int j = 1; j < nJ; ++j)
+    for (int k = m->parent[j]; k > 0; k = m->parent[k]) anc[j] |= (1u << k);
+
+  DevModel& d = m->d;
+  d.V = V; d.nJ = nJ; d.nS = nS; d.P = P; d.nL = nL; d.nLevels = maxd;
+  d.nVTiles = (V + kVTile - 1) / kVTile;
+  HIP_TRY(m->mem.upload(&d.parent, m->parent));
+  HIP_TRY(m->mem.upload(&d.level_off, level_off));
+  HIP_TRY(m->mem.upload(&d.level_joint, level_joint));
+  HIP_TRY(m->mem.upload(&d.anc_mask, anc));
+  HIP_TRY(m->mem.upload(&d.offset, m->offset));
+  HIP_TRY(m->mem.upload(&d.dS, dS));
+  HIP_TRY(m->mem.upload(&d.Jc0, Jc0));
+  HIP_TRY(m->mem.upload(&d.Sc, Sc));
+
+  // landmarks
+  {
+    std::vector<int> woff(nL + 1, 0), wj;
+    std::vector<double> ww, vt((size_t)nL * 3), sd((size_t)nL * 3 * std::max(nS, 1), 0.0),
+        pd((size_t)nL * 3 * std::max(P, 1), 0.0);
+    for (int l = 0; l < nL; ++l) {
+      const int vid = desc->landmark_vid[l];
+      for (int j = 0; j < nJ; ++j) {
+        const double w = desc->weights[(size_t)vid * nJ + j];
+        if (w != 0.0) { wj.push_back(j); ww.push_back(w); }
+      }
+      woff[l + 1] = (int)wj.size();
+      if (woff[l + 1] - woff[l] > kMaxLmNnz)
+        return fail(BODYFIT_ERR_INVALID, "landmark vertex has more than 8 skinning weights");
+      for (int a = 0; a < 3; ++a) {
+        vt[l * 3 + a] = desc->v_template[(size_t)vid * 3 + a] - J0[a];
+        for (int k = 0; k < nS; ++k)
+          sd[(size_t)(l * 3 + a) * nS + k] = desc->shapedirs[((size_t)vid * 3 + a) * nS + k] - S[(size_t)a * nS + k];
+        for (int k = 0; k < P; ++k) pd[(size_t)(l * 3 + a) * P + k] = desc->posedirs[((size_t)vid * 3 + a) * P + k];
+      }
+    }
+    HIP_TRY(m->mem.upload(&d.lm_woff, woff));
+    HIP_TRY(m->mem.upload(&d.lm_wj, wj));
+    HIP_TRY(m->mem.upload(&d.lm_ww, ww));
+    HIP_TRY(m->mem.upload(&d.lm_vt, vt));
+    HIP_TRY(m->mem.upload(&d.lm_sd, sd));
+    HIP_TRY(m->mem.upload(&d.lm_pd, pd));
+  }
+
+  // mesh operands in MFMA fragment order
+  {
+    const int nVT = d.nVTiles;
+    std::vector<uint16_t> dirsB((size_t)nVT * 3 * kPoseKSteps * 2 * 64 * 8, 0);
+    std::vector<float> sdB((size_t)nVT * 3 * kShapeKSteps * 64, 0.0f), vtB((size_t)nVT * 3 * 32, 0.0f);
+    std::vector<uint32_t> wIdx((size_t)nVT * 32, 0u);
+    std::vector<float> wVal((size_t)nVT * 32 * 4, 0.0f);
+    for (int vt_i = 0; vt_i < nVT; ++vt_i)
+      for (int col = 0; col < 32; ++col) {
+        const int v = vt_i * 32 + col;
+        if (v >= V) continue;
+        for (int c = 0; c < 3; ++c) {
+          vtB[((size_t)vt_i * 3 + c) * 32 + col] = (float)(desc->v_template[(size_t)v * 3 + c] - J0[c]);
+          for (int k = 0; k < nS; ++k) {
+            const int ks = k >> 1, hh = k & 1;  // 32x32x2: B[k = lane>>5][j = lane&31]
+            sdB[(((size_t)vt_i * 3 + c) * kShapeKSteps + ks) * 64 + hh * 32 + col] =
+                (float)(desc->shapedirs[((size_t)v * 3 + c) * nS + k] - S[(size_t)c * nS + k]);
+          }
+          for (int k = 0; k < P; ++k) {
+            const int ks = k >> 4, hh = (k >> 3) & 1, jj = k & 7;  // 32x32x16: B[k = 8h + j][col]
+            const float x = (float)desc->posedirs[((size_t)v * 3 + c) * P + k];
+            const uint16_t hi = f32_to_bf16(x);
+            const uint16_t lo = f32_to_bf16(x - bf16_to_f32(hi));
+            const size_t base = ((((size_t)vt_i * 3 + c) * kPoseKSteps + ks) * 2) * 64 * 8;
+            dirsB[base + (size_t)(hh * 32 + col) * 8 + jj] = hi;
+            dirsB[base + (size_t)64 * 8 + (size_t)(hh * 32 + col) * 8 + jj] = lo;
+          }
+        }
+        int cnt = 0;
+        uint32_t packed = 0;
+        for (int j = 0; j < nJ; ++j) {
+          const double w = desc->weights[(size_t)v * nJ + j];
+          if (w == 0.0) continue;
+          if (cnt < kMeshNnz) {
+            packed |= ((uint32_t)j) << (8 * cnt);
+            wVal[((size_t)vt_i * 32 + col) * 4 + cnt] = (float)w;
+          }
+          ++cnt;
+        }
+        if (cnt > kMeshNnz) m->mesh_ok = false;
+        wIdx[(size_t)vt_i * 32 + col] = packed;
+      }
+    HIP_TRY(m->mem.upload(&d.dirsB, dirsB));
+    HIP_TRY(m->mem.upload(&d.sdB, sdB));
+    HIP_TRY(m->mem.upload(&d.vtB, vtB));
+    HIP_TRY(m->mem.upload(&d.wIdx, wIdx));
+    HIP_TRY(m->mem.upload(&d.wVal, wVal));
+  }
+  *out = guard.release();
+  return BODYFIT_OK;
+}
+
+void bodyfit_model_destroy(bodyfit_model* m) {
+  if (!m) return;
+  (void)hipSetDevice(m->device);
+  delete m;
+}
+
+int bodyfit_model_get_derived(const bodyfit_model* m, double* joints0, double* joint_shape_reg, double* offset) {
+  if (!m) return fail(BODYFIT_ERR_INVALID, "null model");
+  if (joints0) std::memcpy(joints0, m->J0.data(), (size_t)m->nJ * 3 * sizeof(double));
+  if (joint_shape_reg) std::memcpy(joint_shape_reg, m->S.data(), (size_t)m->nJ * 3 * m->nS * sizeof(double));
+  if (offset) std::memcpy(offset, m->offset.data(), (size_t)m->nJ * 3 * sizeof(double));
+  return BODYFIT_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// GMM (ark::GaussianMixture restated: precision Cholesky + SMPLify max-mixture constants)
+// ------------------------------------------------------------------------------------------------
+int bodyfit_gmm_create(int K, int D, const double* weights, const double* means, const double* covs,
+                       double resid_scale, int device, bodyfit_gmm** out) {
+  if (!out || !weights || !means || !covs || K <= 0 || D <= 0 || D > 128)
+    return fail(BODYFIT_ERR_INVALID, "bad GMM arguments");
+  *out = nullptr;
+  HIP_TRY(hipSetDevice(device));
+  std::unique_ptr<bodyfit_gmm> g(new bodyfit_gmm());
+  g->device = device;
+  g->prec_cho.assign((size_t)K * D * D, 0.0);
+  g->neg_log_w.assign(K, 0.0);
+  g->mean.assign(means, means + (size_t)K * D);
+  std::vector<double> hld(K);
+  for (int k = 0; k < K; ++k) {
+    std::vector<double> C(covs + (size_t)k * D * D, covs + (size_t)(k + 1) * D * D);
+    if (!chol_lower(C, D)) return fail(BODYFIT_ERR_NUMERIC, "GMM covariance is not SPD");
+    double ld = 0;
+    for (int i = 0; i < D; ++i) ld += std::log(C[(size_t)i * D + i]);
+    hld[k] = ld;
+    // Y = C^{-1} by forward substitution on the identity; precision = Y^T Y
+    std::vector<double> Y((size_t)D * D, 0.0);
+    for (int c = 0; c < D; ++c)
+      for (int r = c; r < D; ++r) {
+        double s = (r == c) ? 1.0 : 0.0;
+        for (int t = c; t < r; ++t) s -= C[(size_t)r * D + t] * Y[(size_t)t * D + c];
+        Y[(size_t)r * D + c] = s / C[(size_t)r * D + r];
+      }
+    std::vector<double> Pm((size_t)D * D, 0.0);
+    for (int r = 0; r < D; ++r)
+      for (int c = 0; c <= r; ++c) {
+        double s = 0;
+        for (int t = r; t < D; ++t) s += Y[(size_t)t * D + r] * Y[(size_t)t * D + c];
+        Pm[(size_t)r * D + c] = s;
+        Pm[(size_t)c * D + r] = s;
+      }
+    if (!chol_lower(Pm, D)) return fail(BODYFIT_ERR_NUMERIC, "GMM precision is not SPD");
+    std::memcpy(&g->prec_cho[(size_t)k * D * D], Pm.data(), (size_t)D * D * sizeof(double));
+  }
+  const double mn = *std::min_element(hld.begin(), hld.end());
+  for (int k = 0; k < K; ++k)
+    g->neg_log_w[k] = -(std::log(weights[k]) - 0.5 * D * std::log(2.0 * M_PI) - (hld[k] - mn));
+  g->d.K = K; g->d.D = D; g->d.resid_scale = resid_scale;
+  HIP_TRY(g->mem.upload(&g->d.mean, g->mean));
+  HIP_TRY(g->mem.upload(&g->d.prec_cho, g->prec_cho));
+  HIP_TRY(g->mem.upload(&g->d.neg_log_w, g->neg_log_w));
+  *out = g.release();
+  return BODYFIT_OK;
+}
+
+void bodyfit_gmm_destroy(bodyfit_gmm* g) {
+  if (!g) return;
+  (void)hipSetDevice(g->device);
+  delete g;
+}
+
+int bodyfit_gmm_get(const bodyfit_gmm* g, double* prec_cho, double* neg_log_w) {
+  if (!g) return fail(BODYFIT_ERR_INVALID, "null gmm");
+  if (prec_cho) std::memcpy(prec_cho, g->prec_cho.data(), g->prec_cho.size() * sizeof(double));
+  if (neg_log_w) std::memcpy(neg_log_w, g->neg_log_w.data(), g->neg_log_w.size() * sizeof(double));
+  return BODYFIT_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// problem
+// ------------------------------------------------------------------------------------------------
+int bodyfit_problem_create(const bodyfit_model* m, const bodyfit_problem_desc* desc, bodyfit_problem** out) {
+  if (!m || !desc || !out) return fail(BODYFIT_ERR_INVALID, "null argument");
+  *out = nullptr;
+  const int F = desc->n_frames, nJ = m->nJ, nS = m->nS;
+  const int npose = 7 + 3 * (nJ - 1);
+  if (F <= 0 || !desc->kp_offset || !desc->R0) return fail(BODYFIT_ERR_INVALID, "bad frame arrays");
+  if (desc->n_cols != npose && desc->n_cols != npose + nS) return fail(BODYFIT_ERR_INVALID, "n_cols must be 76 or 76 + n_shape");
+  if (desc->use_shape && desc->n_cols == npose) return fail(BODYFIT_ERR_INVALID, "use_shape needs the shape block (n_cols = 86)");
+  if (desc->kp_offset[0] != 0) return fail(BODYFIT_ERR_INVALID, "kp_offset[0] must be 0");
+  for (int f = 0; f < F; ++f)
+    if (desc->kp_offset[f + 1] < desc->kp_offset[f]) return fail(BODYFIT_ERR_INVALID, "kp_offset must be non-decreasing");
+  const int K = desc->kp_offset[F];
+  if (K > 0 && (!desc->kp_id || !desc->kp_uv)) return fail(BODYFIT_ERR_INVALID, "missing keypoints");
+  for (int k = 0; k < K; ++k)
+    if (desc->kp_id[k] < 0 || desc->kp_id[k] >= nJ + m->nL) return fail(BODYFIT_ERR_INVALID, "keypoint id out of range");
+  if (desc->gmm && desc->gmm->d.D != 3 * (nJ - 1)) return fail(BODYFIT_ERR_INVALID, "GMM dimension must be 3 (n_joints - 1)");
+  if (desc->want_mesh && !m->mesh_ok)
+    return fail(BODYFIT_ERR_INVALID, "mesh path needs <= 4 skinning weights per vertex");
+  if (desc->want_mesh && (nJ != 24 || (m->P != 0 && m->P != 207) || nS > 10))
+    return fail(BODYFIT_ERR_INVALID, "mesh path is built for the SMPL shape (24 joints, 207 pose features)");
+
+  HIP_TRY(hipSetDevice(m->device));
+  std::unique_ptr<bodyfit_problem> p(new bodyfit_problem());
+  p->m = m;
+  p->desc = *desc;
+  p->desc.kp_offset = nullptr; p->desc.kp_id = nullptr; p->desc.kp_uv = nullptr; p->desc.R0 = nullptr;
+  p->kp_offset.assign(desc->kp_offset, desc->kp_offset + F + 1);
+  p->kp_id.assign(desc->kp_id, desc->kp_id + K);
+  p->kp_uv.assign(desc->kp_uv, desc->kp_uv + (size_t)2 * K);
+  p->kp_frame.resize(K);
+  for (int f = 0; f < F; ++f)
+    for (int k = p->kp_offset[f]; k < p->kp_offset[f + 1]; ++k) p->kp_frame[k] = f;
+  p->has_gmm = desc->gmm != nullptr && desc->beta_pose > 0.0;
+  if (p->has_gmm) p->gmm = desc->gmm->d;
+
+  bodyfit_layout& L = p->lay;
+  L.n_keypoints = K;
+  L.n_cols = desc->n_cols;
+  L.reproj_rows = 2 * K;
+  L.prior_rows_per_frame = desc->beta_pose > 0.0 ? (p->has_gmm ? 3 * (nJ - 1) + 1 : 3 * (nJ - 1)) : 0;
+  const bool has_beta = desc->n_cols > npose;
+  L.shape_rows = (desc->beta_shape > 0.0 && has_beta && nS > 0) ? (desc->beta_per_frame ? F * nS : nS) : 0;
+  p->n_pairs = desc->lambda_temporal > 0.0 ? (F - 1 + (desc->temporal_halo ? 1 : 0)) : 0;
+  L.temporal_rows = p->n_pairs * (6 + 3 * (nJ - 1));
+  p->row_prior = L.reproj_rows;
+  p->row_shape = p->row_prior + F * L.prior_rows_per_frame;
+  p->row_temporal = p->row_shape + L.shape_rows;
+  L.total_rows = p->row_temporal + L.temporal_rows;
+  p->n_param_rows = F + (desc->temporal_halo ? 1 : 0);
+
+  DevProblem& d = p->d;
+  d.F = F; d.K = K; d.ncols = desc->n_cols; d.use_shape = desc->use_shape ? 1 : 0;
+  d.beta_stride = desc->beta_per_frame ? nS : 0;
+  d.pose_blend = (desc->pose_blend && m->P > 0) ? 1 : 0;
+  d.nFTiles = (F + kFTile - 1) / kFTile;
+  d.fx = desc->fx; d.fy = desc->fy; d.cx = desc->cx; d.cy = desc->cy;
+  HIP_TRY(p->mem.upload(&d.kp_offset, p->kp_offset));
+  HIP_TRY(p->mem.upload(&d.kp_id, p->kp_id));
+  HIP_TRY(p->mem.upload(&d.kp_uv, p->kp_uv));
+  std::vector<double> R0(desc->R0, desc->R0 + (size_t)F * 9);
+  HIP_TRY(p->mem.upload(&d.R0, R0));
+
+  HIP_TRY(p->mem.alloc(&p->d_params, (size_t)p->n_param_rows * npose));
+  HIP_TRY(p->mem.alloc(&p->d_beta, (size_t)std::max(1, desc->beta_per_frame ? F * nS : nS)));
+  HIP_TRY(p->mem.alloc(&p->d_r, (size_t)L.total_rows));
+  HIP_TRY(p->mem.alloc(&p->d_J, (size_t)L.reproj_rows * L.n_cols));
+  HIP_TRY(p->mem.alloc(&p->d_joints, (size_t)F * nJ * 3));
+  HIP_TRY(p->mem.alloc(&p->d_comp, (size_t)F));
+  HIP_TRY(p->mem.alloc(&p->d_partials, (size_t)reduce_partials_doubles()));
+  HIP_TRY(p->mem.alloc(&p->d_normal, (size_t)66));
+  HIP_TRY(hipMemset(p->d_r, 0, (size_t)std::max(1, L.total_rows) * sizeof(double)));
+  HIP_TRY(hipMemset(p->d_comp, 0, (size_t)F * sizeof(int)));
+  HIP_TRY(hipMemset(p->d_beta, 0, (size_t)std::max(1, desc->beta_per_frame ? F * nS : nS) * sizeof(double)));
+  if (desc->want_mesh) {
+    const size_t nfa = (size_t)d.nFTiles * kPoseKSteps * 2 * 64 * 8;
+    const size_t nba = (size_t)d.nFTiles * kShapeKSteps * 64;
+    HIP_TRY(p->mem.alloc(&p->mc.featA, nfa));
+    HIP_TRY(p->mem.alloc(&p->mc.betaA, nba));
+    HIP_TRY(p->mem.alloc(&p->mc.skinT, (size_t)F * nJ * 12));
+    HIP_TRY(p->mem.alloc(&p->d_cloud, (size_t)F * m->V * 3));
+    HIP_TRY(hipMemset(p->mc.featA, 0, nfa * sizeof(uint16_t)));
+    HIP_TRY(hipMemset(p->mc.betaA, 0, nba * sizeof(float)));
+  }
+  *out = p.release();
+  return BODYFIT_OK;
+}
+
+void bodyfit_problem_destroy(bodyfit_problem* p) {
+  if (!p) return;
+  (void)hipSetDevice(p->m->device);
+  delete p;
+}
+
+int bodyfit_problem_layout(const bodyfit_problem* p, bodyfit_layout* out) {
+  if (!p || !out) return fail(BODYFIT_ERR_INVALID, "null argument");
+  *out = p->lay;
+  return BODYFIT_OK;
+}
+
+int bodyfit_problem_views(bodyfit_problem* p, bodyfit_device_views* out) {
+  if (!p || !out) return fail(BODYFIT_ERR_INVALID, "null argument");
+  out->residuals = p->d_r;
+  out->jacobian = p->d_J;
+  out->gmm_comp = p->d_comp;
+  out->cloud = p->d_cloud;
+  out->joints = p->d_joints;
+  out->normal_eq = p->d_normal;
+  return BODYFIT_OK;
+}
+
+int bodyfit_evaluate_device(bodyfit_problem* p, const double* d_frame_params, const double* d_beta,
+                            int want_jacobian, void* stream) {
+  if (!p || !d_frame_params) return fail(BODYFIT_ERR_INVALID, "null argument");
+  HIP_TRY(hipSetDevice(p->m->device));
+  return sweep(p, d_frame_params, d_beta, want_jacobian, p->desc.want_mesh != 0, static_cast<hipStream_t>(stream));
+}
+
+int bodyfit_evaluate_batch(bodyfit_problem* p, const double* frame_params, const double* beta, double* residuals,
+                           double* jacobian, int* gmm_comp, int want_jacobian) {
+  if (!p || !frame_params) return fail(BODYFIT_ERR_INVALID, "null argument");
+  const bodyfit_model* m = p->m;
+  const int npose = 7 + 3 * (m->nJ - 1);
+  const bool has_beta = p->lay.n_cols > npose;
+  if (has_beta && !beta) return fail(BODYFIT_ERR_INVALID, "beta required when the shape block is present");
+  HIP_TRY(hipSetDevice(m->device));
+  std::lock_guard<std::mutex> lock(p->mu);
+  const size_t npar = (size_t)p->n_param_rows * npose;
+  const size_t nbeta = has_beta ? (size_t)(p->desc.beta_per_frame ? p->d.F * m->nS : m->nS) : 0;
+  HIP_TRY(hipMemcpyAsync(p->d_params, frame_params, npar * sizeof(double), hipMemcpyHostToDevice, nullptr));
+  if (nbeta) HIP_TRY(hipMemcpyAsync(p->d_beta, beta, nbeta * sizeof(double), hipMemcpyHostToDevice, nullptr));
+  const int wj = (want_jacobian && p->lay.reproj_rows > 0) ? 1 : 0;
+  int rc = sweep(p, p->d_params, has_beta ? p->d_beta : nullptr, wj, p->desc.want_mesh != 0, nullptr);
+  if (rc) return rc;
+  p->c_params.assign(frame_params, frame_params + npar);
+  p->c_beta.assign(beta ? beta : frame_params, (beta ? beta : frame_params) + nbeta);
+  p->c_r.resize((size_t)p->lay.total_rows);
+  p->c_comp.resize((size_t)p->d.F);
+  HIP_TRY(hipMemcpyAsync(p->c_r.data(), p->d_r, p->c_r.size() * sizeof(double), hipMemcpyDeviceToHost, nullptr));
+  HIP_TRY(hipMemcpyAsync(p->c_comp.data(), p->d_comp, p->c_comp.size() * sizeof(int), hipMemcpyDeviceToHost, nullptr));
+  if (wj) {
+    p->c_J.resize((size_t)p->lay.reproj_rows * p->lay.n_cols);
+    HIP_TRY(hipMemcpyAsync(p->c_J.data(), p->d_J, p->c_J.size() * sizeof(double), hipMemcpyDeviceToHost, nullptr));
+  }
+  HIP_TRY(hipStreamSynchronize(nullptr));
+  p->cache_valid = true;
+  p->cache_has_jac = wj != 0;
+  if (residuals) std::memcpy(residuals, p->c_r.data(), p->c_r.size() * sizeof(double));
+  if (jacobian && wj) std::memcpy(jacobian, p->c_J.data(), p->c_J.size() * sizeof(double));
+  if (gmm_comp) std::memcpy(gmm_comp, p->c_comp.data(), p->c_comp.size() * sizeof(int));
+  return BODYFIT_OK;
+}
+
+int bodyfit_reduce_shared_device(bodyfit_problem* p, double* d_out66, void* stream) {
+  if (!p) return fail(BODYFIT_ERR_INVALID, "null argument");
+  HIP_TRY(hipSetDevice(p->m->device));
+  const int npose = 7 + 3 * (p->m->nJ - 1);
+  const int shared_shape_rows = (!p->desc.beta_per_frame) ? p->lay.shape_rows : 0;
+  launch_reduce_shared_ex(p->lay.n_keypoints, p->lay.n_cols, npose, p->m->nS, p->lay.total_rows, p->d_r, p->d_J,
+                          p->desc.huber_delta, p->row_shape, shared_shape_rows, p->desc.beta_shape, p->d_partials,
+                          d_out66 ? d_out66 : p->d_normal, static_cast<hipStream_t>(stream));
+  HIP_TRY(hipGetLastError());
+  return BODYFIT_OK;
+}
+
+// Per-kernel timing with HIP events on `stream`: `iters` sweeps, avg_ms[0..3] = {frame_resjac, priors,
+// mesh_blend_lbs, reduce_shared} average launch durations in milliseconds.
+int bodyfit_profile_sweep(bodyfit_problem* p, const double* d_frame_params, const double* d_beta,
+                          int want_jacobian, int with_reduce, int iters, void* stream, double* avg_ms) {
+  if (!p || !d_frame_params || !avg_ms || iters <= 0) return fail(BODYFIT_ERR_INVALID, "bad argument");
+  HIP_TRY(hipSetDevice(p->m->device));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  std::vector<hipEvent_t> ev((size_t)iters * 5);
+  for (auto& e : ev) HIP_TRY(hipEventCreate(&e));
+  int rc = BODYFIT_OK;
+  for (int it = 0; it < iters && rc == BODYFIT_OK; ++it) {
+    hipEvent_t* e = ev.data() + (size_t)it * 5;
+    rc = sweep(p, d_frame_params, d_beta, want_jacobian, p->desc.want_mesh != 0, st, e);
+    if (rc == BODYFIT_OK && with_reduce) rc = bodyfit_reduce_shared_device(p, nullptr, stream);
+    (void)hipEventRecord(e[4], st);
+  }
+  hipError_t se = hipStreamSynchronize(st);
+  for (int k = 0; k < 4; ++k) avg_ms[k] = 0.0;
+  if (rc == BODYFIT_OK && se == hipSuccess) {
+    for (int it = 0; it < iters; ++it)
+      for (int k = 0; k < 4; ++k) {
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, ev[(size_t)it * 5 + k], ev[(size_t)it * 5 + k + 1]);
+        avg_ms[k] += ms / iters;
+      }
+  }
+  for (auto& e : ev) (void)hipEventDestroy(e);
+  if (se != hipSuccess) return fail(BODYFIT_ERR_HIP, std::string("profile sync: ") + hipGetErrorString(se));
+  return rc;
+}
+
+int bodyfit_forward(bodyfit_problem* p, const double* frame_params, const double* beta, double* joints,
+                    float* cloud) {
+  if (!p || !frame_params) return fail(BODYFIT_ERR_INVALID, "null argument");
+  const bodyfit_model* m = p->m;
+  const int npose = 7 + 3 * (m->nJ - 1);
+  const bool has_beta = p->lay.n_cols > npose;
+  if (cloud && !p->desc.want_mesh) return fail(BODYFIT_ERR_INVALID, "problem was created without want_mesh");
+  HIP_TRY(hipSetDevice(m->device));
+  std::lock_guard<std::mutex> lock(p->mu);
+  p->cache_valid = false;
+  const size_t npar = (size_t)p->n_param_rows * npose;
+  const size_t nbeta = (has_beta && beta) ? (size_t)(p->desc.beta_per_frame ? p->d.F * m->nS : m->nS) : 0;
+  HIP_TRY(hipMemcpy(p->d_params, frame_params, npar * sizeof(double), hipMemcpyHostToDevice));
+  if (nbeta) HIP_TRY(hipMemcpy(p->d_beta, beta, nbeta * sizeof(double), hipMemcpyHostToDevice));
+  int rc = sweep(p, p->d_params, nbeta ? p->d_beta : nullptr, 0, cloud != nullptr, nullptr);
+  if (rc) return rc;
+  if (joints)
+    HIP_TRY(hipMemcpy(joints, p->d_joints, (size_t)p->d.F * m->nJ * 3 * sizeof(double), hipMemcpyDeviceToHost));
+  if (cloud)
+    HIP_TRY(hipMemcpy(cloud, p->d_cloud, (size_t)p->d.F * m->V * 3 * sizeof(float), hipMemcpyDeviceToHost));
+  HIP_TRY(hipDeviceSynchronize());
+  return BODYFIT_OK;
+}
+
+double bodyfit_mean_pixel_error(int n_kp, const int* jid, const double* uv, const double* joints, double fx,
+                                double fy, double cx, double cy) {
+  if (n_kp <= 0) return 0.0;  // include/Utils.h:106
+  double sum = 0.0;
+  for (int k = 0; k < n_kp; ++k) {
+    const double* J = joints + 3 * jid[k];
+    const double u = fx * J[0] / J[2] + cx, v = fy * J[1] / J[2] + cy;
+    sum += std::hypot(u - uv[2 * k], v - uv[2 * k + 1]);
+  }
+  return sum / n_kp;
+}
+
+// ------------------------------------------------------------------------------------------------
+// ceres::CostFunction::Evaluate for one block, served from the cached sweep when the caller's
+// parameters match it; otherwise the affected frame is re-evaluated on the device first.
+// ------------------------------------------------------------------------------------------------
+int bodyfit_evaluate_block(bodyfit_problem* p, int kind, int index, const double* const* parameters,
+                           double* residuals, double** jacobians) {
+  if (!p || !parameters || !residuals) return fail(BODYFIT_ERR_INVALID, "null argument");
+  const bodyfit_model* m = p->m;
+  const int nJ = m->nJ, nS = m->nS, npose = 7 + 3 * (nJ - 1), D = 3 * (nJ - 1);
+  const bodyfit_layout& L = p->lay;
+  const bool has_beta = L.n_cols > npose;
+  if (kind == 1) {  // pose prior: constant-structure Jacobian, evaluate through the batch of frame `index`
+    if (index < 0 || index >= p->d.F || L.prior_rows_per_frame == 0) return fail(BODYFIT_ERR_INVALID, "bad prior block");
+  }
+  if (kind == 2) {
+    if (L.shape_rows == 0) return fail(BODYFIT_ERR_INVALID, "no shape prior in this problem");
+    const double bs = p->desc.beta_shape;
+    for (int i = 0; i < nS; ++i) residuals[i] = bs * parameters[0][i];          // include/Sim3BA.h:336
+    if (jacobians && jacobians[0]) {
+      std::fill(jacobians[0], jacobians[0] + (size_t)nS * nS, 0.0);
+      for (int i = 0; i < nS; ++i) jacobians[0][(size_t)i * nS + i] = bs;       // :338-340
+    }
+    return BODYFIT_OK;
+  }
+  if (kind == 3) {
+    const double lam = p->desc.lambda_temporal;
+    for (int i = 0; i < 3; ++i) residuals[i] = (parameters[0][i] - parameters[1][i]) * lam;  // MultiFrameBA.h:24
+    if (jacobians) {
+      for (int b = 0; b < 2; ++b)
+        if (jacobians[b]) {
+          std::fill(jacobians[b], jacobians[b] + 9, 0.0);
+          for (int i = 0; i < 3; ++i) jacobians[b][i * 3 + i] = b == 0 ? lam : -lam;
+        }
+    }
+    return BODYFIT_OK;
+  }
+  if (kind != 0 && kind != 1) return fail(BODYFIT_ERR_INVALID, "unknown block kind");
+  int frame;
+  if (kind == 0) {
+    if (index < 0 || index >= L.n_keypoints) return fail(BODYFIT_ERR_INVALID, "keypoint index out of range");
+    frame = p->kp_frame[index];
+  } else {
+    frame = index;
+  }
+  // gather the caller's parameter blocks into the packed frame row
+  std::vector<double> x(npose), b(nS, 0.0);
+  if (kind == 0) {
+    x[0] = parameters[0][0];
+    for (int i = 0; i < 3; ++i) { x[1 + i] = parameters[1][i]; x[4 + i] = parameters[2][i]; }
+    for (int j = 1; j < nJ; ++j)
+      for (int i = 0; i < 3; ++i) x[7 + 3 * (j - 1) + i] = parameters[3 + (j - 1)][i];
+    if (has_beta)
+      for (int i = 0; i < nS; ++i) b[i] = parameters[3 + (nJ - 1)][i];
+  } else {
+    for (int j = 1; j < nJ; ++j)
+      for (int i = 0; i < 3; ++i) x[7 + 3 * (j - 1) + i] = parameters[j - 1][i];
+  }
+  {
+    std::unique_lock<std::mutex> lock(p->mu);
+    bool hit = p->cache_valid && (p->cache_has_jac || !jacobians);
+    if (hit) {
+      const double* cx = p->c_params.data() + (size_t)frame * npose;
+      const int i0 = (kind == 0) ? 0 : 7;
+      hit = std::memcmp(cx + i0, x.data() + i0, (size_t)(npose - i0) * sizeof(double)) == 0;
+      if (hit && kind == 0 && has_beta) {
+        const double* cb = p->c_beta.data() + (p->desc.beta_per_frame ? (size_t)frame * nS : 0);
+        hit = std::memcmp(cb, b.data(), (size_t)nS * sizeof(double)) == 0;
+      }
+    }
+    if (!hit) {
+      // refresh the cached parameter set with this frame's values and sweep again
+      std::vector<double> par = p->c_params, be = p->c_beta;
+      if (par.size() != (size_t)p->n_param_rows * npose) {
+        par.assign((size_t)p->n_param_rows * npose, 0.0);
+        for (int f = 0; f < p->n_param_rows; ++f) { par[(size_t)f * npose] = 1.0; par[(size_t)f * npose + 6] = 3.0; }
+      }
+      const size_t nb = has_beta ? (size_t)(p->desc.beta_per_frame ? p->d.F * nS : nS) : 0;
+      if (be.size() != nb) be.assign(nb, 0.0);
+      const int i0 = (kind == 0) ? 0 : 7;
+      std::memcpy(par.data() + (size_t)frame * npose + i0, x.data() + i0, (size_t)(npose - i0) * sizeof(double));
+      if (kind == 0 && has_beta)
+        std::memcpy(be.data() + (p->desc.beta_per_frame ? (size_t)frame * nS : 0), b.data(), (size_t)nS * sizeof(double));
+      lock.unlock();
+      int rc = bodyfit_evaluate_batch(p, par.data(), nb ? be.data() : nullptr, nullptr, nullptr, nullptr, 1);
+      if (rc) return rc;
+      lock.lock();
+    }
+    if (kind == 0) {
+      residuals[0] = p->c_r[2 * (size_t)index];
+      residuals[1] = p->c_r[2 * (size_t)index + 1];
+      if (jacobians) {
+        const double* J0 = p->c_J.data() + (size_t)(2 * index) * L.n_cols;
+        const double* J1 = J0 + L.n_cols;
+        const int nblocks = 3 + (nJ - 1) + (has_beta ? 1 : 0);
+        for (int blk = 0; blk < nblocks; ++blk) {
+          if (!jacobians[blk]) continue;
+          const int off = blk == 0 ? 0 : (blk == 1 ? 1 : (blk == 2 ? 4 : (blk < 3 + (nJ - 1) ? 7 + 3 * (blk - 3) : npose)));
+          const int sz = blk == 0 ? 1 : (blk < 3 + (nJ - 1) ? 3 : nS);
+          for (int i = 0; i < sz; ++i) {
+            jacobians[blk][i] = J0[off + i];
+            jacobians[blk][sz + i] = J1[off + i];
+          }
+        }
+      }
+    } else {
+      const int nRes = L.prior_rows_per_frame;
+      const double* r = p->c_r.data() + p->row_prior + (size_t)frame * nRes;
+      std::memcpy(residuals, r, (size_t)nRes * sizeof(double));
+      if (jacobians) {
+        const double bp = p->desc.beta_pose;
+        const int comp = p->c_comp[frame];
+        for (int j = 0; j < nJ - 1; ++j) {
+          if (!jacobians[j]) continue;
+          double* Jb = jacobians[j];  // nRes x 3 row-major (include/Sim3BA.h:293,306)
+          std::fill(Jb, Jb + (size_t)nRes * 3, 0.0);
+          if (p->has_gmm) {
+            const double* Lk = p->desc.gmm->prec_cho.data() + (size_t)comp * D * D;
+            for (int row = 0; row < D; ++row)
+              for (int c = 0; c < 3; ++c) Jb[(size_t)row * 3 + c] = Lk[(size_t)(3 * j + c) * D + row] * bp;  // :298-299
+          } else {
+            for (int c = 0; c < 3; ++c) Jb[(size_t)(3 * j + c) * 3 + c] = bp;  // :308-309
+          }
+        }
+      }
+    }
+  }
+  return BODYFIT_OK;
+}
+
+}  // extern "C"

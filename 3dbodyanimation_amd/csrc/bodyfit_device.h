@@ -1,0 +1,98 @@
+// bodyfit_device.h — device-side views shared by the HIP kernels and the host API (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace bodyfit {
+
+constexpr int kMaxJoints = 24;     // SMPL
+constexpr int kMaxShape = 10;
+constexpr int kMaxLandmarks = 32;  // vertex-landmark keypoints per model
+constexpr int kMaxLmNnz = 8;       // skinning weights per landmark vertex (SMPL has <= 4)
+constexpr int kFrameParams = 76;   // [s, rootAA, rootT, jointAA[1..23]]
+constexpr int kMeshNnz = 4;        // packed skinning weights per mesh vertex
+
+// mesh operand geometry (k_mesh_blend_lbs.hip)
+constexpr int kVTile = 32;         // vertices per MFMA column tile
+constexpr int kFTile = 32;         // frames per MFMA row tile
+constexpr int kPoseKSteps = 13;    // 207 -> 208 = 13 x 16 (bf16 32x32x16)
+constexpr int kShapeKSteps = 5;    // 10 = 5 x 2 (f32 32x32x2)
+
+struct DevModel {
+  int V, nJ, nS, P, nL, nLevels, nVTiles;
+  // skeleton, f64
+  const int* parent;           // [nJ]
+  const int* level_off;        // [nLevels+1]  joints of depth d+1
+  const int* level_joint;      // [nJ-1]
+  const unsigned* anc_mask;    // [nJ] bit k: k is a proper ancestor of j, k != root
+  const double* offset;        // [nJ][3]       include/Sim3BA.h:372-392
+  const double* dS;            // [nJ][3][nS]   S_j - S_par(j)   (j = 0: S_0)
+  const double* Jc0;           // [nJ][3]       rest joints, root at origin, beta = 0
+  const double* Sc;            // [nJ][3][nS]   S_j - S_0
+  // vertex landmarks, f64
+  const int* lm_woff;          // [nL+1]
+  const int* lm_wj;            // [nnz]
+  const double* lm_ww;         // [nnz]
+  const double* lm_vt;         // [nL][3]       v_template - J0_root
+  const double* lm_sd;         // [nL][3][nS]   shapedirs  - S_root
+  const double* lm_pd;         // [nL][3][P]
+  // mesh operands (packed in MFMA fragment order at upload)
+  const uint16_t* dirsB;       // [nVTiles][3][kPoseKSteps][2 hi/lo][64][8] bf16
+  const float* sdB;            // [nVTiles][3][kShapeKSteps][64] f32
+  const float* vtB;            // [nVTiles][3][32] f32
+  const uint32_t* wIdx;        // [nVTiles*32] 4 x u8 joint ids
+  const float* wVal;           // [nVTiles*32][4]
+};
+
+struct DevProblem {
+  int F, K, ncols, use_shape, beta_stride, pose_blend, nFTiles;
+  const int* kp_offset;   // [F+1]
+  const int* kp_id;       // [K]
+  const double* kp_uv;    // [K][2]
+  const double* R0;       // [F][9]
+  double fx, fy, cx, cy;
+};
+
+// operands the per-frame kernel prepares for the mesh kernel
+struct MeshCoef {
+  uint16_t* featA;   // [nFTiles][kPoseKSteps][2 hi/lo][64][8] bf16
+  float* betaA;      // [nFTiles][kShapeKSteps][64] f32
+  float* skinT;      // [F][nJ][12] f32: rows of [s R_root R0 A_j | s R_root R0 (P_j - A_j Jc_j) + t]
+};
+
+struct DevGmm {
+  int K, D;
+  const double* mean;       // [K][D]
+  const double* prec_cho;   // [K][D][D] lower
+  const double* neg_log_w;  // [K]
+  double resid_scale;
+};
+
+// f32 -> bf16 round-to-nearest-even (finite inputs)
+__host__ __device__ inline uint16_t f32_to_bf16(float x) {
+  union { float f; uint32_t u; } c;
+  c.f = x;
+  return (uint16_t)((c.u + 0x7FFFu + ((c.u >> 16) & 1u)) >> 16);
+}
+__host__ __device__ inline float bf16_to_f32(uint16_t b) {
+  union { float f; uint32_t u; } c;
+  c.u = ((uint32_t)b) << 16;
+  return c.f;
+}
+
+// kernel launchers (defined in the .hip files)
+void launch_frame_resjac(const DevModel& M, const DevProblem& P, const double* d_params, const double* d_beta,
+                         double* d_r, double* d_J, double* d_joints, const MeshCoef& mc, int want_jac,
+                         hipStream_t s);
+void launch_priors(const DevProblem& P, int nJ, int nS, const double* d_params, const double* d_beta,
+                   double beta_pose, const DevGmm* gmm /*host struct or null*/, double beta_shape,
+                   double lambda_t, int n_pairs, double* d_r_prior, double* d_r_shape, double* d_r_temporal,
+                   int* d_comp, hipStream_t s);
+void launch_mesh(const DevModel& M, const DevProblem& P, const MeshCoef& mc, float* d_cloud, hipStream_t s);
+void launch_reduce_shared_ex(int K, int ncols, int npose, int nS, int total_rows, const double* d_r,
+                             const double* d_J, double huber_delta, int shape_row0, int shape_rows,
+                             double beta_shape, double* d_partials, double* d_out66, hipStream_t s);
+int reduce_partials_doubles();
+void launch_regress(int nJ, int V, int ncol, const double* d_reg, const double* d_x, double* d_out, hipStream_t s);
+
+}  // namespace bodyfit

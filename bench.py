@@ -1,0 +1,200 @@
+#!/usr/bin/env python3
+"""bench.py — SMPL residual+Jacobian evaluations per second on MI355X (BASELINE.json metric).
+
+One "step" = one pass of the hot path over one batch of synthetic frames, inputs resident in HBM:
+  frame_resjac (f64 residuals + analytic Jacobian, FK joints + vertex landmarks, mesh operands)
+  -> priors (pose prior incl. GMM sweep, shape prior, temporal) -> mesh_blend_lbs (6890-vertex forward)
+  [-> reduce_shared + RCCL all-reduce of 66 doubles for the shared-shape workload].
+One "eval" = all of that for one frame.
+
+Workloads
+  c3 (default)  256 independent frames per GPU, BODY_25 keypoints, --opt-shape (per-frame beta, 86
+                columns), GMM prior on, mesh on.  BASELINE.json configs[2]; frames are independent, so
+                N GPUs run N shards with no data-path collective ("scaling": "weak").
+  c5            one multi-frame window of --window frames (default 1024) sharded over the GPUs, shared
+                beta, L2 pose prior + temporal links, one all-reduce of [cost, g_beta, H_bb] per step
+                ("scaling": "strong").  BASELINE.json configs[4].
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+# algorithmic bytes (SURVEY.md §8d / BASELINE.md §4), f32 model tensors read once per launch
+B_MODEL_MESH = 82_680 + 826_800 + 17_114_760 + 661_440      # v_template + shapedirs + posedirs + weights
+B_MODEL_ALL = B_MODEL_MESH + 661_440                         # + dense J_regressor (whole pipeline figure)
+B_FRAME_MESH = 82_680 + 24 * 12 * 4 + 217 * 4                # cloud out + skin transforms + blend coefficients
+B_FRAME_ALL = 118_588                                        # params 608 + kps 500 + r 400 + J 34,400 + cloud 82,680
+
+
+def cpu_baseline(synth, model, seq, F_sample, gmm_np):
+    """The oracle (CPU restatement, kind 'port') on the host cores over a bounded sample of the same
+    workload: reference-like residual+Jacobian (stride-4 dual-number passes, threads over blocks) plus the
+    SMPL forward (threads over frames)."""
+    from oracle import oracle
+    om = oracle.OracleModel(model)
+    nthr = oracle.max_threads()
+    class S: pass
+    s = S()
+    s.kp_offset = seq.kp_offset[:F_sample + 1]; s.kp_id = seq.kp_id; s.kp_uv = seq.kp_uv
+    s.intr = seq.intr; s.R0 = seq.R0[:F_sample]
+    x = seq.gt_params[:F_sample]; beta = np.tile(seq.gt_beta, (F_sample, 1))
+    om.evaluate_batch(s, x[:8] if F_sample >= 8 else x, beta, 86, True, True, mode=1, nthreads=nthr)  # warm the pool
+    t0 = time.perf_counter()
+    om.evaluate_batch(s, x, beta, 86, True, True, mode=1, nthreads=nthr)
+    t_ad = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    om.evaluate_batch(s, x, beta, 86, True, True, mode=0, nthreads=nthr)
+    t_an = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    om.forward_batch(x, beta, s.R0, nthreads=nthr)
+    t_fw = time.perf_counter() - t0
+    return {"value": F_sample / (t_ad + t_fw), "unit": "evals/s", "cores": nthr, "kind": "port",
+            "sample": f"{F_sample} frames of the bench workload: autodiff-style residual+Jacobian {t_ad:.2f}s "
+                      f"+ f64 SMPL forward {t_fw:.2f}s (analytic-Jacobian variant {t_an:.3f}s)",
+            "evals_per_s_analytic_jacobian": F_sample / (t_an + t_fw)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="c3", choices=["c3", "c5"])
+    ap.add_argument("--frames-per-gpu", type=int, default=256)
+    ap.add_argument("--window", type=int, default=1024)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-frames", type=int, default=0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+
+    api = importlib.import_module("3dbodyanimation_amd.api")
+    synth = importlib.import_module("3dbodyanimation_amd.synth")
+    model = synth.make_model(0)
+    gm = api.Model(model, device=local_rank)
+
+    if args.workload == "c3":
+        F = args.frames_per_gpu
+        seq = synth.make_sequence(model, F, seed=rank)
+        w, mu, cov = synth.make_gmm(0)
+        gmm = api.Gmm(w, mu, cov, device=local_rank)
+        prob = api.Problem.from_sequence(gm, seq, n_cols=86, use_shape=True, beta_per_frame=True, pose_blend=True,
+                                         beta_pose=20.0, gmm=gmm, beta_shape=30.0, want_mesh=True)
+        beta_h = np.tile(seq.gt_beta, (F, 1)) + 0.01
+        params_h = seq.gt_params + 0.01
+        total_frames = F * world
+        scaling, with_reduce = "weak", False
+        wl_name = (f"C3: {F} independent frames per GPU, BODY_25 (14 FK joints + 11 vertex landmarks), "
+                   "opt-shape (per-frame beta, 86 cols), GMM prior on, 6890-vertex mesh on")
+    else:
+        total_frames = args.window
+        per = (total_frames + world - 1) // world
+        f0, f1 = rank * per, min(total_frames, (rank + 1) * per)
+        full = synth.make_sequence(model, total_frames, seed=0)
+        F = f1 - f0
+        halo = f1 < total_frames
+        ko = full.kp_offset[f0:f1 + 1] - full.kp_offset[f0]
+        sl = slice(full.kp_offset[f0], full.kp_offset[f1])
+        prob = api.Problem(gm, ko, full.kp_id[sl], full.kp_uv[sl], full.intr, full.R0[f0:f1], n_cols=86,
+                           use_shape=True, beta_per_frame=False, pose_blend=True, beta_pose=5.0,
+                           beta_shape=25.0 if rank == 0 else 0.0, lambda_temporal=3.0, temporal_halo=halo,
+                           want_mesh=True)
+        seq = full
+        params_h = full.gt_params[f0:f1 + (1 if halo else 0)] + 0.01
+        beta_h = full.gt_beta + 0.01
+        scaling, with_reduce = "strong", True
+        wl_name = (f"C5: one {total_frames}-frame multi-frame window sharded over {world} GPU(s), shared beta, "
+                   "L2 pose prior + temporal, mesh on, all-reduce of [cost,g_beta,H_bb] (66 f64) per step")
+
+    dev = torch.device("cuda", local_rank)
+    d_params = torch.from_numpy(np.ascontiguousarray(params_h)).to(dev)
+    d_beta = torch.from_numpy(np.ascontiguousarray(beta_h)).to(dev)
+    d_red = torch.zeros(66, dtype=torch.float64, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        prob.evaluate_device(d_params.data_ptr(), d_beta.data_ptr(), True, stream)
+        if with_reduce:
+            prob.reduce_shared_device(d_red.data_ptr(), stream)
+            if world > 1:
+                dist.all_reduce(d_red)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # per-kernel durations with HIP events on the launch stream (same inputs, same stream)
+    prof = prob.profile_sweep(d_params.data_ptr(), d_beta.data_ptr(), True, with_reduce, min(100, max(10, args.steps)), stream)
+
+    if rank == 0:
+        ms_step = dt / args.steps * 1e3
+        evals_s = total_frames * args.steps / dt
+        dom = max(("mesh_blend_lbs", "frame_resjac", "priors"), key=lambda k: prof[k])
+        if dom == "mesh_blend_lbs":
+            bytes_launch = B_MODEL_MESH + F * B_FRAME_MESH
+        elif dom == "frame_resjac":
+            bytes_launch = F * (608 + 80 + 500 + 400 + 34_400 + 24 * 12 * 4 + 217 * 4)
+        else:
+            bytes_launch = 8 * 69 * 69 * 8 + F * (608 + 70 * 8)
+        ach = bytes_launch / (prof[dom] * 1e-3) / 1e9
+        whole = (B_MODEL_ALL + F * B_FRAME_ALL) / (ms_step * 1e-3) / 1e9
+        out = {
+            "metric": "SMPL residual+Jacobian evals/sec (6890v, 10 beta, 24 joints)",
+            "value": evals_s, "unit": "evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_step, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
+            "dtype": "f64 residual/Jacobian; f32 mesh (f32 + split-bf16 MFMA blend)", "data": "synthetic",
+            "config": {"workload": wl_name, "frames_per_gpu": F, "keypoints_per_frame": 25, "n_cols": 86},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": bytes_launch, "avg_launch_ms": prof[dom]},
+            "kernel_ms": prof,
+            "pipeline": {"algorithmic_bytes_per_step": B_MODEL_ALL + F * B_FRAME_ALL, "achieved_GBps": whole,
+                         "frac_of_hbm_peak": whole / HBM_PEAK_GBS},
+        }
+        if not args.no_cpu_baseline:
+            n_cpu = args.cpu_sample_frames or min(F, 256)
+            cseq = seq if args.workload == "c3" else synth.make_sequence(model, n_cpu, seed=0)
+            out["cpu_baseline"] = cpu_baseline(synth, model, cseq, n_cpu, None)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

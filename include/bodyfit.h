@@ -1,0 +1,185 @@
+/* bodyfit.h — C ABI of the MI355X-native SMPL residual/Jacobian evaluator (libbodyfit.so).
+ *
+ * Drop-in boundary for the hot path of jonH34400/3DBodyAnimation: everything the reference
+ * executes inside ceres::Solve's iteration loop (CostFunction::Evaluate of its residual blocks)
+ * plus the SMPL forward (ark::Avatar::update) those blocks are defined on.  Plain pointers and
+ * sizes only; no C++/torch types.  Every entry point returns 0 on success and a non-zero
+ * bodyfit_status otherwise (Ceres convention: Evaluate()==false marks an infeasible step, so a
+ * HIP failure maps to "false", never to an exception).  bodyfit_last_error() gives the text.
+ *
+ * Reference interfaces replaced (paths relative to the reference repository):
+ *   bodyfit_model_*            ark::AvatarModel (external/avatar, absent) as used at
+ *                              include/Sim3BA.h:360-372, include/MultiFrameBA.h:46-60;
+ *                              tensors = SMPL npz keys (scripts/npz_fixer.py:4-17)
+ *   bodyfit_gmm_*              ark::GaussianMixture (include/Sim3BA.h:249,257,266,280,288);
+ *                              data format scripts/convert_gmm_to_avatar.py:14-29
+ *   bodyfit_problem_create     the residual blocks added by include/Sim3BA.h:410-470,572-638 and
+ *                              include/MultiFrameBA.h:71-142 (PixelKP list include/Sim3BA.h:9)
+ *   bodyfit_evaluate_batch     one sweep of CostFunction::Evaluate over all those blocks:
+ *                              ReprojCost / ReprojCostShape (include/Sim3BA.h:34-88,126-227) with an
+ *                              analytic Jacobian in place of DynamicAutoDiffCostFunction (:420,581),
+ *                              PosePriorAAAnalytic (:263-315), ShapePriorL2Analytic (:331-343),
+ *                              Vec3DiffCost (include/MultiFrameBA.h:20-28)
+ *   bodyfit_evaluate_block     ceres::CostFunction::Evaluate(parameters, residuals, jacobians)
+ *                              for ONE block, same null conventions (include/Sim3BA.h:263-264)
+ *   bodyfit_forward            ark::Avatar::update() (include/Sim3BA.h:371,538;
+ *                              include/MultiFrameBA.h:53,173; src/main_single_frame.cpp:213,254)
+ *   bodyfit_mean_pixel_error   mean_pixel_error (include/Utils.h:102-115)
+ *   bodyfit_optimize_*         OptimizePoseReprojection / OptimizePoseShapeReprojection
+ *                              (include/Sim3BA.h:348-358,515-525), OptimizeMultiFrame
+ *                              (include/MultiFrameBA.h:33-43)
+ */
+#ifndef BODYFIT_H_
+#define BODYFIT_H_
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum bodyfit_status {
+  BODYFIT_OK = 0,
+  BODYFIT_ERR_INVALID = 1,   /* bad argument / shape                                  */
+  BODYFIT_ERR_HIP = 2,       /* a HIP runtime call failed (no device, OOM, fault ...) */
+  BODYFIT_ERR_NUMERIC = 3    /* non-SPD covariance etc.                               */
+} bodyfit_status;
+
+typedef struct bodyfit_model bodyfit_model;     /* device-resident SMPL model            */
+typedef struct bodyfit_gmm bodyfit_gmm;         /* device-resident max-mixture pose prior */
+typedef struct bodyfit_problem bodyfit_problem; /* residual blocks of one solve           */
+
+/* SMPL tensors, host pointers, row-major f64 (the reference keeps Eigen doubles).          */
+typedef struct bodyfit_model_desc {
+  int n_verts;               /* 6890 */
+  int n_joints;              /* 24   */
+  int n_shape;               /* 10   */
+  int n_pose_feat;           /* 207 = 9 (n_joints-1); 0 disables pose-corrective blendshapes */
+  const double* v_template;  /* [n_verts][3]              */
+  const double* shapedirs;   /* [n_verts][3][n_shape]     */
+  const double* posedirs;    /* [n_verts][3][n_pose_feat] or NULL */
+  const double* j_regressor; /* [n_joints][n_verts]       */
+  const double* weights;     /* [n_verts][n_joints]       */
+  const int* parent;         /* [n_joints], root = -1 (scripts/npz_fixer.py) */
+  int n_landmarks;           /* vertex-landmark keypoints (0 = none) */
+  const int* landmark_vid;   /* [n_landmarks] vertex ids  */
+} bodyfit_model_desc;
+
+int bodyfit_model_create(const bodyfit_model_desc* desc, int device, bodyfit_model** out);
+void bodyfit_model_destroy(bodyfit_model* m);
+/* initialJointPos [nJ][3], jointShapeReg [3 nJ][nS], rest offsets [nJ][3] (include/Sim3BA.h:372-392),
+ * regressed on the device at create time.  Any pointer may be NULL.                         */
+int bodyfit_model_get_derived(const bodyfit_model* m, double* joints0, double* joint_shape_reg,
+                              double* offset);
+
+/* pose_prior.txt contents: K weights, K x D means, K x D x D covariances (row-major).
+ * resid_scale: factor on L_k^T (x - mu_k) inside residual(); sqrt(0.5) = recalled upstream.  */
+int bodyfit_gmm_create(int n_comp, int dim, const double* weights, const double* means,
+                       const double* covs, double resid_scale, int device, bodyfit_gmm** out);
+void bodyfit_gmm_destroy(bodyfit_gmm* g);
+/* prec_cho [K][D][D] (lower L, precision = L L^T) and -log of the normalised weights [K]. */
+int bodyfit_gmm_get(const bodyfit_gmm* g, double* prec_cho, double* neg_log_w);
+
+/* Frame parameter packing (order is load-bearing, include/Sim3BA.h:36-40,421-430):
+ *   x[76] = [scale, rootAA(3), rootT(3), jointAA[1](3) ... jointAA[23](3)]                  */
+#define BODYFIT_FRAME_PARAMS 76
+
+typedef struct bodyfit_problem_desc {
+  int n_frames;
+  const int* kp_offset;   /* [n_frames+1] CSR over keypoints (frames may be empty)            */
+  const int* kp_id;       /* [K] id < n_joints: SMPL joint (PixelKP::jid);
+                                 id >= n_joints: vertex landmark id - n_joints                */
+  const double* kp_uv;    /* [K][2] observed pixels (PixelKP::u,v)                            */
+  double fx, fy, cx, cy;
+  const double* R0;       /* [n_frames][9] row-major fixed root orientation (avatar.r[0])     */
+  int n_cols;             /* 76: blocks of ReprojCost; 76+n_shape: + the shape block          */
+  int use_shape;          /* jointShapeReg handed to the functor (betaShape > 0); else the
+                             shape block, if present, gets zero columns (MultiFrameBA.h:88)   */
+  int beta_per_frame;     /* 0: one shared beta[n_shape]; 1: beta[n_frames][n_shape]          */
+  int pose_blend;         /* apply posedirs in vertex landmarks and the mesh                  */
+  double beta_pose;       /* PosePriorAAAnalytic weight; 0 = no prior block                   */
+  const bodyfit_gmm* gmm; /* NULL = L2 fallback (include/Sim3BA.h:283)                        */
+  double beta_shape;      /* ShapePriorL2Analytic weight; 0 = none                            */
+  double lambda_temporal; /* Vec3DiffCost weight between frames f, f+1; 0 = none              */
+  int temporal_halo;      /* 1: frame_params holds n_frames+1 rows; the last row is the next
+                             shard's first frame and only feeds the last temporal block       */
+  double huber_delta;     /* HuberLoss on reprojection blocks (3.0 in the reference)          */
+  int want_mesh;          /* also produce the 6890-vertex cloud per frame on each evaluation  */
+} bodyfit_problem_desc;
+
+int bodyfit_problem_create(const bodyfit_model* m, const bodyfit_problem_desc* desc, bodyfit_problem** out);
+void bodyfit_problem_destroy(bodyfit_problem* p);
+
+/* Row layout of the batched residual vector (bodyfit_problem_layout):
+ *   [reproj: 2 per keypoint, frame-major][pose prior: n_prior_rows per frame]
+ *   [shape prior: n_shape per beta][temporal: 75 per adjacent pair: rootT, rootAA, joints 1..23]
+ * The reprojection Jacobian is a dense row-major [2K][n_cols] panel (columns = the frame's 76
+ * parameters, then beta).  Prior/temporal Jacobians are constant (beta I, beta_p L_k^T, +-lambda I)
+ * and are reproduced by bodyfit_evaluate_block / the host solver from gmm_comp.               */
+typedef struct bodyfit_layout {
+  int n_keypoints;      /* K                                  */
+  int n_cols;
+  int reproj_rows;      /* 2 K                                */
+  int prior_rows_per_frame; /* 0, 69 (L2) or 70 (GMM)         */
+  int shape_rows;       /* 0, nS or F nS                      */
+  int temporal_rows;    /* 0 or 75 (F-1 [+1 with halo])       */
+  int total_rows;
+} bodyfit_layout;
+int bodyfit_problem_layout(const bodyfit_problem* p, bodyfit_layout* out);
+
+/* Host-pointer form: H2D of the parameters, one device sweep, D2H of the results.
+ *   frame_params [F(+1)][76], beta [nS] or [F][nS] (NULL if n_cols == 76)
+ *   residuals [total_rows]; jacobian [2K][n_cols] or NULL (want_jacobian = 0);
+ *   gmm_comp [F] or NULL: selected mixture component per frame.                               */
+int bodyfit_evaluate_batch(bodyfit_problem* p, const double* frame_params, const double* beta,
+                           double* residuals, double* jacobian, int* gmm_comp, int want_jacobian);
+
+/* Device-pointer form (inputs already resident in HBM, asynchronous on `stream`, a hipStream_t
+ * passed as void*; NULL = the default stream).  Results stay in the problem's device buffers.  */
+int bodyfit_evaluate_device(bodyfit_problem* p, const double* d_frame_params, const double* d_beta,
+                            int want_jacobian, void* stream);
+
+typedef struct bodyfit_device_views {
+  double* residuals;    /* [total_rows]          */
+  double* jacobian;     /* [2K][n_cols]          */
+  int* gmm_comp;        /* [F]                   */
+  float* cloud;         /* [F][n_verts][3] f32, camera frame (want_mesh)          */
+  double* joints;       /* [F][n_joints][3] camera-frame posed joints             */
+  double* normal_eq;    /* [66] see bodyfit_reduce_shared_device                  */
+} bodyfit_device_views;
+int bodyfit_problem_views(bodyfit_problem* p, bodyfit_device_views* out);
+
+/* Shared-shape reduction for frame-sharded solves: after an evaluation, reduce over the local
+ * frames  out[0] = cost = sum 1/2 rho(|r|^2) (+ 1/2 |r|^2 of the prior/temporal rows),
+ *         out[1..10] = g_beta = sum J_beta^T (rho' r),  out[11..65] = upper(H_bb) = sum rho' J_beta^T J_beta.
+ * d_out66 (device, 66 doubles) is what the caller all-reduces across ranks (RCCL).            */
+int bodyfit_reduce_shared_device(bodyfit_problem* p, double* d_out66, void* stream);
+
+/* Measurement aid: `iters` sweeps with HIP events around every kernel on `stream`;
+ * avg_ms[4] = average launch duration (ms) of {frame_resjac, priors, mesh_blend_lbs, reduce_shared}. */
+int bodyfit_profile_sweep(bodyfit_problem* p, const double* d_frame_params, const double* d_beta,
+                          int want_jacobian, int with_reduce, int iters, void* stream, double* avg_ms);
+
+/* ceres::CostFunction::Evaluate for ONE residual block, Ceres pointer conventions
+ * (jacobians may be NULL; jacobians[b] may be NULL; blocks row-major num_residuals x size).
+ *   kind 0: reprojection block `index` (keypoint), parameters = 26 or 27 blocks
+ *   kind 1: pose prior of frame `index`, parameters = 23 blocks of 3
+ *   kind 2: shape prior (index = frame when beta_per_frame), parameters = 1 block of nS
+ *   kind 3: temporal link `index` = 25*pair + slot, parameters = 2 blocks of 3                */
+int bodyfit_evaluate_block(bodyfit_problem* p, int kind, int index, const double* const* parameters,
+                           double* residuals, double** jacobians);
+
+/* ark::Avatar::update(): camera-frame joints [F][nJ][3] (f64) and cloud [F][V][3] (f32) for the
+ * problem's frames at the given parameters; either output may be NULL.                       */
+int bodyfit_forward(bodyfit_problem* p, const double* frame_params, const double* beta,
+                    double* joints, float* cloud);
+
+/* include/Utils.h:102-115 on the joints of bodyfit_forward (no Sim3 scale: pass scale = 1). */
+double bodyfit_mean_pixel_error(int n_kp, const int* jid, const double* uv, const double* joints,
+                                double fx, double fy, double cx, double cy);
+
+const char* bodyfit_last_error(void);
+int bodyfit_device_count(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BODYFIT_H_ */

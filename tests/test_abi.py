@@ -1,0 +1,34 @@
+"""CPU: the C-ABI library loads and exports every symbol include/bodyfit.h declares (no compute)."""
+import ctypes
+import os
+import subprocess
+
+import pytest
+
+
+def test_library_exports_every_declared_symbol(api):
+    if not os.path.exists(api.LIB_PATH):
+        subprocess.check_call(["make", "-C", os.path.join(os.path.dirname(api.LIB_PATH), "csrc"), "-s", "-j4"])
+    lib = ctypes.CDLL(api.LIB_PATH)
+    syms = api.declared_symbols()
+    assert len(syms) >= 18
+    missing = [s for s in syms if not hasattr(lib, s)]
+    assert not missing, f"declared in bodyfit.h but not exported: {missing}"
+
+
+def test_no_cpu_fallback_and_errors_are_loud(api, model):
+    lib = api.load_library()
+    if lib.bodyfit_device_count() > 0:
+        pytest.skip("GPU present: covered by the -m gpu tests")
+    with pytest.raises(api.BodyfitError):
+        api.Model(model, device=0)  # no device -> BODYFIT_ERR_HIP, never a silent CPU path
+
+
+def test_product_does_not_reference_the_oracle():
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pkg = os.path.join(root, "3dbodyanimation_amd")
+    for dp, _, fns in os.walk(pkg):
+        for fn in fns:
+            if fn.endswith((".py", ".hip", ".cpp", ".h", ".hpp", "Makefile")):
+                txt = open(os.path.join(dp, fn), errors="ignore").read()
+                assert "liboracle" not in txt and "from oracle" not in txt and "import oracle" not in txt, fn

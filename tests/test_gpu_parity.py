@@ -1,0 +1,238 @@
+"""GPU parity: the HIP path through the C ABI against the CPU restatement (oracle/) on identical seeded
+inputs, and against the committed golden fixtures.  f64 residual/Jacobian tolerance 1e-9 abs (scaled by
+the Jacobian magnitude ~6e2 -> 1e-12 relative); f32 mesh tolerance stated per test."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import random_params
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _oracle_full(oracle_mod, omodel, seq, x, beta, n_cols, use_shape, pose_blend, beta_pose, ogmm, beta_shape,
+                 lam, halo=False):
+    """The whole batched residual vector in the ABI's row layout, from the oracle."""
+    F = len(seq.kp_offset) - 1
+    r, J = omodel.evaluate_batch(seq, x[:F], beta, n_cols, use_shape, pose_blend, mode=0)
+    parts = [r]
+    comps = np.zeros(F, int)
+    if beta_pose > 0:
+        for f in range(F):
+            rp, _, k = oracle_mod.pose_prior(ogmm, beta_pose, x[f, 7:])
+            parts.append(rp); comps[f] = k
+    if beta_shape > 0 and n_cols > 76:
+        parts.append(beta_shape * np.asarray(beta).reshape(-1))
+    if lam > 0:
+        n_pairs = F - 1 + (1 if halo else 0)
+        for f in range(n_pairs):
+            a, b = x[f], x[f + 1]
+            parts.append(lam * np.concatenate([a[4:7] - b[4:7], a[1:4] - b[1:4], a[7:] - b[7:]]))
+    return np.concatenate(parts), J, comps
+
+
+@pytest.mark.parametrize("cfg", ["pose_only_76", "shape_shared", "shape_per_frame_gmm", "shape_unused_Q12"])
+def test_residual_and_jacobian_match_oracle(api, synth, model, gpu_model, oracle_mod, omodel, cfg):
+    F = 37
+    seq = synth.make_sequence(model, F, seed=5, ragged=True)
+    rng = np.random.default_rng(21)
+    x = random_params(rng, F)
+    x[3, 7:] = 0.0           # all-zero pose: first-order Rodrigues branch
+    x[4, 7:10] = 1e-9        # tiny but non-zero angle inside the first-order branch
+    x[5, 7:10] = 3e-8        # just above the branch threshold
+    kw = dict(pose_blend=True, huber_delta=3.0)
+    ogmm = None
+    if cfg == "pose_only_76":
+        beta, n_cols, use_shape = None, 76, False
+        kw.update(n_cols=76, use_shape=False, beta_pose=20.0)
+        bp, bs, lam = 20.0, 0.0, 0.0
+    elif cfg == "shape_shared":
+        beta, n_cols, use_shape = rng.normal(size=10), 86, True
+        kw.update(n_cols=86, use_shape=True, beta_pose=5.0, beta_shape=25.0, lambda_temporal=3.0)
+        bp, bs, lam = 5.0, 25.0, 3.0
+    elif cfg == "shape_per_frame_gmm":
+        beta, n_cols, use_shape = rng.normal(size=(F, 10)), 86, True
+        w, mu, cov = synth.make_gmm(0)
+        ogmm = oracle_mod.OracleGmm(w, mu, cov)
+        kw.update(n_cols=86, use_shape=True, beta_per_frame=True, beta_pose=20.0, gmm=api.Gmm(w, mu, cov),
+                  beta_shape=30.0)
+        bp, bs, lam = 20.0, 30.0, 0.0
+    else:
+        beta, n_cols, use_shape = rng.normal(size=10), 86, False
+        kw.update(n_cols=86, use_shape=False)
+        bp, bs, lam = 0.0, 0.0, 0.0
+    prob = api.Problem.from_sequence(gpu_model, seq, **kw)
+    r, J, comp = prob.evaluate(x, beta, True)
+    ro, Jo, co = _oracle_full(oracle_mod, omodel, seq, x, beta if beta is not None else np.zeros(10), n_cols,
+                              use_shape, True, bp, ogmm, bs, lam)
+    assert r.shape == ro.shape
+    assert np.abs(r - ro).max() < 1e-9
+    assert np.abs(J - Jo).max() < 1e-9 * max(1.0, np.abs(Jo).max())
+    if ogmm is not None:
+        assert np.array_equal(comp, co)
+    # residual-only sweep returns the same residuals
+    r2, J2, _ = prob.evaluate(x, beta, False)
+    assert J2 is None and np.array_equal(r, r2)
+
+
+def test_golden_fixture(api, gpu_model):
+    g = np.load(os.path.join(GOLD, "oracle_golden.npz"))
+    prob = api.Problem(gpu_model, g["kp_offset"], g["kp_id"], g["kp_uv"], g["intr"], g["R0"], n_cols=86,
+                       use_shape=True, want_mesh=True)
+    r, J, _ = prob.evaluate(g["params"], g["beta"], True)
+    assert np.abs(r - g["r"]).max() < 1e-9 and np.abs(J - g["J"]).max() < 1e-9 * np.abs(g["J"]).max()
+    joints, cloud = prob.forward(g["params"], g["beta"])
+    assert np.abs(joints[0] - g["joints0"]).max() < 1e-11
+    assert np.abs(cloud[0][g["cloud_vids"]] - g["cloud0_sample"]).max() < 5e-6  # f32 mesh, metres
+
+
+def test_reference_pose_prior_data(api, gpu_model, synth, model, oracle_mod):
+    """The reference's own pose_prior.txt (8 x 69) through the HIP GMM sweep vs the oracle."""
+    g = np.load(os.path.join(GOLD, "pose_prior_reference.npz"))
+    gm = api.Gmm(g["weights"], g["means"], g["covs"])
+    og = oracle_mod.OracleGmm(g["weights"], g["means"], g["covs"])
+    L, nlw = gm.get(); Lo, nlwo = og.get()
+    assert np.abs(L - Lo).max() < 1e-9 * np.abs(Lo).max() and np.abs(nlw - nlwo).max() < 1e-9
+    F = 16
+    seq = synth.make_sequence(model, F, seed=9)
+    rng = np.random.default_rng(5)
+    x = random_params(rng, F, pose_sigma=0.4)
+    x[0, 7:] = 0.0
+    prob = api.Problem.from_sequence(gpu_model, seq, n_cols=76, use_shape=False, beta_pose=20.0, gmm=gm)
+    r, _, comp = prob.evaluate(x, None, False)
+    L_ = prob.layout
+    rp = r[L_.reproj_rows:].reshape(F, 70)
+    for f in range(F):
+        ro, _, k = oracle_mod.pose_prior(og, 20.0, x[f, 7:])
+        assert comp[f] == k and np.abs(rp[f] - ro).max() < 1e-8
+    assert comp[0] == int(g["comp_at_zero"]) and np.abs(rp[0] - 20.0 * g["resid_at_zero"]).max() < 1e-8
+
+
+def test_derived_tables_match(gpu_model, omodel):
+    J0, S, off = gpu_model.derived()
+    J0o, So, offo = omodel.derived()
+    assert np.abs(J0 - J0o).max() < 1e-13 and np.abs(S - So).max() < 1e-13 and np.abs(off - offo).max() < 1e-13
+
+
+@pytest.mark.parametrize("F", [1, 33, 256])
+def test_mesh_forward_matches_oracle(api, synth, model, gpu_model, omodel, F):
+    seq = synth.make_sequence(model, F, seed=3)
+    rng = np.random.default_rng(31)
+    x = random_params(rng, F)
+    x[0, 7:] = 0.0
+    beta = rng.normal(size=(F, 10))
+    prob = api.Problem.from_sequence(gpu_model, seq, n_cols=86, use_shape=True, beta_per_frame=True, want_mesh=True)
+    joints, cloud = prob.forward(x, beta)
+    check = sorted(set([0, F // 2, F - 1]))
+    worst = 0.0
+    for f in check:
+        jo, co = omodel.forward(x[f], beta[f], seq.R0[f])
+        assert np.abs(joints[f] - jo).max() < 1e-11
+        worst = max(worst, np.abs(cloud[f] - co).max())
+    # f32 skinning of metre-scale coordinates (ulp 2.4e-7 at 3 m) + bf16x2-split pose blend (<= 2^-16 relative)
+    assert worst < 5e-6, worst
+    # size-independent properties at full size: zero pose/shape gives the template; rigid motion commutes
+    x0 = np.zeros((F, 76)); x0[:, 0] = 1.0
+    eyeR0 = np.tile(np.eye(3).reshape(1, 9), (F, 1))
+    prob0 = api.Problem(gpu_model, seq.kp_offset, seq.kp_id, seq.kp_uv, seq.intr, eyeR0, n_cols=86, use_shape=True,
+                        beta_per_frame=True, want_mesh=True)
+    _, c0 = prob0.forward(x0, np.zeros((F, 10)))
+    J0 = gpu_model.derived()[0]
+    assert np.abs(c0[F - 1] - (model.v_template - J0[0])).max() < 1e-6
+    assert np.abs(c0[0] - c0[F - 1]).max() == 0.0
+
+
+def test_mesh_without_pose_blend_and_landmark_consistency(api, synth, model, gpu_model, omodel):
+    F = 8
+    seq = synth.make_sequence(model, F, seed=4)
+    rng = np.random.default_rng(41)
+    x = random_params(rng, F); beta = rng.normal(size=10)
+    prob = api.Problem.from_sequence(gpu_model, seq, n_cols=86, use_shape=True, pose_blend=False, want_mesh=True)
+    _, cloud = prob.forward(x, beta)
+    _, co = omodel.forward(x[2], beta, seq.R0[2], pose_blend=False)
+    assert np.abs(cloud[2] - co).max() < 5e-6
+    # f64 landmark keypoints of the residual kernel agree with the f32 mesh vertices they name
+    prob2 = api.Problem.from_sequence(gpu_model, seq, n_cols=86, use_shape=True, pose_blend=True, want_mesh=True)
+    r, _, _ = prob2.evaluate(x, beta, False)
+    _, cloud2 = prob2.forward(x, beta)
+    for f in [0, 5]:
+        for k in range(seq.kp_offset[f], seq.kp_offset[f + 1]):
+            if seq.kp_id[k] >= 24:
+                X = cloud2[f][model.landmark_vid[seq.kp_id[k] - 24]].astype(np.float64)
+                uv = np.array([seq.intr[0] * X[0] / X[2] + seq.intr[2], seq.intr[1] * X[1] / X[2] + seq.intr[3]])
+                assert np.abs((uv - seq.kp_uv[k]) - r[2 * k:2 * k + 2]).max() < 5e-3  # pixels
+
+
+def test_evaluate_block_is_ceres_evaluate(api, synth, model, gpu_model, oracle_mod, omodel):
+    F = 5
+    seq = synth.make_sequence(model, F, seed=6)
+    rng = np.random.default_rng(51)
+    x = random_params(rng, F); beta = rng.normal(size=10)
+    prob = api.Problem.from_sequence(gpu_model, seq, n_cols=86, use_shape=True, beta_pose=5.0, beta_shape=25.0,
+                                     lambda_temporal=3.0)
+    prob.evaluate(x, beta, True)  # EvaluationCallback-style: one sweep, then per-block reads
+    k = int(seq.kp_offset[2]) + 3
+    f = 2
+    blocks = [x[f, 0:1], x[f, 1:4], x[f, 4:7]] + [x[f, 7 + 3 * j:10 + 3 * j] for j in range(23)] + [beta]
+    want = [True] * 27
+    want[5] = False  # a constant block: jacobians[b] == NULL (include/Sim3BA.h:608-611)
+    r, jacs = prob.evaluate_block(0, k, blocks, 2, want)
+    ro, Jo = omodel.kp_block(seq.kp_id[k], seq.kp_uv[k], seq.intr, seq.R0[f], np.concatenate([x[f], beta]))
+    assert np.abs(r - ro).max() < 1e-9
+    Jcat = np.concatenate([j for j in jacs], axis=1)
+    cols = np.ones(86, bool); cols[7 + 3 * 2:10 + 3 * 2] = False
+    assert np.abs(Jcat[:, cols] - Jo[:, cols]).max() < 1e-9 * np.abs(Jo).max()
+    assert np.isnan(jacs[5]).all()  # untouched
+    # a block evaluated at parameters that differ from the last sweep triggers a fresh device sweep
+    blocks2 = [b.copy() for b in blocks]; blocks2[4] = blocks2[4] + 0.05
+    x2 = np.concatenate(blocks2[:26])
+    r2, jacs2 = prob.evaluate_block(0, k, blocks2, 2)
+    ro2, Jo2 = omodel.kp_block(seq.kp_id[k], seq.kp_uv[k], seq.intr, seq.R0[f], np.concatenate([x2, beta]))
+    assert np.abs(r2 - ro2).max() < 1e-9 and np.abs(np.concatenate(jacs2, 1) - Jo2).max() < 1e-9 * np.abs(Jo2).max()
+    # pose prior (L2), shape prior, temporal
+    rp, jp = prob.evaluate_block(1, 1, [x[1, 7 + 3 * j:10 + 3 * j] for j in range(23)], 69)
+    assert np.allclose(rp, 5.0 * x[1, 7:]) and np.allclose(jp[4][12:15], 5.0 * np.eye(3)) and jp[4][:12].max() == 0
+    rs, js = prob.evaluate_block(2, 0, [beta], 10)
+    assert np.allclose(rs, 25.0 * beta) and np.allclose(js[0], 25.0 * np.eye(10))
+    rt, jt = prob.evaluate_block(3, 0, [x[0, 4:7], x[1, 4:7]], 3)
+    assert np.allclose(rt, 3.0 * (x[0, 4:7] - x[1, 4:7])) and np.allclose(jt[1], -3.0 * np.eye(3))
+
+
+def test_shared_reduction_matches_numpy(api, synth, model, gpu_model, oracle_mod):
+    import torch
+    F = 40
+    seq = synth.make_sequence(model, F, seed=8, noise_px=4.0)
+    rng = np.random.default_rng(61)
+    x = seq.gt_params + rng.normal(scale=0.02, size=seq.gt_params.shape)
+    beta = seq.gt_beta + 0.1
+    prob = api.Problem.from_sequence(gpu_model, seq, n_cols=86, use_shape=True, beta_pose=5.0, beta_shape=25.0,
+                                     lambda_temporal=3.0)
+    r, J, _ = prob.evaluate(x, beta, True)
+    out = torch.zeros(66, dtype=torch.float64, device="cuda")
+    prob.reduce_shared_device(out.data_ptr(), None)
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    K = prob.layout.n_keypoints
+    rk = r[:2 * K].reshape(K, 2); Jb = J[:, 76:].reshape(K, 2, 10)
+    s = (rk ** 2).sum(1)
+    rho = np.array([oracle_mod.huber(3.0, v) for v in s])
+    assert (s > 9).any() and (s <= 9).any()  # both Huber regions are exercised
+    cost = 0.5 * rho[:, 0].sum() + 0.5 * (r[2 * K:] ** 2).sum()
+    g = np.einsum("k,kri,kr->i", rho[:, 1], Jb, rk) + 25.0 * (25.0 * beta)
+    H = np.einsum("k,kri,krj->ij", rho[:, 1], Jb, Jb) + 25.0 ** 2 * np.eye(10)
+    assert abs(got[0] - cost) < 1e-9 * cost
+    assert np.abs(got[1:11] - g).max() < 1e-9 * np.abs(g).max()
+    assert np.abs(got[11:] - H[np.triu_indices(10)]).max() < 1e-9 * np.abs(H).max()
+
+
+def test_invalid_arguments_fail_loudly(api, synth, model, gpu_model):
+    seq = synth.make_sequence(model, 2, seed=1)
+    with pytest.raises(api.BodyfitError):
+        api.Problem.from_sequence(gpu_model, seq, n_cols=80)
+    bad = seq.kp_id.copy(); bad[0] = 99
+    with pytest.raises(api.BodyfitError):
+        api.Problem(gpu_model, seq.kp_offset, bad, seq.kp_uv, seq.intr, seq.R0)
+    with pytest.raises(api.BodyfitError):
+        api.Problem.from_sequence(gpu_model, seq, n_cols=76, use_shape=True)

@@ -1,0 +1,243 @@
+"""CPU suite: the oracle against itself (analytic == dual-number autodiff == finite differences),
+hand-derivable known answers, and the committed golden fixtures."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import random_params
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+INTR = np.array([1728.0, 1728.0, 960.0, 540.0])
+R0 = -np.eye(3).reshape(-1)
+
+
+def test_rodrigues_matches_finite_differences(oracle_mod):
+    rng = np.random.default_rng(0)
+    for scale in [1.0, 1e-2, 1e-5]:
+        a = rng.normal(size=3) * scale
+        R, dR = oracle_mod.rodrigues(a)
+        assert np.allclose(R @ R.T, np.eye(3), atol=1e-14)
+        for c in range(3):
+            h = 1e-6
+            ap, am = a.copy(), a.copy()
+            ap[c] += h; am[c] -= h
+            fd = (oracle_mod.rodrigues(ap)[0] - oracle_mod.rodrigues(am)[0]) / (2 * h)
+            assert np.abs(fd - dR[c]).max() < 1e-8
+
+
+def test_rodrigues_first_order_branch(oracle_mod):
+    # theta^2 <= DBL_EPSILON: R = I + [a]x and dR_c = [e_c]x (Ceres' Taylor branch)
+    a = np.array([1e-9, -2e-9, 0.5e-9])
+    R, dR = oracle_mod.rodrigues(a)
+    K = np.array([[0, -a[2], a[1]], [a[2], 0, -a[0]], [-a[1], a[0], 0]])
+    assert np.array_equal(R, np.eye(3) + K)
+    assert dR[0][2, 1] == 1 and dR[0][1, 2] == -1 and dR[2][1, 0] == 1
+    R0_, dR0 = oracle_mod.rodrigues(np.zeros(3))
+    assert np.array_equal(R0_, np.eye(3))
+
+
+@pytest.mark.parametrize("use_shape", [True, False])
+@pytest.mark.parametrize("pose_blend", [True, False])
+def test_analytic_equals_autodiff_all_keypoints(omodel, model, use_shape, pose_blend):
+    rng = np.random.default_rng(3)
+    x = random_params(rng, 1)[0]
+    beta = rng.normal(size=10)
+    xx = np.concatenate([x, beta])
+    for kid in range(24 + len(model.landmark_vid)):
+        uv = rng.uniform(0, 1000, 2)
+        ra, Ja = omodel.kp_block(kid, uv, INTR, R0, xx, use_shape, pose_blend, mode=0)
+        rb, Jb = omodel.kp_block(kid, uv, INTR, R0, xx, use_shape, pose_blend, mode=1)
+        assert np.abs(ra - rb).max() < 1e-9
+        assert np.abs(Ja - Jb).max() < 1e-9 * max(1.0, np.abs(Jb).max())
+        if not use_shape:
+            assert np.all(Ja[:, 76:] == 0.0)  # quirk Q12: shape block present but ignored
+
+
+def test_analytic_equals_central_differences(omodel, model):
+    rng = np.random.default_rng(4)
+    x = random_params(rng, 1)[0]
+    xx = np.concatenate([x, rng.normal(size=10)])
+    for kid in [0, 4, 15, 21, 23, 24, 29, 34]:
+        _, Ja = omodel.kp_block(kid, (500.0, 400.0), INTR, R0, xx, True, True, 0)
+        fd = np.zeros_like(Ja)
+        for c in range(len(xx)):
+            h = 1e-6
+            xp, xm = xx.copy(), xx.copy()
+            xp[c] += h; xm[c] -= h
+            rp, _ = omodel.kp_block(kid, (500.0, 400.0), INTR, R0, xp, True, True, 0, want_jac=False)
+            rm, _ = omodel.kp_block(kid, (500.0, 400.0), INTR, R0, xm, True, True, 0, want_jac=False)
+            fd[:, c] = (rp - rm) / (2 * h)
+        assert np.abs(fd - Ja).max() < 2e-5 * max(1.0, np.abs(Ja).max())
+
+
+def test_zero_pose_is_first_order_branch_and_agrees(omodel):
+    # the reference's initial iterate (all joint angles exactly 0) goes through the Taylor branch
+    x = np.zeros(76); x[0] = 1.0; x[6] = 3.0
+    xx = np.concatenate([x, np.zeros(10)])
+    for kid in [1, 12, 21, 24, 30]:
+        ra, Ja = omodel.kp_block(kid, (900.0, 500.0), INTR, R0, xx, True, True, 0)
+        rb, Jb = omodel.kp_block(kid, (900.0, 500.0), INTR, R0, xx, True, True, 1)
+        assert np.abs(ra - rb).max() < 1e-10 and np.abs(Ja - Jb).max() < 1e-9
+
+
+def test_known_answers(omodel, model):
+    J0, S, off = omodel.derived()
+    x = np.zeros(76); x[0] = 1.0; x[4:7] = [0.1, -0.2, 3.0]
+    xx = np.concatenate([x, np.zeros(10)])
+    # jid = 0 with beta = 0: X = t  -> residual = projection of t minus observation
+    r, _ = omodel.kp_block(0, (0.0, 0.0), INTR, np.eye(3).reshape(-1), xx, True, True, 0)
+    assert np.allclose(r, [1728 * 0.1 / 3 + 960, 1728 * -0.2 / 3 + 540], atol=1e-12)
+    # all-zero pose: body position = sum of offsets along the chain (include/Sim3BA.h:52-67)
+    for jid in [7, 15, 23]:
+        q = np.zeros(3); j = jid
+        while j > 0:
+            q += off[j]; j = model.parent[j]
+        X = q + x[4:7]
+        r, _ = omodel.kp_block(jid, (0.0, 0.0), INTR, np.eye(3).reshape(-1), xx, True, True, 0)
+        assert np.allclose(r, [1728 * X[0] / X[2] + 960, 1728 * X[1] / X[2] + 540], atol=1e-10)
+    # pure scale: s = 2 doubles the body vector before the translation
+    x2 = xx.copy(); x2[0] = 2.0
+    q = off[1]
+    X = 2 * q + x[4:7]
+    r, _ = omodel.kp_block(1, (0.0, 0.0), INTR, np.eye(3).reshape(-1), x2, True, True, 0)
+    assert np.allclose(r, [1728 * X[0] / X[2] + 960, 1728 * X[1] / X[2] + 540], atol=1e-10)
+    # jid = 0 with beta != 0 uses S_0 beta without a parent term (reference quirk)
+    b = np.arange(10) * 0.1
+    x3 = np.concatenate([x, b])
+    X = (S[0:3] @ b) + x[4:7]
+    r, _ = omodel.kp_block(0, (0.0, 0.0), INTR, np.eye(3).reshape(-1), x3, True, True, 0)
+    assert np.allclose(r, [1728 * X[0] / X[2] + 960, 1728 * X[1] / X[2] + 540], atol=1e-10)
+
+
+def test_single_joint_quarter_turn(omodel, model):
+    # rotate joint 1 (l_hip) by 90 deg about z: its child 4's offset turns, joint 4 position = off1 + Rz off4
+    J0, S, off = omodel.derived()
+    x = np.zeros(76); x[0] = 1.0; x[6] = 3.0
+    x[7 + 3 * 0 + 2] = np.pi / 2
+    Rz = np.array([[0, -1, 0], [1, 0, 0], [0, 0, 1.0]])
+    X = off[1] + Rz @ off[4] + x[4:7]
+    r, _ = omodel.kp_block(4, (0.0, 0.0), INTR, np.eye(3).reshape(-1), np.concatenate([x, np.zeros(10)]), True, True, 0)
+    assert np.allclose(r, [1728 * X[0] / X[2] + 960, 1728 * X[1] / X[2] + 540], atol=1e-9)
+
+
+def test_forward_properties(omodel, model, synth):
+    J0, S, off = omodel.derived()
+    x = np.zeros(76); x[0] = 1.0
+    j, c = omodel.forward(x, np.zeros(10), np.eye(3).reshape(-1))
+    # zero pose + zero shape: cloud = v_template, joints = J_reg v_template, both centred on the root joint
+    assert np.abs(c - (model.v_template - J0[0])).max() < 1e-14
+    assert np.abs(j - (J0 - J0[0])).max() < 1e-14
+    # partition of unity
+    assert np.abs(model.weights.sum(1) - 1).max() < 1e-14
+    # rigid root rotation/translation/scale = rigid motion of the posed cloud
+    rng = np.random.default_rng(5)
+    xp = random_params(rng, 1)[0]
+    beta = rng.normal(size=10)
+    xb = xp.copy(); xb[0] = 1.0; xb[1:7] = 0
+    jb, cb = omodel.forward(xb, beta, np.eye(3).reshape(-1))
+    jf, cf = omodel.forward(xp, beta, R0)
+    M = xp[0] * synth.rodrigues(xp[1:4]) @ R0.reshape(3, 3)
+    assert np.abs(cf - (cb @ M.T + xp[4:7])).max() < 1e-12
+    # the FK joints of the residual are the posed SMPL joints: landmark on a joint-coincident check via numpy
+    jn, cn = synth.forward_numpy(model, xp, beta, R0.reshape(3, 3))
+    assert np.abs(jn - jf).max() < 1e-13 and np.abs(cn - cf).max() < 1e-12
+    # linear in beta at zero pose without pose blend
+    x0 = np.zeros(76); x0[0] = 1
+    _, c1 = omodel.forward(x0, beta, np.eye(3).reshape(-1), pose_blend=False)
+    _, c2 = omodel.forward(x0, 2 * beta, np.eye(3).reshape(-1), pose_blend=False)
+    _, c0 = omodel.forward(x0, 0 * beta, np.eye(3).reshape(-1), pose_blend=False)
+    assert np.abs((c2 - c0) - 2 * (c1 - c0)).max() < 1e-13
+
+
+def test_fk_joint_keypoints_equal_forward_joints(omodel, model):
+    # reference chain (jid >= 1) == SMPL posed joints projected; this ties the two keypoint models together
+    rng = np.random.default_rng(6)
+    x = random_params(rng, 1)[0]; beta = rng.normal(size=10)
+    j, _ = omodel.forward(x, beta, R0, want_cloud=False)
+    for jid in range(1, 24):
+        r, _ = omodel.kp_block(jid, (0.0, 0.0), INTR, R0, np.concatenate([x, beta]), True, True, 0)
+        assert np.allclose(r, [1728 * j[jid, 0] / j[jid, 2] + 960, 1728 * j[jid, 1] / j[jid, 2] + 540], atol=1e-9)
+
+
+def test_pose_prior_l2_and_gmm(oracle_mod, synth):
+    rng = np.random.default_rng(7)
+    x = rng.normal(scale=0.3, size=69)
+    r, J, k = oracle_mod.pose_prior(None, 5.0, x)
+    assert r.shape == (69,) and np.array_equal(r, 5.0 * x) and np.array_equal(J, 5.0 * np.eye(69))
+    w, mu, cov = synth.make_gmm(0)
+    g = oracle_mod.OracleGmm(w, mu, cov)
+    L, nlw = g.get()
+    for kk in range(8):
+        assert np.abs(L[kk] @ L[kk].T - np.linalg.inv(cov[kk])).max() < 1e-6 * np.abs(np.linalg.inv(cov[kk])).max()
+        assert np.allclose(L[kk], np.tril(L[kk]))
+    # independent numpy restatement of the SMPLify max-mixture residual
+    sqd = np.array([np.sqrt(np.linalg.det(c)) for c in cov])
+    wprime = w / ((2 * np.pi) ** (69 / 2) * (sqd / sqd.min()))
+    cand = [np.sqrt(0.5) * np.linalg.cholesky(np.linalg.inv(cov[kk])).T @ (x - mu[kk]) for kk in range(8)]
+    vals = [c @ c - np.log(wprime[kk]) for kk, c in enumerate(cand)]
+    kbest = int(np.argmin(vals))
+    rr, kk = g.residual(x)
+    assert kk == kbest
+    assert np.abs(rr[:69] - cand[kbest]).max() < 1e-7 and abs(rr[69] - np.sqrt(-np.log(wprime[kbest]))) < 1e-9
+    r, J, k2 = oracle_mod.pose_prior(g, 2.0, x)
+    assert k2 == kbest and r.shape == (70,) and np.allclose(r, 2.0 * rr)
+    assert np.allclose(J[:69], 2.0 * L[kbest].T) and np.all(J[69] == 0)  # include/Sim3BA.h:298-299, last row zero
+
+
+def test_huber(oracle_mod):
+    assert np.allclose(oracle_mod.huber(3.0, 4.0), [4.0, 1.0, 0.0])
+    rho = oracle_mod.huber(3.0, 25.0)
+    assert np.allclose(rho, [2 * 3 * 5 - 9, 3 / 5, -(3 / 5) / 50])
+
+
+def test_batch_modes_and_ragged(omodel, model, synth):
+    seq = synth.make_sequence(model, 9, seed=2, ragged=True)
+    assert (np.diff(seq.kp_offset) == 0).any()  # at least one empty frame, as in the shipped '[]' JSONs
+    rng = np.random.default_rng(8)
+    x = random_params(rng, 9)
+    beta = rng.normal(size=10)
+    ra, Ja = omodel.evaluate_batch(seq, x, beta, 86, True, True, mode=0)
+    rb, Jb = omodel.evaluate_batch(seq, x, beta, 86, True, True, mode=1, nthreads=2)
+    assert np.abs(ra - rb).max() < 1e-9 and np.abs(Ja - Jb).max() < 1e-8
+    # per-frame beta == shared beta when all rows are equal
+    rc, Jc = omodel.evaluate_batch(seq, x, np.tile(beta, (9, 1)), 86, True, True, mode=0)
+    assert np.array_equal(ra, rc) and np.array_equal(Ja, Jc)
+    # 76 columns (ReprojCost) == 86 columns with beta = 0 restricted to the first 76
+    r76, J76 = omodel.evaluate_batch(seq, x, np.zeros(10), 76, False, True, mode=0)
+    r86, J86 = omodel.evaluate_batch(seq, x, np.zeros(10), 86, True, True, mode=0)
+    assert np.abs(r76 - r86).max() < 1e-12 and np.abs(J76 - J86[:, :76]).max() < 1e-12
+
+
+def test_mean_pixel_error(oracle_mod):
+    joints = np.array([[0, 0, 2.0], [1, 0, 2.0]])
+    e = oracle_mod.mean_pixel_error([0, 1], np.array([[960.0, 540.0], [960.0 + 864 + 3, 540 + 4.0]]), joints, INTR)
+    assert abs(e - 2.5) < 1e-12
+    assert oracle_mod.mean_pixel_error([], np.zeros((0, 2)), joints, INTR) == 0.0
+
+
+def test_golden_fixture(omodel, model):
+    g = np.load(os.path.join(GOLD, "oracle_golden.npz"))
+    class S: pass
+    s = S(); s.kp_offset = g["kp_offset"]; s.kp_id = g["kp_id"]; s.kp_uv = g["kp_uv"]; s.intr = g["intr"]; s.R0 = g["R0"]
+    r, J = omodel.evaluate_batch(s, g["params"], g["beta"], 86, True, True, mode=0)
+    assert np.abs(r - g["r"]).max() < 1e-10 and np.abs(J - g["J"]).max() < 1e-9
+    j, c = omodel.forward(g["params"][0], g["beta"], g["R0"][0])
+    assert np.abs(j - g["joints0"]).max() < 1e-12
+    assert np.abs(c[g["cloud_vids"]] - g["cloud0_sample"]).max() < 1e-12
+
+
+def test_reference_pose_prior_fixture(oracle_mod):
+    """data/avatar-model/pose_prior.txt of the reference, converted by tests/golden/make_golden.py."""
+    g = np.load(os.path.join(GOLD, "pose_prior_reference.npz"))
+    w, mu, cov = g["weights"], g["means"], g["covs"]
+    assert mu.shape == (8, 69) and cov.shape == (8, 69, 69) and abs(w.sum() - 1) < 1e-9
+    gm = oracle_mod.OracleGmm(w, mu, cov)
+    L, nlw = gm.get()
+    assert np.all(nlw > 0)  # sqrt(-log w') is real
+    # the mean of a component has zero whitened residual and selects a component with finite constant
+    r, k = gm.residual(mu[3])
+    assert np.isfinite(r).all()
+    # at x = 0 (the reference's initial pose) the residual is finite and reproducible
+    r0, k0 = gm.residual(np.zeros(69))
+    assert k0 == int(g["comp_at_zero"]) and np.abs(r0 - g["resid_at_zero"]).max() < 1e-9
