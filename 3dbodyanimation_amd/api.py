@@ -70,6 +70,13 @@ def load_library():
     if not os.path.exists(LIB_PATH):
         raise BodyfitError(f"{LIB_PATH} is missing: build it with `make -C 3dbodyanimation_amd/csrc` "
                            "(__graft_entry__.build()). There is no CPU fallback.")
+    # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64; loading the system one first
+    # makes torch.cuda see no GPU.  Importing torch first lets libbodyfit.so bind to the runtime torch
+    # already mapped (same soname), so streams / tensors / RCCL and our kernels share one context.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     lib.bodyfit_last_error.restype = C.c_char_p
     lib.bodyfit_mean_pixel_error.restype = C.c_double

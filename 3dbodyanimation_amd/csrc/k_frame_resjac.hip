@@ -475,6 +475,12 @@ void launch_frame_resjac(const DevModel& M, const DevProblem& P, const double* d
                          hipStream_t s) {
   if (P.F <= 0) return;
   const size_t lds = (size_t)(OFF_LM + M.nL * LM_STRIDE) * sizeof(double);
+  static size_t lds_granted = 48 * 1024;
+  if (lds > lds_granted) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_frame_resjac), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds);
+    lds_granted = lds;
+  }
   hipLaunchKernelGGL(k_frame_resjac, dim3(P.F), dim3(64), lds, s, M, P, d_params, d_beta, d_r, d_J, d_joints, mc,
                      want_jac);
 }
