@@ -359,8 +359,8 @@ int bodyfit_model_get_derived(const bodyfit_model* m, double* joints0, double* j
 // ------------------------------------------------------------------------------------------------
 int bodyfit_gmm_create(int K, int D, const double* weights, const double* means, const double* covs,
                        double resid_scale, int device, bodyfit_gmm** out) {
-  if (!out || !weights || !means || !covs || K <= 0 || D <= 0 || D > 128)
-    return fail(BODYFIT_ERR_INVALID, "bad GMM arguments");
+  if (!out || !weights || !means || !covs || K <= 0 || K > 8 || D <= 0 || D > 72)
+    return fail(BODYFIT_ERR_INVALID, "bad GMM arguments (1..8 components, dimension <= 72)");
   *out = nullptr;
   HIP_TRY(hipSetDevice(device));
   std::unique_ptr<bodyfit_gmm> g(new bodyfit_gmm());

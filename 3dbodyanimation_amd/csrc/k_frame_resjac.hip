@@ -1,4 +1,4 @@
-// k_frame_resjac.hip — per-frame keypoint residuals + analytic Jacobian, f64, one wavefront per frame.
+// k_frame_resjac.hip — per-frame keypoint residuals + analytic Jacobian, f64, one 4-wave workgroup per frame.
 //
 // Replaces, for every reprojection block of a frame at once, what the reference evaluates through
 // ceres::DynamicAutoDiffCostFunction<ReprojCost[Shape]> (include/Sim3BA.h:34-88,126-227,420,581;
@@ -6,13 +6,15 @@
 // Jacobian.  The same wave also prepares the operands of the mesh kernel (pose-feature fragments in
 // bf16 hi/lo, shape coefficients, 24 skinning transforms) so the two kernels share one Rodrigues pass.
 //
-// Work layout (64 lanes = one CDNA4 wavefront, no inter-wave traffic):
+// Work layout (256 threads = 4 CDNA4 wavefronts per frame, one per SIMD of the CU; phases separated by
+// workgroup barriers, all intermediate state in LDS):
 //   lanes = joints      Rodrigues R_j, dR_j/da (both branches of Ceres' AngleAxisRotatePoint)
 //   lanes = (joint,e)   level-synchronous kinematic chain A_j, P_j, dP_j/dbeta, staged in LDS
 //   lanes = (k,c)       W_{k,c} = A_par(k) dR_{k,c} R_k^T A_par(k)^T  (d x / d a_{k,c} = W (x - P_k))
-//   wave reductions     landmark blend rows  v_p = v_t + sd.beta + pd.feat   (coalesced 512-B reads)
+//   wave reductions     landmark blend rows  v_p = v_t + sd.beta + pd.feat   (coalesced 512-B reads, one
+//                       landmark per wave at a time)
 //   lanes = columns     the dense row-major [2K][ncols] panel is written with consecutive lanes on
-//                       consecutive columns (coalesced 512-B stores)
+//                       consecutive columns (coalesced 512-B stores), keypoints dealt round-robin to waves
 #include "bodyfit_device.h"
 
 namespace bodyfit {
@@ -83,6 +85,7 @@ __device__ inline double wave_sum(double v) {
 }
 
 constexpr int KC = 32;  // keypoints staged per chunk
+constexpr int kThreads = 256;
 
 // LDS carve (doubles)
 constexpr int OFF_X = 0;                       // 88
@@ -97,21 +100,33 @@ constexpr int OFF_B = OFF_W + 624;             // 24*30
 constexpr int OFF_FEAT = OFF_B + 720;          // 208
 constexpr int OFF_CAM = OFF_FEAT + 208;        // Rr0[9], dRr0[27], pad -> 40
 constexpr int OFF_KP = OFF_CAM + 40;           // KC*18
-constexpr int OFF_LM = OFF_KP + KC * 18;       // landmarks: nL * LM_STRIDE
+constexpr int OFF_TAB = OFF_KP + KC * 18;      // int tables (as 4-byte words): 128 ints = 64 doubles
+constexpr int OFF_LM = OFF_TAB + 64;           // landmarks: nL * LM_STRIDE
 constexpr int LM_VP = 0;                       // 3
 constexpr int LM_Q = 3;                        // 3
 constexpr int LM_A = 6;                        // 9  blended rotation
 constexpr int LM_X = 15;                       // kMaxLmNnz*3 = 24
-constexpr int LM_PD = 39;                      // 69*3 = 207
-constexpr int LM_STRIDE = 246;
+constexpr int LM_W = 39;                       // kMaxLmNnz weights
+constexpr int LM_J = 47;                       // kMaxLmNnz joint ids (stored as doubles' worth of ints: 8 ints = 4 doubles)
+constexpr int LM_NW = 51;                      // weight count (as double)
+constexpr int LM_BETA = 52;                    // 10*3 = 30   d q / d beta
+constexpr int LM_PD = 82;                      // 69*3 = 207  pose-blend Jacobian term
+constexpr int LM_STRIDE = 290;
+// int table layout inside OFF_TAB
+constexpr int TAB_PARENT = 0;                  // 24
+constexpr int TAB_ANC = 24;                    // 24
+constexpr int TAB_LVOFF = 48;                  // 25
+constexpr int TAB_LVJ = 73;                    // 23
+constexpr int TAB_KPID = 96;                   // KC
 
-__global__ __launch_bounds__(64) void k_frame_resjac(DevModel M, DevProblem Pb, const double* __restrict__ params,
+__global__ __launch_bounds__(kThreads) void k_frame_resjac(DevModel M, DevProblem Pb, const double* __restrict__ params,
                                                       const double* __restrict__ beta, double* __restrict__ r_out,
                                                       double* __restrict__ J_out, double* __restrict__ joints_out,
                                                       MeshCoef mc, int want_jac) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int f = blockIdx.x;
-  const int lane = threadIdx.x;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
   const int nJ = M.nJ, nS = M.nS, P = M.P, nL = M.nL;
   const int ncols = Pb.ncols;
   const int npose = 7 + 3 * (nJ - 1);
@@ -128,26 +143,46 @@ __global__ __launch_bounds__(64) void k_frame_resjac(DevModel M, DevProblem Pb, 
   double* sFeat = sm + OFF_FEAT;
   double* sCam = sm + OFF_CAM;
   double* sKp = sm + OFF_KP;
+  int* sTab = reinterpret_cast<int*>(sm + OFF_TAB);
   double* sLm = sm + OFF_LM;
+  int* sParent = sTab + TAB_PARENT;
+  unsigned* sAnc = reinterpret_cast<unsigned*>(sTab + TAB_ANC);
+  int* sLvOff = sTab + TAB_LVOFF;
+  int* sLvJ = sTab + TAB_LVJ;
+  int* sKpId = sTab + TAB_KPID;
 
+  // ---- 0. small model tables into LDS (every later loop reads them from there) ----------------
+  if (tid < nJ) { sParent[tid] = M.parent[tid]; sAnc[tid] = M.anc_mask[tid]; }
+  if (tid <= M.nLevels) sLvOff[tid] = M.level_off[tid];
+  if (tid < nJ - 1) sLvJ[tid] = M.level_joint[tid];
+  if (tid < nL) {
+    const int w0 = M.lm_woff[tid], nw = M.lm_woff[tid + 1] - w0;
+    double* L = sLm + tid * LM_STRIDE;
+    int* Lj = reinterpret_cast<int*>(L + LM_J);
+    L[LM_NW] = (double)nw;
+    for (int i = 0; i < kMaxLmNnz; ++i) {
+      L[LM_W + i] = (i < nw) ? M.lm_ww[w0 + i] : 0.0;
+      Lj[i] = (i < nw) ? M.lm_wj[w0 + i] : 0;
+    }
+  }
   // ---- 1. parameters -------------------------------------------------------------------------
-  for (int i = lane; i < npose; i += 64) sx[i] = params[(size_t)f * npose + i];
-  for (int i = lane; i < nS; i += 64) sx[npose + i] = (use_shape && beta) ? beta[(size_t)f * Pb.beta_stride + i] : 0.0;
+  for (int i = tid; i < npose; i += kThreads) sx[i] = params[(size_t)f * npose + i];
+  for (int i = tid; i < nS; i += kThreads) sx[npose + i] = (use_shape && beta) ? beta[(size_t)f * Pb.beta_stride + i] : 0.0;
   __syncthreads();
   const double* sbeta = sx + npose;
 
   // ---- 2. Rodrigues + gradient per joint (lane = joint; joint 0 = root angle-axis) -------------
-  if (lane < nJ) {
-    const double* aa = (lane == 0) ? (sx + 1) : (sx + 7 + 3 * (lane - 1));
+  if (tid < nJ) {
+    const double* aa = (tid == 0) ? (sx + 1) : (sx + 7 + 3 * (tid - 1));
     double R[9], dR[27];
     rodrigues_grad(aa[0], aa[1], aa[2], R, dR);
 #pragma unroll
-    for (int i = 0; i < 9; ++i) sR[lane * 9 + i] = R[i];
+    for (int i = 0; i < 9; ++i) sR[tid * 9 + i] = R[i];
 #pragma unroll
-    for (int i = 0; i < 27; ++i) sdR[lane * 27 + i] = dR[i];
+    for (int i = 0; i < 27; ++i) sdR[tid * 27 + i] = dR[i];
   }
   // ---- 3. chain offsets o_j(beta) (include/Sim3BA.h:142-170,179-205) and centred rest joints ----
-  for (int i = lane; i < nJ * 3; i += 64) {
+  for (int i = tid; i < nJ * 3; i += kThreads) {
     double o = M.offset[i], jc = M.Jc0[i];
     if (use_shape) {
       for (int k = 0; k < nS; ++k) {
@@ -158,12 +193,12 @@ __global__ __launch_bounds__(64) void k_frame_resjac(DevModel M, DevProblem Pb, 
     sO[i] = (i < 3) ? 0.0 : o;
     sJc[i] = jc;
   }
-  if (lane < 9) sA[lane] = (lane % 4 == 0) ? 1.0 : 0.0;
-  if (lane < 3) sP[lane] = 0.0;
-  for (int i = lane; i < 3 * nS; i += 64) sB[i] = 0.0;
+  if (tid < 9) sA[tid] = (tid % 4 == 0) ? 1.0 : 0.0;
+  if (tid < 3) sP[tid] = 0.0;
+  for (int i = tid; i < 3 * nS; i += kThreads) sB[i] = 0.0;
   __syncthreads();
   // pose feature vec(R_j - I), j = 1..nJ-1 (row-major), zero padded to 208
-  for (int i = lane; i < 208; i += 64) {
+  for (int i = tid; i < 208; i += kThreads) {
     double v = 0.0;
     if (i < 9 * (nJ - 1)) {
       const int e = i % 9;
@@ -174,23 +209,23 @@ __global__ __launch_bounds__(64) void k_frame_resjac(DevModel M, DevProblem Pb, 
 
   // ---- 4. level-synchronous chain: A_j = A_p R_j, P_j = P_p + A_p o_j, B_j = B_p + A_p dS_j -----
   for (int lv = 0; lv < M.nLevels; ++lv) {
-    const int j0 = M.level_off[lv], nj = M.level_off[lv + 1] - j0;
-    for (int i = lane; i < nj * 9; i += 64) {
-      const int j = M.level_joint[j0 + i / 9], e = i % 9, r = e / 3, c = e % 3;
-      const int p = M.parent[j];
+    const int j0 = sLvOff[lv], nj = sLvOff[lv + 1] - j0;
+    for (int i = tid; i < nj * 9; i += kThreads) {
+      const int j = sLvJ[j0 + i / 9], e = i % 9, r = e / 3, c = e % 3;
+      const int p = sParent[j];
       sA[j * 9 + e] = sA[p * 9 + r * 3] * sR[j * 9 + c] + sA[p * 9 + r * 3 + 1] * sR[j * 9 + 3 + c] +
                       sA[p * 9 + r * 3 + 2] * sR[j * 9 + 6 + c];
     }
-    for (int i = lane; i < nj * 3; i += 64) {
-      const int j = M.level_joint[j0 + i / 3], r = i % 3;
-      const int p = M.parent[j];
+    for (int i = tid; i < nj * 3; i += kThreads) {
+      const int j = sLvJ[j0 + i / 3], r = i % 3;
+      const int p = sParent[j];
       sP[j * 3 + r] = sP[p * 3 + r] + sA[p * 9 + r * 3] * sO[j * 3] + sA[p * 9 + r * 3 + 1] * sO[j * 3 + 1] +
                       sA[p * 9 + r * 3 + 2] * sO[j * 3 + 2];
     }
     if (use_shape && want_jac) {
-      for (int i = lane; i < nj * 3 * nS; i += 64) {
-        const int j = M.level_joint[j0 + i / (3 * nS)], rem = i % (3 * nS), r = rem / nS, k = rem % nS;
-        const int p = M.parent[j];
+      for (int i = tid; i < nj * 3 * nS; i += kThreads) {
+        const int j = sLvJ[j0 + i / (3 * nS)], rem = i % (3 * nS), r = rem / nS, k = rem % nS;
+        const int p = sParent[j];
         const double* d = M.dS + (size_t)j * 3 * nS;
         sB[(j * 3 + r) * nS + k] = sB[(p * 3 + r) * nS + k] + sA[p * 9 + r * 3] * d[k] +
                                    sA[p * 9 + r * 3 + 1] * d[nS + k] + sA[p * 9 + r * 3 + 2] * d[2 * nS + k];
@@ -202,16 +237,16 @@ __global__ __launch_bounds__(64) void k_frame_resjac(DevModel M, DevProblem Pb, 
   // ---- 5. camera matrices: Rr0 = R_root R0, dRr0_c = dR_root,c R0 -------------------------------
   {
     const double* R0 = Pb.R0 + (size_t)f * 9;
-    if (lane < 36) {
-      const int mtx = lane / 9, e = lane % 9, r = e / 3, c = e % 3;
+    if (tid < 36) {
+      const int mtx = tid / 9, e = tid % 9, r = e / 3, c = e % 3;
       const double* L = (mtx == 0) ? sR : (sdR + (mtx - 1) * 9);
-      sCam[lane] = L[r * 3] * R0[c] + L[r * 3 + 1] * R0[3 + c] + L[r * 3 + 2] * R0[6 + c];
+      sCam[tid] = L[r * 3] * R0[c] + L[r * 3 + 1] * R0[3 + c] + L[r * 3 + 2] * R0[6 + c];
     }
   }
   // ---- 6. W_{k,c} = A_p (dR_{k,c} R_k^T) A_p^T  (lane = (k,c)) -------------------------------------
   if (want_jac) {
-    for (int i = lane; i < 3 * (nJ - 1); i += 64) {
-      const int k = 1 + i / 3, c = i % 3, p = M.parent[k];
+    for (int i = tid; i < 3 * (nJ - 1); i += kThreads) {
+      const int k = 1 + i / 3, c = i % 3, p = sParent[k];
       double T1[9], T2[9], Wm[9];
       mul33_bt(sdR + k * 27 + c * 9, sR + k * 9, T1);
       mul33(sA + p * 9, T1, T2);
@@ -226,13 +261,14 @@ __global__ __launch_bounds__(64) void k_frame_resjac(DevModel M, DevProblem Pb, 
   const double* dRr0 = sCam + 9;
 
   // ---- 7. outputs for the mesh kernel and the posed joints -----------------------------------------
-  if (lane < nJ) {
+  if (tid < nJ) {
+    const int jj = tid;
     double RA[9], t[3], q[3];
-    mul33(Rr0, sA + lane * 9, RA);
-    mv3(sA + lane * 9, sJc[lane * 3], sJc[lane * 3 + 1], sJc[lane * 3 + 2], q);
-    mv3(Rr0, sP[lane * 3] - q[0], sP[lane * 3 + 1] - q[1], sP[lane * 3 + 2] - q[2], t);
+    mul33(Rr0, sA + jj * 9, RA);
+    mv3(sA + jj * 9, sJc[jj * 3], sJc[jj * 3 + 1], sJc[jj * 3 + 2], q);
+    mv3(Rr0, sP[jj * 3] - q[0], sP[jj * 3 + 1] - q[1], sP[jj * 3 + 2] - q[2], t);
     if (mc.skinT) {
-      float* T = mc.skinT + ((size_t)f * nJ + lane) * 12;
+      float* T = mc.skinT + ((size_t)f * nJ + jj) * 12;
 #pragma unroll
       for (int r = 0; r < 3; ++r) {
         T[r * 4 + 0] = (float)(s * RA[r * 3 + 0]);
@@ -242,14 +278,14 @@ __global__ __launch_bounds__(64) void k_frame_resjac(DevModel M, DevProblem Pb, 
       }
     }
     if (joints_out) {
-      mv3(Rr0, sP[lane * 3], sP[lane * 3 + 1], sP[lane * 3 + 2], t);
+      mv3(Rr0, sP[jj * 3], sP[jj * 3 + 1], sP[jj * 3 + 2], t);
 #pragma unroll
-      for (int r = 0; r < 3; ++r) joints_out[((size_t)f * nJ + lane) * 3 + r] = s * t[r] + sx[4 + r];
+      for (int r = 0; r < 3; ++r) joints_out[((size_t)f * nJ + jj) * 3 + r] = s * t[r] + sx[4 + r];
     }
   }
   if (mc.featA) {
     const int ftile = f / kFTile, row = f % kFTile;
-    if (lane < kPoseKSteps * 4) {
+    if (wave == 1 && lane < kPoseKSteps * 4) {
       const int kstep = lane >> 2, h = (lane >> 1) & 1, hl = lane & 1;
       uint32_t pk[4];
 #pragma unroll
@@ -266,30 +302,43 @@ __global__ __launch_bounds__(64) void k_frame_resjac(DevModel M, DevProblem Pb, 
       uint4* dst = reinterpret_cast<uint4*>(mc.featA + ((((size_t)ftile * kPoseKSteps + kstep) * 2 + hl) * 64 + (h * 32 + row)) * 8);
       *dst = make_uint4(pk[0], pk[1], pk[2], pk[3]);
     }
-    if (lane < 2 * kShapeKSteps) {
+    if (wave == 2 && lane < 2 * kShapeKSteps) {
       const int kstep = lane >> 1, h = lane & 1, k = 2 * kstep + h;
       mc.betaA[((size_t)ftile * kShapeKSteps + kstep) * 64 + h * 32 + row] = (k < nS) ? (float)sbeta[k] : 0.0f;
     }
   }
 
-  // ---- 8. vertex landmarks: blend rows by wave reductions, then LBS per landmark -------------------
+  // ---- 8. vertex landmarks: blend rows by wave reductions (3 rows in flight), then LBS per landmark ---
   if (nL > 0) {
-    for (int row = 0; row < 3 * nL; ++row) {
-      double acc = 0.0;
-      if (Pb.pose_blend && P > 0)
-        for (int i = lane; i < P; i += 64) acc += M.lm_pd[(size_t)row * P + i] * sFeat[i];
-      if (use_shape && lane < nS) acc += M.lm_sd[(size_t)row * nS + lane] * sbeta[lane];
-      acc = wave_sum(acc);
-      if (lane == 0) sLm[(row / 3) * LM_STRIDE + LM_VP + row % 3] = M.lm_vt[row] + acc;
+    for (int l = wave; l < nL; l += kThreads / 64) {
+      double acc[3] = {0.0, 0.0, 0.0};
+      if (Pb.pose_blend && P > 0) {
+        for (int i = lane; i < P; i += 64) {
+          const double ft = sFeat[i];
+#pragma unroll
+          for (int a = 0; a < 3; ++a) acc[a] += M.lm_pd[((size_t)l * 3 + a) * P + i] * ft;
+        }
+      }
+      if (use_shape && lane < nS) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) acc[a] += M.lm_sd[((size_t)l * 3 + a) * nS + lane] * sbeta[lane];
+      }
+#pragma unroll
+      for (int a = 0; a < 3; ++a) acc[a] = wave_sum(acc[a]);
+      if (lane == 0) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) sLm[l * LM_STRIDE + LM_VP + a] = M.lm_vt[l * 3 + a] + acc[a];
+      }
     }
     __syncthreads();
-    if (lane < nL) {
-      double* L = sLm + lane * LM_STRIDE;
+    if (tid < nL) {
+      double* L = sLm + tid * LM_STRIDE;
+      const int* Lj = reinterpret_cast<const int*>(L + LM_J);
       double q[3] = {0, 0, 0}, Ab[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-      const int w0 = M.lm_woff[lane], nw = M.lm_woff[lane + 1] - w0;
+      const int nw = (int)L[LM_NW];
       for (int i = 0; i < nw; ++i) {
-        const int j = M.lm_wj[w0 + i];
-        const double w = M.lm_ww[w0 + i];
+        const int j = Lj[i];
+        const double w = L[LM_W + i];
         double xj[3];
         mv3(sA + j * 9, L[LM_VP] - sJc[j * 3], L[LM_VP + 1] - sJc[j * 3 + 1], L[LM_VP + 2] - sJc[j * 3 + 2], xj);
 #pragma unroll
@@ -308,26 +357,61 @@ __global__ __launch_bounds__(64) void k_frame_resjac(DevModel M, DevProblem Pb, 
     }
     __syncthreads();
     if (want_jac) {
-      // pose-blend term  Ablend . (pd[:, 9(k-1):9k] . vec(dR_{k,c}))   (lane = (k,c), rows streamed once)
-      for (int i = lane; i < 3 * (nJ - 1); i += 64) {
-        const int k = 1 + i / 3, c = i % 3;
-        const double* d = sdR + k * 27 + c * 9;
-        for (int l = 0; l < nL; ++l) {
-          double h[3] = {0, 0, 0};
-          if (Pb.pose_blend && P > 0) {
+      // pose-blend term  Ablend . (pd[:, 9(k-1):9k] . vec(dR_{k,c}))   item = (landmark, joint k):
+      // 27 independent loads (72 contiguous bytes per row, consecutive lanes on consecutive k)
+      const int nItems = nL * (nJ - 1);
+      for (int it = tid; it < nItems; it += kThreads) {
+        const int l = it / (nJ - 1), k = 1 + it % (nJ - 1);
+        double pdv[27];
+        if (Pb.pose_blend && P > 0) {
 #pragma unroll
-            for (int a = 0; a < 3; ++a) {
-              const double* pd = M.lm_pd + ((size_t)l * 3 + a) * P + 9 * (k - 1);
-              double acc = 0;
+          for (int a = 0; a < 3; ++a)
 #pragma unroll
-              for (int e = 0; e < 9; ++e) acc += pd[e] * d[e];
-              h[a] = acc;
-            }
+            for (int e = 0; e < 9; ++e) pdv[a * 9 + e] = M.lm_pd[((size_t)l * 3 + a) * P + 9 * (k - 1) + e];
+        } else {
+#pragma unroll
+          for (int e = 0; e < 27; ++e) pdv[e] = 0.0;
+        }
+        const double* Ab = sLm + l * LM_STRIDE + LM_A;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const double* d = sdR + k * 27 + c * 9;
+          double h[3];
+#pragma unroll
+          for (int a = 0; a < 3; ++a) {
+            double acc = 0;
+#pragma unroll
+            for (int e = 0; e < 9; ++e) acc += pdv[a * 9 + e] * d[e];
+            h[a] = acc;
           }
           double t[3];
-          mv3(sLm + l * LM_STRIDE + LM_A, h[0], h[1], h[2], t);
-          double* o = sLm + l * LM_STRIDE + LM_PD + i * 3;
+          mv3(Ab, h[0], h[1], h[2], t);
+          double* o = sLm + l * LM_STRIDE + LM_PD + (3 * (k - 1) + c) * 3;
           o[0] = t[0]; o[1] = t[1]; o[2] = t[2];
+        }
+      }
+      // shape columns  d q / d beta_k = sum_i w_i (A_j (sd_l - Sc_j) + B_j)[:, k]   item = (landmark, k)
+      if (use_shape) {
+        for (int it = tid; it < nL * nS; it += kThreads) {
+          const int l = it / nS, k = it % nS;
+          const double* L = sLm + l * LM_STRIDE;
+          const int* Lj = reinterpret_cast<const int*>(L + LM_J);
+          const int nw = (int)L[LM_NW];
+          const double s0 = M.lm_sd[(size_t)(l * 3 + 0) * nS + k], s1 = M.lm_sd[(size_t)(l * 3 + 1) * nS + k],
+                       s2 = M.lm_sd[(size_t)(l * 3 + 2) * nS + k];
+          double d0 = 0, d1 = 0, d2 = 0;
+          for (int i = 0; i < nw; ++i) {
+            const int j = Lj[i];
+            const double w = L[LM_W + i];
+            double t[3];
+            mv3(sA + j * 9, s0 - M.Sc[(size_t)(j * 3 + 0) * nS + k], s1 - M.Sc[(size_t)(j * 3 + 1) * nS + k],
+                s2 - M.Sc[(size_t)(j * 3 + 2) * nS + k], t);
+            d0 += w * (t[0] + sB[(j * 3 + 0) * nS + k]);
+            d1 += w * (t[1] + sB[(j * 3 + 1) * nS + k]);
+            d2 += w * (t[2] + sB[(j * 3 + 2) * nS + k]);
+          }
+          double* o = sLm + l * LM_STRIDE + LM_BETA + k * 3;
+          o[0] = d0; o[1] = d1; o[2] = d2;
         }
       }
       __syncthreads();
@@ -338,12 +422,13 @@ __global__ __launch_bounds__(64) void k_frame_resjac(DevModel M, DevProblem Pb, 
   const int k_begin = Pb.kp_offset[f], k_end = Pb.kp_offset[f + 1];
   for (int kc0 = k_begin; kc0 < k_end; kc0 += KC) {
     const int nk = min(KC, k_end - kc0);
-    if (lane < nk) {
-      const int kg = kc0 + lane;
+    if (tid < nk) {
+      const int kg = kc0 + tid;
       const int id = Pb.kp_id[kg];
+      sKpId[tid] = id;
       double q[3];
       if (id < nJ) {
-        if (id == 0 || M.parent[id] < 0) {
+        if (id == 0 || sParent[id] < 0) {
           // include/Sim3BA.h:142-170 without a chain: q = offset + S_id beta (no parent term)
 #pragma unroll
           for (int a = 0; a < 3; ++a) {
@@ -366,7 +451,7 @@ __global__ __launch_bounds__(64) void k_frame_resjac(DevModel M, DevProblem Pb, 
       const double iz = 1.0 / X2;                        // :222-223, Z unguarded as in the reference
       r_out[2 * (size_t)kg] = Pb.fx * X0 * iz + Pb.cx - Pb.kp_uv[2 * (size_t)kg];
       r_out[2 * (size_t)kg + 1] = Pb.fy * X1 * iz + Pb.cy - Pb.kp_uv[2 * (size_t)kg + 1];
-      double* kp = sKp + lane * 18;
+      double* kp = sKp + tid * 18;
       const double dpi[6] = {Pb.fx * iz, 0.0, -Pb.fx * X0 * iz * iz, 0.0, Pb.fy * iz, -Pb.fy * X1 * iz * iz};
 #pragma unroll
       for (int a = 0; a < 3; ++a) { kp[a] = q[a]; kp[3 + a] = z[a]; }
@@ -380,9 +465,9 @@ __global__ __launch_bounds__(64) void k_frame_resjac(DevModel M, DevProblem Pb, 
     }
     __syncthreads();
     if (want_jac) {
-      for (int kk = 0; kk < nk; ++kk) {
+      for (int kk = wave; kk < nk; kk += kThreads / 64) {
         const int kg = kc0 + kk;
-        const int id = Pb.kp_id[kg];
+        const int id = sKpId[kk];
         const double* kp = sKp + kk * 18;
         const double* G = kp + 12;
         for (int col = lane; col < ncols; col += 64) {
@@ -403,7 +488,7 @@ __global__ __launch_bounds__(64) void k_frame_resjac(DevModel M, DevProblem Pb, 
             if (col < npose) {
               const int kc = col - 7, k = 1 + kc / 3;
               if (id < nJ) {
-                if ((M.anc_mask[id] >> k) & 1u) {
+                if ((sAnc[id] >> k) & 1u) {
                   double t[3];
                   mv3(sW + kc * 9, kp[0] - sP[k * 3], kp[1] - sP[k * 3 + 1], kp[2] - sP[k * 3 + 2], t);
                   d0 = t[0]; d1 = t[1]; d2 = t[2];
@@ -411,12 +496,13 @@ __global__ __launch_bounds__(64) void k_frame_resjac(DevModel M, DevProblem Pb, 
               } else {
                 const int l = id - nJ;
                 const double* L = sLm + l * LM_STRIDE;
-                const int w0 = M.lm_woff[l], nw = M.lm_woff[l + 1] - w0;
+                const int* Lj = reinterpret_cast<const int*>(L + LM_J);
+                const int nw = (int)L[LM_NW];
                 double a0 = 0, a1 = 0, a2 = 0;
                 for (int i = 0; i < nw; ++i) {
-                  const int j = M.lm_wj[w0 + i];
-                  if (j == k || ((M.anc_mask[j] >> k) & 1u)) {
-                    const double w = M.lm_ww[w0 + i];
+                  const int j = Lj[i];
+                  if (j == k || ((sAnc[j] >> k) & 1u)) {
+                    const double w = L[LM_W + i];
                     a0 += w * (L[LM_X + i * 3] - sP[k * 3]);
                     a1 += w * (L[LM_X + i * 3 + 1] - sP[k * 3 + 1]);
                     a2 += w * (L[LM_X + i * 3 + 2] - sP[k * 3 + 2]);
@@ -431,7 +517,7 @@ __global__ __launch_bounds__(64) void k_frame_resjac(DevModel M, DevProblem Pb, 
             } else if (use_shape) {
               const int k = col - npose;
               if (id < nJ) {
-                if (id == 0 || M.parent[id] < 0) {
+                if (id == 0 || sParent[id] < 0) {
                   d0 = M.dS[(size_t)(id * 3 + 0) * nS + k];
                   d1 = M.dS[(size_t)(id * 3 + 1) * nS + k];
                   d2 = M.dS[(size_t)(id * 3 + 2) * nS + k];
@@ -441,19 +527,8 @@ __global__ __launch_bounds__(64) void k_frame_resjac(DevModel M, DevProblem Pb, 
                   d2 = sB[(id * 3 + 2) * nS + k];
                 }
               } else {
-                const int l = id - nJ;
-                const int w0 = M.lm_woff[l], nw = M.lm_woff[l + 1] - w0;
-                for (int i = 0; i < nw; ++i) {
-                  const int j = M.lm_wj[w0 + i];
-                  const double w = M.lm_ww[w0 + i];
-                  double t[3];
-                  mv3(sA + j * 9, M.lm_sd[(size_t)(l * 3 + 0) * nS + k] - M.Sc[(size_t)(j * 3 + 0) * nS + k],
-                      M.lm_sd[(size_t)(l * 3 + 1) * nS + k] - M.Sc[(size_t)(j * 3 + 1) * nS + k],
-                      M.lm_sd[(size_t)(l * 3 + 2) * nS + k] - M.Sc[(size_t)(j * 3 + 2) * nS + k], t);
-                  d0 += w * (t[0] + sB[(j * 3 + 0) * nS + k]);
-                  d1 += w * (t[1] + sB[(j * 3 + 1) * nS + k]);
-                  d2 += w * (t[2] + sB[(j * 3 + 2) * nS + k]);
-                }
+                const double* o = sLm + (id - nJ) * LM_STRIDE + LM_BETA + k * 3;
+                d0 = o[0]; d1 = o[1]; d2 = o[2];
               }
             }
             j0 = G[0] * d0 + G[1] * d1 + G[2] * d2;
@@ -481,7 +556,7 @@ void launch_frame_resjac(const DevModel& M, const DevProblem& P, const double* d
                               (int)lds);
     lds_granted = lds;
   }
-  hipLaunchKernelGGL(k_frame_resjac, dim3(P.F), dim3(64), lds, s, M, P, d_params, d_beta, d_r, d_J, d_joints, mc,
+  hipLaunchKernelGGL(k_frame_resjac, dim3(P.F), dim3(kThreads), lds, s, M, P, d_params, d_beta, d_r, d_J, d_joints, mc,
                      want_jac);
 }
 

@@ -8,11 +8,16 @@
 //   shape blend     v_mfma_f32_32x32x2_f32, K = 10 -> 5 steps, exact f32 (per-frame beta supported)
 //   pose blend      v_mfma_f32_32x32x16_bf16, K = 207 -> 13 steps, operands split hi+lo in bf16 and
 //                   three products hi.hi + hi.lo + lo.hi (relative product error <= 2^-16), 5.3x the
-//                   f32-MFMA rate; posedirs were pre-split and stored in B-fragment order at upload so
-//                   every wave load is one contiguous 1 KiB (coalesced 16 B/lane)
-// The accumulator layout puts the vertex on the lane and 16 frames in registers, so the skinning
-// epilogue keeps each lane's 4 packed weights in registers, gathers the 3x4 transforms of its frames,
-// and writes 384 contiguous bytes per frame row.  The blend result never touches HBM.
+//                   f32-MFMA rate
+// Data movement (the 17 MB posedirs stream is the only large read):
+//   * the vertex tile's B operands (78 KiB pose hi/lo + 1.9 KiB shape, stored in fragment order at
+//     upload) go HBM -> LDS by LDS-DMA (global_load_lds_dwordx4: 1 KiB contiguous per wave-instruction),
+//     once per workgroup, and are reused by all four waves for every frame tile;
+//   * A operands (pose-feature hi/lo, beta) come from L2 in fragment order, one 1 KiB load per k-step;
+//   * the skinning transforms of 16 frames (18 KiB, contiguous) are LDS-DMA'd per wave and gathered by
+//     joint id with ds_read_b128; the blended vertices never touch HBM;
+//   * output rows are 384 contiguous bytes per frame (lane = vertex).
+// LDS: 79.9 KiB (B) + 4 x 18 KiB (transforms) = 151.9 KiB of the CU's 160 KiB; one workgroup per CU.
 #include "bodyfit_device.h"
 
 namespace bodyfit {
@@ -21,24 +26,68 @@ namespace {
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
+constexpr int kPosePieces = 3 * kPoseKSteps * 2;                 // 78 x 1 KiB
+constexpr int kPoseBytes = kPosePieces * 1024;                   // 79,872
+constexpr int kShapeFloats = 3 * kShapeKSteps * 64;              // 960 f32 = 3,840 B
+constexpr int kSkinRows = 16;                                    // frames per epilogue half
+constexpr int kSkinBytes = kSkinRows * kMaxJoints * 48;          // 18,432
+constexpr int kLdsBytes = kPoseBytes + kShapeFloats * 4 + 4 * kSkinBytes;   // 157,440
+
+__device__ inline void lds_dma_16(const void* g, void* l) {
+  __builtin_amdgcn_global_load_lds(g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+
 __global__ __launch_bounds__(256) void k_mesh_blend_lbs(DevModel M, DevProblem Pb, MeshCoef mc,
                                                          float* __restrict__ cloud) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int vtile = blockIdx.x;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int col = lane & 31, h = lane >> 5;
   const int v = vtile * kVTile + col;
   const int V = M.V, nJ = M.nJ, F = Pb.F;
+  const bool pose = Pb.pose_blend && M.P > 0;
 
+  unsigned char* sPose = lds;                                           // [ks][c][hl][64][16 B]
+  float* sShape = reinterpret_cast<float*>(lds + kPoseBytes);           // [c][ks][64]
+  unsigned char* sSkin = lds + kPoseBytes + kShapeFloats * 4 + wave * kSkinBytes;
+
+  // ---- stage this vertex tile's B operands: HBM -> LDS, 1 KiB per wave-instruction -----------------
+  {
+    const unsigned char* gp = reinterpret_cast<const unsigned char*>(M.dirsB) + (size_t)vtile * kPoseBytes;
+    if (pose) {
+      for (int p = wave; p < kPosePieces; p += 4) {
+        // LDS piece p = (ks, c, hl) k-step-major; global layout is [c][ks][hl]
+        const int ks = p / 6, c = (p % 6) >> 1, hl = p & 1;
+        const int gpiece = (c * kPoseKSteps + ks) * 2 + hl;
+        lds_dma_16(gp + (size_t)gpiece * 1024 + lane * 16, sPose + (size_t)p * 1024);
+      }
+    }
+    const float* gs = M.sdB + (size_t)vtile * kShapeFloats;
+    for (int i = threadIdx.x; i < kShapeFloats; i += 256) sShape[i] = gs[i];
+  }
   float vt[3];
 #pragma unroll
   for (int c = 0; c < 3; ++c) vt[c] = M.vtB[((size_t)vtile * 3 + c) * 32 + col];
   const uint32_t widx = M.wIdx[(size_t)vtile * 32 + col];
   const float4 wv = reinterpret_cast<const float4*>(M.wVal)[(size_t)vtile * 32 + col];
   const float wgt[4] = {wv.x, wv.y, wv.z, wv.w};
-  const uint4* dirs = reinterpret_cast<const uint4*>(M.dirsB);
+  int jo[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) jo[i] = (int)((widx >> (8 * i)) & 0xffu) * 48;
   const uint4* feat = reinterpret_cast<const uint4*>(mc.featA);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
 
   for (int ftile = wave; ftile < Pb.nFTiles; ftile += 4) {
+    // kick off the first half's skinning transforms (frames ftile*32 .. +15), contiguous in HBM
+    const unsigned char* gskin = reinterpret_cast<const unsigned char*>(mc.skinT) + (size_t)ftile * 32 * nJ * 48;
+    const int frames_left = F - ftile * 32;
+    {
+      const int nbytes = min(kSkinRows, frames_left) * nJ * 48;
+      for (int p = 0; p * 1024 < nbytes; ++p)
+        if (p * 1024 + lane * 16 < nbytes) lds_dma_16(gskin + p * 1024 + lane * 16, sSkin + p * 1024);
+    }
+
     f32x16 acc[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c)
@@ -51,51 +100,75 @@ __global__ __launch_bounds__(256) void k_mesh_blend_lbs(DevModel M, DevProblem P
       const float a = mc.betaA[((size_t)ftile * kShapeKSteps + ks) * 64 + lane];
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
-        const float b = M.sdB[(((size_t)vtile * 3 + c) * kShapeKSteps + ks) * 64 + lane];
+        const float b = sShape[(c * kShapeKSteps + ks) * 64 + lane];
         acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[c], 0, 0, 0);
       }
     }
-    // pose blend, bf16 hi/lo split
-    if (Pb.pose_blend && M.P > 0) {
-#pragma unroll 1
+    // pose blend, bf16 hi/lo split; A fragments straight from L2, B fragments from LDS
+    if (pose) {
+      uint4 ahi[kPoseKSteps], alo[kPoseKSteps];
+#pragma unroll
       for (int ks = 0; ks < kPoseKSteps; ++ks) {
         const size_t fa = (((size_t)ftile * kPoseKSteps + ks) * 2) * 64 + lane;
-        const bf16x8 ahi = __builtin_bit_cast(bf16x8, feat[fa]);
-        const bf16x8 alo = __builtin_bit_cast(bf16x8, feat[fa + 64]);
+        ahi[ks] = feat[fa];
+        alo[ks] = feat[fa + 64];
+      }
+#pragma unroll
+      for (int ks = 0; ks < kPoseKSteps; ++ks) {
+        const bf16x8 a_hi = __builtin_bit_cast(bf16x8, ahi[ks]);
+        const bf16x8 a_lo = __builtin_bit_cast(bf16x8, alo[ks]);
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-          const size_t fb = ((((size_t)vtile * 3 + c) * kPoseKSteps + ks) * 2) * 64 + lane;
-          const bf16x8 bhi = __builtin_bit_cast(bf16x8, dirs[fb]);
-          const bf16x8 blo = __builtin_bit_cast(bf16x8, dirs[fb + 64]);
-          acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, bhi, acc[c], 0, 0, 0);
-          acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, blo, acc[c], 0, 0, 0);
-          acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo, bhi, acc[c], 0, 0, 0);
+          const uint4* bp = reinterpret_cast<const uint4*>(sPose + (size_t)((ks * 3 + c) * 2) * 1024) + lane;
+          const bf16x8 bhi = __builtin_bit_cast(bf16x8, bp[0]);
+          const bf16x8 blo = __builtin_bit_cast(bf16x8, bp[64]);
+          acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, bhi, acc[c], 0, 0, 0);
+          acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, blo, acc[c], 0, 0, 0);
+          acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo, bhi, acc[c], 0, 0, 0);
         }
       }
     }
-    // skinning epilogue: lane = vertex, register = frame row (r&3) + 8 (r>>2) + 4 h
+
+    // skinning epilogue in two halves of 16 frame rows: lane = vertex, register r = frame row
+    //   row(r, h) = (r & 3) + 8 (r >> 2) + 4 h ;  half 0: r in 0..7, half 1: r in 8..15
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int f = ftile * kFTile + (r & 3) + 8 * (r >> 2) + 4 * h;
-      if (f < F && v < V) {
-        const float4* T = reinterpret_cast<const float4*>(mc.skinT + (size_t)f * nJ * 12);
+    for (int half = 0; half < 2; ++half) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's transforms have landed in its LDS slice
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int rr = 0; rr < 8; ++rr) {
+        const int r = half * 8 + rr;
+        const int row16 = (rr & 3) + 8 * (rr >> 2) + 4 * h;      // row inside this half
+        const int f = ftile * kFTile + half * 16 + row16;
+        const unsigned char* Trow = sSkin + row16 * (nJ * 48);
         float4 t0 = make_float4(0, 0, 0, 0), t1 = t0, t2 = t0;
 #pragma unroll
         for (int i = 0; i < kMeshNnz; ++i) {
-          const int j = (widx >> (8 * i)) & 0xffu;
+          const float4* T = reinterpret_cast<const float4*>(Trow + jo[i]);
           const float w = wgt[i];
-          const float4 a0 = T[j * 3 + 0], a1 = T[j * 3 + 1], a2 = T[j * 3 + 2];
+          const float4 a0 = T[0], a1 = T[1], a2 = T[2];
           t0.x += w * a0.x; t0.y += w * a0.y; t0.z += w * a0.z; t0.w += w * a0.w;
           t1.x += w * a1.x; t1.y += w * a1.y; t1.z += w * a1.z; t1.w += w * a1.w;
           t2.x += w * a2.x; t2.y += w * a2.y; t2.z += w * a2.z; t2.w += w * a2.w;
         }
-        const float px = acc[0][r], py = acc[1][r], pz = acc[2][r];
-        float* o = cloud + ((size_t)f * V + v) * 3;
-        o[0] = t0.x * px + t0.y * py + t0.z * pz + t0.w;
-        o[1] = t1.x * px + t1.y * py + t1.z * pz + t1.w;
-        o[2] = t2.x * px + t2.y * py + t2.z * pz + t2.w;
+        if (f < F && v < V) {
+          const float px = acc[0][r], py = acc[1][r], pz = acc[2][r];
+          float* o = cloud + ((size_t)f * V + v) * 3;
+          o[0] = t0.x * px + t0.y * py + t0.z * pz + t0.w;
+          o[1] = t1.x * px + t1.y * py + t1.z * pz + t1.w;
+          o[2] = t2.x * px + t2.y * py + t2.z * pz + t2.w;
+        }
+      }
+      if (half == 0) {
+        // second half's transforms (frames +16..+31) into the same slice once every lane has read the first
+        __builtin_amdgcn_wave_barrier();
+        const int nbytes = max(0, min(kSkinRows, frames_left - kSkinRows)) * nJ * 48;
+        const unsigned char* g2 = gskin + (size_t)kSkinRows * nJ * 48;
+        for (int p = 0; p * 1024 < nbytes; ++p)
+          if (p * 1024 + lane * 16 < nbytes) lds_dma_16(g2 + p * 1024 + lane * 16, sSkin + p * 1024);
       }
     }
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
@@ -103,7 +176,13 @@ __global__ __launch_bounds__(256) void k_mesh_blend_lbs(DevModel M, DevProblem P
 
 void launch_mesh(const DevModel& M, const DevProblem& P, const MeshCoef& mc, float* d_cloud, hipStream_t s) {
   if (P.F <= 0) return;
-  hipLaunchKernelGGL(k_mesh_blend_lbs, dim3(M.nVTiles), dim3(256), 0, s, M, P, mc, d_cloud);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_mesh_blend_lbs),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(k_mesh_blend_lbs, dim3(M.nVTiles), dim3(256), kLdsBytes, s, M, P, mc, d_cloud);
 }
 
 }  // namespace bodyfit
