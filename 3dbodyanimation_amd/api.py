@@ -14,7 +14,7 @@ from dataclasses import dataclass, field
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libbodyfit.so")
+LIB_PATH = os.environ.get("BODYFIT_LIB", os.path.join(_HERE, "libbodyfit.so"))
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "bodyfit.h")
 N_FRAME_PARAMS = 76
 

@@ -104,7 +104,15 @@ struct bodyfit_problem {
   bool cache_valid = false, cache_has_jac = false;
   std::vector<double> c_params, c_beta, c_r, c_J;
   std::vector<int> c_comp;
+  // priors run beside the keypoint + mesh kernels on their own stream (they only read the parameters)
+  hipStream_t side = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   Allocs mem;
+  ~bodyfit_problem() {
+    if (ev_fork) (void)hipEventDestroy(ev_fork);
+    if (ev_join) (void)hipEventDestroy(ev_join);
+    if (side) (void)hipStreamDestroy(side);
+  }
 };
 
 namespace {
@@ -126,24 +134,35 @@ bool chol_lower(std::vector<double>& A, int n) {
   return true;
 }
 
+// One evaluation sweep.  ev (optional, 6 events): [0] start, [1] after frame_resjac, [2]/[3] around the
+// priors on the side stream, [4] after the mesh kernel; [5] is recorded by the caller.
 int sweep(bodyfit_problem* p, const double* d_params, const double* d_beta, int want_jac, bool mesh,
           hipStream_t st, hipEvent_t* ev = nullptr) {
   const bodyfit_model* m = p->m;
   MeshCoef mc = p->mc;
   if (!mesh) mc = MeshCoef{};
+  const bodyfit_problem_desc& D = p->desc;
+  const bool priors = D.beta_pose > 0.0 || D.beta_shape > 0.0 || D.lambda_temporal > 0.0;
   if (ev) (void)hipEventRecord(ev[0], st);
+  if (priors) {
+    (void)hipEventRecord(p->ev_fork, st);
+    (void)hipStreamWaitEvent(p->side, p->ev_fork, 0);
+    if (ev) (void)hipEventRecord(ev[2], p->side);
+    launch_priors(p->d, m->nJ, m->nS, d_params, d_beta, D.beta_pose, p->has_gmm ? &p->gmm : nullptr,
+                  p->lay.shape_rows > 0 ? D.beta_shape : 0.0, D.lambda_temporal, p->n_pairs,
+                  p->d_r + p->row_prior, p->d_r + p->row_shape, p->d_r + p->row_temporal, p->d_comp, p->side);
+    if (ev) (void)hipEventRecord(ev[3], p->side);
+    (void)hipEventRecord(p->ev_join, p->side);
+  } else if (ev) {
+    (void)hipEventRecord(ev[2], st);
+    (void)hipEventRecord(ev[3], st);
+  }
   launch_frame_resjac(m->d, p->d, d_params, d_beta, p->d_r, want_jac ? p->d_J : nullptr, p->d_joints, mc,
                       want_jac, st);
   if (ev) (void)hipEventRecord(ev[1], st);
-  const bodyfit_problem_desc& D = p->desc;
-  if (D.beta_pose > 0.0 || D.beta_shape > 0.0 || D.lambda_temporal > 0.0) {
-    launch_priors(p->d, m->nJ, m->nS, d_params, d_beta, D.beta_pose, p->has_gmm ? &p->gmm : nullptr,
-                  p->lay.shape_rows > 0 ? D.beta_shape : 0.0, D.lambda_temporal, p->n_pairs,
-                  p->d_r + p->row_prior, p->d_r + p->row_shape, p->d_r + p->row_temporal, p->d_comp, st);
-  }
-  if (ev) (void)hipEventRecord(ev[2], st);
   if (mesh) launch_mesh(m->d, p->d, p->mc, p->d_cloud, st);
-  if (ev) (void)hipEventRecord(ev[3], st);
+  if (ev) (void)hipEventRecord(ev[4], st);
+  if (priors) (void)hipStreamWaitEvent(st, p->ev_join, 0);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(BODYFIT_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
   return BODYFIT_OK;
@@ -261,18 +280,22 @@ int bodyfit_model_create(const bodyfit_model_desc* desc, int device, bodyfit_mod
 
   // landmarks
   {
-    std::vector<int> woff(nL + 1, 0), wj;
-    std::vector<double> ww, vt((size_t)nL * 3), sd((size_t)nL * 3 * std::max(nS, 1), 0.0),
-        pd((size_t)nL * 3 * std::max(P, 1), 0.0);
+    // fixed-stride skinning weights per landmark: kMaxLmNnz slots padded with weight 0; woff[l] = count
+    std::vector<int> woff(nL + 1, 0), wj((size_t)std::max(nL, 1) * kMaxLmNnz, 0);
+    std::vector<double> ww((size_t)std::max(nL, 1) * kMaxLmNnz, 0.0), vt((size_t)nL * 3),
+        sd((size_t)nL * 3 * std::max(nS, 1), 0.0), pd((size_t)nL * 3 * std::max(P, 1), 0.0);
     for (int l = 0; l < nL; ++l) {
       const int vid = desc->landmark_vid[l];
+      int cnt = 0;
       for (int j = 0; j < nJ; ++j) {
         const double w = desc->weights[(size_t)vid * nJ + j];
-        if (w != 0.0) { wj.push_back(j); ww.push_back(w); }
+        if (w == 0.0) continue;
+        if (cnt >= kMaxLmNnz) return fail(BODYFIT_ERR_INVALID, "landmark vertex has more than 8 skinning weights");
+        wj[(size_t)l * kMaxLmNnz + cnt] = j;
+        ww[(size_t)l * kMaxLmNnz + cnt] = w;
+        ++cnt;
       }
-      woff[l + 1] = (int)wj.size();
-      if (woff[l + 1] - woff[l] > kMaxLmNnz)
-        return fail(BODYFIT_ERR_INVALID, "landmark vertex has more than 8 skinning weights");
+      woff[l] = cnt;
       for (int a = 0; a < 3; ++a) {
         vt[l * 3 + a] = desc->v_template[(size_t)vid * 3 + a] - J0[a];
         for (int k = 0; k < nS; ++k)
@@ -483,6 +506,9 @@ int bodyfit_problem_create(const bodyfit_model* m, const bodyfit_problem_desc* d
   std::vector<double> R0(desc->R0, desc->R0 + (size_t)F * 9);
   HIP_TRY(p->mem.upload(&d.R0, R0));
 
+  HIP_TRY(hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking));
+  HIP_TRY(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
+  HIP_TRY(hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming));
   HIP_TRY(p->mem.alloc(&p->d_params, (size_t)p->n_param_rows * npose));
   HIP_TRY(p->mem.alloc(&p->d_beta, (size_t)std::max(1, desc->beta_per_frame ? F * nS : nS)));
   HIP_TRY(p->mem.alloc(&p->d_r, (size_t)L.total_rows));
@@ -592,22 +618,24 @@ int bodyfit_profile_sweep(bodyfit_problem* p, const double* d_frame_params, cons
   if (!p || !d_frame_params || !avg_ms || iters <= 0) return fail(BODYFIT_ERR_INVALID, "bad argument");
   HIP_TRY(hipSetDevice(p->m->device));
   hipStream_t st = static_cast<hipStream_t>(stream);
-  std::vector<hipEvent_t> ev((size_t)iters * 5);
+  std::vector<hipEvent_t> ev((size_t)iters * 6);
   for (auto& e : ev) HIP_TRY(hipEventCreate(&e));
   int rc = BODYFIT_OK;
   for (int it = 0; it < iters && rc == BODYFIT_OK; ++it) {
-    hipEvent_t* e = ev.data() + (size_t)it * 5;
+    hipEvent_t* e = ev.data() + (size_t)it * 6;
     rc = sweep(p, d_frame_params, d_beta, want_jacobian, p->desc.want_mesh != 0, st, e);
     if (rc == BODYFIT_OK && with_reduce) rc = bodyfit_reduce_shared_device(p, nullptr, stream);
-    (void)hipEventRecord(e[4], st);
+    (void)hipEventRecord(e[5], st);
   }
   hipError_t se = hipStreamSynchronize(st);
+  if (se == hipSuccess) se = hipStreamSynchronize(p->side);
   for (int k = 0; k < 4; ++k) avg_ms[k] = 0.0;
   if (rc == BODYFIT_OK && se == hipSuccess) {
+    const int a[4] = {0, 2, 1, 4}, b[4] = {1, 3, 4, 5};   // resjac, priors (side stream), mesh, reduce (+join)
     for (int it = 0; it < iters; ++it)
       for (int k = 0; k < 4; ++k) {
         float ms = 0.f;
-        (void)hipEventElapsedTime(&ms, ev[(size_t)it * 5 + k], ev[(size_t)it * 5 + k + 1]);
+        (void)hipEventElapsedTime(&ms, ev[(size_t)it * 6 + a[k]], ev[(size_t)it * 6 + b[k]]);
         avg_ms[k] += ms / iters;
       }
   }
@@ -615,6 +643,14 @@ int bodyfit_profile_sweep(bodyfit_problem* p, const double* d_frame_params, cons
   if (se != hipSuccess) return fail(BODYFIT_ERR_HIP, std::string("profile sync: ") + hipGetErrorString(se));
   return rc;
 }
+
+#ifdef BODYFIT_STAMPS
+// diagnostic builds only; not part of include/bodyfit.h
+int bodyfit_debug_set_stamp_buffer(bodyfit_problem* p, unsigned long long* d_buf) {
+  p->d.dbg = d_buf;
+  return BODYFIT_OK;
+}
+#endif
 
 int bodyfit_forward(bodyfit_problem* p, const double* frame_params, const double* beta, double* joints,
                     float* cloud) {

@@ -30,9 +30,9 @@ struct DevModel {
   const double* Jc0;           // [nJ][3]       rest joints, root at origin, beta = 0
   const double* Sc;            // [nJ][3][nS]   S_j - S_0
   // vertex landmarks, f64
-  const int* lm_woff;          // [nL+1]
-  const int* lm_wj;            // [nnz]
-  const double* lm_ww;         // [nnz]
+  const int* lm_woff;          // [nL]  number of skinning weights of the landmark vertex
+  const int* lm_wj;            // [nL][kMaxLmNnz] joint ids, padded
+  const double* lm_ww;         // [nL][kMaxLmNnz] weights, padded with 0
   const double* lm_vt;         // [nL][3]       v_template - J0_root
   const double* lm_sd;         // [nL][3][nS]   shapedirs  - S_root
   const double* lm_pd;         // [nL][3][P]
@@ -51,6 +51,7 @@ struct DevProblem {
   const double* kp_uv;    // [K][2]
   const double* R0;       // [F][9]
   double fx, fy, cx, cy;
+  unsigned long long* dbg;   // diagnostic builds only (-DBODYFIT_STAMPS): per-phase s_memtime stamps
 };
 
 // operands the per-frame kernel prepares for the mesh kernel

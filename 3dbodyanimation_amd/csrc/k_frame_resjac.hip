@@ -84,6 +84,19 @@ __device__ inline double wave_sum(double v) {
   return v;
 }
 
+#ifdef BODYFIT_STAMPS
+#define STAMP(i)                                                                              \
+  do {                                                                                        \
+    if (Pb.dbg && (threadIdx.x & 63) == 0) {                                                  \
+      unsigned long long t_;                                                                  \
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");              \
+      Pb.dbg[((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16 + (i)] = t_;                  \
+    }                                                                                         \
+  } while (0)
+#else
+#define STAMP(i)
+#endif
+
 constexpr int KC = 32;  // keypoints staged per chunk
 constexpr int kThreads = 256;
 
@@ -101,7 +114,11 @@ constexpr int OFF_FEAT = OFF_B + 720;          // 208
 constexpr int OFF_CAM = OFF_FEAT + 208;        // Rr0[9], dRr0[27], pad -> 40
 constexpr int OFF_KP = OFF_CAM + 40;           // KC*18
 constexpr int OFF_TAB = OFF_KP + KC * 18;      // int tables (as 4-byte words): 128 ints = 64 doubles
-constexpr int OFF_LM = OFF_TAB + 64;           // landmarks: nL * LM_STRIDE
+constexpr int OFF_KPUV = OFF_TAB + 64;         // KC*2 observed pixels of the first keypoint chunk
+constexpr int OFF_DS = OFF_KPUV + 2 * KC;      // 24*3*10  S_j - S_par(j)
+constexpr int OFF_SC = OFF_DS + 720;           // 24*3*10  S_j - S_0
+constexpr int OFF_PART = OFF_SC + 720;         // landmark blend-row partial sums: kMaxLandmarks*3*8
+constexpr int OFF_LM = OFF_PART + kMaxLandmarks * 3 * 8;   // landmarks: nL * LM_STRIDE
 constexpr int LM_VP = 0;                       // 3
 constexpr int LM_Q = 3;                        // 3
 constexpr int LM_A = 6;                        // 9  blended rotation
@@ -115,8 +132,6 @@ constexpr int LM_STRIDE = 290;
 // int table layout inside OFF_TAB
 constexpr int TAB_PARENT = 0;                  // 24
 constexpr int TAB_ANC = 24;                    // 24
-constexpr int TAB_LVOFF = 48;                  // 25
-constexpr int TAB_LVJ = 73;                    // 23
 constexpr int TAB_KPID = 96;                   // KC
 
 __global__ __launch_bounds__(kThreads) void k_frame_resjac(DevModel M, DevProblem Pb, const double* __restrict__ params,
@@ -144,34 +159,44 @@ __global__ __launch_bounds__(kThreads) void k_frame_resjac(DevModel M, DevProble
   double* sCam = sm + OFF_CAM;
   double* sKp = sm + OFF_KP;
   int* sTab = reinterpret_cast<int*>(sm + OFF_TAB);
+  double* sKpUv = sm + OFF_KPUV;
+  double* sDS = sm + OFF_DS;
+  double* sSc = sm + OFF_SC;
+  double* sPart = sm + OFF_PART;
   double* sLm = sm + OFF_LM;
   int* sParent = sTab + TAB_PARENT;
   unsigned* sAnc = reinterpret_cast<unsigned*>(sTab + TAB_ANC);
-  int* sLvOff = sTab + TAB_LVOFF;
-  int* sLvJ = sTab + TAB_LVJ;
   int* sKpId = sTab + TAB_KPID;
 
-  // ---- 0. small model tables into LDS (every later loop reads them from there) ----------------
+  STAMP(0);
+  // ---- A. small model tables, landmark weights and the frame's parameters into LDS --------------------
   if (tid < nJ) { sParent[tid] = M.parent[tid]; sAnc[tid] = M.anc_mask[tid]; }
-  if (tid <= M.nLevels) sLvOff[tid] = M.level_off[tid];
-  if (tid < nJ - 1) sLvJ[tid] = M.level_joint[tid];
-  if (tid < nL) {
-    const int w0 = M.lm_woff[tid], nw = M.lm_woff[tid + 1] - w0;
-    double* L = sLm + tid * LM_STRIDE;
-    int* Lj = reinterpret_cast<int*>(L + LM_J);
-    L[LM_NW] = (double)nw;
-    for (int i = 0; i < kMaxLmNnz; ++i) {
-      L[LM_W + i] = (i < nw) ? M.lm_ww[w0 + i] : 0.0;
-      Lj[i] = (i < nw) ? M.lm_wj[w0 + i] : 0;
+  for (int it = tid; it < nL * kMaxLmNnz; it += kThreads) {
+    // landmark skinning weights, fixed stride (padded with weight 0) -> one round trip
+    const int l = it / kMaxLmNnz, i = it % kMaxLmNnz;
+    double* L = sLm + l * LM_STRIDE;
+    L[LM_W + i] = M.lm_ww[it];
+    reinterpret_cast<int*>(L + LM_J)[i] = M.lm_wj[it];
+    if (i == 0) L[LM_NW] = (double)M.lm_woff[l];   // weight count
+  }
+  for (int i = tid; i < nJ * 3 * nS; i += kThreads) { sDS[i] = M.dS[i]; sSc[i] = M.Sc[i]; }
+  {
+    const int k_begin0 = Pb.kp_offset[f], nk0 = min(KC, Pb.kp_offset[f + 1] - k_begin0);
+    if (tid < nk0) {
+      sTab[TAB_KPID + tid] = Pb.kp_id[k_begin0 + tid];
+      sKpUv[2 * tid] = Pb.kp_uv[2 * (size_t)(k_begin0 + tid)];
+      sKpUv[2 * tid + 1] = Pb.kp_uv[2 * (size_t)(k_begin0 + tid) + 1];
     }
   }
-  // ---- 1. parameters -------------------------------------------------------------------------
-  for (int i = tid; i < npose; i += kThreads) sx[i] = params[(size_t)f * npose + i];
-  for (int i = tid; i < nS; i += kThreads) sx[npose + i] = (use_shape && beta) ? beta[(size_t)f * Pb.beta_stride + i] : 0.0;
+  if (tid >= 128 && tid - 128 < npose) sx[tid - 128] = params[(size_t)f * npose + tid - 128];
+  if (tid >= 224 && tid - 224 < nS)
+    sx[npose + tid - 224] = (use_shape && beta) ? beta[(size_t)f * Pb.beta_stride + tid - 224] : 0.0;
   __syncthreads();
   const double* sbeta = sx + npose;
 
-  // ---- 2. Rodrigues + gradient per joint (lane = joint; joint 0 = root angle-axis) -------------
+  STAMP(1);
+  // ---- B. wave 0: Rodrigues + gradient per joint (joint 0 = root angle-axis);
+  //         waves 1-3: chain offsets o_j(beta) (include/Sim3BA.h:142-170,179-205), centred rest joints ------
   if (tid < nJ) {
     const double* aa = (tid == 0) ? (sx + 1) : (sx + 7 + 3 * (tid - 1));
     double R[9], dR[27];
@@ -181,101 +206,162 @@ __global__ __launch_bounds__(kThreads) void k_frame_resjac(DevModel M, DevProble
 #pragma unroll
     for (int i = 0; i < 27; ++i) sdR[tid * 27 + i] = dR[i];
   }
-  // ---- 3. chain offsets o_j(beta) (include/Sim3BA.h:142-170,179-205) and centred rest joints ----
-  for (int i = tid; i < nJ * 3; i += kThreads) {
-    double o = M.offset[i], jc = M.Jc0[i];
-    if (use_shape) {
-      for (int k = 0; k < nS; ++k) {
-        o += M.dS[(size_t)i * nS + k] * sbeta[k];
-        jc += M.Sc[(size_t)i * nS + k] * sbeta[k];
+  if (tid >= 64) {
+    for (int i = tid - 64; i < nJ * 3; i += kThreads - 64) {
+      double o = M.offset[i], jc = M.Jc0[i];
+      if (use_shape) {
+        for (int k = 0; k < nS; ++k) {
+          o += sDS[i * nS + k] * sbeta[k];
+          jc += sSc[i * nS + k] * sbeta[k];
+        }
       }
+      sO[i] = (i < 3) ? 0.0 : o;
+      sJc[i] = jc;
     }
-    sO[i] = (i < 3) ? 0.0 : o;
-    sJc[i] = jc;
   }
-  if (tid < 9) sA[tid] = (tid % 4 == 0) ? 1.0 : 0.0;
-  if (tid < 3) sP[tid] = 0.0;
-  for (int i = tid; i < 3 * nS; i += kThreads) sB[i] = 0.0;
   __syncthreads();
-  // pose feature vec(R_j - I), j = 1..nJ-1 (row-major), zero padded to 208
+
+  STAMP(2);
+  // ---- C. everything that only needs R_j and o_j, with no ordering between items:
+  //   pose feature vec(R_j - I); chain quantities as 3-vector walks up the kinematic chain
+  //     A_j[:,c] : v = R_j[:,c];   v <- R_k v            (k = ancestors of j below the root)
+  //     P_j      : v = o_j;        v <- R_k v + o_k        (the reference's own walk, Sim3BA.h:173-207)
+  //     B_j[:,b] : v = dS_j[:,b];  v <- R_k v + dS_k[:,b]  (d P_j / d beta_b)
+  //   and the landmark blend rows (wave reductions over the 207 pose-blend columns) --------------------------
   for (int i = tid; i < 208; i += kThreads) {
     double v = 0.0;
-    if (i < 9 * (nJ - 1)) {
-      const int e = i % 9;
-      v = sR[9 + i] - ((e % 4 == 0) ? 1.0 : 0.0);
-    }
+    if (i < 9 * (nJ - 1)) v = sR[9 + i] - (((i % 9) % 4 == 0) ? 1.0 : 0.0);
     sFeat[i] = v;
   }
-
-  // ---- 4. level-synchronous chain: A_j = A_p R_j, P_j = P_p + A_p o_j, B_j = B_p + A_p dS_j -----
-  for (int lv = 0; lv < M.nLevels; ++lv) {
-    const int j0 = sLvOff[lv], nj = sLvOff[lv + 1] - j0;
-    for (int i = tid; i < nj * 9; i += kThreads) {
-      const int j = sLvJ[j0 + i / 9], e = i % 9, r = e / 3, c = e % 3;
-      const int p = sParent[j];
-      sA[j * 9 + e] = sA[p * 9 + r * 3] * sR[j * 9 + c] + sA[p * 9 + r * 3 + 1] * sR[j * 9 + 3 + c] +
-                      sA[p * 9 + r * 3 + 2] * sR[j * 9 + 6 + c];
-    }
-    for (int i = tid; i < nj * 3; i += kThreads) {
-      const int j = sLvJ[j0 + i / 3], r = i % 3;
-      const int p = sParent[j];
-      sP[j * 3 + r] = sP[p * 3 + r] + sA[p * 9 + r * 3] * sO[j * 3] + sA[p * 9 + r * 3 + 1] * sO[j * 3 + 1] +
-                      sA[p * 9 + r * 3 + 2] * sO[j * 3 + 2];
-    }
-    if (use_shape && want_jac) {
-      for (int i = tid; i < nj * 3 * nS; i += kThreads) {
-        const int j = sLvJ[j0 + i / (3 * nS)], rem = i % (3 * nS), r = rem / nS, k = rem % nS;
-        const int p = sParent[j];
-        const double* d = M.dS + (size_t)j * 3 * nS;
-        sB[(j * 3 + r) * nS + k] = sB[(p * 3 + r) * nS + k] + sA[p * 9 + r * 3] * d[k] +
-                                   sA[p * 9 + r * 3 + 1] * d[nS + k] + sA[p * 9 + r * 3 + 2] * d[2 * nS + k];
-      }
-    }
-    __syncthreads();
-  }
-
-  // ---- 5. camera matrices: Rr0 = R_root R0, dRr0_c = dR_root,c R0 -------------------------------
   {
-    const double* R0 = Pb.R0 + (size_t)f * 9;
-    if (tid < 36) {
-      const int mtx = tid / 9, e = tid % 9, r = e / 3, c = e % 3;
-      const double* L = (mtx == 0) ? sR : (sdR + (mtx - 1) * 9);
-      sCam[tid] = L[r * 3] * R0[c] + L[r * 3 + 1] * R0[3 + c] + L[r * 3 + 2] * R0[6 + c];
+    const int nA = 3 * (nJ - 1), nP = nJ - 1, nB = (use_shape && want_jac) ? nS * (nJ - 1) : 0;
+    for (int it = tid; it < nA + nP + nB; it += kThreads) {
+      int j, kind, sel;
+      if (it < nA) { kind = 0; j = 1 + it / 3; sel = it % 3; }
+      else if (it < nA + nP) { kind = 1; j = 1 + (it - nA); sel = 0; }
+      else { kind = 2; j = 1 + (it - nA - nP) / nS; sel = (it - nA - nP) % nS; }
+      double v0, v1, v2;
+      if (kind == 0) { v0 = sR[j * 9 + sel]; v1 = sR[j * 9 + 3 + sel]; v2 = sR[j * 9 + 6 + sel]; }
+      else if (kind == 1) { v0 = sO[j * 3]; v1 = sO[j * 3 + 1]; v2 = sO[j * 3 + 2]; }
+      else {
+        v0 = sDS[(j * 3 + 0) * nS + sel]; v1 = sDS[(j * 3 + 1) * nS + sel]; v2 = sDS[(j * 3 + 2) * nS + sel];
+      }
+      for (int k = sParent[j]; k > 0; k = sParent[k]) {
+        const double* R = sR + k * 9;
+        double t0 = R[0] * v0 + R[1] * v1 + R[2] * v2;
+        double t1 = R[3] * v0 + R[4] * v1 + R[5] * v2;
+        double t2 = R[6] * v0 + R[7] * v1 + R[8] * v2;
+        if (kind == 1) { t0 += sO[k * 3]; t1 += sO[k * 3 + 1]; t2 += sO[k * 3 + 2]; }
+        else if (kind == 2) {
+          t0 += sDS[(k * 3 + 0) * nS + sel]; t1 += sDS[(k * 3 + 1) * nS + sel]; t2 += sDS[(k * 3 + 2) * nS + sel];
+        }
+        v0 = t0; v1 = t1; v2 = t2;
+      }
+      if (kind == 0) { sA[j * 9 + sel] = v0; sA[j * 9 + 3 + sel] = v1; sA[j * 9 + 6 + sel] = v2; }
+      else if (kind == 1) { sP[j * 3] = v0; sP[j * 3 + 1] = v1; sP[j * 3 + 2] = v2; }
+      else { sB[(j * 3 + 0) * nS + sel] = v0; sB[(j * 3 + 1) * nS + sel] = v1; sB[(j * 3 + 2) * nS + sel] = v2; }
+    }
+    if (tid < 9) sA[tid] = (tid % 4 == 0) ? 1.0 : 0.0;       // root: A_0 = I, P_0 = 0, B_0 = 0
+    if (tid >= 16 && tid < 19) sP[tid - 16] = 0.0;
+    if (tid >= 32 && tid - 32 < 3 * nS) sB[tid - 32] = 0.0;
+  }
+  STAMP(3);
+  __syncthreads();   // sFeat complete before the landmark rows read it
+  if (nL > 0) {
+    // v_p rows: item = (row, part), 8 parts per row with stride-8 columns: every load independent,
+    // 8 consecutive threads on 64 contiguous bytes; partials meet in LDS
+    for (int it = tid; it < nL * 3 * 8; it += kThreads) {
+      const int row = it >> 3, part = it & 7;
+      double acc = 0.0;
+      if (Pb.pose_blend && P > 0) {
+        // 207 = 8 x 26 - 1: fixed trip count so all 26 loads are in flight together (a runtime-bounded
+        // loop here serialises one L2 round trip per element)
+        double pv[26];
+#pragma unroll
+        for (int u = 0; u < 26; ++u) {
+          const int i = part + 8 * u;
+          pv[u] = (i < P) ? M.lm_pd[(size_t)row * P + i] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 26; ++u) acc += pv[u] * sFeat[part + 8 * u];
+      }
+      if (use_shape) {
+        double sv0 = (part < nS) ? M.lm_sd[(size_t)row * nS + part] : 0.0;
+        double sv1 = (part + 8 < nS) ? M.lm_sd[(size_t)row * nS + part + 8] : 0.0;
+        acc += sv0 * sbeta[min(part, kMaxShape - 1)] + sv1 * sbeta[min(part + 8, kMaxShape - 1)];
+      }
+      sPart[it] = acc;
     }
   }
-  // ---- 6. W_{k,c} = A_p (dR_{k,c} R_k^T) A_p^T  (lane = (k,c)) -------------------------------------
-  if (want_jac) {
-    for (int i = tid; i < 3 * (nJ - 1); i += kThreads) {
-      const int k = 1 + i / 3, c = i % 3, p = sParent[k];
-      double T1[9], T2[9], Wm[9];
-      mul33_bt(sdR + k * 27 + c * 9, sR + k * 9, T1);
-      mul33(sA + p * 9, T1, T2);
-      mul33_bt(T2, sA + p * 9, Wm);
+  __syncthreads();
+  if (tid < nL * 3) {
+    const double* pp = sPart + tid * 8;
+    sLm[(tid / 3) * LM_STRIDE + LM_VP + tid % 3] =
+        M.lm_vt[tid] + (((pp[0] + pp[1]) + (pp[2] + pp[3])) + ((pp[4] + pp[5]) + (pp[6] + pp[7])));
+  }
+  __syncthreads();
+
+  STAMP(4);
+  // ---- D. wave 0-1: W_{k,c} = A_p (dR_{k,c} R_k^T) A_p^T ; wave 2: landmark LBS ; wave 3: camera matrices ----
+  if (want_jac && tid < 3 * (nJ - 1)) {
+    const int k = 1 + tid / 3, c = tid % 3, p = sParent[k];
+    double T1[9], T2[9], Wm[9];
+    mul33_bt(sdR + k * 27 + c * 9, sR + k * 9, T1);
+    mul33(sA + p * 9, T1, T2);
+    mul33_bt(T2, sA + p * 9, Wm);
 #pragma unroll
-      for (int e = 0; e < 9; ++e) sW[i * 9 + e] = Wm[e];
+    for (int e = 0; e < 9; ++e) sW[tid * 9 + e] = Wm[e];
+  }
+  if (wave == 2 && lane < nL) {
+    double* L = sLm + lane * LM_STRIDE;
+    const int* Lj = reinterpret_cast<const int*>(L + LM_J);
+    double q[3] = {0, 0, 0}, Ab[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const int nw = (int)L[LM_NW];
+    for (int i = 0; i < nw; ++i) {
+      const int j = Lj[i];
+      const double w = L[LM_W + i];
+      double xj[3];
+      mv3(sA + j * 9, L[LM_VP] - sJc[j * 3], L[LM_VP + 1] - sJc[j * 3 + 1], L[LM_VP + 2] - sJc[j * 3 + 2], xj);
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        xj[a] += sP[j * 3 + a];
+        q[a] += w * xj[a];
+        L[LM_X + i * 3 + a] = xj[a];
+      }
+#pragma unroll
+      for (int e = 0; e < 9; ++e) Ab[e] += w * sA[j * 9 + e];
     }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) L[LM_Q + a] = q[a];
+#pragma unroll
+    for (int e = 0; e < 9; ++e) L[LM_A + e] = Ab[e];
+  }
+  if (wave == 3 && lane < 36) {
+    // Rr0 = R_root R0, dRr0_c = dR_root,c R0
+    const double* R0 = Pb.R0 + (size_t)f * 9;
+    const int mtx = lane / 9, e = lane % 9, r = e / 3, c = e % 3;
+    const double* L = (mtx == 0) ? sR : (sdR + (mtx - 1) * 9);
+    sCam[lane] = L[r * 3] * R0[c] + L[r * 3 + 1] * R0[3 + c] + L[r * 3 + 2] * R0[6 + c];
   }
   __syncthreads();
   const double s = sx[0];
   const double* Rr0 = sCam;
   const double* dRr0 = sCam + 9;
 
-  // ---- 7. outputs for the mesh kernel and the posed joints -----------------------------------------
-  if (tid < nJ) {
-    const int jj = tid;
+  STAMP(5);
+  // ---- E. independent items: mesh operands + posed joints, landmark Jacobian terms ---------------------------
+  if (wave == 3 && lane < nJ) {
+    const int jj = lane;
     double RA[9], t[3], q[3];
     mul33(Rr0, sA + jj * 9, RA);
     mv3(sA + jj * 9, sJc[jj * 3], sJc[jj * 3 + 1], sJc[jj * 3 + 2], q);
     mv3(Rr0, sP[jj * 3] - q[0], sP[jj * 3 + 1] - q[1], sP[jj * 3 + 2] - q[2], t);
     if (mc.skinT) {
-      float* T = mc.skinT + ((size_t)f * nJ + jj) * 12;
+      float4* T = reinterpret_cast<float4*>(mc.skinT + ((size_t)f * nJ + jj) * 12);
 #pragma unroll
-      for (int r = 0; r < 3; ++r) {
-        T[r * 4 + 0] = (float)(s * RA[r * 3 + 0]);
-        T[r * 4 + 1] = (float)(s * RA[r * 3 + 1]);
-        T[r * 4 + 2] = (float)(s * RA[r * 3 + 2]);
-        T[r * 4 + 3] = (float)(s * t[r] + sx[4 + r]);
-      }
+      for (int r = 0; r < 3; ++r)
+        T[r] = make_float4((float)(s * RA[r * 3 + 0]), (float)(s * RA[r * 3 + 1]), (float)(s * RA[r * 3 + 2]),
+                           (float)(s * t[r] + sx[4 + r]));
     }
     if (joints_out) {
       mv3(Rr0, sP[jj * 3], sP[jj * 3 + 1], sP[jj * 3 + 2], t);
@@ -285,7 +371,7 @@ __global__ __launch_bounds__(kThreads) void k_frame_resjac(DevModel M, DevProble
   }
   if (mc.featA) {
     const int ftile = f / kFTile, row = f % kFTile;
-    if (wave == 1 && lane < kPoseKSteps * 4) {
+    if (wave == 2 && lane < kPoseKSteps * 4) {
       const int kstep = lane >> 2, h = (lane >> 1) & 1, hl = lane & 1;
       uint32_t pk[4];
 #pragma unroll
@@ -302,129 +388,84 @@ __global__ __launch_bounds__(kThreads) void k_frame_resjac(DevModel M, DevProble
       uint4* dst = reinterpret_cast<uint4*>(mc.featA + ((((size_t)ftile * kPoseKSteps + kstep) * 2 + hl) * 64 + (h * 32 + row)) * 8);
       *dst = make_uint4(pk[0], pk[1], pk[2], pk[3]);
     }
-    if (wave == 2 && lane < 2 * kShapeKSteps) {
+    if (wave == 1 && lane < 2 * kShapeKSteps) {
       const int kstep = lane >> 1, h = lane & 1, k = 2 * kstep + h;
       mc.betaA[((size_t)ftile * kShapeKSteps + kstep) * 64 + h * 32 + row] = (k < nS) ? (float)sbeta[k] : 0.0f;
     }
   }
-
-  // ---- 8. vertex landmarks: blend rows by wave reductions (3 rows in flight), then LBS per landmark ---
-  if (nL > 0) {
-    for (int l = wave; l < nL; l += kThreads / 64) {
-      double acc[3] = {0.0, 0.0, 0.0};
+  if (nL > 0 && want_jac) {
+    // pose-blend term  Ablend . (pd[:, 9(k-1):9k] . vec(dR_{k,c}))   item = (landmark, joint k):
+    // 27 independent loads (72 contiguous bytes per row, consecutive threads on consecutive k)
+    const int nItems = nL * (nJ - 1);
+    for (int it = tid; it < nItems; it += kThreads) {
+      const int l = it / (nJ - 1), k = 1 + it % (nJ - 1);
+      double pdv[27];
       if (Pb.pose_blend && P > 0) {
-        for (int i = lane; i < P; i += 64) {
-          const double ft = sFeat[i];
 #pragma unroll
-          for (int a = 0; a < 3; ++a) acc[a] += M.lm_pd[((size_t)l * 3 + a) * P + i] * ft;
-        }
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+          for (int e = 0; e < 9; ++e) pdv[a * 9 + e] = M.lm_pd[((size_t)l * 3 + a) * P + 9 * (k - 1) + e];
+      } else {
+#pragma unroll
+        for (int e = 0; e < 27; ++e) pdv[e] = 0.0;
       }
-      if (use_shape && lane < nS) {
+      const double* Ab = sLm + l * LM_STRIDE + LM_A;
 #pragma unroll
-        for (int a = 0; a < 3; ++a) acc[a] += M.lm_sd[((size_t)l * 3 + a) * nS + lane] * sbeta[lane];
-      }
-#pragma unroll
-      for (int a = 0; a < 3; ++a) acc[a] = wave_sum(acc[a]);
-      if (lane == 0) {
-#pragma unroll
-        for (int a = 0; a < 3; ++a) sLm[l * LM_STRIDE + LM_VP + a] = M.lm_vt[l * 3 + a] + acc[a];
-      }
-    }
-    __syncthreads();
-    if (tid < nL) {
-      double* L = sLm + tid * LM_STRIDE;
-      const int* Lj = reinterpret_cast<const int*>(L + LM_J);
-      double q[3] = {0, 0, 0}, Ab[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-      const int nw = (int)L[LM_NW];
-      for (int i = 0; i < nw; ++i) {
-        const int j = Lj[i];
-        const double w = L[LM_W + i];
-        double xj[3];
-        mv3(sA + j * 9, L[LM_VP] - sJc[j * 3], L[LM_VP + 1] - sJc[j * 3 + 1], L[LM_VP + 2] - sJc[j * 3 + 2], xj);
+      for (int c = 0; c < 3; ++c) {
+        const double* d = sdR + k * 27 + c * 9;
+        double h[3];
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
-          xj[a] += sP[j * 3 + a];
-          q[a] += w * xj[a];
-          L[LM_X + i * 3 + a] = xj[a];
+          double acc = 0;
+#pragma unroll
+          for (int e = 0; e < 9; ++e) acc += pdv[a * 9 + e] * d[e];
+          h[a] = acc;
         }
-#pragma unroll
-        for (int e = 0; e < 9; ++e) Ab[e] += w * sA[j * 9 + e];
+        double t[3];
+        mv3(Ab, h[0], h[1], h[2], t);
+        double* o = sLm + l * LM_STRIDE + LM_PD + (3 * (k - 1) + c) * 3;
+        o[0] = t[0]; o[1] = t[1]; o[2] = t[2];
       }
-#pragma unroll
-      for (int a = 0; a < 3; ++a) L[LM_Q + a] = q[a];
-#pragma unroll
-      for (int e = 0; e < 9; ++e) L[LM_A + e] = Ab[e];
     }
-    __syncthreads();
-    if (want_jac) {
-      // pose-blend term  Ablend . (pd[:, 9(k-1):9k] . vec(dR_{k,c}))   item = (landmark, joint k):
-      // 27 independent loads (72 contiguous bytes per row, consecutive lanes on consecutive k)
-      const int nItems = nL * (nJ - 1);
-      for (int it = tid; it < nItems; it += kThreads) {
-        const int l = it / (nJ - 1), k = 1 + it % (nJ - 1);
-        double pdv[27];
-        if (Pb.pose_blend && P > 0) {
-#pragma unroll
-          for (int a = 0; a < 3; ++a)
-#pragma unroll
-            for (int e = 0; e < 9; ++e) pdv[a * 9 + e] = M.lm_pd[((size_t)l * 3 + a) * P + 9 * (k - 1) + e];
-        } else {
-#pragma unroll
-          for (int e = 0; e < 27; ++e) pdv[e] = 0.0;
-        }
-        const double* Ab = sLm + l * LM_STRIDE + LM_A;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          const double* d = sdR + k * 27 + c * 9;
-          double h[3];
-#pragma unroll
-          for (int a = 0; a < 3; ++a) {
-            double acc = 0;
-#pragma unroll
-            for (int e = 0; e < 9; ++e) acc += pdv[a * 9 + e] * d[e];
-            h[a] = acc;
-          }
+    // shape columns  d q / d beta_k = sum_i w_i (A_j (sd_l - Sc_j) + B_j)[:, k]   item = (landmark, k)
+    if (use_shape) {
+      for (int it = kThreads - 1 - tid; it < nL * nS; it += kThreads) {
+        const int l = it / nS, k = it % nS;
+        const double* L = sLm + l * LM_STRIDE;
+        const int* Lj = reinterpret_cast<const int*>(L + LM_J);
+        const int nw = (int)L[LM_NW];
+        const double s0 = M.lm_sd[(size_t)(l * 3 + 0) * nS + k], s1 = M.lm_sd[(size_t)(l * 3 + 1) * nS + k],
+                     s2 = M.lm_sd[(size_t)(l * 3 + 2) * nS + k];
+        double d0 = 0, d1 = 0, d2 = 0;
+        for (int i = 0; i < nw; ++i) {
+          const int j = Lj[i];
+          const double w = L[LM_W + i];
           double t[3];
-          mv3(Ab, h[0], h[1], h[2], t);
-          double* o = sLm + l * LM_STRIDE + LM_PD + (3 * (k - 1) + c) * 3;
-          o[0] = t[0]; o[1] = t[1]; o[2] = t[2];
+          mv3(sA + j * 9, s0 - sSc[(j * 3 + 0) * nS + k], s1 - sSc[(j * 3 + 1) * nS + k],
+              s2 - sSc[(j * 3 + 2) * nS + k], t);
+          d0 += w * (t[0] + sB[(j * 3 + 0) * nS + k]);
+          d1 += w * (t[1] + sB[(j * 3 + 1) * nS + k]);
+          d2 += w * (t[2] + sB[(j * 3 + 2) * nS + k]);
         }
+        double* o = sLm + l * LM_STRIDE + LM_BETA + k * 3;
+        o[0] = d0; o[1] = d1; o[2] = d2;
       }
-      // shape columns  d q / d beta_k = sum_i w_i (A_j (sd_l - Sc_j) + B_j)[:, k]   item = (landmark, k)
-      if (use_shape) {
-        for (int it = tid; it < nL * nS; it += kThreads) {
-          const int l = it / nS, k = it % nS;
-          const double* L = sLm + l * LM_STRIDE;
-          const int* Lj = reinterpret_cast<const int*>(L + LM_J);
-          const int nw = (int)L[LM_NW];
-          const double s0 = M.lm_sd[(size_t)(l * 3 + 0) * nS + k], s1 = M.lm_sd[(size_t)(l * 3 + 1) * nS + k],
-                       s2 = M.lm_sd[(size_t)(l * 3 + 2) * nS + k];
-          double d0 = 0, d1 = 0, d2 = 0;
-          for (int i = 0; i < nw; ++i) {
-            const int j = Lj[i];
-            const double w = L[LM_W + i];
-            double t[3];
-            mv3(sA + j * 9, s0 - M.Sc[(size_t)(j * 3 + 0) * nS + k], s1 - M.Sc[(size_t)(j * 3 + 1) * nS + k],
-                s2 - M.Sc[(size_t)(j * 3 + 2) * nS + k], t);
-            d0 += w * (t[0] + sB[(j * 3 + 0) * nS + k]);
-            d1 += w * (t[1] + sB[(j * 3 + 1) * nS + k]);
-            d2 += w * (t[2] + sB[(j * 3 + 2) * nS + k]);
-          }
-          double* o = sLm + l * LM_STRIDE + LM_BETA + k * 3;
-          o[0] = d0; o[1] = d1; o[2] = d2;
-        }
-      }
-      __syncthreads();
     }
   }
 
-  // ---- 9. keypoints of this frame, KC at a time ------------------------------------------------------
+  STAMP(6);
+  // ---- F. keypoints of this frame, KC at a time: stage per-keypoint data, then the flat (keypoint, column)
+  //         sweep over all 256 threads (consecutive threads on consecutive columns of the row-major panel) ------
   const int k_begin = Pb.kp_offset[f], k_end = Pb.kp_offset[f + 1];
   for (int kc0 = k_begin; kc0 < k_end; kc0 += KC) {
     const int nk = min(KC, k_end - kc0);
+    __syncthreads();   // phase E results visible / previous chunk's staging consumed
     if (tid < nk) {
       const int kg = kc0 + tid;
-      const int id = Pb.kp_id[kg];
+      const bool first = kc0 == k_begin;
+      const int id = first ? sKpId[tid] : Pb.kp_id[kg];
+      const double u_obs = first ? sKpUv[2 * tid] : Pb.kp_uv[2 * (size_t)kg];
+      const double v_obs = first ? sKpUv[2 * tid + 1] : Pb.kp_uv[2 * (size_t)kg + 1];
       sKpId[tid] = id;
       double q[3];
       if (id < nJ) {
@@ -434,7 +475,7 @@ __global__ __launch_bounds__(kThreads) void k_frame_resjac(DevModel M, DevProble
           for (int a = 0; a < 3; ++a) {
             double v = M.offset[id * 3 + a];
             if (use_shape)
-              for (int k = 0; k < nS; ++k) v += M.dS[(size_t)(id * 3 + a) * nS + k] * sbeta[k];
+              for (int k = 0; k < nS; ++k) v += sDS[(id * 3 + a) * nS + k] * sbeta[k];
             q[a] = v;
           }
         } else {
@@ -449,8 +490,8 @@ __global__ __launch_bounds__(kThreads) void k_frame_resjac(DevModel M, DevProble
       mv3(Rr0, q[0], q[1], q[2], z);                     // include/Sim3BA.h:210-216
       const double X0 = s * z[0] + sx[4], X1 = s * z[1] + sx[5], X2 = s * z[2] + sx[6];  // :217-219
       const double iz = 1.0 / X2;                        // :222-223, Z unguarded as in the reference
-      r_out[2 * (size_t)kg] = Pb.fx * X0 * iz + Pb.cx - Pb.kp_uv[2 * (size_t)kg];
-      r_out[2 * (size_t)kg + 1] = Pb.fy * X1 * iz + Pb.cy - Pb.kp_uv[2 * (size_t)kg + 1];
+      r_out[2 * (size_t)kg] = Pb.fx * X0 * iz + Pb.cx - u_obs;
+      r_out[2 * (size_t)kg + 1] = Pb.fy * X1 * iz + Pb.cy - v_obs;
       double* kp = sKp + tid * 18;
       const double dpi[6] = {Pb.fx * iz, 0.0, -Pb.fx * X0 * iz * iz, 0.0, Pb.fy * iz, -Pb.fy * X1 * iz * iz};
 #pragma unroll
@@ -464,83 +505,103 @@ __global__ __launch_bounds__(kThreads) void k_frame_resjac(DevModel M, DevProble
           kp[12 + rr * 3 + c] = s * (dpi[rr * 3] * Rr0[c] + dpi[rr * 3 + 1] * Rr0[3 + c] + dpi[rr * 3 + 2] * Rr0[6 + c]);
     }
     __syncthreads();
+    STAMP(7);
     if (want_jac) {
-      for (int kk = wave; kk < nk; kk += kThreads / 64) {
+      // (1) joint columns: thread = (column kc, keypoint group g).  W_{k,c} and P_k stay in registers for
+      //     all keypoints of the group; consecutive threads write consecutive columns of a row; the
+      //     FK / landmark branch is uniform across the threads of a group.
+      const int njc = npose - 7;
+      const int ngrp = kThreads / njc;                      // 3 groups of 69 columns
+      if (tid < ngrp * njc) {
+        const int g = tid / njc, kc = tid - g * njc, k = 1 + kc / 3;
+        double Wm[9];
+#pragma unroll
+        for (int e9 = 0; e9 < 9; ++e9) Wm[e9] = sW[kc * 9 + e9];
+        const double pk0 = sP[k * 3], pk1 = sP[k * 3 + 1], pk2 = sP[k * 3 + 2];
+        for (int kk = g; kk < nk; kk += ngrp) {
+          const int kg = kc0 + kk;
+          const int id = sKpId[kk];
+          const double* kp = sKp + kk * 18;
+          const double* G = kp + 12;
+          double d0 = 0.0, d1 = 0.0, d2 = 0.0;
+          if (id < nJ) {
+            if ((sAnc[id] >> k) & 1u) {
+              const double x0 = kp[0] - pk0, x1 = kp[1] - pk1, x2 = kp[2] - pk2;
+              d0 = Wm[0] * x0 + Wm[1] * x1 + Wm[2] * x2;
+              d1 = Wm[3] * x0 + Wm[4] * x1 + Wm[5] * x2;
+              d2 = Wm[6] * x0 + Wm[7] * x1 + Wm[8] * x2;
+            }
+          } else {
+            const double* L = sLm + (id - nJ) * LM_STRIDE;
+            const int* Lj = reinterpret_cast<const int*>(L + LM_J);
+            const int nw = (int)L[LM_NW];
+            double a0 = 0, a1 = 0, a2 = 0;
+            for (int i = 0; i < nw; ++i) {
+              const int j = Lj[i];
+              if (j == k || ((sAnc[j] >> k) & 1u)) {
+                const double w = L[LM_W + i];
+                a0 += w * (L[LM_X + i * 3] - pk0);
+                a1 += w * (L[LM_X + i * 3 + 1] - pk1);
+                a2 += w * (L[LM_X + i * 3 + 2] - pk2);
+              }
+            }
+            d0 = Wm[0] * a0 + Wm[1] * a1 + Wm[2] * a2 + L[LM_PD + kc * 3];
+            d1 = Wm[3] * a0 + Wm[4] * a1 + Wm[5] * a2 + L[LM_PD + kc * 3 + 1];
+            d2 = Wm[6] * a0 + Wm[7] * a1 + Wm[8] * a2 + L[LM_PD + kc * 3 + 2];
+          }
+          J_out[(size_t)(2 * kg) * ncols + 7 + kc] = G[0] * d0 + G[1] * d1 + G[2] * d2;
+          J_out[(size_t)(2 * kg + 1) * ncols + 7 + kc] = G[3] * d0 + G[4] * d1 + G[5] * d2;
+        }
+      }
+      // (2) Sim3 columns (7) and shape columns (ncols - npose) per keypoint
+      const int nsc = 7 + (ncols - npose);
+      for (int e = tid; e < nk * nsc; e += kThreads) {
+        const int kk = e / nsc, c = e - kk * nsc;
         const int kg = kc0 + kk;
         const int id = sKpId[kk];
         const double* kp = sKp + kk * 18;
         const double* G = kp + 12;
-        for (int col = lane; col < ncols; col += 64) {
-          double j0, j1;
-          if (col == 0) {
-            j0 = kp[6] * kp[3] + kp[7] * kp[4] + kp[8] * kp[5];
-            j1 = kp[9] * kp[3] + kp[10] * kp[4] + kp[11] * kp[5];
-          } else if (col < 4) {
-            double t[3];
-            mv3(dRr0 + (col - 1) * 9, kp[0], kp[1], kp[2], t);
-            j0 = s * (kp[6] * t[0] + kp[7] * t[1] + kp[8] * t[2]);
-            j1 = s * (kp[9] * t[0] + kp[10] * t[1] + kp[11] * t[2]);
-          } else if (col < 7) {
-            j0 = kp[6 + (col - 4)];
-            j1 = kp[9 + (col - 4)];
-          } else {
-            double d0 = 0.0, d1 = 0.0, d2 = 0.0;
-            if (col < npose) {
-              const int kc = col - 7, k = 1 + kc / 3;
-              if (id < nJ) {
-                if ((sAnc[id] >> k) & 1u) {
-                  double t[3];
-                  mv3(sW + kc * 9, kp[0] - sP[k * 3], kp[1] - sP[k * 3 + 1], kp[2] - sP[k * 3 + 2], t);
-                  d0 = t[0]; d1 = t[1]; d2 = t[2];
-                }
+        double j0, j1;
+        int col;
+        if (c == 0) {
+          col = 0;
+          j0 = kp[6] * kp[3] + kp[7] * kp[4] + kp[8] * kp[5];
+          j1 = kp[9] * kp[3] + kp[10] * kp[4] + kp[11] * kp[5];
+        } else if (c < 4) {
+          col = c;
+          double t[3];
+          mv3(dRr0 + (c - 1) * 9, kp[0], kp[1], kp[2], t);
+          j0 = s * (kp[6] * t[0] + kp[7] * t[1] + kp[8] * t[2]);
+          j1 = s * (kp[9] * t[0] + kp[10] * t[1] + kp[11] * t[2]);
+        } else if (c < 7) {
+          col = c;
+          j0 = kp[6 + (c - 4)];
+          j1 = kp[9 + (c - 4)];
+        } else {
+          const int k = c - 7;
+          col = npose + k;
+          double d0 = 0.0, d1 = 0.0, d2 = 0.0;
+          if (use_shape) {
+            if (id < nJ) {
+              if (id == 0 || sParent[id] < 0) {
+                d0 = sDS[(id * 3 + 0) * nS + k]; d1 = sDS[(id * 3 + 1) * nS + k]; d2 = sDS[(id * 3 + 2) * nS + k];
               } else {
-                const int l = id - nJ;
-                const double* L = sLm + l * LM_STRIDE;
-                const int* Lj = reinterpret_cast<const int*>(L + LM_J);
-                const int nw = (int)L[LM_NW];
-                double a0 = 0, a1 = 0, a2 = 0;
-                for (int i = 0; i < nw; ++i) {
-                  const int j = Lj[i];
-                  if (j == k || ((sAnc[j] >> k) & 1u)) {
-                    const double w = L[LM_W + i];
-                    a0 += w * (L[LM_X + i * 3] - sP[k * 3]);
-                    a1 += w * (L[LM_X + i * 3 + 1] - sP[k * 3 + 1]);
-                    a2 += w * (L[LM_X + i * 3 + 2] - sP[k * 3 + 2]);
-                  }
-                }
-                double t[3];
-                mv3(sW + kc * 9, a0, a1, a2, t);
-                d0 = t[0] + L[LM_PD + kc * 3];
-                d1 = t[1] + L[LM_PD + kc * 3 + 1];
-                d2 = t[2] + L[LM_PD + kc * 3 + 2];
+                d0 = sB[(id * 3 + 0) * nS + k]; d1 = sB[(id * 3 + 1) * nS + k]; d2 = sB[(id * 3 + 2) * nS + k];
               }
-            } else if (use_shape) {
-              const int k = col - npose;
-              if (id < nJ) {
-                if (id == 0 || sParent[id] < 0) {
-                  d0 = M.dS[(size_t)(id * 3 + 0) * nS + k];
-                  d1 = M.dS[(size_t)(id * 3 + 1) * nS + k];
-                  d2 = M.dS[(size_t)(id * 3 + 2) * nS + k];
-                } else {
-                  d0 = sB[(id * 3 + 0) * nS + k];
-                  d1 = sB[(id * 3 + 1) * nS + k];
-                  d2 = sB[(id * 3 + 2) * nS + k];
-                }
-              } else {
-                const double* o = sLm + (id - nJ) * LM_STRIDE + LM_BETA + k * 3;
-                d0 = o[0]; d1 = o[1]; d2 = o[2];
-              }
+            } else {
+              const double* o = sLm + (id - nJ) * LM_STRIDE + LM_BETA + k * 3;
+              d0 = o[0]; d1 = o[1]; d2 = o[2];
             }
-            j0 = G[0] * d0 + G[1] * d1 + G[2] * d2;
-            j1 = G[3] * d0 + G[4] * d1 + G[5] * d2;
           }
-          J_out[(size_t)(2 * kg) * ncols + col] = j0;
-          J_out[(size_t)(2 * kg + 1) * ncols + col] = j1;
+          j0 = G[0] * d0 + G[1] * d1 + G[2] * d2;
+          j1 = G[3] * d0 + G[4] * d1 + G[5] * d2;
         }
+        J_out[(size_t)(2 * kg) * ncols + col] = j0;
+        J_out[(size_t)(2 * kg + 1) * ncols + col] = j1;
       }
     }
-    __syncthreads();
   }
+  STAMP(8);
 }
 
 }  // namespace

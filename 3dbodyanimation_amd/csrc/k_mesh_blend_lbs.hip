@@ -14,10 +14,12 @@
 //     upload) go HBM -> LDS by LDS-DMA (global_load_lds_dwordx4: 1 KiB contiguous per wave-instruction),
 //     once per workgroup, and are reused by all four waves for every frame tile;
 //   * A operands (pose-feature hi/lo, beta) come from L2 in fragment order, one 1 KiB load per k-step;
-//   * the skinning transforms of 16 frames (18 KiB, contiguous) are LDS-DMA'd per wave and gathered by
+//   * the skinning transforms of 8 frames (9 KiB, contiguous) are LDS-DMA'd per wave and gathered by
 //     joint id with ds_read_b128; the blended vertices never touch HBM;
 //   * output rows are 384 contiguous bytes per frame (lane = vertex).
-// LDS: 79.9 KiB (B) + 4 x 18 KiB (transforms) = 151.9 KiB of the CU's 160 KiB; one workgroup per CU.
+// Eight waves per workgroup = two per SIMD, so one wave's LDS-DMA / store-retire waits (CDNA4 counts
+// stores in vmcnt) are covered by its partner's MFMA or skinning VALU work.
+// LDS: 79.9 KiB (B) + 3.75 KiB (shape) + 8 x 9 KiB (transforms) = 153.75 KiB of the CU's 160 KiB.
 #include "bodyfit_device.h"
 
 namespace bodyfit {
@@ -29,15 +31,39 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 constexpr int kPosePieces = 3 * kPoseKSteps * 2;                 // 78 x 1 KiB
 constexpr int kPoseBytes = kPosePieces * 1024;                   // 79,872
 constexpr int kShapeFloats = 3 * kShapeKSteps * 64;              // 960 f32 = 3,840 B
-constexpr int kSkinRows = 16;                                    // frames per epilogue half
-constexpr int kSkinBytes = kSkinRows * kMaxJoints * 48;          // 18,432
-constexpr int kLdsBytes = kPoseBytes + kShapeFloats * 4 + 4 * kSkinBytes;   // 157,440
+constexpr int kSkinRows = 8;                                     // frames per epilogue quarter
+constexpr int kWaves = 8;
+constexpr int kSkinBytes = kSkinRows * kMaxJoints * 48;          // 9,216
+constexpr int kLdsBytes = kPoseBytes + kShapeFloats * 4 + kWaves * kSkinBytes;   // 157,440
 
 __device__ inline void lds_dma_16(const void* g, void* l) {
   __builtin_amdgcn_global_load_lds(g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 }
 
-__global__ __launch_bounds__(256) void k_mesh_blend_lbs(DevModel M, DevProblem Pb, MeshCoef mc,
+// One output row of the skinning epilogue.  R (compile-time) = accumulator register = frame row
+// (R & 3) + 8 (R >> 2) + 4 h of the tile; the row's 24 transforms sit at Trow in this wave's LDS slice.
+template <int R>
+__device__ __forceinline__ void skin_row(const f32x16 (&acc)[3], const unsigned char* Trow, const int (&jo)[4],
+                                         const float (&wgt)[4], float* __restrict__ o, bool live) {
+  float4 t0 = make_float4(0, 0, 0, 0), t1 = t0, t2 = t0;
+#pragma unroll
+  for (int i = 0; i < kMeshNnz; ++i) {
+    const float4* T = reinterpret_cast<const float4*>(Trow + jo[i]);
+    const float w = wgt[i];
+    const float4 a0 = T[0], a1 = T[1], a2 = T[2];
+    t0.x += w * a0.x; t0.y += w * a0.y; t0.z += w * a0.z; t0.w += w * a0.w;
+    t1.x += w * a1.x; t1.y += w * a1.y; t1.z += w * a1.z; t1.w += w * a1.w;
+    t2.x += w * a2.x; t2.y += w * a2.y; t2.z += w * a2.z; t2.w += w * a2.w;
+  }
+  const float px = acc[0][R], py = acc[1][R], pz = acc[2][R];
+  if (live) {
+    o[0] = t0.x * px + t0.y * py + t0.z * pz + t0.w;
+    o[1] = t1.x * px + t1.y * py + t1.z * pz + t1.w;
+    o[2] = t2.x * px + t2.y * py + t2.z * pz + t2.w;
+  }
+}
+
+__global__ __launch_bounds__(64 * kWaves, 2) void k_mesh_blend_lbs(DevModel M, DevProblem Pb, MeshCoef mc,
                                                          float* __restrict__ cloud) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int vtile = blockIdx.x;
@@ -55,7 +81,7 @@ __global__ __launch_bounds__(256) void k_mesh_blend_lbs(DevModel M, DevProblem P
   {
     const unsigned char* gp = reinterpret_cast<const unsigned char*>(M.dirsB) + (size_t)vtile * kPoseBytes;
     if (pose) {
-      for (int p = wave; p < kPosePieces; p += 4) {
+      for (int p = wave; p < kPosePieces; p += kWaves) {
         // LDS piece p = (ks, c, hl) k-step-major; global layout is [c][ks][hl]
         const int ks = p / 6, c = (p % 6) >> 1, hl = p & 1;
         const int gpiece = (c * kPoseKSteps + ks) * 2 + hl;
@@ -63,7 +89,7 @@ __global__ __launch_bounds__(256) void k_mesh_blend_lbs(DevModel M, DevProblem P
       }
     }
     const float* gs = M.sdB + (size_t)vtile * kShapeFloats;
-    for (int i = threadIdx.x; i < kShapeFloats; i += 256) sShape[i] = gs[i];
+    for (int i = threadIdx.x; i < kShapeFloats; i += 64 * kWaves) sShape[i] = gs[i];
   }
   float vt[3];
 #pragma unroll
@@ -78,8 +104,8 @@ __global__ __launch_bounds__(256) void k_mesh_blend_lbs(DevModel M, DevProblem P
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
-  for (int ftile = wave; ftile < Pb.nFTiles; ftile += 4) {
-    // kick off the first half's skinning transforms (frames ftile*32 .. +15), contiguous in HBM
+  for (int ftile = wave; ftile < Pb.nFTiles; ftile += kWaves) {
+    // kick off the first quarter's skinning transforms (frames ftile*32 .. +7), contiguous in HBM
     const unsigned char* gskin = reinterpret_cast<const unsigned char*>(mc.skinT) + (size_t)ftile * 32 * nJ * 48;
     const int frames_left = F - ftile * 32;
     {
@@ -106,17 +132,15 @@ __global__ __launch_bounds__(256) void k_mesh_blend_lbs(DevModel M, DevProblem P
     }
     // pose blend, bf16 hi/lo split; A fragments straight from L2, B fragments from LDS
     if (pose) {
-      uint4 ahi[kPoseKSteps], alo[kPoseKSteps];
-#pragma unroll
+      // A fragments one k-step ahead in registers (keeps the wave under 256 VGPRs at two waves per SIMD)
+      const uint4* fa = feat + ((size_t)ftile * kPoseKSteps * 2) * 64 + lane;
+      uint4 ah = fa[0], al = fa[64];
+#pragma unroll 1
       for (int ks = 0; ks < kPoseKSteps; ++ks) {
-        const size_t fa = (((size_t)ftile * kPoseKSteps + ks) * 2) * 64 + lane;
-        ahi[ks] = feat[fa];
-        alo[ks] = feat[fa + 64];
-      }
-#pragma unroll
-      for (int ks = 0; ks < kPoseKSteps; ++ks) {
-        const bf16x8 a_hi = __builtin_bit_cast(bf16x8, ahi[ks]);
-        const bf16x8 a_lo = __builtin_bit_cast(bf16x8, alo[ks]);
+        const int kn = min(ks + 1, kPoseKSteps - 1);
+        const uint4 nh = fa[(size_t)kn * 128], nl = fa[(size_t)kn * 128 + 64];
+        const bf16x8 a_hi = __builtin_bit_cast(bf16x8, ah);
+        const bf16x8 a_lo = __builtin_bit_cast(bf16x8, al);
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
           const uint4* bp = reinterpret_cast<const uint4*>(sPose + (size_t)((ks * 3 + c) * 2) * 1024) + lane;
@@ -126,44 +150,48 @@ __global__ __launch_bounds__(256) void k_mesh_blend_lbs(DevModel M, DevProblem P
           acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, blo, acc[c], 0, 0, 0);
           acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo, bhi, acc[c], 0, 0, 0);
         }
+        ah = nh; al = nl;
       }
     }
 
-    // skinning epilogue in two halves of 16 frame rows: lane = vertex, register r = frame row
-    //   row(r, h) = (r & 3) + 8 (r >> 2) + 4 h ;  half 0: r in 0..7, half 1: r in 8..15
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's transforms have landed in its LDS slice
-      __builtin_amdgcn_wave_barrier();
-#pragma unroll
-      for (int rr = 0; rr < 8; ++rr) {
-        const int r = half * 8 + rr;
-        const int row16 = (rr & 3) + 8 * (rr >> 2) + 4 * h;      // row inside this half
-        const int f = ftile * kFTile + half * 16 + row16;
-        const unsigned char* Trow = sSkin + row16 * (nJ * 48);
-        float4 t0 = make_float4(0, 0, 0, 0), t1 = t0, t2 = t0;
-#pragma unroll
-        for (int i = 0; i < kMeshNnz; ++i) {
-          const float4* T = reinterpret_cast<const float4*>(Trow + jo[i]);
-          const float w = wgt[i];
-          const float4 a0 = T[0], a1 = T[1], a2 = T[2];
-          t0.x += w * a0.x; t0.y += w * a0.y; t0.z += w * a0.z; t0.w += w * a0.w;
-          t1.x += w * a1.x; t1.y += w * a1.y; t1.z += w * a1.z; t1.w += w * a1.w;
-          t2.x += w * a2.x; t2.y += w * a2.y; t2.z += w * a2.z; t2.w += w * a2.w;
-        }
-        if (f < F && v < V) {
-          const float px = acc[0][r], py = acc[1][r], pz = acc[2][r];
-          float* o = cloud + ((size_t)f * V + v) * 3;
-          o[0] = t0.x * px + t0.y * py + t0.z * pz + t0.w;
-          o[1] = t1.x * px + t1.y * py + t1.z * pz + t1.w;
-          o[2] = t2.x * px + t2.y * py + t2.z * pz + t2.w;
-        }
-      }
-      if (half == 0) {
-        // second half's transforms (frames +16..+31) into the same slice once every lane has read the first
+    // skinning epilogue, one frame row per step (lane = vertex): accumulator register r holds frame row
+    // (r & 3) + 8 (r >> 2) + 4 h, so registers 4q..4q+3 cover rows 8q..8q+7 = one LDS-DMA'd quarter.
+    // The runtime loop + switch keeps every row's 12 transform reads in its own scheduling region
+    // (a fully unrolled epilogue hoists 192 VGPRs of reads and spills at two waves per SIMD).
+#pragma unroll 1
+    for (int r = 0; r < 16; ++r) {
+      const int q = r >> 2, rr = r & 3;
+      if (rr == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this quarter's transforms have landed
         __builtin_amdgcn_wave_barrier();
-        const int nbytes = max(0, min(kSkinRows, frames_left - kSkinRows)) * nJ * 48;
-        const unsigned char* g2 = gskin + (size_t)kSkinRows * nJ * 48;
+      }
+      const int f = ftile * kFTile + q * 8 + rr + 4 * h;
+      const unsigned char* Trow = sSkin + (rr + 4 * h) * (nJ * 48);
+      float* o = cloud + ((size_t)f * V + v) * 3;
+      const bool live = f < F && v < V;
+      switch (r) {
+        case 0: skin_row<0>(acc, Trow, jo, wgt, o, live); break;
+        case 1: skin_row<1>(acc, Trow, jo, wgt, o, live); break;
+        case 2: skin_row<2>(acc, Trow, jo, wgt, o, live); break;
+        case 3: skin_row<3>(acc, Trow, jo, wgt, o, live); break;
+        case 4: skin_row<4>(acc, Trow, jo, wgt, o, live); break;
+        case 5: skin_row<5>(acc, Trow, jo, wgt, o, live); break;
+        case 6: skin_row<6>(acc, Trow, jo, wgt, o, live); break;
+        case 7: skin_row<7>(acc, Trow, jo, wgt, o, live); break;
+        case 8: skin_row<8>(acc, Trow, jo, wgt, o, live); break;
+        case 9: skin_row<9>(acc, Trow, jo, wgt, o, live); break;
+        case 10: skin_row<10>(acc, Trow, jo, wgt, o, live); break;
+        case 11: skin_row<11>(acc, Trow, jo, wgt, o, live); break;
+        case 12: skin_row<12>(acc, Trow, jo, wgt, o, live); break;
+        case 13: skin_row<13>(acc, Trow, jo, wgt, o, live); break;
+        case 14: skin_row<14>(acc, Trow, jo, wgt, o, live); break;
+        default: skin_row<15>(acc, Trow, jo, wgt, o, live); break;
+      }
+      if (rr == 3 && q < 3) {
+        // every lane has consumed this quarter's transforms: the next quarter goes in flight
+        __builtin_amdgcn_wave_barrier();
+        const int nbytes = max(0, min(kSkinRows, frames_left - (q + 1) * kSkinRows)) * nJ * 48;
+        const unsigned char* g2 = gskin + (size_t)(q + 1) * kSkinRows * nJ * 48;
         for (int p = 0; p * 1024 < nbytes; ++p)
           if (p * 1024 + lane * 16 < nbytes) lds_dma_16(g2 + p * 1024 + lane * 16, sSkin + p * 1024);
       }
@@ -182,7 +210,7 @@ void launch_mesh(const DevModel& M, const DevProblem& P, const MeshCoef& mc, flo
                               hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
     attr_set = true;
   }
-  hipLaunchKernelGGL(k_mesh_blend_lbs, dim3(M.nVTiles), dim3(256), kLdsBytes, s, M, P, mc, d_cloud);
+  hipLaunchKernelGGL(k_mesh_blend_lbs, dim3(M.nVTiles), dim3(64 * kWaves), kLdsBytes, s, M, P, mc, d_cloud);
 }
 
 }  // namespace bodyfit
