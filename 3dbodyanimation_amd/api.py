@@ -48,6 +48,16 @@ class Layout(C.Structure):
                 ("total_rows", C.c_int)]
 
 
+class FitOptions(C.Structure):
+    _fields_ = [("max_iters", C.c_int), ("scale_lo", C.c_double), ("scale_hi", C.c_double), ("verbose", C.c_int)]
+
+
+class FitSummary(C.Structure):
+    _fields_ = [("iterations", C.c_int), ("termination", C.c_int), ("usable", C.c_int), ("n_successful", C.c_int),
+                ("n_unsuccessful", C.c_int), ("n_sweeps", C.c_int), ("initial_cost", C.c_double),
+                ("final_cost", C.c_double)]
+
+
 class DeviceViews(C.Structure):
     _fields_ = [("residuals", C.c_void_p), ("jacobian", C.c_void_p), ("gmm_comp", C.c_void_p),
                 ("cloud", C.c_void_p), ("joints", C.c_void_p), ("normal_eq", C.c_void_p)]
@@ -95,6 +105,8 @@ def load_library():
     lib.bodyfit_evaluate_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
     lib.bodyfit_reduce_shared_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     lib.bodyfit_profile_sweep.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, _dp]
+    lib.bodyfit_solve.argtypes = [C.c_void_p, _dp, _dp, C.POINTER(C.c_ubyte), C.c_int, C.POINTER(FitOptions),
+                                  C.POINTER(FitSummary), C.c_int]
     lib.bodyfit_forward.argtypes = [C.c_void_p, _dp, _dp, _dp, _fp]
     lib.bodyfit_evaluate_block.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(_dp), _dp, C.POINTER(_dp)]
     _lib = lib
@@ -294,6 +306,21 @@ class Problem:
         _check(load_library().bodyfit_forward(self.h, _d(x), _d(b), _d(joints),
                                               cloud.ctypes.data_as(_fp) if cloud is not None else None))
         return joints, cloud
+
+    def solve(self, frame_params, beta=None, constant=None, independent=False, max_iters=100, scale_bounds=(0.3, 3.0),
+              verbose=False):
+        """Ceres-like LM over this problem (bodyfit_solve).  Returns fitted params, beta, [FitSummary]."""
+        x = _c64(frame_params).copy()
+        b = _c64(beta).copy() if beta is not None else None
+        cst = None
+        if constant is not None:
+            cst = np.ascontiguousarray(constant, dtype=np.uint8)
+        n_sum = self.n_frames if independent else 1
+        sums = (FitSummary * n_sum)()
+        opt = FitOptions(int(max_iters), float(scale_bounds[0]), float(scale_bounds[1]), int(verbose))
+        _check(load_library().bodyfit_solve(self.h, _d(x), _d(b), cst.ctypes.data_as(C.POINTER(C.c_ubyte)) if cst is not None else None,
+                                            int(independent), C.byref(opt), sums, n_sum))
+        return x, b, list(sums)
 
     def evaluate_block(self, kind: int, index: int, blocks: list[np.ndarray], n_res: int, want=None):
         """ceres::CostFunction::Evaluate on one block.  `want[b]` False -> jacobians[b] = NULL."""

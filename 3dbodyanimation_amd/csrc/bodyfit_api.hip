@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "bodyfit_device.h"
+#include "solver_view.h"
 
 using namespace bodyfit;
 
@@ -642,6 +643,18 @@ int bodyfit_profile_sweep(bodyfit_problem* p, const double* d_frame_params, cons
   for (auto& e : ev) (void)hipEventDestroy(e);
   if (se != hipSuccess) return fail(BODYFIT_ERR_HIP, std::string("profile sync: ") + hipGetErrorString(se));
   return rc;
+}
+
+int bodyfit_internal_solver_view(bodyfit_problem* p, bodyfit_solver_view* out) {
+  if (!p || !out) return BODYFIT_ERR_INVALID;
+  out->n_frames = p->d.F; out->n_joints = p->m->nJ; out->n_shape = p->m->nS;
+  out->beta_per_frame = p->desc.beta_per_frame; out->has_gmm = p->has_gmm ? 1 : 0;
+  out->temporal_halo = p->desc.temporal_halo;
+  out->beta_pose = p->desc.beta_pose; out->beta_shape = p->desc.beta_shape;
+  out->lambda_temporal = p->desc.lambda_temporal; out->huber_delta = p->desc.huber_delta;
+  out->kp_offset = p->kp_offset.data();
+  out->prec_cho = p->has_gmm ? p->desc.gmm->prec_cho.data() : nullptr;
+  return BODYFIT_OK;
 }
 
 #ifdef BODYFIT_STAMPS

@@ -1,1 +1,584 @@
-// placeholder until the LM solver lands
+// host_solver.cpp — the outer loop the reference leaves to ceres::Solve, restated for hosts without Ceres.
+//
+// The reference configures Ceres as: trust-region Levenberg-Marquardt, DENSE_QR, HuberLoss(3.0) on the
+// reprojection blocks, bounds on the scale, max_num_iterations, everything else default
+// (include/Sim3BA.h:406-407,449-451,472-479,641-647; include/MultiFrameBA.h:63-64,144-151).  Ceres is
+// not available here, so this file follows Ceres 1.14's documented algorithm:
+//   * Triggs corrector with rho'' <= 0 for Huber: residuals and Jacobian rows scaled by sqrt(rho')
+//   * Jacobi column scaling 1 / (1 + ||J_col||) fixed at the first iterate
+//   * LM step: (J^T J + diag(clamp(diag(J^T J), 1e-6, 1e32)) / radius) d = -J^T r
+//   * step quality rho = cost change / model cost change; accept if rho > 1e-3;
+//     radius /= max(1/3, 1 - (2 rho - 1)^3) on success, radius /= 2^k after k consecutive failures
+//   * termination: |dcost|/cost < 1e-6, max |g| < 1e-10, |d| < 1e-8 (|x| + 1e-8), or max iterations
+//   * box bounds by projecting the candidate point
+// Every evaluation is one sweep of the HIP evaluator (bodyfit_evaluate_batch); the only CPU arithmetic
+// here is the linear algebra of the normal equations.  DENSE_QR is replaced by a block-tridiagonal
+// Cholesky (76x76 frame blocks coupled by the temporal term) with a Schur complement on the shared
+// shape block: same minimiser, O(F 76^3) instead of O(m n^2).
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <string>
+#include <vector>
+
+#include "../../include/bodyfit.h"
+#include "solver_view.h"
+
+namespace {
+
+constexpr int NP = BODYFIT_FRAME_PARAMS;
+
+// ---- small dense helpers (row-major) ------------------------------------------------------------
+bool chol_inplace(double* A, int n) {  // lower Cholesky in the lower triangle
+  for (int j = 0; j < n; ++j) {
+    double d = A[j * n + j];
+    for (int k = 0; k < j; ++k) d -= A[j * n + k] * A[j * n + k];
+    if (!(d > 0.0) || !std::isfinite(d)) return false;
+    d = std::sqrt(d);
+    A[j * n + j] = d;
+    const double inv = 1.0 / d;
+    for (int i = j + 1; i < n; ++i) {
+      double s = A[i * n + j];
+      for (int k = 0; k < j; ++k) s -= A[i * n + k] * A[j * n + k];
+      A[i * n + j] = s * inv;
+    }
+  }
+  return true;
+}
+// X <- L^{-1} X, X is n x m
+void fwd_solve(const double* L, int n, double* X, int m) {
+  for (int i = 0; i < n; ++i) {
+    for (int k = 0; k < i; ++k) {
+      const double l = L[i * n + k];
+      if (l == 0.0) continue;
+      for (int c = 0; c < m; ++c) X[i * m + c] -= l * X[k * m + c];
+    }
+    const double inv = 1.0 / L[i * n + i];
+    for (int c = 0; c < m; ++c) X[i * m + c] *= inv;
+  }
+}
+// X <- L^{-T} X
+void bwd_solve(const double* L, int n, double* X, int m) {
+  for (int i = n - 1; i >= 0; --i) {
+    const double inv = 1.0 / L[i * n + i];
+    for (int c = 0; c < m; ++c) X[i * m + c] *= inv;
+    for (int k = 0; k < i; ++k) {
+      const double l = L[i * n + k];
+      if (l == 0.0) continue;
+      for (int c = 0; c < m; ++c) X[k * m + c] -= l * X[i * m + c];
+    }
+  }
+}
+
+struct Group {  // frames [f0, f1) sharing one LM state (and one beta block when present)
+  int f0 = 0, f1 = 0;
+  double radius = 1e4, decrease_factor = 2.0;
+  double cost = 0.0;
+  bool active = true;
+  int termination = 1;  // 0 convergence, 1 no convergence (iterations), 2 failure
+  int iterations = 0, n_ok = 0, n_bad = 0;
+  double initial_cost = 0.0;
+  std::vector<double> scale;  // Jacobi column scaling, [nf*NP + nb]
+  std::string why;
+};
+
+struct Ctx {
+  bodyfit_problem* p;
+  bodyfit_layout lay;
+  int F, nS, nb;           // nb = size of the beta block (0 if absent)
+  bool beta_per_frame;
+  double beta_pose, beta_shape, lambda_t, huber;
+  int prior_rows;          // 0, 69 or 70
+  const double* prec_cho;  // [K][69][69] when the GMM prior is on
+  std::vector<int> kp_off; // per-frame keypoint offsets
+};
+
+double huber_rho(double delta, double s, double* rho1) {
+  const double b = delta * delta;
+  if (delta > 0.0 && s > b) {
+    const double rt = std::sqrt(s);
+    *rho1 = delta / rt;
+    return 2.0 * delta * rt - b;
+  }
+  *rho1 = 1.0;
+  return s;
+}
+
+// cost of a group from the residual vector (1/2 sum rho)
+double group_cost(const Ctx& c, const Group& g, const double* r) {
+  double cost = 0.0;
+  for (int k = c.kp_off[g.f0]; k < c.kp_off[g.f1]; ++k) {
+    double r1;
+    cost += 0.5 * huber_rho(c.huber, r[2 * k] * r[2 * k] + r[2 * k + 1] * r[2 * k + 1], &r1);
+  }
+  const int D = NP - 7;
+  if (c.prior_rows > 0) {
+    const double* rp = r + c.lay.reproj_rows;
+    for (int f = g.f0; f < g.f1; ++f)
+      for (int i = 0; i < c.prior_rows; ++i) cost += 0.5 * rp[(size_t)f * c.prior_rows + i] * rp[(size_t)f * c.prior_rows + i];
+  }
+  if (c.lay.shape_rows > 0) {
+    const double* rs = r + c.lay.reproj_rows + (size_t)c.F * c.prior_rows;
+    if (c.beta_per_frame) {
+      for (int f = g.f0; f < g.f1; ++f)
+        for (int i = 0; i < c.nS; ++i) cost += 0.5 * rs[(size_t)f * c.nS + i] * rs[(size_t)f * c.nS + i];
+    } else {
+      for (int i = 0; i < c.nS; ++i) cost += 0.5 * rs[i] * rs[i];
+    }
+  }
+  if (c.lay.temporal_rows > 0) {
+    const double* rt = r + c.lay.reproj_rows + (size_t)c.F * c.prior_rows + c.lay.shape_rows;
+    for (int f = g.f0; f + 1 < g.f1; ++f)
+      for (int i = 0; i < 6 + D; ++i) cost += 0.5 * rt[(size_t)f * (6 + D) + i] * rt[(size_t)f * (6 + D) + i];
+  }
+  return cost;
+}
+
+// Normal equations of one group in block form.
+struct Normal {
+  int nf, nb;
+  std::vector<double> A;   // [nf][NP*NP] diagonal blocks
+  std::vector<double> E;   // [nf-1][NP]   diagonal of the (diagonal) coupling blocks  A_{f,f+1} = diag(E_f)
+  std::vector<double> B;   // [nf][NP*nb]  frame x beta
+  std::vector<double> C;   // [nb*nb]
+  std::vector<double> g;   // [nf*NP + nb] gradient J^T r
+};
+
+void build_normal(const Ctx& c, const Group& g, const double* r, const double* J, const int* comp, Normal& N) {
+  const int nf = g.f1 - g.f0, nb = c.nb, ncols = c.lay.n_cols, D = NP - 7;
+  N.nf = nf; N.nb = nb;
+  N.A.assign((size_t)nf * NP * NP, 0.0);
+  N.E.assign((size_t)std::max(0, nf - 1) * NP, 0.0);
+  N.B.assign((size_t)nf * NP * std::max(nb, 1), 0.0);
+  N.C.assign((size_t)std::max(nb, 1) * std::max(nb, 1), 0.0);
+  N.g.assign((size_t)nf * NP + nb, 0.0);
+  for (int lf = 0; lf < nf; ++lf) {
+    const int f = g.f0 + lf;
+    double* A = &N.A[(size_t)lf * NP * NP];
+    double* B = &N.B[(size_t)lf * NP * std::max(nb, 1)];
+    double* gf = &N.g[(size_t)lf * NP];
+    double* gb = &N.g[(size_t)nf * NP];
+    for (int k = c.kp_off[f]; k < c.kp_off[f + 1]; ++k) {
+      const double r0 = r[2 * k], r1 = r[2 * k + 1];
+      double rho1;
+      huber_rho(c.huber, r0 * r0 + r1 * r1, &rho1);
+      for (int row = 0; row < 2; ++row) {
+        const double* Jr = J + (size_t)(2 * k + row) * ncols;
+        const double rr = (row ? r1 : r0) * rho1;
+        // sparsity: a keypoint row touches Sim3 + a few chain joints + beta
+        int nz[NP + 16], nnz = 0;
+        for (int i = 0; i < ncols; ++i)
+          if (Jr[i] != 0.0) nz[nnz++] = i;
+        for (int a = 0; a < nnz; ++a) {
+          const int ia = nz[a];
+          const double ja = Jr[ia] * rho1;
+          if (ia < NP) gf[ia] += Jr[ia] * rr; else gb[ia - NP] += Jr[ia] * rr;
+          for (int b2 = 0; b2 <= a; ++b2) {
+            const int ib = nz[b2];
+            const double v = ja * Jr[ib];
+            if (ia < NP) A[ia * NP + ib] += v;                       // ib <= ia < NP (lower triangle)
+            else if (ib < NP) B[ib * nb + (ia - NP)] += v;           // frame x beta
+            else N.C[(ia - NP) * nb + (ib - NP)] += v;               // beta x beta (lower)
+          }
+        }
+      }
+    }
+    // pose prior
+    if (c.prior_rows > 0) {
+      const double* rp = r + c.lay.reproj_rows + (size_t)f * c.prior_rows;
+      const double bp = c.beta_pose;
+      if (c.prec_cho) {
+        // J = beta_p L_k^T on the top 69 rows (include/Sim3BA.h:298-299): J^T J = beta_p^2 L L^T, J^T r = beta_p L r
+        const double* L = c.prec_cho + (size_t)comp[f] * D * D;
+        for (int i = 0; i < D; ++i) {
+          double gi = 0.0;
+          for (int k = 0; k <= i; ++k) gi += L[i * D + k] * rp[k];
+          gf[7 + i] += bp * gi;
+          for (int j = 0; j <= i; ++j) {
+            double s = 0.0;
+            const int kmax = std::min(i, j);
+            for (int k = 0; k <= kmax; ++k) s += L[i * D + k] * L[j * D + k];
+            A[(7 + i) * NP + 7 + j] += bp * bp * s;
+          }
+        }
+      } else {
+        for (int i = 0; i < D; ++i) { A[(7 + i) * NP + 7 + i] += bp * bp; gf[7 + i] += bp * rp[i]; }
+      }
+    }
+    // per-frame shape prior
+    if (c.lay.shape_rows > 0 && c.beta_per_frame) {
+      const double* rs = r + c.lay.reproj_rows + (size_t)c.F * c.prior_rows + (size_t)f * c.nS;
+      for (int i = 0; i < nb; ++i) { N.C[i * nb + i] += c.beta_shape * c.beta_shape; gb[i] += c.beta_shape * rs[i]; }
+    }
+    // temporal link f -> f+1 inside the group: rows lambda (a_f[src] - a_{f+1}[src])
+    if (c.lay.temporal_rows > 0 && lf + 1 < nf) {
+      const double* rt = r + c.lay.reproj_rows + (size_t)c.F * c.prior_rows + c.lay.shape_rows + (size_t)f * (6 + D);
+      const double lam = c.lambda_t;
+      double* A2 = &N.A[(size_t)(lf + 1) * NP * NP];
+      double* g2 = &N.g[(size_t)(lf + 1) * NP];
+      for (int i = 0; i < 6 + D; ++i) {
+        const int src = (i < 3) ? (4 + i) : (i < 6 ? (1 + (i - 3)) : (7 + (i - 6)));
+        A[src * NP + src] += lam * lam;
+        A2[src * NP + src] += lam * lam;
+        N.E[(size_t)lf * NP + src] = -lam * lam;
+        gf[src] += lam * rt[i];
+        g2[src] -= lam * rt[i];
+      }
+    }
+  }
+  if (c.lay.shape_rows > 0 && !c.beta_per_frame) {
+    const double* rs = r + c.lay.reproj_rows + (size_t)c.F * c.prior_rows;
+    double* gb = &N.g[(size_t)nf * NP];
+    for (int i = 0; i < nb; ++i) { N.C[i * nb + i] += c.beta_shape * c.beta_shape; gb[i] += c.beta_shape * rs[i]; }
+  }
+  // mirror lower -> upper
+  for (int lf = 0; lf < nf; ++lf) {
+    double* A = &N.A[(size_t)lf * NP * NP];
+    for (int i = 0; i < NP; ++i)
+      for (int j = 0; j < i; ++j) A[j * NP + i] = A[i * NP + j];
+  }
+  for (int i = 0; i < nb; ++i)
+    for (int j = 0; j < i; ++j) N.C[j * nb + i] = N.C[i * nb + j];
+}
+
+// Solve (S H S + diag(clamp(diag(S H S)))/radius) ds = -S g for the scaled step, return d = S ds and the
+// model cost change  -d^T (g + 1/2 H d).  `free_mask` zeroes constant parameters.
+bool solve_step(const Normal& N, const std::vector<double>& scale, const unsigned char* constant, double radius,
+                std::vector<double>& d, double* model_change) {
+  const int nf = N.nf, nb = N.nb, n = nf * NP + nb;
+  std::vector<double> A(N.A), B(N.B), C(N.C), E(N.E), rhs(n);
+  auto is_const = [&](int idx) { return constant && idx < nf * NP && constant[idx % NP]; };
+  // scale, damp, pin constants
+  for (int lf = 0; lf < nf; ++lf) {
+    double* Af = &A[(size_t)lf * NP * NP];
+    const double* s = &scale[(size_t)lf * NP];
+    for (int i = 0; i < NP; ++i)
+      for (int j = 0; j < NP; ++j) Af[i * NP + j] *= s[i] * s[j];
+    if (nb)
+      for (int i = 0; i < NP; ++i)
+        for (int j = 0; j < nb; ++j) B[((size_t)lf * NP + i) * nb + j] *= s[i] * scale[(size_t)nf * NP + j];
+    if (lf + 1 < nf)
+      for (int i = 0; i < NP; ++i) E[(size_t)lf * NP + i] *= s[i] * scale[(size_t)(lf + 1) * NP + i];
+    for (int i = 0; i < NP; ++i) rhs[lf * NP + i] = -N.g[lf * NP + i] * s[i];
+    for (int i = 0; i < NP; ++i) {
+      if (constant && constant[i]) {
+        for (int j = 0; j < NP; ++j) { Af[i * NP + j] = 0.0; Af[j * NP + i] = 0.0; }
+        Af[i * NP + i] = 1.0;
+        for (int j = 0; j < nb; ++j) B[((size_t)lf * NP + i) * nb + j] = 0.0;
+        if (lf + 1 < nf) E[(size_t)lf * NP + i] = 0.0;
+        if (lf > 0) E[(size_t)(lf - 1) * NP + i] = 0.0;
+        rhs[lf * NP + i] = 0.0;
+      } else {
+        const double dg = std::min(std::max(Af[i * NP + i], 1e-6), 1e32);
+        Af[i * NP + i] += dg / radius;
+      }
+    }
+  }
+  for (int i = 0; i < nb; ++i) {
+    for (int j = 0; j < nb; ++j) C[i * nb + j] *= scale[(size_t)nf * NP + i] * scale[(size_t)nf * NP + j];
+    rhs[nf * NP + i] = -N.g[nf * NP + i] * scale[(size_t)nf * NP + i];
+  }
+  for (int i = 0; i < nb; ++i) C[i * nb + i] += std::min(std::max(C[i * nb + i], 1e-6), 1e32) / radius;
+  (void)is_const;
+
+  // block-tridiagonal Cholesky T = L L^T:  Ld_f = chol(A_f - Ls_{f-1} Ls_{f-1}^T),  Ls_f = diag(E_f) Ld_f^{-T}
+  // then forward substitution of the nb + 1 right-hand sides [B | rhs].
+  const int m = nb + 1;
+  std::vector<double> Ls((size_t)std::max(0, nf - 1) * NP * NP, 0.0);  // Ls_f: block (f+1, f)
+  std::vector<double> Y((size_t)nf * NP * m);                          // L^{-1} [B | rhs]
+  for (int lf = 0; lf < nf; ++lf) {
+    double* Af = &A[(size_t)lf * NP * NP];
+    double* Yf = &Y[(size_t)lf * NP * m];
+    for (int i = 0; i < NP; ++i) {
+      for (int j = 0; j < nb; ++j) Yf[i * m + j] = B[((size_t)lf * NP + i) * nb + j];
+      Yf[i * m + nb] = rhs[lf * NP + i];
+    }
+    if (lf > 0) {
+      const double* Lp = &Ls[(size_t)(lf - 1) * NP * NP];
+      const double* Yp = &Y[(size_t)(lf - 1) * NP * m];
+      for (int i = 0; i < NP; ++i)
+        for (int k = 0; k < NP; ++k) {
+          const double l = Lp[i * NP + k];
+          if (l == 0.0) continue;
+          for (int j = 0; j <= i; ++j) Af[i * NP + j] -= l * Lp[j * NP + k];
+          for (int j = 0; j < m; ++j) Yf[i * m + j] -= l * Yp[k * m + j];
+        }
+    }
+    if (!chol_inplace(Af, NP)) return false;
+    fwd_solve(Af, NP, Yf, m);
+    if (lf + 1 < nf) {
+      // Ls = diag(E) Ld^{-T}:  solve Ld X^T = diag(E)  ->  X = Ls
+      double* Lsf = &Ls[(size_t)lf * NP * NP];
+      std::vector<double> X((size_t)NP * NP, 0.0);
+      for (int i = 0; i < NP; ++i) X[i * NP + i] = E[(size_t)lf * NP + i];
+      fwd_solve(Af, NP, X.data(), NP);             // X = Ld^{-1} diag(E)
+      for (int i = 0; i < NP; ++i)
+        for (int j = 0; j < NP; ++j) Lsf[i * NP + j] = X[j * NP + i];   // transpose
+    }
+  }
+  // Schur complement on beta: S = C - Yb^T Yb, rb = rhs_b - Yb^T y
+  std::vector<double> db(nb, 0.0);
+  if (nb) {
+    std::vector<double> S(C), rb(nb);
+    for (int i = 0; i < nb; ++i) rb[i] = rhs[nf * NP + i];
+    for (int lf = 0; lf < nf; ++lf) {
+      const double* Yf = &Y[(size_t)lf * NP * m];
+      for (int k = 0; k < NP; ++k)
+        for (int i = 0; i < nb; ++i) {
+          const double yi = Yf[k * m + i];
+          if (yi == 0.0) continue;
+          rb[i] -= yi * Yf[k * m + nb];
+          for (int j = 0; j <= i; ++j) S[i * nb + j] -= yi * Yf[k * m + j];
+        }
+    }
+    if (!chol_inplace(S.data(), nb)) return false;
+    fwd_solve(S.data(), nb, rb.data(), 1);
+    bwd_solve(S.data(), nb, rb.data(), 1);
+    db = rb;
+  }
+  // back substitution:  z = y - Yb db ;  x = L^{-T} z  (block bidiagonal)
+  std::vector<double> ds(n, 0.0);
+  std::vector<double> z((size_t)nf * NP);
+  for (int lf = 0; lf < nf; ++lf)
+    for (int i = 0; i < NP; ++i) {
+      double v = Y[((size_t)lf * NP + i) * m + nb];
+      for (int j = 0; j < nb; ++j) v -= Y[((size_t)lf * NP + i) * m + j] * db[j];
+      z[lf * NP + i] = v;
+    }
+  for (int lf = nf - 1; lf >= 0; --lf) {
+    double* zf = &z[(size_t)lf * NP];
+    if (lf + 1 < nf) {
+      const double* Lsf = &Ls[(size_t)lf * NP * NP];   // block (lf+1, lf): contributes Ls^T x_{lf+1}
+      const double* xn = &ds[(size_t)(lf + 1) * NP];
+      for (int i = 0; i < NP; ++i)
+        for (int k = 0; k < NP; ++k) zf[k] -= Lsf[i * NP + k] * xn[i];
+    }
+    bwd_solve(&A[(size_t)lf * NP * NP], NP, zf, 1);
+    for (int i = 0; i < NP; ++i) ds[lf * NP + i] = zf[i];
+  }
+  for (int i = 0; i < nb; ++i) ds[nf * NP + i] = db[i];
+  // unscale and model change with the UNDAMPED, unscaled system:  -d^T g - 1/2 d^T H d
+  d.assign(n, 0.0);
+  for (int i = 0; i < n; ++i) d[i] = ds[i] * scale[i];
+  double dg = 0.0, dHd = 0.0;
+  for (int i = 0; i < n; ++i) dg += d[i] * N.g[i];
+  for (int lf = 0; lf < nf; ++lf) {
+    const double* Af = &N.A[(size_t)lf * NP * NP];
+    const double* x = &d[(size_t)lf * NP];
+    for (int i = 0; i < NP; ++i) {
+      double s = 0.0;
+      for (int j = 0; j < NP; ++j) s += Af[i * NP + j] * x[j];
+      for (int j = 0; j < nb; ++j) s += 2.0 * N.B[((size_t)lf * NP + i) * nb + j] * d[nf * NP + j];
+      if (lf + 1 < nf) s += 2.0 * N.E[(size_t)lf * NP + i] * d[(size_t)(lf + 1) * NP + i];
+      dHd += x[i] * s;
+    }
+  }
+  for (int i = 0; i < nb; ++i)
+    for (int j = 0; j < nb; ++j) dHd += d[nf * NP + i] * N.C[i * nb + j] * d[nf * NP + j];
+  *model_change = -dg - 0.5 * dHd;
+  return true;
+}
+
+}  // namespace
+
+extern "C" int bodyfit_solve(bodyfit_problem* p, double* frame_params, double* beta,
+                             const unsigned char* param_constant, int independent_frames,
+                             const bodyfit_fit_options* opt_in, bodyfit_fit_summary* summaries, int n_summaries) {
+  if (!p || !frame_params) return BODYFIT_ERR_INVALID;
+  bodyfit_solver_view view;
+  if (bodyfit_internal_solver_view(p, &view) != BODYFIT_OK) return BODYFIT_ERR_INVALID;
+  bodyfit_fit_options opt;
+  opt.max_iters = 100; opt.scale_lo = 0.3; opt.scale_hi = 3.0; opt.verbose = 0;
+  if (opt_in) opt = *opt_in;
+  Ctx c;
+  c.p = p;
+  if (bodyfit_problem_layout(p, &c.lay) != BODYFIT_OK) return BODYFIT_ERR_INVALID;
+  c.F = view.n_frames; c.nS = view.n_shape;
+  c.nb = c.lay.n_cols > NP ? view.n_shape : 0;
+  c.beta_per_frame = view.beta_per_frame != 0;
+  c.beta_pose = view.beta_pose; c.beta_shape = view.beta_shape; c.lambda_t = view.lambda_temporal;
+  c.huber = view.huber_delta;
+  c.prior_rows = c.lay.prior_rows_per_frame;
+  c.prec_cho = view.has_gmm ? view.prec_cho : nullptr;
+  c.kp_off.assign(view.kp_offset, view.kp_offset + c.F + 1);
+  if (view.n_joints != 24 || view.temporal_halo) return BODYFIT_ERR_INVALID;   // solver works on whole windows
+  if (c.nb && !beta) return BODYFIT_ERR_INVALID;
+  if (independent_frames && (c.lambda_t > 0.0 || (c.nb && !c.beta_per_frame))) return BODYFIT_ERR_INVALID;
+  if (!independent_frames && c.nb && c.beta_per_frame) return BODYFIT_ERR_INVALID;
+
+  const int F = c.F, nb = c.nb;
+  std::vector<Group> groups;
+  if (independent_frames) {
+    groups.resize(F);
+    for (int f = 0; f < F; ++f) { groups[f].f0 = f; groups[f].f1 = f + 1; }
+  } else {
+    groups.resize(1);
+    groups[0].f0 = 0; groups[0].f1 = F;
+  }
+  const size_t nbeta = nb ? (size_t)(c.beta_per_frame ? F * nb : nb) : 0;
+  std::vector<double> x(frame_params, frame_params + (size_t)F * NP), xb(nbeta);
+  if (nbeta) std::memcpy(xb.data(), beta, nbeta * sizeof(double));
+  std::vector<double> r((size_t)c.lay.total_rows), rn((size_t)c.lay.total_rows);
+  std::vector<double> J((size_t)c.lay.reproj_rows * c.lay.n_cols);
+  std::vector<int> comp(F, 0), compn(F, 0);
+  std::vector<double> xn(x), xbn(xb);
+  int rc = bodyfit_evaluate_batch(p, x.data(), nbeta ? xb.data() : nullptr, r.data(), J.data(), comp.data(), 1);
+  if (rc) return rc;
+  int n_sweeps = 1;
+  std::vector<Normal> normals(groups.size());
+  std::vector<char> normal_valid(groups.size(), 0), has_cand(groups.size(), 0);
+  std::vector<std::vector<double>> steps(groups.size());
+  std::vector<double> model_change(groups.size(), 0.0);
+  auto beta_of = [&](const Group& g, std::vector<double>& vb) -> double* {
+    return nb ? vb.data() + (c.beta_per_frame ? (size_t)g.f0 * nb : 0) : nullptr;
+  };
+  for (size_t gi = 0; gi < groups.size(); ++gi) {
+    Group& g = groups[gi];
+    g.cost = g.initial_cost = group_cost(c, g, r.data());
+    if (!std::isfinite(g.cost)) { g.active = false; g.termination = 2; g.why = "initial cost is not finite"; }
+  }
+  for (int it = 0; it < opt.max_iters; ++it) {
+    bool any_active = false, any_cand = false;
+    xn = x; xbn = xb;
+    for (size_t gi = 0; gi < groups.size(); ++gi) {
+      Group& g = groups[gi];
+      has_cand[gi] = 0;
+      if (!g.active) continue;
+      any_active = true;
+      const int nf = g.f1 - g.f0, n = nf * NP + nb;
+      if (!normal_valid[gi]) {
+        build_normal(c, g, r.data(), J.data(), comp.data(), normals[gi]);
+        normal_valid[gi] = 1;
+      }
+      const Normal& N = normals[gi];
+      if (g.scale.empty()) {   // Jacobi scaling from the first iterate
+        g.scale.assign(n, 1.0);
+        for (int lf = 0; lf < nf; ++lf)
+          for (int i = 0; i < NP; ++i) g.scale[lf * NP + i] = 1.0 / (1.0 + std::sqrt(N.A[(size_t)lf * NP * NP + i * NP + i]));
+        for (int i = 0; i < nb; ++i) g.scale[nf * NP + i] = 1.0 / (1.0 + std::sqrt(N.C[i * nb + i]));
+      }
+      // gradient tolerance (projected for the bounded scale)
+      double gmax = 0.0;
+      for (int lf = 0; lf < nf; ++lf)
+        for (int i = 0; i < NP; ++i) {
+          if (param_constant && param_constant[i]) continue;
+          double gi2 = N.g[lf * NP + i];
+          if (i == 0) {
+            const double s0 = x[(size_t)(g.f0 + lf) * NP];
+            const double proj = std::min(std::max(s0 - gi2, opt.scale_lo), opt.scale_hi);
+            gi2 = s0 - proj;
+          }
+          gmax = std::max(gmax, std::fabs(gi2));
+        }
+      for (int i = 0; i < nb; ++i) gmax = std::max(gmax, std::fabs(N.g[nf * NP + i]));
+      if (gmax <= 1e-10) { g.active = false; g.termination = 0; g.why = "gradient tolerance"; continue; }
+      if (!solve_step(N, g.scale, param_constant, g.radius, steps[gi], &model_change[gi])) {
+        g.radius /= g.decrease_factor; g.decrease_factor *= 2.0; ++g.n_bad; ++g.iterations;
+        if (g.radius < 1e-32) { g.active = false; g.termination = 2; g.why = "trust region collapsed"; }
+        continue;
+      }
+      std::vector<double>& d = steps[gi];
+      // candidate, projected onto the scale bounds; the model change is re-evaluated for the projected step
+      bool projected = false;
+      for (int lf = 0; lf < nf; ++lf) {
+        const size_t o = (size_t)(g.f0 + lf) * NP;
+        const double s_new = std::min(std::max(x[o] + d[lf * NP], opt.scale_lo), opt.scale_hi);
+        if (s_new != x[o] + d[lf * NP]) { d[lf * NP] = s_new - x[o]; projected = true; }
+        for (int i = 0; i < NP; ++i) xn[o + i] = x[o + i] + d[lf * NP + i];
+      }
+      if (nb) {
+        double* b0 = beta_of(g, xb);
+        double* b1 = beta_of(g, xbn);
+        for (int i = 0; i < nb; ++i) b1[i] = b0[i] + d[nf * NP + i];
+      }
+      if (projected) {
+        double dg = 0.0, dHd = 0.0;
+        for (int i = 0; i < n; ++i) dg += d[i] * N.g[i];
+        for (int lf = 0; lf < nf; ++lf) {
+          const double* Af = &N.A[(size_t)lf * NP * NP];
+          for (int i = 0; i < NP; ++i) {
+            double s = 0.0;
+            for (int j = 0; j < NP; ++j) s += Af[i * NP + j] * d[lf * NP + j];
+            for (int j = 0; j < nb; ++j) s += 2.0 * N.B[((size_t)lf * NP + i) * nb + j] * d[nf * NP + j];
+            if (lf + 1 < nf) s += 2.0 * N.E[(size_t)lf * NP + i] * d[(lf + 1) * NP + i];
+            dHd += d[lf * NP + i] * s;
+          }
+        }
+        for (int i = 0; i < nb; ++i)
+          for (int j = 0; j < nb; ++j) dHd += d[nf * NP + i] * N.C[i * nb + j] * d[nf * NP + j];
+        model_change[gi] = -dg - 0.5 * dHd;
+      }
+      // parameter tolerance
+      double dn = 0.0, xnorm = 0.0;
+      for (int i = 0; i < n; ++i) dn += d[i] * d[i];
+      for (int lf = 0; lf < nf; ++lf)
+        for (int i = 0; i < NP; ++i) xnorm += x[(size_t)(g.f0 + lf) * NP + i] * x[(size_t)(g.f0 + lf) * NP + i];
+      if (nb) { const double* b0 = beta_of(g, xb); for (int i = 0; i < nb; ++i) xnorm += b0[i] * b0[i]; }
+      if (std::sqrt(dn) <= 1e-8 * (std::sqrt(xnorm) + 1e-8)) {
+        g.active = false; g.termination = 0; g.why = "parameter tolerance";
+        for (int lf = 0; lf < nf; ++lf)
+          for (int i = 0; i < NP; ++i) xn[(size_t)(g.f0 + lf) * NP + i] = x[(size_t)(g.f0 + lf) * NP + i];
+        if (nb) std::memcpy(beta_of(g, xbn), beta_of(g, xb), nb * sizeof(double));
+        continue;
+      }
+      has_cand[gi] = 1;
+      any_cand = true;
+    }
+    if (!any_active) break;
+    if (!any_cand) continue;
+    rc = bodyfit_evaluate_batch(p, xn.data(), nbeta ? xbn.data() : nullptr, rn.data(), nullptr, compn.data(), 0);
+    if (rc) return rc;
+    ++n_sweeps;
+    bool any_accept = false;
+    for (size_t gi = 0; gi < groups.size(); ++gi) {
+      if (!has_cand[gi]) continue;
+      Group& g = groups[gi];
+      ++g.iterations;
+      const double new_cost = group_cost(c, g, rn.data());
+      const double change = g.cost - new_cost;
+      const double rho = change / model_change[gi];
+      const int nf = g.f1 - g.f0;
+      if (std::isfinite(new_cost) && model_change[gi] > 0.0 && rho > 1e-3) {
+        for (int lf = 0; lf < nf; ++lf)
+          std::memcpy(&x[(size_t)(g.f0 + lf) * NP], &xn[(size_t)(g.f0 + lf) * NP], NP * sizeof(double));
+        if (nb) std::memcpy(beta_of(g, xb), beta_of(g, xbn), nb * sizeof(double));
+        const double old_cost = g.cost;
+        g.cost = new_cost;
+        const double t = 2.0 * rho - 1.0;
+        g.radius = std::min(1e16, g.radius / std::max(1.0 / 3.0, 1.0 - t * t * t));
+        g.decrease_factor = 2.0;
+        ++g.n_ok;
+        normal_valid[gi] = 0;
+        any_accept = true;
+        if (std::fabs(change) < 1e-6 * old_cost) { g.active = false; g.termination = 0; g.why = "function tolerance"; }
+      } else {
+        g.radius /= g.decrease_factor; g.decrease_factor *= 2.0; ++g.n_bad;
+        if (g.radius < 1e-32) { g.active = false; g.termination = 2; g.why = "trust region collapsed"; }
+      }
+      if (opt.verbose && groups.size() == 1)
+        std::printf("[bodyfit] it %3d cost %.6e change %.3e rho %.3f radius %.3e\n", g.iterations, g.cost, change, rho, g.radius);
+    }
+    if (any_accept) {
+      rc = bodyfit_evaluate_batch(p, x.data(), nbeta ? xb.data() : nullptr, r.data(), J.data(), comp.data(), 1);
+      if (rc) return rc;
+      ++n_sweeps;
+    }
+  }
+  std::memcpy(frame_params, x.data(), x.size() * sizeof(double));
+  if (nbeta) std::memcpy(beta, xb.data(), nbeta * sizeof(double));
+  if (summaries) {
+    for (int i = 0; i < n_summaries && i < (int)groups.size(); ++i) {
+      const Group& g = groups[i];
+      bodyfit_fit_summary& s = summaries[i];
+      s.iterations = g.iterations; s.termination = g.termination;
+      s.usable = (g.termination != 2) ? 1 : 0;   // ceres::Solver::Summary::IsSolutionUsable
+      s.n_successful = g.n_ok; s.n_unsuccessful = g.n_bad;
+      s.initial_cost = g.initial_cost; s.final_cost = g.cost;
+      s.n_sweeps = n_sweeps;
+    }
+  }
+  return BODYFIT_OK;
+}

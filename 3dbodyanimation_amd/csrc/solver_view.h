@@ -1,0 +1,16 @@
+// solver_view.h — private view of a bodyfit_problem for the host solver (not part of the public ABI).
+#pragma once
+#ifdef __cplusplus
+extern "C" {
+#endif
+typedef struct bodyfit_solver_view {
+  int n_frames, n_joints, n_shape;
+  int beta_per_frame, has_gmm, temporal_halo;
+  double beta_pose, beta_shape, lambda_temporal, huber_delta;
+  const int* kp_offset;     /* [F+1] host */
+  const double* prec_cho;   /* [K][D][D] host, when has_gmm */
+} bodyfit_solver_view;
+int bodyfit_internal_solver_view(bodyfit_problem* p, bodyfit_solver_view* out);
+#ifdef __cplusplus
+}
+#endif

@@ -176,6 +176,32 @@ int bodyfit_forward(bodyfit_problem* p, const double* frame_params, const double
 double bodyfit_mean_pixel_error(int n_kp, const int* jid, const double* uv, const double* joints,
                                 double fx, double fy, double cx, double cy);
 
+/* ---- outer loop (what the reference hands to ceres::Solve) ------------------------------------
+ * Ceres-like trust-region Levenberg-Marquardt over one bodyfit_problem (see host_solver.cpp for the
+ * restated algorithm).  Every evaluation is one device sweep; the linear solve is a block-tridiagonal
+ * Cholesky with a Schur complement on the shared shape block.
+ *   frame_params [F][76] in/out, beta [nS] or [F][nS] in/out (NULL when n_cols == 76)
+ *   param_constant [76] flags or NULL: 1 = SetParameterBlockConstant (include/Sim3BA.h:608-611)
+ *   independent_frames 1: every frame is its own problem with its own LM state (3dba_single: frames
+ *   are fitted independently, src/main_single_frame.cpp:192); 0: one problem over all frames
+ *   (OptimizeMultiFrame).  summaries: one per problem (F or 1).                                  */
+typedef struct bodyfit_fit_options {
+  int max_iters;            /* ceres::Solver::Options::max_num_iterations */
+  double scale_lo, scale_hi;/* SetParameterLowerBound / UpperBound on the scale: 0.3, 3.0 */
+  int verbose;
+} bodyfit_fit_options;
+typedef struct bodyfit_fit_summary {
+  int iterations;           /* LM iterations (successful + unsuccessful) */
+  int termination;          /* 0 convergence, 1 iteration limit, 2 failure */
+  int usable;               /* Summary::IsSolutionUsable() */
+  int n_successful, n_unsuccessful;
+  int n_sweeps;             /* device evaluations issued by the whole solve */
+  double initial_cost, final_cost;
+} bodyfit_fit_summary;
+int bodyfit_solve(bodyfit_problem* p, double* frame_params, double* beta, const unsigned char* param_constant,
+                  int independent_frames, const bodyfit_fit_options* options, bodyfit_fit_summary* summaries,
+                  int n_summaries);
+
 const char* bodyfit_last_error(void);
 int bodyfit_device_count(void);
 

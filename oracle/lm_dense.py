@@ -1,0 +1,136 @@
+"""Dense numpy Levenberg-Marquardt over the oracle evaluator (TEST INFRASTRUCTURE ONLY).
+
+An independent restatement of the Ceres 1.14 trust-region LM the reference configures
+(include/Sim3BA.h:472-479, include/MultiFrameBA.h:144-151): full dense Jacobian of every
+residual block, Triggs-corrected Huber rows, Jacobi scaling, dense Cholesky of the damped normal equations.
+The product's solver (3dbodyanimation_amd/csrc/host_solver.cpp) implements the same published algorithm
+with a structured linear solve and the HIP evaluator; the parity tests compare the fitted parameters.
+PARITY UNPINNED w.r.t. a real Ceres build (Ceres is not available in this environment).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import oracle as O
+
+NP_ = 76
+
+
+def _rows(om, seq, x, beta, n_cols, use_shape, pose_blend, beta_pose, ogmm, beta_shape, lam, huber, want_jac):
+    """All residual rows (robustified) and the dense Jacobian of one problem with a shared beta."""
+    F = x.shape[0]
+    nb = n_cols - NP_
+    n = F * NP_ + nb
+    r, J = om.evaluate_batch(seq, x, beta if nb else np.zeros(10), n_cols, use_shape, pose_blend, mode=0,
+                             want_jac=want_jac)
+    K = len(r) // 2
+    s = r.reshape(K, 2)
+    sq = (s ** 2).sum(1)
+    rho = np.array([O.huber(huber, v) for v in sq]) if K else np.zeros((0, 3))
+    cost = 0.5 * rho[:, 0].sum() if K else 0.0
+    sw = np.sqrt(rho[:, 1]) if K else np.zeros(0)
+    res = [np.repeat(sw, 2) * r]
+    jac = []
+    if want_jac:
+        Jd = np.zeros((2 * K, n))
+        for f in range(F):
+            k0, k1 = seq.kp_offset[f], seq.kp_offset[f + 1]
+            Jd[2 * k0:2 * k1, f * NP_:(f + 1) * NP_] = J[2 * k0:2 * k1, :NP_]
+            if nb:
+                Jd[2 * k0:2 * k1, F * NP_:] = J[2 * k0:2 * k1, NP_:]
+        jac.append(np.repeat(sw, 2)[:, None] * Jd)
+    if beta_pose > 0:
+        for f in range(F):
+            rp, Jp, _ = O.pose_prior(ogmm, beta_pose, x[f, 7:], want_jac)
+            res.append(rp)
+            cost += 0.5 * rp @ rp
+            if want_jac:
+                Jf = np.zeros((len(rp), n)); Jf[:, f * NP_ + 7:(f + 1) * NP_] = Jp
+                jac.append(Jf)
+    if beta_shape > 0 and nb:
+        rs = beta_shape * beta
+        res.append(rs); cost += 0.5 * rs @ rs
+        if want_jac:
+            Jf = np.zeros((nb, n)); Jf[:, F * NP_:] = beta_shape * np.eye(nb)
+            jac.append(Jf)
+    if lam > 0:
+        src = np.concatenate([np.arange(4, 7), np.arange(1, 4), np.arange(7, NP_)])
+        for f in range(F - 1):
+            rt = lam * (x[f, src] - x[f + 1, src])
+            res.append(rt); cost += 0.5 * rt @ rt
+            if want_jac:
+                Jf = np.zeros((75, n))
+                Jf[np.arange(75), f * NP_ + src] = lam
+                Jf[np.arange(75), (f + 1) * NP_ + src] = -lam
+                jac.append(Jf)
+    return cost, np.concatenate(res), (np.concatenate(jac, 0) if want_jac else None)
+
+
+def solve(om, seq, x0, beta0, n_cols=86, use_shape=True, pose_blend=True, beta_pose=0.0, ogmm=None, beta_shape=0.0,
+          lam=0.0, huber=3.0, max_iters=100, constant=None, scale_bounds=(0.3, 3.0), verbose=False):
+    """One problem over all frames of `seq` with a shared beta.  Returns x, beta, info."""
+    F = x0.shape[0]
+    nb = n_cols - NP_
+    x = x0.copy(); beta = np.array(beta0, float).copy() if nb else np.zeros(0)
+    n = F * NP_ + nb
+    free = np.ones(n, bool)
+    if constant is not None:
+        for f in range(F):
+            free[f * NP_:(f + 1) * NP_] = ~np.asarray(constant, bool)
+    args = (n_cols, use_shape, pose_blend, beta_pose, ogmm, beta_shape, lam, huber)
+    cost, r, J = _rows(om, seq, x, beta, *args, True)
+    info = dict(initial_cost=cost, iterations=0, n_ok=0, n_bad=0, termination=1)
+    radius, dec = 1e4, 2.0
+    scale = None
+    for it in range(max_iters):
+        H = J.T @ J
+        g = J.T @ r
+        if scale is None:
+            scale = 1.0 / (1.0 + np.sqrt(np.diag(H)))
+        gp = g.copy()
+        for f in range(F):
+            s0 = x[f, 0]
+            gp[f * NP_] = s0 - np.clip(s0 - g[f * NP_], *scale_bounds)
+        if np.abs(gp[free]).max() <= 1e-10:
+            info["termination"] = 0; break
+        Hs = H * np.outer(scale, scale)
+        gs = g * scale
+        Hd = Hs + np.diag(np.clip(np.diag(Hs), 1e-6, 1e32) / radius)
+        idx = np.where(free)[0]
+        try:
+            L = np.linalg.cholesky(Hd[np.ix_(idx, idx)])
+            ds = np.zeros(n)
+            ds[idx] = -np.linalg.solve(L.T, np.linalg.solve(L, gs[idx]))
+        except np.linalg.LinAlgError:
+            radius /= dec; dec *= 2; info["n_bad"] += 1; info["iterations"] += 1
+            continue
+        d = ds * scale
+        xn = x + d[:F * NP_].reshape(F, NP_)
+        clipped = np.clip(xn[:, 0], *scale_bounds)
+        if np.any(clipped != xn[:, 0]):
+            d[np.arange(F) * NP_] = clipped - x[:, 0]
+            xn[:, 0] = clipped
+        bn = beta + d[F * NP_:] if nb else beta
+        model = -(d @ g) - 0.5 * d @ (H @ d)
+        if np.linalg.norm(d) <= 1e-8 * (np.sqrt((x ** 2).sum() + (beta ** 2).sum()) + 1e-8):
+            info["termination"] = 0; break
+        new_cost, rn, _ = _rows(om, seq, xn, bn, *args, False)
+        info["iterations"] += 1
+        change = cost - new_cost
+        rho = change / model
+        if np.isfinite(new_cost) and model > 0 and rho > 1e-3:
+            x, beta = xn, bn
+            old = cost
+            cost, r, J = _rows(om, seq, x, beta, *args, True)
+            radius = min(1e16, radius / max(1.0 / 3.0, 1.0 - (2 * rho - 1) ** 3)); dec = 2.0
+            info["n_ok"] += 1
+            if verbose:
+                print(f"[dense-lm] it {info['iterations']} cost {cost:.6e} rho {rho:.3f} radius {radius:.2e}")
+            if abs(change) < 1e-6 * old:
+                info["termination"] = 0; break
+        else:
+            radius /= dec; dec *= 2; info["n_bad"] += 1
+            if radius < 1e-32:
+                info["termination"] = 2; break
+    info["final_cost"] = cost
+    return x, beta, info
