@@ -6,84 +6,122 @@
 //                                blocks only, include/MultiFrameBA.h:64,102,110,117,128)
 //        out[1..10]  g_beta    = sum_kp rho' J_beta^T r   (+ shape-prior rows)
 //        out[11..65] H_bb (upper, row-major) = sum_kp rho' J_beta^T J_beta (+ beta_s^2 I)
-//     The 66 doubles are what the ranks all-reduce over xGMI.  Two deterministic stages (per-block
-//     partials in fixed order, then one block) so the result does not depend on atomics order.
+//     The 66 doubles are what the ranks all-reduce over xGMI.  H_bb and g_beta are one Gram product of the
+//     robustified [J_beta | r] rows on the f64 matrix cores; two deterministic stages (per-wave partials,
+//     then one workgroup summing them in fixed order), no atomics.
 // (2) k_regress: out[j][c] = sum_v reg[j][v] x[v][c]  (initialJointPos, jointShapeReg) by wave reductions.
 #include "bodyfit_device.h"
 
 namespace bodyfit {
 namespace {
 
-constexpr int kRedBlocks = 64;
-constexpr int kRedThreads = 128;  // 66 live entries
+typedef __attribute__((ext_vector_type(4))) double d4;
+constexpr int kRedWaves = 512;      // stage-1 wavefronts (one per workgroup)
+constexpr int kPartial = 256 + 2;   // 16x16 Gram tile + [huber cost, plain cost] per stage-1 wave
 
-__device__ inline void tri_index(int e, int& a, int& b) {  // e in [0,55) -> (a<=b) upper, row-major
-  int row = 0, rem = e;
-  while (rem >= 10 - row) { rem -= 10 - row; ++row; }
-  a = row; b = row + rem;
+__device__ inline double wave_sum64(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
 }
 
-__global__ __launch_bounds__(kRedThreads) void k_reduce_stage1(int K, int ncols, int npose, int nS, int total_rows,
-                                                                const double* __restrict__ r,
-                                                                const double* __restrict__ J, double delta,
-                                                                int shape_row0, int shape_rows, double beta_shape,
-                                                                double* __restrict__ partials) {
-  const int e = threadIdx.x;
-  const int nb = gridDim.x, b = blockIdx.x;
+// Stage 1.  The reprojection rows, robustified by sqrt(rho'), form Jhat = [sqrt(rho') J_beta | sqrt(rho') r]
+// ([2K x 11]).  Its Gram matrix Jhat^T Jhat holds H_bb (10x10), g_beta (column 10) in one symmetric product,
+// so it runs on the f64 matrix cores: v_mfma_f64_16x16x4_f64 with the SAME register as A and B operand
+// (A[i][k] = Jhat[row k][i], B[k][j] = Jhat[row k][j]), four rows per instruction, rows dealt to 256 waves.
+__global__ __launch_bounds__(64) void k_reduce_stage1(int K, int ncols, int npose, int nS, int total_rows,
+                                                       const double* __restrict__ r, const double* __restrict__ J,
+                                                       double delta, double* __restrict__ partials) {
+  const int lane = threadIdx.x, w = blockIdx.x, nw = gridDim.x;
+  const int col = lane & 15, kk = lane >> 4;
   const bool has_beta = (ncols > npose) && J;
-  int ia = 0, ib = 0;
-  if (e >= 11 && e < 66) tri_index(e - 11, ia, ib);
-  double acc = 0.0;
   const double d2 = delta * delta;
-  // keypoint blocks, contiguous chunk per block
-  const int per = (K + nb - 1) / nb;
-  const int k0 = b * per, k1 = min(K, k0 + per);
-  for (int k = k0; k < k1; ++k) {
-    const double r0 = r[2 * (size_t)k], r1 = r[2 * (size_t)k + 1];
-    const double sq = r0 * r0 + r1 * r1;
-    double rho = sq, rho1 = 1.0;
-    if (delta > 0.0 && sq > d2) {
-      const double rt = sqrt(sq);
-      rho = 2.0 * delta * rt - d2;
-      rho1 = delta / rt;
+  const int nrows = 2 * K;
+  const int steps = (nrows + 3) / 4;
+  const int per = (steps + nw - 1) / nw;
+  const int s0 = w * per, s1 = min(steps, s0 + per);
+  d4 acc = {0.0, 0.0, 0.0, 0.0};
+  double hub = 0.0;
+  if (has_beta) {
+    for (int sb = s0; sb < s1; sb += 4) {
+      double v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {   // four independent steps: their loads are in flight together
+        const int row = 4 * (sb + u) + kk;
+        v[u] = 0.0;
+        if (sb + u < s1 && row < nrows) {
+          const int k = row >> 1;
+          const double r0 = r[2 * (size_t)k], r1 = r[2 * (size_t)k + 1];
+          const double sq = r0 * r0 + r1 * r1;
+          const double rho1 = (delta > 0.0 && sq > d2) ? delta / sqrt(sq) : 1.0;
+          const double sw = sqrt(rho1);
+          if (col < nS) v[u] = sw * J[(size_t)row * ncols + npose + col];
+          else if (col == 10) v[u] = sw * ((row & 1) ? r1 : r0);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(v[u], v[u], acc, 0, 0, 0);
     }
-    if (e == 0) {
-      acc += 0.5 * rho;
-    } else if (has_beta && e < 66) {
-      const double* j0 = J + (size_t)(2 * k) * ncols + npose;
-      const double* j1 = j0 + ncols;
-      if (e < 11) {
-        if (e - 1 < nS) acc += rho1 * (j0[e - 1] * r0 + j1[e - 1] * r1);
-      } else if (ib < nS) {
-        acc += rho1 * (j0[ia] * j0[ib] + j1[ia] * j1[ib]);
+  }
+  // Huber cost of the keypoints and plain least squares of the remaining rows: lanes over rows
+  {
+    const int kper = (K + nw - 1) / nw;
+    const int k0 = w * kper, k1 = min(K, k0 + kper);
+    for (int k = k0 + lane; k < k1; k += 64) {
+      const double r0 = r[2 * (size_t)k], r1 = r[2 * (size_t)k + 1];
+      const double sq = r0 * r0 + r1 * r1;
+      hub += 0.5 * ((delta > 0.0 && sq > d2) ? 2.0 * delta * sqrt(sq) - d2 : sq);
+    }
+    const int rows = total_rows - nrows;
+    const int rper = (rows + nw - 1) / nw;
+    const int q0 = nrows + w * rper, q1 = min(total_rows, q0 + rper);
+    double pl = 0.0;
+    for (int q = q0 + lane; q < q1; q += 64) pl += 0.5 * r[q] * r[q];
+    hub = wave_sum64(hub);
+    pl = wave_sum64(pl);
+    if (lane == 0) { partials[(size_t)w * kPartial + 256] = hub; partials[(size_t)w * kPartial + 257] = pl; }
+  }
+  // D layout (f64 16x16): column = lane & 15, row = (lane >> 4) + 4 q
+#pragma unroll
+  for (int q = 0; q < 4; ++q) partials[(size_t)w * kPartial + (kk + 4 * q) * 16 + col] = acc[q];
+}
+
+// Stage 2: fixed-order sum of the per-wave partials (deterministic), then pack [cost, g(10), upper H(55)].
+__global__ __launch_bounds__(1024) void k_reduce_stage2(int nw, const double* __restrict__ partials, int shape_row0,
+                                                         int shape_rows, double beta_shape,
+                                                         const double* __restrict__ r, double* __restrict__ out) {
+  __shared__ double sred[4][kPartial];
+  const int tid = threadIdx.x;
+  for (int idx = tid; idx < 4 * kPartial; idx += 1024) {
+    const int slice = idx / kPartial, e = idx % kPartial;
+    double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // eight loads in flight per pass, summed in a fixed order
+    for (int w0 = slice; w0 < nw; w0 += 32) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int w = w0 + 4 * u;
+        a[u] += (w < nw) ? partials[(size_t)w * kPartial + e] : 0.0;
       }
     }
+    sred[slice][e] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
   }
-  // remaining rows (priors, temporal): plain least squares
-  if (e == 0) {
-    const int rows = total_rows - 2 * K;
-    const int rper = (rows + nb - 1) / nb;
-    const int q0 = 2 * K + b * rper, q1 = min(total_rows, q0 + rper);
-    for (int q = q0; q < q1; ++q) acc += 0.5 * r[q] * r[q];
-  }
-  // shared shape prior rows: J = beta_s I
-  if (b == 0 && shape_rows > 0 && e >= 1 && e < 66) {
-    if (e < 11) {
-      if (e - 1 < shape_rows) acc += beta_shape * r[shape_row0 + e - 1];
-    } else if (ia == ib && ia < shape_rows) {
-      acc += beta_shape * beta_shape;
+  __syncthreads();
+  if (tid < 66) {
+    auto G = [&](int i, int j) { return (sred[0][i * 16 + j] + sred[1][i * 16 + j]) + (sred[2][i * 16 + j] + sred[3][i * 16 + j]); };
+    double v;
+    if (tid == 0) {
+      v = (sred[0][256] + sred[1][256]) + (sred[2][256] + sred[3][256]) +
+          (sred[0][257] + sred[1][257]) + (sred[2][257] + sred[3][257]);
+    } else if (tid < 11) {
+      v = G(tid - 1, 10);
+      if (tid - 1 < shape_rows) v += beta_shape * r[shape_row0 + tid - 1];     // shared shape prior, J = beta_s I
+    } else {
+      int row = 0, rem = tid - 11;
+      while (rem >= 10 - row) { rem -= 10 - row; ++row; }
+      v = G(row, row + rem);
+      if (rem == 0 && row < shape_rows) v += beta_shape * beta_shape;
     }
+    out[tid] = v;
   }
-  if (e < 66) partials[(size_t)b * 66 + e] = acc;
-}
-
-__global__ __launch_bounds__(kRedThreads) void k_reduce_stage2(int nb, const double* __restrict__ partials,
-                                                                double* __restrict__ out) {
-  const int e = threadIdx.x;
-  if (e >= 66) return;
-  double acc = 0.0;
-  for (int b = 0; b < nb; ++b) acc += partials[(size_t)b * 66 + e];
-  out[e] = acc;
 }
 
 __global__ __launch_bounds__(256) void k_regress(int V, int ncol, const double* __restrict__ reg,
@@ -101,14 +139,15 @@ __global__ __launch_bounds__(256) void k_regress(int V, int ncol, const double* 
 
 }  // namespace
 
-int reduce_partials_doubles() { return kRedBlocks * 66; }
+int reduce_partials_doubles() { return kRedWaves * kPartial; }
 
 void launch_reduce_shared_ex(int K, int ncols, int npose, int nS, int total_rows, const double* d_r,
                              const double* d_J, double huber_delta, int shape_row0, int shape_rows,
                              double beta_shape, double* d_partials, double* d_out66, hipStream_t s) {
-  hipLaunchKernelGGL(k_reduce_stage1, dim3(kRedBlocks), dim3(kRedThreads), 0, s, K, ncols, npose, nS, total_rows, d_r,
-                     d_J, huber_delta, shape_row0, shape_rows, beta_shape, d_partials);
-  hipLaunchKernelGGL(k_reduce_stage2, dim3(1), dim3(kRedThreads), 0, s, kRedBlocks, d_partials, d_out66);
+  hipLaunchKernelGGL(k_reduce_stage1, dim3(kRedWaves), dim3(64), 0, s, K, ncols, npose, nS, total_rows, d_r, d_J,
+                     huber_delta, d_partials);
+  hipLaunchKernelGGL(k_reduce_stage2, dim3(1), dim3(1024), 0, s, kRedWaves, d_partials, shape_row0, shape_rows,
+                     beta_shape, d_r, d_out66);
 }
 
 void launch_regress(int nJ, int V, int ncol, const double* d_reg, const double* d_x, double* d_out, hipStream_t s) {
