@@ -645,6 +645,8 @@ int bodyfit_profile_sweep(bodyfit_problem* p, const double* d_frame_params, cons
   return rc;
 }
 
+int bodyfit_internal_fail(int code, const char* msg) { return fail(code, msg ? msg : ""); }
+
 int bodyfit_internal_solver_view(bodyfit_problem* p, bodyfit_solver_view* out) {
   if (!p || !out) return BODYFIT_ERR_INVALID;
   out->n_frames = p->d.F; out->n_joints = p->m->nJ; out->n_shape = p->m->nS;

@@ -387,7 +387,7 @@ bool solve_step(const Normal& N, const std::vector<double>& scale, const unsigne
 extern "C" int bodyfit_solve(bodyfit_problem* p, double* frame_params, double* beta,
                              const unsigned char* param_constant, int independent_frames,
                              const bodyfit_fit_options* opt_in, bodyfit_fit_summary* summaries, int n_summaries) {
-  if (!p || !frame_params) return BODYFIT_ERR_INVALID;
+  if (!p || !frame_params) return bodyfit_internal_fail(BODYFIT_ERR_INVALID, "bodyfit_solve: null argument");
   bodyfit_solver_view view;
   if (bodyfit_internal_solver_view(p, &view) != BODYFIT_OK) return BODYFIT_ERR_INVALID;
   bodyfit_fit_options opt;
@@ -404,10 +404,14 @@ extern "C" int bodyfit_solve(bodyfit_problem* p, double* frame_params, double* b
   c.prior_rows = c.lay.prior_rows_per_frame;
   c.prec_cho = view.has_gmm ? view.prec_cho : nullptr;
   c.kp_off.assign(view.kp_offset, view.kp_offset + c.F + 1);
-  if (view.n_joints != 24 || view.temporal_halo) return BODYFIT_ERR_INVALID;   // solver works on whole windows
-  if (c.nb && !beta) return BODYFIT_ERR_INVALID;
-  if (independent_frames && (c.lambda_t > 0.0 || (c.nb && !c.beta_per_frame))) return BODYFIT_ERR_INVALID;
-  if (!independent_frames && c.nb && c.beta_per_frame) return BODYFIT_ERR_INVALID;
+  if (view.n_joints != 24 || view.temporal_halo)
+    return bodyfit_internal_fail(BODYFIT_ERR_INVALID, "bodyfit_solve: needs a 24-joint model and a whole window (no halo)");
+  if (c.nb && !beta) return bodyfit_internal_fail(BODYFIT_ERR_INVALID, "bodyfit_solve: beta required (shape block present)");
+  if (independent_frames && c.F > 1 && (c.lambda_t > 0.0 || (c.nb && !c.beta_per_frame)))
+    return bodyfit_internal_fail(BODYFIT_ERR_INVALID,
+                                 "bodyfit_solve: independent frames cannot share beta or temporal links");
+  if (!independent_frames && c.F > 1 && c.nb && c.beta_per_frame)
+    return bodyfit_internal_fail(BODYFIT_ERR_INVALID, "bodyfit_solve: one problem over all frames needs a shared beta");
 
   const int F = c.F, nb = c.nb;
   std::vector<Group> groups;

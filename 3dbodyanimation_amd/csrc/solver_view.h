@@ -11,6 +11,7 @@ typedef struct bodyfit_solver_view {
   const double* prec_cho;   /* [K][D][D] host, when has_gmm */
 } bodyfit_solver_view;
 int bodyfit_internal_solver_view(bodyfit_problem* p, bodyfit_solver_view* out);
+int bodyfit_internal_fail(int code, const char* msg);   /* sets bodyfit_last_error(), returns code */
 #ifdef __cplusplus
 }
 #endif
