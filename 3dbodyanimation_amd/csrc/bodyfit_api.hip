@@ -97,6 +97,8 @@ struct bodyfit_problem {
   double* d_normal = nullptr;
   int* d_comp = nullptr;
   float* d_cloud = nullptr;
+  double* d_gmm_T = nullptr;   // [F][K][72] whitened residual of every component (GMM prior only)
+  double* d_gmm_v = nullptr;   // [F][K]
   // host copies
   std::vector<int> kp_offset, kp_id, kp_frame;
   std::vector<double> kp_uv;
@@ -145,13 +147,17 @@ int sweep(bodyfit_problem* p, const double* d_params, const double* d_beta, int 
   const bodyfit_problem_desc& D = p->desc;
   const bool priors = D.beta_pose > 0.0 || D.beta_shape > 0.0 || D.lambda_temporal > 0.0;
   if (ev) (void)hipEventRecord(ev[0], st);
+  // the priors only read the parameters: they fork onto the side stream first.  Their kernels are made of
+  // single-wave workgroups (GMM: one per (16 frames, component)) that co-reside with the one-workgroup-per-CU
+  // kernels below instead of claiming whole CUs.
   if (priors) {
     (void)hipEventRecord(p->ev_fork, st);
     (void)hipStreamWaitEvent(p->side, p->ev_fork, 0);
     if (ev) (void)hipEventRecord(ev[2], p->side);
     launch_priors(p->d, m->nJ, m->nS, d_params, d_beta, D.beta_pose, p->has_gmm ? &p->gmm : nullptr,
                   p->lay.shape_rows > 0 ? D.beta_shape : 0.0, D.lambda_temporal, p->n_pairs,
-                  p->d_r + p->row_prior, p->d_r + p->row_shape, p->d_r + p->row_temporal, p->d_comp, p->side);
+                  p->d_r + p->row_prior, p->d_r + p->row_shape, p->d_r + p->row_temporal, p->d_comp, p->d_gmm_T,
+                  p->d_gmm_v, p->side);
     if (ev) (void)hipEventRecord(ev[3], p->side);
     (void)hipEventRecord(p->ev_join, p->side);
   } else if (ev) {
@@ -424,6 +430,21 @@ int bodyfit_gmm_create(int K, int D, const double* weights, const double* means,
   g->d.K = K; g->d.D = D; g->d.resid_scale = resid_scale;
   HIP_TRY(g->mem.upload(&g->d.mean, g->mean));
   HIP_TRY(g->mem.upload(&g->d.prec_cho, g->prec_cho));
+  {
+    // B-fragment order of v_mfma_f64_16x16x4_f64 (B[k = lane>>4][j = lane&15]), two column tiles per
+    // 16-byte load: frag[k][ks][pair][lane][t] = L[4 ks + (lane>>4)][16 (2 pair + t) + (lane&15)], zero padded
+    std::vector<double> frag((size_t)K * 18 * 3 * 64 * 2, 0.0);
+    for (int k = 0; k < K; ++k)
+      for (int ks = 0; ks < 18; ++ks)
+        for (int pr = 0; pr < 3; ++pr)
+          for (int lane = 0; lane < 64; ++lane)
+            for (int t = 0; t < 2; ++t) {
+              const int r = 4 * ks + (lane >> 4), c = 16 * (2 * pr + t) + (lane & 15);
+              if (r < D && c < D && 2 * pr + t < 5)
+                frag[((((size_t)k * 18 + ks) * 3 + pr) * 64 + lane) * 2 + t] = g->prec_cho[((size_t)k * D + r) * D + c];
+            }
+    HIP_TRY(g->mem.upload(&g->d.prec_frag, frag));
+  }
   HIP_TRY(g->mem.upload(&g->d.neg_log_w, g->neg_log_w));
   *out = g.release();
   return BODYFIT_OK;
@@ -521,6 +542,10 @@ int bodyfit_problem_create(const bodyfit_model* m, const bodyfit_problem_desc* d
   HIP_TRY(hipMemset(p->d_r, 0, (size_t)std::max(1, L.total_rows) * sizeof(double)));
   HIP_TRY(hipMemset(p->d_comp, 0, (size_t)F * sizeof(int)));
   HIP_TRY(hipMemset(p->d_beta, 0, (size_t)std::max(1, desc->beta_per_frame ? F * nS : nS) * sizeof(double)));
+  if (p->has_gmm) {
+    HIP_TRY(p->mem.alloc(&p->d_gmm_T, (size_t)F * p->gmm.K * 72));
+    HIP_TRY(p->mem.alloc(&p->d_gmm_v, (size_t)F * p->gmm.K));
+  }
   if (desc->want_mesh) {
     const size_t nfa = (size_t)d.nFTiles * kPoseKSteps * 2 * 64 * 8;
     const size_t nba = (size_t)d.nFTiles * kShapeKSteps * 64;

@@ -65,6 +65,7 @@ struct DevGmm {
   int K, D;
   const double* mean;       // [K][D]
   const double* prec_cho;   // [K][D][D] lower
+  const double* prec_frag;  // [K][18 k-steps][3 column-tile pairs][64 lanes][2]: L in f64-MFMA B-fragment order
   const double* neg_log_w;  // [K]
   double resid_scale;
 };
@@ -88,7 +89,7 @@ void launch_frame_resjac(const DevModel& M, const DevProblem& P, const double* d
 void launch_priors(const DevProblem& P, int nJ, int nS, const double* d_params, const double* d_beta,
                    double beta_pose, const DevGmm* gmm /*host struct or null*/, double beta_shape,
                    double lambda_t, int n_pairs, double* d_r_prior, double* d_r_shape, double* d_r_temporal,
-                   int* d_comp, hipStream_t s);
+                   int* d_comp, double* d_gmm_T, double* d_gmm_v, hipStream_t s);
 void launch_mesh(const DevModel& M, const DevProblem& P, const MeshCoef& mc, float* d_cloud, hipStream_t s);
 void launch_reduce_shared_ex(int K, int ncols, int npose, int nS, int total_rows, const double* d_r,
                              const double* d_J, double huber_delta, int shape_row0, int shape_rows,

@@ -93,8 +93,17 @@ __device__ inline double wave_sum(double v) {
       Pb.dbg[((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16 + (i)] = t_;                  \
     }                                                                                         \
   } while (0)
+#define STAMP_REAL(i)                                                                         \
+  do {                                                                                        \
+    if (Pb.dbg && (threadIdx.x & 63) == 0) {                                                  \
+      unsigned long long t_;                                                                  \
+      asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");          \
+      Pb.dbg[((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16 + (i)] = t_;                  \
+    }                                                                                         \
+  } while (0)
 #else
 #define STAMP(i)
+#define STAMP_REAL(i)
 #endif
 
 constexpr int KC = 32;  // keypoints staged per chunk
@@ -168,6 +177,7 @@ __global__ __launch_bounds__(kThreads) void k_frame_resjac(DevModel M, DevProble
   unsigned* sAnc = reinterpret_cast<unsigned*>(sTab + TAB_ANC);
   int* sKpId = sTab + TAB_KPID;
 
+  STAMP_REAL(10);
   STAMP(0);
   // ---- A. small model tables, landmark weights and the frame's parameters into LDS --------------------
   if (tid < nJ) { sParent[tid] = M.parent[tid]; sAnc[tid] = M.anc_mask[tid]; }
@@ -602,6 +612,7 @@ __global__ __launch_bounds__(kThreads) void k_frame_resjac(DevModel M, DevProble
     }
   }
   STAMP(8);
+  STAMP_REAL(11);
 }
 
 }  // namespace

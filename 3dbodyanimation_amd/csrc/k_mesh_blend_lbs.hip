@@ -4,7 +4,7 @@
 //
 // Per workgroup: one tile of 32 vertices (MFMA N), all frames in tiles of 32 (MFMA M), K = blend
 // coefficients.  D[frame][vertex] per coordinate, accumulated in f32:
-//   C-in            v_template (centred on the rest root joint), exact
+//   template        v_template (centred on the rest root joint), added to the accumulators in the epilogue
 //   shape blend     v_mfma_f32_32x32x2_f32, K = 10 -> 5 steps, exact f32 (per-frame beta supported)
 //   pose blend      v_mfma_f32_32x32x16_bf16, K = 207 -> 13 steps, operands split hi+lo in bf16 and
 //                   three products hi.hi + hi.lo + lo.hi (relative product error <= 2^-16), 5.3x the
@@ -14,7 +14,8 @@
 //     upload) go HBM -> LDS by LDS-DMA (global_load_lds_dwordx4: 1 KiB contiguous per wave-instruction),
 //     once per workgroup, and are reused by all four waves for every frame tile;
 //   * A operands (pose-feature hi/lo, beta) come from L2 in fragment order, one 1 KiB load per k-step;
-//   * the skinning transforms of 8 frames (9 KiB, contiguous) are LDS-DMA'd per wave and gathered by
+//   * the skinning transforms of 8 frames (9 KiB, contiguous) are register-staged per wave (loads for the
+//     next 8 frames issued before the current 8 are skinned, written to LDS afterwards) and gathered by
 //     joint id with ds_read_b128; the blended vertices never touch HBM;
 //   * output rows are 384 contiguous bytes per frame (lane = vertex).
 // Eight waves per workgroup = two per SIMD, so one wave's LDS-DMA / store-retire waits (CDNA4 counts
@@ -36,6 +37,19 @@ constexpr int kWaves = 8;
 constexpr int kSkinBytes = kSkinRows * kMaxJoints * 48;          // 9,216
 constexpr int kLdsBytes = kPoseBytes + kShapeFloats * 4 + kWaves * kSkinBytes;   // 157,440
 
+#ifdef BODYFIT_STAMPS
+#define MSTAMP(i)                                                                             \
+  do {                                                                                        \
+    if (Pb.dbg && (threadIdx.x & 63) == 0) {                                                  \
+      unsigned long long t_;                                                                  \
+      asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");          \
+      Pb.dbg[((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 16 + (i)] = t_;                  \
+    }                                                                                         \
+  } while (0)
+#else
+#define MSTAMP(i)
+#endif
+
 __device__ inline void lds_dma_16(const void* g, void* l) {
   __builtin_amdgcn_global_load_lds(g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 }
@@ -43,8 +57,8 @@ __device__ inline void lds_dma_16(const void* g, void* l) {
 // One output row of the skinning epilogue.  R (compile-time) = accumulator register = frame row
 // (R & 3) + 8 (R >> 2) + 4 h of the tile; the row's 24 transforms sit at Trow in this wave's LDS slice.
 template <int R>
-__device__ __forceinline__ void skin_row(const f32x16 (&acc)[3], const unsigned char* Trow, const int (&jo)[4],
-                                         const float (&wgt)[4], float* __restrict__ o, bool live) {
+__device__ __forceinline__ void skin_row(const f32x16 (&acc)[3], const float (&vt)[3], const unsigned char* Trow,
+                                         const int (&jo)[4], const float (&wgt)[4], float* __restrict__ o, bool live) {
   float4 t0 = make_float4(0, 0, 0, 0), t1 = t0, t2 = t0;
 #pragma unroll
   for (int i = 0; i < kMeshNnz; ++i) {
@@ -55,12 +69,27 @@ __device__ __forceinline__ void skin_row(const f32x16 (&acc)[3], const unsigned 
     t1.x += w * a1.x; t1.y += w * a1.y; t1.z += w * a1.z; t1.w += w * a1.w;
     t2.x += w * a2.x; t2.y += w * a2.y; t2.z += w * a2.z; t2.w += w * a2.w;
   }
-  const float px = acc[0][R], py = acc[1][R], pz = acc[2][R];
+  const float px = acc[0][R] + vt[0], py = acc[1][R] + vt[1], pz = acc[2][R] + vt[2];
   if (live) {
     o[0] = t0.x * px + t0.y * py + t0.z * pz + t0.w;
     o[1] = t1.x * px + t1.y * py + t1.z * pz + t1.w;
     o[2] = t2.x * px + t2.y * py + t2.z * pz + t2.w;
   }
+}
+
+constexpr int kSkinVec = kSkinBytes / (64 * 16);   // uint4 per lane per 8-frame block = 9
+
+// issue the loads of one 8-frame block of skinning transforms (contiguous in HBM) into registers
+__device__ __forceinline__ void skin_load(const unsigned char* g, int nbytes, int lane, uint4 (&reg)[kSkinVec]) {
+#pragma unroll
+  for (int i = 0; i < kSkinVec; ++i) {
+    const int off = (i * 64 + lane) * 16;
+    reg[i] = (off < nbytes) ? *reinterpret_cast<const uint4*>(g + off) : make_uint4(0, 0, 0, 0);
+  }
+}
+__device__ __forceinline__ void skin_store(unsigned char* l, int lane, const uint4 (&reg)[kSkinVec]) {
+#pragma unroll
+  for (int i = 0; i < kSkinVec; ++i) *reinterpret_cast<uint4*>(l + (i * 64 + lane) * 16) = reg[i];
 }
 
 __global__ __launch_bounds__(64 * kWaves, 2) void k_mesh_blend_lbs(DevModel M, DevProblem Pb, MeshCoef mc,
@@ -73,6 +102,7 @@ __global__ __launch_bounds__(64 * kWaves, 2) void k_mesh_blend_lbs(DevModel M, D
   const int V = M.V, nJ = M.nJ, F = Pb.F;
   const bool pose = Pb.pose_blend && M.P > 0;
 
+  MSTAMP(0);
   unsigned char* sPose = lds;                                           // [ks][c][hl][64][16 B]
   float* sShape = reinterpret_cast<float*>(lds + kPoseBytes);           // [c][ks][64]
   unsigned char* sSkin = lds + kPoseBytes + kShapeFloats * 4 + wave * kSkinBytes;
@@ -103,22 +133,29 @@ __global__ __launch_bounds__(64 * kWaves, 2) void k_mesh_blend_lbs(DevModel M, D
   const uint4* feat = reinterpret_cast<const uint4*>(mc.featA);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  MSTAMP(1);
 
   for (int ftile = wave; ftile < Pb.nFTiles; ftile += kWaves) {
-    // kick off the first quarter's skinning transforms (frames ftile*32 .. +7), contiguous in HBM
+    // first 8-frame block of skinning transforms: loads in flight across the whole MFMA section
     const unsigned char* gskin = reinterpret_cast<const unsigned char*>(mc.skinT) + (size_t)ftile * 32 * nJ * 48;
     const int frames_left = F - ftile * 32;
-    {
-      const int nbytes = min(kSkinRows, frames_left) * nJ * 48;
-      for (int p = 0; p * 1024 < nbytes; ++p)
-        if (p * 1024 + lane * 16 < nbytes) lds_dma_16(gskin + p * 1024 + lane * 16, sSkin + p * 1024);
+    uint4 treg[kSkinVec];
+    skin_load(gskin, min(kSkinRows, frames_left) * nJ * 48, lane, treg);
+    // A fragments (pose-feature hi/lo, L2) run kAhead k-steps ahead of the MFMAs in a register ring
+    constexpr int kAhead = 5;
+    const uint4* fa = feat + ((size_t)ftile * kPoseKSteps * 2) * 64 + lane;
+    uint4 ahi[kPoseKSteps], alo[kPoseKSteps];
+    if (pose) {
+#pragma unroll
+      for (int ks = 0; ks < kAhead; ++ks) { ahi[ks] = fa[(size_t)ks * 128]; alo[ks] = fa[(size_t)ks * 128 + 64]; }
     }
 
     f32x16 acc[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[c][r] = vt[c];
+      for (int r = 0; r < 16; ++r) acc[c][r] = 0.0f;   // the template is added in the epilogue (a 16-wide
+                                                       // loop-invariant C-in per coordinate costs 48 VGPRs)
 
     // shape blend, exact f32
 #pragma unroll
@@ -132,15 +169,14 @@ __global__ __launch_bounds__(64 * kWaves, 2) void k_mesh_blend_lbs(DevModel M, D
     }
     // pose blend, bf16 hi/lo split; A fragments straight from L2, B fragments from LDS
     if (pose) {
-      // A fragments one k-step ahead in registers (keeps the wave under 256 VGPRs at two waves per SIMD)
-      const uint4* fa = feat + ((size_t)ftile * kPoseKSteps * 2) * 64 + lane;
-      uint4 ah = fa[0], al = fa[64];
-#pragma unroll 1
+#pragma unroll
       for (int ks = 0; ks < kPoseKSteps; ++ks) {
-        const int kn = min(ks + 1, kPoseKSteps - 1);
-        const uint4 nh = fa[(size_t)kn * 128], nl = fa[(size_t)kn * 128 + 64];
-        const bf16x8 a_hi = __builtin_bit_cast(bf16x8, ah);
-        const bf16x8 a_lo = __builtin_bit_cast(bf16x8, al);
+        if (ks + kAhead < kPoseKSteps) {
+          ahi[ks + kAhead] = fa[(size_t)(ks + kAhead) * 128];
+          alo[ks + kAhead] = fa[(size_t)(ks + kAhead) * 128 + 64];
+        }
+        const bf16x8 a_hi = __builtin_bit_cast(bf16x8, ahi[ks]);
+        const bf16x8 a_lo = __builtin_bit_cast(bf16x8, alo[ks]);
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
           const uint4* bp = reinterpret_cast<const uint4*>(sPose + (size_t)((ks * 3 + c) * 2) * 1024) + lane;
@@ -150,10 +186,11 @@ __global__ __launch_bounds__(64 * kWaves, 2) void k_mesh_blend_lbs(DevModel M, D
           acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, blo, acc[c], 0, 0, 0);
           acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo, bhi, acc[c], 0, 0, 0);
         }
-        ah = nh; al = nl;
+        asm volatile("" ::: "memory");   // keep the A ring at kAhead k-steps (no further hoisting: VGPR budget)
       }
     }
 
+    MSTAMP(2);
     // skinning epilogue, one frame row per step (lane = vertex): accumulator register r holds frame row
     // (r & 3) + 8 (r >> 2) + 4 h, so registers 4q..4q+3 cover rows 8q..8q+7 = one LDS-DMA'd quarter.
     // The runtime loop + switch keeps every row's 12 transform reads in its own scheduling region
@@ -162,41 +199,40 @@ __global__ __launch_bounds__(64 * kWaves, 2) void k_mesh_blend_lbs(DevModel M, D
     for (int r = 0; r < 16; ++r) {
       const int q = r >> 2, rr = r & 3;
       if (rr == 0) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this quarter's transforms have landed
+        // this block's transforms: registers -> this wave's LDS slice; next block's loads go in flight
+        skin_store(sSkin, lane, treg);
+        if (q < 3)
+          skin_load(gskin + (size_t)(q + 1) * kSkinRows * nJ * 48,
+                    max(0, min(kSkinRows, frames_left - (q + 1) * kSkinRows)) * nJ * 48, lane, treg);
         __builtin_amdgcn_wave_barrier();
+        if (q == 0) MSTAMP(3);
       }
       const int f = ftile * kFTile + q * 8 + rr + 4 * h;
       const unsigned char* Trow = sSkin + (rr + 4 * h) * (nJ * 48);
       float* o = cloud + ((size_t)f * V + v) * 3;
       const bool live = f < F && v < V;
       switch (r) {
-        case 0: skin_row<0>(acc, Trow, jo, wgt, o, live); break;
-        case 1: skin_row<1>(acc, Trow, jo, wgt, o, live); break;
-        case 2: skin_row<2>(acc, Trow, jo, wgt, o, live); break;
-        case 3: skin_row<3>(acc, Trow, jo, wgt, o, live); break;
-        case 4: skin_row<4>(acc, Trow, jo, wgt, o, live); break;
-        case 5: skin_row<5>(acc, Trow, jo, wgt, o, live); break;
-        case 6: skin_row<6>(acc, Trow, jo, wgt, o, live); break;
-        case 7: skin_row<7>(acc, Trow, jo, wgt, o, live); break;
-        case 8: skin_row<8>(acc, Trow, jo, wgt, o, live); break;
-        case 9: skin_row<9>(acc, Trow, jo, wgt, o, live); break;
-        case 10: skin_row<10>(acc, Trow, jo, wgt, o, live); break;
-        case 11: skin_row<11>(acc, Trow, jo, wgt, o, live); break;
-        case 12: skin_row<12>(acc, Trow, jo, wgt, o, live); break;
-        case 13: skin_row<13>(acc, Trow, jo, wgt, o, live); break;
-        case 14: skin_row<14>(acc, Trow, jo, wgt, o, live); break;
-        default: skin_row<15>(acc, Trow, jo, wgt, o, live); break;
+        case 0: skin_row<0>(acc, vt, Trow, jo, wgt, o, live); break;
+        case 1: skin_row<1>(acc, vt, Trow, jo, wgt, o, live); break;
+        case 2: skin_row<2>(acc, vt, Trow, jo, wgt, o, live); break;
+        case 3: skin_row<3>(acc, vt, Trow, jo, wgt, o, live); break;
+        case 4: skin_row<4>(acc, vt, Trow, jo, wgt, o, live); break;
+        case 5: skin_row<5>(acc, vt, Trow, jo, wgt, o, live); break;
+        case 6: skin_row<6>(acc, vt, Trow, jo, wgt, o, live); break;
+        case 7: skin_row<7>(acc, vt, Trow, jo, wgt, o, live); break;
+        case 8: skin_row<8>(acc, vt, Trow, jo, wgt, o, live); break;
+        case 9: skin_row<9>(acc, vt, Trow, jo, wgt, o, live); break;
+        case 10: skin_row<10>(acc, vt, Trow, jo, wgt, o, live); break;
+        case 11: skin_row<11>(acc, vt, Trow, jo, wgt, o, live); break;
+        case 12: skin_row<12>(acc, vt, Trow, jo, wgt, o, live); break;
+        case 13: skin_row<13>(acc, vt, Trow, jo, wgt, o, live); break;
+        case 14: skin_row<14>(acc, vt, Trow, jo, wgt, o, live); break;
+        default: skin_row<15>(acc, vt, Trow, jo, wgt, o, live); break;
       }
-      if (rr == 3 && q < 3) {
-        // every lane has consumed this quarter's transforms: the next quarter goes in flight
-        __builtin_amdgcn_wave_barrier();
-        const int nbytes = max(0, min(kSkinRows, frames_left - (q + 1) * kSkinRows)) * nJ * 48;
-        const unsigned char* g2 = gskin + (size_t)(q + 1) * kSkinRows * nJ * 48;
-        for (int p = 0; p * 1024 < nbytes; ++p)
-          if (p * 1024 + lane * 16 < nbytes) lds_dma_16(g2 + p * 1024 + lane * 16, sSkin + p * 1024);
-      }
+      if (rr == 3) __builtin_amdgcn_wave_barrier();   // every lane has read this block before it is overwritten
     }
     __builtin_amdgcn_wave_barrier();
+    MSTAMP(4);
   }
 }
 

@@ -25,7 +25,8 @@ b = torch.from_numpy(np.tile(seq.gt_beta, (F, 1))).cuda()
 for _ in range(5):
     prob.evaluate_device(x.data_ptr(), b.data_ptr(), True, None)
 torch.cuda.synchronize()
-t = buf.cpu().numpy().reshape(F, 4, 16)[:, :, :9].astype(np.float64)
+raw = buf.cpu().numpy().reshape(F, 4, 16)
+t = raw[:, :, :9].astype(np.float64)
 names = ["A tables", "B rodrigues/offsets", "C feat+chain walks", "C2 landmark rows", "D W/lmLBS/cam",
          "E mesh ops + lm jac terms", "F1 kp stage", "F2 jacobian sweep"]
 d = np.diff(t, axis=2)  # [F,4,8]
@@ -34,3 +35,12 @@ for i, n in enumerate(names):
     print(f"  {n:28s}", np.median(d[:, :, i], axis=0).astype(int), " max-wave median:", int(np.median(d[:, :, i].max(1))))
 tot = t[:, :, 8].max(1) - t[:, :, 0].min(1)
 print("block total (median):", int(np.median(tot)), "cycles")
+start = t[:, :, 0].min(1); end = t[:, :, 8].max(1)
+print("block duration cycles: min/median/p90/max", int(tot.min()), int(np.median(tot)), int(np.percentile(tot, 90)), int(tot.max()))
+print("start spread (cycles, relative to first block): median/max", int(np.median(start - start.min())), int((start - start.min()).max()))
+print("kernel span (first start -> last end):", int(end.max() - start.min()), "cycles")
+real = (raw[:, 0, 11] - raw[:, 0, 10]).astype(np.float64)   # 100 MHz ticks
+clk = (t[:, 0, 8] - t[:, 0, 0]) / real * 100e6
+print("in-kernel clock (GHz): median", round(float(np.median(clk)) / 1e9, 3), " block wall (us): median", round(float(np.median(real)) / 100, 2))
+rs = raw[:, 0, 10].astype(np.float64); re_ = raw[:, 0, 11].astype(np.float64)
+print("kernel span by s_memrealtime (us):", (re_.max() - rs.min()) / 100, " start spread (us):", (rs.max() - rs.min()) / 100)
