@@ -22,6 +22,7 @@
 #include <cstring>
 #include <limits>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/bodyfit.h"
@@ -71,6 +72,26 @@ void bwd_solve(const double* L, int n, double* X, int m) {
       for (int c = 0; c < m; ++c) X[k * m + c] -= l * X[i * m + c];
     }
   }
+}
+
+// Independent problems (one per frame in the batched single-frame mode) are solved on host threads: the
+// per-problem normal equations are 86 x 86, far too small to be worth a round trip each, and there are
+// hundreds of them per LM iteration.
+template <typename Fn>
+void parallel_groups(size_t n, Fn&& fn) {
+  const size_t hw = std::max(1u, std::thread::hardware_concurrency());
+  const size_t nt = std::min<size_t>(std::min<size_t>(hw, 64), n);
+  if (nt <= 1) {
+    for (size_t i = 0; i < n; ++i) fn(i);
+    return;
+  }
+  std::vector<std::thread> th;
+  th.reserve(nt);
+  for (size_t t = 0; t < nt; ++t)
+    th.emplace_back([&, t]() {
+      for (size_t i = t; i < n; i += nt) fn(i);
+    });
+  for (auto& x : th) x.join();
 }
 
 struct Group {  // frames [f0, f1) sharing one LM state (and one beta block when present)
@@ -433,7 +454,7 @@ extern "C" int bodyfit_solve(bodyfit_problem* p, double* frame_params, double* b
   if (rc) return rc;
   int n_sweeps = 1;
   std::vector<Normal> normals(groups.size());
-  std::vector<char> normal_valid(groups.size(), 0), has_cand(groups.size(), 0);
+  std::vector<char> normal_valid(groups.size(), 0), has_cand(groups.size(), 0), was_active(groups.size(), 0);
   std::vector<std::vector<double>> steps(groups.size());
   std::vector<double> model_change(groups.size(), 0.0);
   auto beta_of = [&](const Group& g, std::vector<double>& vb) -> double* {
@@ -447,11 +468,12 @@ extern "C" int bodyfit_solve(bodyfit_problem* p, double* frame_params, double* b
   for (int it = 0; it < opt.max_iters; ++it) {
     bool any_active = false, any_cand = false;
     xn = x; xbn = xb;
-    for (size_t gi = 0; gi < groups.size(); ++gi) {
+    auto process_group = [&](size_t gi) {
       Group& g = groups[gi];
       has_cand[gi] = 0;
-      if (!g.active) continue;
-      any_active = true;
+      was_active[gi] = 0;
+      if (!g.active) return;
+      was_active[gi] = 1;
       const int nf = g.f1 - g.f0, n = nf * NP + nb;
       if (!normal_valid[gi]) {
         build_normal(c, g, r.data(), J.data(), comp.data(), normals[gi]);
@@ -478,11 +500,11 @@ extern "C" int bodyfit_solve(bodyfit_problem* p, double* frame_params, double* b
           gmax = std::max(gmax, std::fabs(gi2));
         }
       for (int i = 0; i < nb; ++i) gmax = std::max(gmax, std::fabs(N.g[nf * NP + i]));
-      if (gmax <= 1e-10) { g.active = false; g.termination = 0; g.why = "gradient tolerance"; continue; }
+      if (gmax <= 1e-10) { g.active = false; g.termination = 0; g.why = "gradient tolerance"; return; }
       if (!solve_step(N, g.scale, param_constant, g.radius, steps[gi], &model_change[gi])) {
         g.radius /= g.decrease_factor; g.decrease_factor *= 2.0; ++g.n_bad; ++g.iterations;
         if (g.radius < 1e-32) { g.active = false; g.termination = 2; g.why = "trust region collapsed"; }
-        continue;
+        return;
       }
       std::vector<double>& d = steps[gi];
       // candidate, projected onto the scale bounds; the model change is re-evaluated for the projected step
@@ -526,11 +548,12 @@ extern "C" int bodyfit_solve(bodyfit_problem* p, double* frame_params, double* b
         for (int lf = 0; lf < nf; ++lf)
           for (int i = 0; i < NP; ++i) xn[(size_t)(g.f0 + lf) * NP + i] = x[(size_t)(g.f0 + lf) * NP + i];
         if (nb) std::memcpy(beta_of(g, xbn), beta_of(g, xb), nb * sizeof(double));
-        continue;
+        return;
       }
       has_cand[gi] = 1;
-      any_cand = true;
-    }
+    };
+    parallel_groups(groups.size(), process_group);
+    for (size_t gi = 0; gi < groups.size(); ++gi) { any_active |= was_active[gi] != 0; any_cand |= has_cand[gi] != 0; }
     if (!any_active) break;
     if (!any_cand) continue;
     rc = bodyfit_evaluate_batch(p, xn.data(), nbeta ? xbn.data() : nullptr, rn.data(), nullptr, compn.data(), 0);

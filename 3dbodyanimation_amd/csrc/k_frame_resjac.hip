@@ -189,7 +189,22 @@ __global__ __launch_bounds__(kThreads) void k_frame_resjac(DevModel M, DevProble
     reinterpret_cast<int*>(L + LM_J)[i] = M.lm_wj[it];
     if (i == 0) L[LM_NW] = (double)M.lm_woff[l];   // weight count
   }
-  for (int i = tid; i < nJ * 3 * nS; i += kThreads) { sDS[i] = M.dS[i]; sSc[i] = M.Sc[i]; }
+  {
+    // 720 = 24 x 3 x 10 doubles each: fixed 3 predicated passes so all six loads are in flight together
+    double t0[3], t1[3];
+    const int nds = nJ * 3 * nS;
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      const int i = tid + u * kThreads;
+      t0[u] = (i < nds) ? M.dS[i] : 0.0;
+      t1[u] = (i < nds) ? M.Sc[i] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      const int i = tid + u * kThreads;
+      if (i < nds) { sDS[i] = t0[u]; sSc[i] = t1[u]; }
+    }
+  }
   {
     const int k_begin0 = Pb.kp_offset[f], nk0 = min(KC, Pb.kp_offset[f + 1] - k_begin0);
     if (tid < nk0) {

@@ -40,10 +40,21 @@ __global__ __launch_bounds__(64) void k_gmm_whiten(int F, int nJ, const double* 
   for (int s = 0; s < kKS; ++s)
 #pragma unroll
     for (int pr = 0; pr < 3; ++pr) b[s][pr] = Lf[(size_t)(s * 3 + pr) * 64];
-  // the 16 frames' pose vectors minus the component mean, through LDS (coalesced)
-  for (int i = lane; i < kTileF * D; i += 64) {
-    const int f = f0 + i / D, c = i % D;
-    sx[(i / D) * 72 + c] = (f < F) ? params[(size_t)f * npose + 7 + c] - g.mean[(size_t)k * D + c] : 0.0;
+  // the 16 frames' pose vectors minus the component mean, through LDS.  Fixed trip count (16 x 72 / 64 = 18
+  // fully unrolled, predicated iterations) so every load is in flight at once: a runtime-bounded loop here
+  // serialises one memory round trip per iteration.
+  {
+    double xv[18], mv[18];
+#pragma unroll
+    for (int it = 0; it < 18; ++it) {
+      const int idx = it * 64 + lane, fr = idx / 72, c = idx % 72;
+      const int f = f0 + fr;
+      const bool ok = c < D && f < F;
+      xv[it] = ok ? params[(size_t)f * npose + 7 + c] : 0.0;
+      mv[it] = (c < D) ? g.mean[(size_t)k * D + c] : 0.0;
+    }
+#pragma unroll
+    for (int it = 0; it < 18; ++it) sx[it * 64 + lane] = xv[it] - mv[it];
   }
   __syncthreads();
   d4 acc[kNT];

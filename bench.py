@@ -137,7 +137,10 @@ def main():
     d_params = torch.from_numpy(np.ascontiguousarray(params_h)).to(dev)
     d_beta = torch.from_numpy(np.ascontiguousarray(beta_h)).to(dev)
     d_red = torch.zeros(66, dtype=torch.float64, device=dev)
-    stream = torch.cuda.current_stream().cuda_stream
+    # a non-default stream for the sweep, the reduction and torch's collective
+    work_stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(work_stream)
+    stream = work_stream.cuda_stream
 
     def step():
         prob.evaluate_device(d_params.data_ptr(), d_beta.data_ptr(), True, stream)
@@ -178,6 +181,14 @@ def main():
             bytes_launch = F * (608 + 80 + 500 + 400 + 34_400 + 24 * 12 * 4 + 217 * 4)
         else:
             bytes_launch = 8 * 69 * 69 * 8 + F * (608 + 70 * 8)
+        traffic = None   # HBM bytes of the dominant kernel from the committed PMC passes (same workload only)
+        try:
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic_c3_256.json")))
+            key = {"mesh_blend_lbs": "k_mesh_blend_lbs", "frame_resjac": "k_frame_resjac", "priors": "k_gmm_whiten"}[dom]
+            if args.workload == pm["workload"] and F == pm["frames_per_gpu"]:
+                traffic = pm["kernels"][key]["hbm_bytes"]
+        except Exception:
+            traffic = None
         ach = bytes_launch / (prof[dom] * 1e-3) / 1e9
         whole = (B_MODEL_ALL + F * B_FRAME_ALL) / (ms_step * 1e-3) / 1e9
         out = {
@@ -187,7 +198,7 @@ def main():
             "dtype": "f64 residual/Jacobian; f32 mesh (f32 + split-bf16 MFMA blend)", "data": "synthetic",
             "config": {"workload": wl_name, "frames_per_gpu": F, "keypoints_per_frame": 25, "n_cols": 86},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                         "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": bytes_launch, "avg_launch_ms": prof[dom]},
             "kernel_ms": prof,
             "pipeline": {"algorithmic_bytes_per_step": B_MODEL_ALL + F * B_FRAME_ALL, "achieved_GBps": whole,
