@@ -49,7 +49,8 @@ class Layout(C.Structure):
 
 
 class FitOptions(C.Structure):
-    _fields_ = [("max_iters", C.c_int), ("scale_lo", C.c_double), ("scale_hi", C.c_double), ("verbose", C.c_int)]
+    _fields_ = [("max_iters", C.c_int), ("scale_lo", C.c_double), ("scale_hi", C.c_double), ("verbose", C.c_int),
+                ("solver", C.c_int)]
 
 
 class FitSummary(C.Structure):
@@ -308,7 +309,7 @@ class Problem:
         return joints, cloud
 
     def solve(self, frame_params, beta=None, constant=None, independent=False, max_iters=100, scale_bounds=(0.3, 3.0),
-              verbose=False):
+              verbose=False, solver=0):
         """Ceres-like LM over this problem (bodyfit_solve).  Returns fitted params, beta, [FitSummary]."""
         x = _c64(frame_params).copy()
         b = _c64(beta).copy() if beta is not None else None
@@ -317,7 +318,7 @@ class Problem:
             cst = np.ascontiguousarray(constant, dtype=np.uint8)
         n_sum = self.n_frames if independent else 1
         sums = (FitSummary * n_sum)()
-        opt = FitOptions(int(max_iters), float(scale_bounds[0]), float(scale_bounds[1]), int(verbose))
+        opt = FitOptions(int(max_iters), float(scale_bounds[0]), float(scale_bounds[1]), int(verbose), int(solver))
         _check(load_library().bodyfit_solve(self.h, _d(x), _d(b), cst.ctypes.data_as(C.POINTER(C.c_ubyte)) if cst is not None else None,
                                             int(independent), C.byref(opt), sums, n_sum))
         return x, b, list(sums)

@@ -73,7 +73,7 @@ struct bodyfit_model {
 struct bodyfit_gmm {
   int device = 0;
   DevGmm d{};
-  std::vector<double> prec_cho, neg_log_w, mean;
+  std::vector<double> prec_cho, neg_log_w, mean, prec;
   Allocs mem;
 };
 
@@ -140,8 +140,10 @@ bool chol_lower(std::vector<double>& A, int n) {
 // One evaluation sweep.  ev (optional, 6 events): [0] start, [1] after frame_resjac, [2]/[3] around the
 // priors on the side stream, [4] after the mesh kernel; [5] is recorded by the caller.
 int sweep(bodyfit_problem* p, const double* d_params, const double* d_beta, int want_jac, bool mesh,
-          hipStream_t st, hipEvent_t* ev = nullptr) {
+          hipStream_t st, hipEvent_t* ev = nullptr, double* r_base = nullptr, int* comp_out = nullptr) {
   const bodyfit_model* m = p->m;
+  double* d_r = r_base ? r_base : p->d_r;
+  int* d_comp = comp_out ? comp_out : p->d_comp;
   MeshCoef mc = p->mc;
   if (!mesh) mc = MeshCoef{};
   const bodyfit_problem_desc& D = p->desc;
@@ -156,7 +158,7 @@ int sweep(bodyfit_problem* p, const double* d_params, const double* d_beta, int 
     if (ev) (void)hipEventRecord(ev[2], p->side);
     launch_priors(p->d, m->nJ, m->nS, d_params, d_beta, D.beta_pose, p->has_gmm ? &p->gmm : nullptr,
                   p->lay.shape_rows > 0 ? D.beta_shape : 0.0, D.lambda_temporal, p->n_pairs,
-                  p->d_r + p->row_prior, p->d_r + p->row_shape, p->d_r + p->row_temporal, p->d_comp, p->d_gmm_T,
+                  d_r + p->row_prior, d_r + p->row_shape, d_r + p->row_temporal, d_comp, p->d_gmm_T,
                   p->d_gmm_v, p->side);
     if (ev) (void)hipEventRecord(ev[3], p->side);
     (void)hipEventRecord(p->ev_join, p->side);
@@ -164,7 +166,7 @@ int sweep(bodyfit_problem* p, const double* d_params, const double* d_beta, int 
     (void)hipEventRecord(ev[2], st);
     (void)hipEventRecord(ev[3], st);
   }
-  launch_frame_resjac(m->d, p->d, d_params, d_beta, p->d_r, want_jac ? p->d_J : nullptr, p->d_joints, mc,
+  launch_frame_resjac(m->d, p->d, d_params, d_beta, d_r, want_jac ? p->d_J : nullptr, p->d_joints, mc,
                       want_jac, st);
   if (ev) (void)hipEventRecord(ev[1], st);
   if (mesh) launch_mesh(m->d, p->d, p->mc, p->d_cloud, st);
@@ -421,6 +423,7 @@ int bodyfit_gmm_create(int K, int D, const double* weights, const double* means,
         Pm[(size_t)r * D + c] = s;
         Pm[(size_t)c * D + r] = s;
       }
+    g->prec.insert(g->prec.end(), Pm.begin(), Pm.end());
     if (!chol_lower(Pm, D)) return fail(BODYFIT_ERR_NUMERIC, "GMM precision is not SPD");
     std::memcpy(&g->prec_cho[(size_t)k * D * D], Pm.data(), (size_t)D * D * sizeof(double));
   }
@@ -430,6 +433,7 @@ int bodyfit_gmm_create(int K, int D, const double* weights, const double* means,
   g->d.K = K; g->d.D = D; g->d.resid_scale = resid_scale;
   HIP_TRY(g->mem.upload(&g->d.mean, g->mean));
   HIP_TRY(g->mem.upload(&g->d.prec_cho, g->prec_cho));
+  HIP_TRY(g->mem.upload(&g->d.prec, g->prec));
   {
     // B-fragment order of v_mfma_f64_16x16x4_f64 (B[k = lane>>4][j = lane&15]), two column tiles per
     // 16-byte load: frag[k][ks][pair][lane][t] = L[4 ks + (lane>>4)][16 (2 pair + t) + (lane&15)], zero padded
@@ -672,6 +676,92 @@ int bodyfit_profile_sweep(bodyfit_problem* p, const double* d_frame_params, cons
   return rc;
 }
 
+// Device-resident LM over independent frames (k_lm_batched.hip).  Called by bodyfit_solve.
+int bodyfit_internal_solve_batched_device(bodyfit_problem* p, double* frame_params, double* beta,
+                                          const unsigned char* param_constant, const bodyfit_fit_options* opt,
+                                          bodyfit_fit_summary* summaries, int n_summaries) {
+  const bodyfit_model* m = p->m;
+  const int F = p->d.F, npose = 7 + 3 * (m->nJ - 1), n = p->lay.n_cols, nb = n - npose;
+  HIP_TRY(hipSetDevice(m->device));
+  std::lock_guard<std::mutex> lock(p->mu);
+  p->cache_valid = false;
+  Allocs tmp;
+  LmState S{};
+  LmProblem P{};
+  P.F = F; P.ncols = n; P.kp_offset = p->d.kp_offset;
+  P.huber = p->desc.huber_delta; P.beta_pose = p->desc.beta_pose; P.beta_shape = p->desc.beta_shape;
+  P.scale_lo = opt->scale_lo; P.scale_hi = opt->scale_hi;
+  P.prior_rows = p->lay.prior_rows_per_frame; P.row_prior = p->row_prior;
+  P.shape_rows_per_frame = (p->lay.shape_rows > 0) ? m->nS : 0; P.row_shape = p->row_shape;
+  P.prec = p->has_gmm ? p->gmm.prec : nullptr; P.prec_cho = p->has_gmm ? p->gmm.prec_cho : nullptr;
+  double* d_r_new = nullptr;
+  int* d_comp_new = nullptr;
+  unsigned char* d_const = nullptr;
+  HIP_TRY(tmp.alloc(&S.x, (size_t)F * npose));
+  HIP_TRY(tmp.alloc(&S.beta, (size_t)F * std::max(nb, 1)));
+  HIP_TRY(tmp.alloc(&S.x_new, (size_t)F * npose));
+  HIP_TRY(tmp.alloc(&S.beta_new, (size_t)F * std::max(nb, 1)));
+  HIP_TRY(tmp.alloc(&S.radius, (size_t)F)); HIP_TRY(tmp.alloc(&S.dec, (size_t)F)); HIP_TRY(tmp.alloc(&S.cost, (size_t)F));
+  HIP_TRY(tmp.alloc(&S.initial_cost, (size_t)F)); HIP_TRY(tmp.alloc(&S.model, (size_t)F));
+  HIP_TRY(tmp.alloc(&S.scale, (size_t)F * 86));
+  HIP_TRY(tmp.alloc(&S.flags, (size_t)F)); HIP_TRY(tmp.alloc(&S.iters, (size_t)F)); HIP_TRY(tmp.alloc(&S.n_ok, (size_t)F));
+  HIP_TRY(tmp.alloc(&S.n_bad, (size_t)F)); HIP_TRY(tmp.alloc(&S.active_count, (size_t)1));
+  HIP_TRY(tmp.alloc(&d_r_new, (size_t)p->lay.total_rows));
+  HIP_TRY(tmp.alloc(&d_comp_new, (size_t)F));
+  HIP_TRY(hipMemset(S.active_count, 0, sizeof(int)));
+  HIP_TRY(hipMemcpy(S.x, frame_params, (size_t)F * npose * sizeof(double), hipMemcpyHostToDevice));
+  if (nb) HIP_TRY(hipMemcpy(S.beta, beta, (size_t)F * nb * sizeof(double), hipMemcpyHostToDevice));
+  if (param_constant) {
+    HIP_TRY(tmp.alloc(&d_const, (size_t)npose));
+    HIP_TRY(hipMemcpy(d_const, param_constant, (size_t)npose, hipMemcpyHostToDevice));
+  }
+  hipStream_t st = nullptr;
+  const double* bptr = nb ? S.beta : nullptr;
+  int rc = sweep(p, S.x, bptr, 1, false, st);
+  if (rc) return rc;
+  launch_lm_init(P, S, p->d_r, st);
+  int n_sweeps = 1;
+  for (int it = 0; it < opt->max_iters; ++it) {
+    launch_lm_step(P, S, p->d_r, p->d_J, p->d_comp, d_const, it == 0 ? 1 : 0, st);
+    rc = sweep(p, S.x_new, nb ? S.beta_new : nullptr, 0, false, st, nullptr, d_r_new, d_comp_new);
+    if (rc) return rc;
+    launch_lm_accept(P, S, d_r_new, st);
+    rc = sweep(p, S.x, bptr, 1, false, st);
+    if (rc) return rc;
+    n_sweeps += 2;
+    if ((it & 7) == 7 || it + 1 == opt->max_iters) {   // poll the number of frames still iterating
+      int active = 0;
+      HIP_TRY(hipMemcpyAsync(&active, S.active_count, sizeof(int), hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipStreamSynchronize(st));
+      if (active <= 0) break;
+    }
+  }
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(frame_params, S.x, (size_t)F * npose * sizeof(double), hipMemcpyDeviceToHost));
+  if (nb) HIP_TRY(hipMemcpy(beta, S.beta, (size_t)F * nb * sizeof(double), hipMemcpyDeviceToHost));
+  if (summaries && n_summaries > 0) {
+    std::vector<int> fl(F), itv(F), ok(F), bad(F);
+    std::vector<double> c0(F), c1(F);
+    HIP_TRY(hipMemcpy(fl.data(), S.flags, F * sizeof(int), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(itv.data(), S.iters, F * sizeof(int), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(ok.data(), S.n_ok, F * sizeof(int), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(bad.data(), S.n_bad, F * sizeof(int), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(c0.data(), S.initial_cost, F * sizeof(double), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(c1.data(), S.cost, F * sizeof(double), hipMemcpyDeviceToHost));
+    for (int f = 0; f < F && f < n_summaries; ++f) {
+      bodyfit_fit_summary& s2 = summaries[f];
+      s2.iterations = itv[f];
+      s2.termination = (fl[f] & kLmActive) ? 1 : ((fl[f] & kLmTermMask) >> kLmTermShift);
+      s2.usable = s2.termination != 2;
+      s2.n_successful = ok[f]; s2.n_unsuccessful = bad[f];
+      s2.n_sweeps = n_sweeps;
+      s2.initial_cost = c0[f]; s2.final_cost = c1[f];
+    }
+  }
+  return BODYFIT_OK;
+}
+
 int bodyfit_internal_fail(int code, const char* msg) { return fail(code, msg ? msg : ""); }
 
 int bodyfit_internal_solver_view(bodyfit_problem* p, bodyfit_solver_view* out) {
@@ -682,6 +772,9 @@ int bodyfit_internal_solver_view(bodyfit_problem* p, bodyfit_solver_view* out) {
   out->beta_pose = p->desc.beta_pose; out->beta_shape = p->desc.beta_shape;
   out->lambda_temporal = p->desc.lambda_temporal; out->huber_delta = p->desc.huber_delta;
   out->kp_offset = p->kp_offset.data();
+  out->max_kp_per_frame = 0;
+  for (int f = 0; f < p->d.F; ++f)
+    out->max_kp_per_frame = std::max(out->max_kp_per_frame, p->kp_offset[f + 1] - p->kp_offset[f]);
   out->prec_cho = p->has_gmm ? p->desc.gmm->prec_cho.data() : nullptr;
   return BODYFIT_OK;
 }

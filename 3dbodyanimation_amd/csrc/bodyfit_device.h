@@ -66,9 +66,39 @@ struct DevGmm {
   const double* mean;       // [K][D]
   const double* prec_cho;   // [K][D][D] lower
   const double* prec_frag;  // [K][18 k-steps][3 column-tile pairs][64 lanes][2]: L in f64-MFMA B-fragment order
+  const double* prec;       // [K][D][D] precision matrices L L^T (normal-equation block of the prior)
   const double* neg_log_w;  // [K]
   double resid_scale;
 };
+
+// ---- device-resident LM for batches of independent frames (k_lm_batched.hip) ------------------------
+constexpr int kLmActive = 1;        // flags: frame still iterating
+constexpr int kLmHasCand = 2;       //        a candidate point awaits its residual sweep
+constexpr int kLmTermShift = 4;     //        termination code (0 convergence, 1 iteration limit, 2 failure) << 4
+constexpr int kLmTermMask = 3 << kLmTermShift;
+
+struct LmProblem {
+  int F, ncols;
+  const int* kp_offset;       // [F+1] device
+  double huber, beta_pose, beta_shape, scale_lo, scale_hi;
+  int prior_rows, row_prior;              // pose prior rows per frame, first row in the residual vector
+  int shape_rows_per_frame, row_shape;    // per-frame shape prior rows
+  const double* prec;         // [K][69][69] or null (L2 prior)
+  const double* prec_cho;     // [K][69][69]
+};
+
+struct LmState {              // all device pointers, one entry (or row) per frame
+  double *x, *beta, *x_new, *beta_new;    // [F][76], [F][nb]
+  double *radius, *dec, *cost, *initial_cost, *model, *scale;   // scale [F][86]
+  int *flags, *iters, *n_ok, *n_bad;
+  int* active_count;
+};
+
+size_t lm_step_lds_bytes();
+void launch_lm_init(const LmProblem& P, const LmState& S, const double* d_r, hipStream_t s);
+void launch_lm_step(const LmProblem& P, const LmState& S, const double* d_r, const double* d_J, const int* d_comp,
+                    const unsigned char* d_constant, int first_iter, hipStream_t s);
+void launch_lm_accept(const LmProblem& P, const LmState& S, const double* d_r_new, hipStream_t s);
 
 // f32 -> bf16 round-to-nearest-even (finite inputs)
 __host__ __device__ inline uint16_t f32_to_bf16(float x) {

@@ -412,7 +412,7 @@ extern "C" int bodyfit_solve(bodyfit_problem* p, double* frame_params, double* b
   bodyfit_solver_view view;
   if (bodyfit_internal_solver_view(p, &view) != BODYFIT_OK) return BODYFIT_ERR_INVALID;
   bodyfit_fit_options opt;
-  opt.max_iters = 100; opt.scale_lo = 0.3; opt.scale_hi = 3.0; opt.verbose = 0;
+  opt.max_iters = 100; opt.scale_lo = 0.3; opt.scale_hi = 3.0; opt.verbose = 0; opt.solver = 0;
   if (opt_in) opt = *opt_in;
   Ctx c;
   c.p = p;
@@ -433,6 +433,14 @@ extern "C" int bodyfit_solve(bodyfit_problem* p, double* frame_params, double* b
                                  "bodyfit_solve: independent frames cannot share beta or temporal links");
   if (!independent_frames && c.F > 1 && c.nb && c.beta_per_frame)
     return bodyfit_internal_fail(BODYFIT_ERR_INVALID, "bodyfit_solve: one problem over all frames needs a shared beta");
+
+  // independent frames: the whole LM loop runs on the device (no per-iteration host round trip)
+  const bool device_ok = (independent_frames || c.F == 1) && c.lambda_t == 0.0 && (!c.nb || c.beta_per_frame || c.F == 1) &&
+                         view.max_kp_per_frame <= 32;
+  if (opt.solver == 2 && !device_ok)
+    return bodyfit_internal_fail(BODYFIT_ERR_INVALID, "bodyfit_solve: the device loop handles independent frames with <= 32 keypoints");
+  if (device_ok && opt.solver != 1)
+    return bodyfit_internal_solve_batched_device(p, frame_params, beta, param_constant, &opt, summaries, n_summaries);
 
   const int F = c.F, nb = c.nb;
   std::vector<Group> groups;

@@ -1,0 +1,372 @@
+// k_lm_batched.hip — device-resident Levenberg-Marquardt for batches of INDEPENDENT frames
+// (3dba_single fits every frame on its own: src/main_single_frame.cpp:192-246; BASELINE configs[1], [2]).
+//
+// The reference hands each frame to ceres::Solve (LM + DENSE_QR on a 86-column problem,
+// include/Sim3BA.h:472-479,641-647).  Here the whole LM state of every frame lives in HBM and one
+// workgroup per frame does what DENSE_QR did, per iteration, without a host round trip:
+//   k_lm_step    robustified Gram matrix  H = Jhat^T Jhat, g = Jhat^T rhat  on the f64 matrix cores
+//                (v_mfma_f64_16x16x4_f64, same register as A and B operand, Jhat staged in LDS), prior blocks
+//                added, Jacobi scaling, LM damping, Cholesky with the right-hand side carried as an extra row
+//                (forward substitution for free), backward substitution, step, model cost change, candidate
+//                point projected on the scale bounds
+//   k_lm_accept  cost at the candidate, step quality rho, accept/reject, trust-region radius update,
+//                Ceres' termination tests
+// Algorithm = host_solver.cpp's (Ceres 1.14 defaults); the host only launches
+// {sweep, step, residual sweep, accept} per iteration and polls the active-frame counter now and then.
+#include "bodyfit_device.h"
+
+namespace bodyfit {
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) double d4;
+constexpr int kN = 86;             // max unknowns per frame (76 + 10)
+constexpr int kLd = 88;            // LDS leading dimension of the (n+1) x (n+1) system
+constexpr int kRowsMax = 64;       // reprojection rows per frame handled on the device (32 keypoints)
+constexpr int kJLd = 96;           // Jhat leading dimension: 6 column tiles of 16 (86 columns + rhat + pad)
+static_assert(kRowsMax * kJLd <= kN * kLd, "Jhat must fit in the region it shares with the undamped H");
+
+__device__ inline double huber_rho(double delta, double s, double* rho1) {
+  const double b = delta * delta;
+  if (delta > 0.0 && s > b) {
+    const double rt = sqrt(s);
+    *rho1 = delta / rt;
+    return 2.0 * delta * rt - b;
+  }
+  *rho1 = 1.0;
+  return s;
+}
+
+__device__ inline double block_sum(double v, double* red, int tid) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  __syncthreads();
+  if ((tid & 63) == 0) red[tid >> 6] = v;
+  __syncthreads();
+  return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// cost of one frame from a residual vector: 1/2 sum rho(|r_kp|^2) + 1/2 |prior rows|^2 + 1/2 |shape rows|^2
+__device__ double frame_cost(const LmProblem& P, int f, const double* __restrict__ r, double* red, int tid) {
+  double acc = 0.0;
+  for (int k = P.kp_offset[f] + tid; k < P.kp_offset[f + 1]; k += 256) {
+    const double r0 = r[2 * (size_t)k], r1 = r[2 * (size_t)k + 1];
+    double r1d;
+    acc += 0.5 * huber_rho(P.huber, r0 * r0 + r1 * r1, &r1d);
+  }
+  for (int i = tid; i < P.prior_rows; i += 256) {
+    const double v = r[P.row_prior + (size_t)f * P.prior_rows + i];
+    acc += 0.5 * v * v;
+  }
+  if (P.shape_rows_per_frame > 0)
+    for (int i = tid; i < P.shape_rows_per_frame; i += 256) {
+      const double v = r[P.row_shape + (size_t)f * P.shape_rows_per_frame + i];
+      acc += 0.5 * v * v;
+    }
+  return block_sum(acc, red, tid);
+}
+
+__global__ __launch_bounds__(256) void k_lm_init(LmProblem P, LmState S, const double* __restrict__ r) {
+  __shared__ double red[4];
+  const int f = blockIdx.x, tid = threadIdx.x;
+  const double c = frame_cost(P, f, r, red, tid);
+  if (tid == 0) {
+    S.cost[f] = c;
+    S.initial_cost[f] = c;
+    S.radius[f] = 1e4;
+    S.dec[f] = 2.0;
+    int fl = kLmActive;
+    if (!(c == c) || c > 1e300) fl = (2 << kLmTermShift);   // non-finite initial cost: failure
+    S.flags[f] = fl;
+    S.iters[f] = 0; S.n_ok[f] = 0; S.n_bad[f] = 0;
+    if (fl & kLmActive) atomicAdd(S.active_count, 1);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_lm_step(LmProblem P, LmState S, const double* __restrict__ r,
+                                                  const double* __restrict__ J, const int* __restrict__ comp,
+                                                  const unsigned char* __restrict__ constant, int first_iter) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  double* M = sm;                          // (n+1) x kLd : damped scaled system, then its Cholesky factor
+  double* H0 = sm + (kN + 1) * kLd;        // n x kLd     : undamped unscaled H (aliases Jhat while H is built)
+  double* Jh = H0;                         // kRowsMax x kJLd
+  double* vec = H0 + kN * kLd;             // g[88], scale[88], ds[88], d[88], red[8]
+  double* g = vec;
+  double* sc = vec + 88;
+  double* ds = vec + 176;
+  double* dd = vec + 264;
+  double* red = vec + 352;
+  const int f = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int n = P.ncols, npose = kFrameParams, nb = n - npose;
+  int flags = S.flags[f];
+  if (!(flags & kLmActive)) {
+    if (tid == 0) S.flags[f] = flags & ~kLmHasCand;
+    return;
+  }
+  const int k0 = P.kp_offset[f], nrows = 2 * (P.kp_offset[f + 1] - k0);
+
+  // ---- Jhat = sqrt(rho') [J | r], zero padded to 16 x 6 column tiles and a multiple of 4 rows -------------
+  const int nrows4 = (nrows + 3) & ~3;
+  for (int i = tid; i < nrows4 * kJLd; i += 256) {
+    const int row = i / kJLd, c = i % kJLd;
+    double v = 0.0;
+    if (row < nrows && c <= n) {
+      const int k = k0 + (row >> 1);
+      const double r0 = r[2 * (size_t)k], r1 = r[2 * (size_t)k + 1];
+      double rho1;
+      huber_rho(P.huber, r0 * r0 + r1 * r1, &rho1);
+      const double sw = sqrt(rho1);
+      v = (c < n) ? sw * J[(size_t)(2 * k0 + row) * n + c] : sw * ((row & 1) ? r1 : r0);
+    }
+    Jh[i] = v;
+  }
+  __syncthreads();
+  // ---- Gram matrix on the f64 matrix cores: 21 lower tile pairs dealt to the 4 waves -----------------------
+  {
+    const int m = lane & 15, kk = lane >> 4;
+    int pair = 0;
+    for (int ti = 0; ti < 6; ++ti)
+      for (int tj = 0; tj <= ti; ++tj, ++pair) {
+        if ((pair & 3) != wave) continue;
+        d4 acc = {0.0, 0.0, 0.0, 0.0};
+        for (int s = 0; s < nrows4 / 4; ++s) {
+          const double a = Jh[(4 * s + kk) * kJLd + 16 * ti + m];
+          const double b = Jh[(4 * s + kk) * kJLd + 16 * tj + m];
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+        }
+        // D: column = lane & 15 (B side, tile tj), row = (lane >> 4) + 4 q (A side, tile ti)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int i = 16 * ti + kk + 4 * q, j = 16 * tj + m;
+          if (i <= n && j <= n && j <= i) M[i * kLd + j] = acc[q];   // row n (= rhat column) holds g
+        }
+      }
+  }
+  __syncthreads();
+  // ---- priors: pose prior on the 69 joint columns, shape prior on beta ---------------------------------------
+  const int D = npose - 7;
+  if (P.prior_rows > 0) {
+    const double* rp = r + P.row_prior + (size_t)f * P.prior_rows;
+    const double bp = P.beta_pose;
+    if (P.prec) {
+      const int kc = comp[f];
+      const double* Pm = P.prec + (size_t)kc * D * D;       // L L^T of the selected component
+      const double* L = P.prec_cho + (size_t)kc * D * D;
+      for (int e = tid; e < D * D; e += 256) {
+        const int i = e / D, j = e % D;
+        if (j <= i) M[(7 + i) * kLd + 7 + j] += bp * bp * Pm[e];
+      }
+      if (tid < D) {   // J^T r = beta_p L r[0:69]   (J = beta_p L^T on the top 69 rows, last row zero)
+        double a = 0.0;
+        for (int k = 0; k <= tid; ++k) a += L[(size_t)tid * D + k] * rp[k];
+        M[n * kLd + 7 + tid] += bp * a;
+      }
+    } else if (tid < D) {
+      M[(7 + tid) * kLd + 7 + tid] += bp * bp;
+      M[n * kLd + 7 + tid] += bp * rp[tid];
+    }
+  }
+  if (P.shape_rows_per_frame > 0 && tid >= 128 && tid - 128 < nb) {
+    const int i = tid - 128;
+    M[(npose + i) * kLd + npose + i] += P.beta_shape * P.beta_shape;
+    M[n * kLd + npose + i] += P.beta_shape * r[P.row_shape + (size_t)f * P.shape_rows_per_frame + i];
+  }
+  __syncthreads();
+  // ---- gradient, Jacobi scaling (fixed at the first iterate), undamped copy ----------------------------------
+  if (tid < n) {
+    g[tid] = M[n * kLd + tid];
+    if (first_iter) S.scale[(size_t)f * kN + tid] = 1.0 / (1.0 + sqrt(M[tid * kLd + tid]));
+    sc[tid] = first_iter ? 1.0 / (1.0 + sqrt(M[tid * kLd + tid])) : S.scale[(size_t)f * kN + tid];
+  }
+  __syncthreads();
+  for (int e = tid; e < n * n; e += 256) {
+    const int i = e / n, j = e % n;
+    H0[i * kLd + j] = (j <= i) ? M[i * kLd + j] : M[j * kLd + i];
+  }
+  // gradient tolerance (projected on the scale bounds), Ceres gradient_tolerance = 1e-10
+  double gm = 0.0;
+  if (tid < n && !(tid < npose && constant && constant[tid])) {
+    double gi = g[tid];
+    if (tid == 0) {
+      const double s0 = S.x[(size_t)f * npose];
+      gi = s0 - fmin(fmax(s0 - gi, P.scale_lo), P.scale_hi);
+    }
+    gm = fabs(gi);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) gm = fmax(gm, __shfl_xor(gm, off, 64));
+  __syncthreads();
+  if (lane == 0) red[wave] = gm;
+  __syncthreads();
+  gm = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+  if (gm <= 1e-10) {
+    if (tid == 0) {
+      S.flags[f] = (flags & ~(kLmActive | kLmHasCand | kLmTermMask));   // termination 0: convergence
+      atomicSub(S.active_count, 1);
+    }
+    return;
+  }
+  // ---- scaled, damped system with the right-hand side as row n ------------------------------------------------
+  const double radius = S.radius[f];
+  __syncthreads();
+  for (int e = tid; e < (n + 1) * n; e += 256) {
+    const int i = e / n, j = e % n;
+    if (j > i) continue;
+    const bool ci = i < npose && constant && constant[i];
+    const bool cj = j < npose && constant && constant[j];
+    double v;
+    if (i == n) v = cj ? 0.0 : -g[j] * sc[j];                 // rhs = -S g
+    else if (ci || cj) v = (i == j) ? 1.0 : 0.0;
+    else {
+      v = M[i * kLd + j] * sc[i] * sc[j];
+      if (i == j) v += fmin(fmax(v, 1e-6), 1e32) / radius;
+    }
+    M[i * kLd + j] = v;
+  }
+  __syncthreads();
+  // ---- Cholesky, right-looking, rhs row carried along (after column n-1 row n holds y = L^{-1} rhs) -----------
+  bool ok = true;
+  const int ty = tid >> 4, tx = tid & 15;
+  for (int j = 0; j < n; ++j) {
+    const double piv = M[j * kLd + j];
+    if (!(piv > 0.0)) { ok = false; break; }     // uniform: every thread reads the same LDS word
+    const double inv = 1.0 / sqrt(piv);
+    __syncthreads();
+    for (int i = j + tid; i <= n; i += 256) M[i * kLd + j] = (i == j) ? sqrt(piv) : M[i * kLd + j] * inv;
+    __syncthreads();
+    for (int i = j + 1 + ty; i <= n; i += 16) {
+      const double lij = M[i * kLd + j];
+      for (int k = j + 1 + tx; k <= i && k < n; k += 16) M[i * kLd + k] -= lij * M[k * kLd + j];
+    }
+    __syncthreads();
+  }
+  if (!ok) {
+    if (tid == 0) {
+      const double dec = S.dec[f];
+      const double rad = radius / dec;
+      S.radius[f] = rad;
+      S.dec[f] = dec * 2.0;
+      S.n_bad[f] += 1;
+      S.iters[f] += 1;
+      int fl = flags & ~kLmHasCand;
+      if (rad < 1e-32) { fl = (fl & ~(kLmActive | kLmTermMask)) | (2 << kLmTermShift); atomicSub(S.active_count, 1); }
+      S.flags[f] = fl;
+    }
+    return;
+  }
+  // ---- backward substitution ds = L^{-T} y (column oriented: row j of L is contiguous) ---------------------------
+  if (tid < n) ds[tid] = M[n * kLd + tid];
+  __syncthreads();
+  for (int j = n - 1; j >= 0; --j) {
+    const double xj = ds[j] / M[j * kLd + j];
+    __syncthreads();
+    if (tid == 0) ds[j] = xj;
+    if (tid < j) ds[tid] -= M[j * kLd + tid] * xj;
+    __syncthreads();
+  }
+  // ---- step, projection on the scale bounds, model change -dg - 1/2 d H d with the undamped H ----------------------
+  const double* xf = S.x + (size_t)f * npose;
+  if (tid < n) {
+    double di = ds[tid] * sc[tid];
+    if (tid == 0) {
+      const double s_new = fmin(fmax(xf[0] + di, P.scale_lo), P.scale_hi);
+      di = s_new - xf[0];
+    }
+    dd[tid] = di;
+  }
+  __syncthreads();
+  double part = 0.0, dn = 0.0, xn = 0.0;
+  if (tid < n) {
+    double hd = 0.0;
+    for (int j = 0; j < n; ++j) hd += H0[tid * kLd + j] * dd[j];
+    part = -dd[tid] * g[tid] - 0.5 * dd[tid] * hd;
+    dn = dd[tid] * dd[tid];
+    const double xv = (tid < npose) ? xf[tid] : S.beta[(size_t)f * nb + tid - npose];
+    xn = xv * xv;
+  }
+  const double model = block_sum(part, red, tid);
+  const double dnorm = sqrt(block_sum(dn, red, tid));
+  const double xnorm = sqrt(block_sum(xn, red, tid));
+  if (dnorm <= 1e-8 * (xnorm + 1e-8)) {      // Ceres parameter_tolerance
+    if (tid == 0) {
+      S.flags[f] = (flags & ~(kLmActive | kLmHasCand | kLmTermMask));
+      atomicSub(S.active_count, 1);
+    }
+    return;
+  }
+  if (tid < npose) S.x_new[(size_t)f * npose + tid] = xf[tid] + dd[tid];
+  else if (tid < n) S.beta_new[(size_t)f * nb + tid - npose] = S.beta[(size_t)f * nb + tid - npose] + dd[tid];
+  if (tid == 0) {
+    S.model[f] = model;
+    S.flags[f] = flags | kLmHasCand;
+  }
+}
+
+// candidate bookkeeping for frames without a candidate: x_new = x so the residual sweep stays well defined
+__global__ __launch_bounds__(128) void k_lm_fill(LmProblem P, LmState S) {
+  const int f = blockIdx.x, tid = threadIdx.x;
+  if (S.flags[f] & kLmHasCand) return;
+  const int npose = kFrameParams, nb = P.ncols - npose;
+  if (tid < npose) S.x_new[(size_t)f * npose + tid] = S.x[(size_t)f * npose + tid];
+  else if (tid - npose < nb) S.beta_new[(size_t)f * nb + tid - npose] = S.beta[(size_t)f * nb + tid - npose];
+}
+
+__global__ __launch_bounds__(256) void k_lm_accept(LmProblem P, LmState S, const double* __restrict__ r_new) {
+  __shared__ double red[4];
+  const int f = blockIdx.x, tid = threadIdx.x;
+  const int flags = S.flags[f];
+  if (!(flags & kLmHasCand)) return;
+  const double new_cost = frame_cost(P, f, r_new, red, tid);
+  const int npose = kFrameParams, nb = P.ncols - npose;
+  const double cost = S.cost[f], model = S.model[f];
+  const double change = cost - new_cost;
+  const double rho = change / model;
+  const bool accept = (new_cost == new_cost) && new_cost < 1e300 && model > 0.0 && rho > 1e-3;
+  if (accept) {
+    if (tid < npose) S.x[(size_t)f * npose + tid] = S.x_new[(size_t)f * npose + tid];
+    else if (tid - npose < nb) S.beta[(size_t)f * nb + tid - npose] = S.beta_new[(size_t)f * nb + tid - npose];
+  }
+  if (tid == 0) {
+    int fl = flags & ~kLmHasCand;
+    S.iters[f] += 1;
+    if (accept) {
+      S.cost[f] = new_cost;
+      const double t = 2.0 * rho - 1.0;
+      S.radius[f] = fmin(1e16, S.radius[f] / fmax(1.0 / 3.0, 1.0 - t * t * t));
+      S.dec[f] = 2.0;
+      S.n_ok[f] += 1;
+      if (fabs(change) < 1e-6 * cost) { fl &= ~(kLmActive | kLmTermMask); atomicSub(S.active_count, 1); }   // function tolerance
+    } else {
+      const double dec = S.dec[f];
+      const double rad = S.radius[f] / dec;
+      S.radius[f] = rad;
+      S.dec[f] = dec * 2.0;
+      S.n_bad[f] += 1;
+      if (rad < 1e-32) { fl = (fl & ~(kLmActive | kLmTermMask)) | (2 << kLmTermShift); atomicSub(S.active_count, 1); }
+    }
+    S.flags[f] = fl;
+  }
+}
+
+}  // namespace
+
+size_t lm_step_lds_bytes() { return (size_t)((kN + 1) * kLd + kN * kLd + 360) * sizeof(double); }
+
+void launch_lm_init(const LmProblem& P, const LmState& S, const double* d_r, hipStream_t s) {
+  hipLaunchKernelGGL(k_lm_init, dim3(P.F), dim3(256), 0, s, P, S, d_r);
+}
+void launch_lm_step(const LmProblem& P, const LmState& S, const double* d_r, const double* d_J, const int* d_comp,
+                    const unsigned char* d_constant, int first_iter, hipStream_t s) {
+  static bool attr = false;
+  const size_t lds = lm_step_lds_bytes();
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_lm_step), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr = true;
+  }
+  hipLaunchKernelGGL(k_lm_step, dim3(P.F), dim3(256), lds, s, P, S, d_r, d_J, d_comp, d_constant, first_iter);
+  hipLaunchKernelGGL(k_lm_fill, dim3(P.F), dim3(128), 0, s, P, S);
+}
+void launch_lm_accept(const LmProblem& P, const LmState& S, const double* d_r_new, hipStream_t s) {
+  hipLaunchKernelGGL(k_lm_accept, dim3(P.F), dim3(256), 0, s, P, S, d_r_new);
+}
+
+}  // namespace bodyfit

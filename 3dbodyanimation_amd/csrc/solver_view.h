@@ -7,11 +7,15 @@ typedef struct bodyfit_solver_view {
   int n_frames, n_joints, n_shape;
   int beta_per_frame, has_gmm, temporal_halo;
   double beta_pose, beta_shape, lambda_temporal, huber_delta;
+  int max_kp_per_frame;
   const int* kp_offset;     /* [F+1] host */
   const double* prec_cho;   /* [K][D][D] host, when has_gmm */
 } bodyfit_solver_view;
 int bodyfit_internal_solver_view(bodyfit_problem* p, bodyfit_solver_view* out);
-int bodyfit_internal_fail(int code, const char* msg);   /* sets bodyfit_last_error(), returns code */
+int bodyfit_internal_fail(int code, const char* msg);
+int bodyfit_internal_solve_batched_device(bodyfit_problem* p, double* frame_params, double* beta,
+                                          const unsigned char* param_constant, const bodyfit_fit_options* opt,
+                                          bodyfit_fit_summary* summaries, int n_summaries);   /* sets bodyfit_last_error(), returns code */
 #ifdef __cplusplus
 }
 #endif

@@ -189,6 +189,8 @@ typedef struct bodyfit_fit_options {
   int max_iters;            /* ceres::Solver::Options::max_num_iterations */
   double scale_lo, scale_hi;/* SetParameterLowerBound / UpperBound on the scale: 0.3, 3.0 */
   int verbose;
+  int solver;               /* 0 auto: independent frames iterate on the device (k_lm_batched), a shared-beta
+                               window on the host; 1 force the host loop; 2 force the device loop */
 } bodyfit_fit_options;
 typedef struct bodyfit_fit_summary {
   int iterations;           /* LM iterations (successful + unsuccessful) */

@@ -197,7 +197,7 @@ inline std::pair<bool, std::string> single(const AvatarModel& model, Avatar& ava
   if (freeze_unobserved)                                       // :608-611
     for (int j : {10, 11, 22, 23})
       if (nJ > j) for (int i = 0; i < 3; ++i) constant[7 + 3 * (j - 1) + i] = 1;
-  bodyfit_fit_options opt{max_iters, 0.3, 3.0, 0};             // bounds :450-451,613-614
+  bodyfit_fit_options opt{max_iters, 0.3, 3.0, 0, 0};          // bounds :450-451,613-614
   bodyfit_fit_summary sum{};
   const int rc = bodyfit_solve(pr, x.data(), shape_block ? avatar.w.data() : nullptr, constant.data(), 1, &opt, &sum, 1);
   bodyfit_problem_destroy(pr);
@@ -265,7 +265,7 @@ inline std::pair<bool, std::string> OptimizeMultiFrame(
       for (int i = 0; i < 3; ++i) xf[7 + 3 * (j - 1) + i] = poses[f].jointAA[j][i];
   }
   double* w_block = avatars.front()->w.data();                 // shared shape block (:67)
-  bodyfit_fit_options opt{max_iters, 0.3, 3.0, 0};
+  bodyfit_fit_options opt{max_iters, 0.3, 3.0, 0, 0};
   opt.scale_lo = -1e300; opt.scale_hi = 1e300;                 // the multi-frame problem sets no bounds
   bodyfit_fit_summary sum{};
   const int rc = bodyfit_solve(pr, x.data(), w_block, nullptr, 0, &opt, &sum, 1);
