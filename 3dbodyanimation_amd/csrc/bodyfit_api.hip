@@ -140,8 +140,12 @@ bool chol_lower(std::vector<double>& A, int n) {
 // One evaluation sweep.  ev (optional, 6 events): [0] start, [1] after frame_resjac, [2]/[3] around the
 // priors on the side stream, [4] after the mesh kernel; [5] is recorded by the caller.
 int sweep(bodyfit_problem* p, const double* d_params, const double* d_beta, int want_jac, bool mesh,
-          hipStream_t st, hipEvent_t* ev = nullptr, double* r_base = nullptr, int* comp_out = nullptr) {
+          hipStream_t st, hipEvent_t* ev = nullptr, double* r_base = nullptr, int* comp_out = nullptr,
+          const int* frame_flags = nullptr, int frame_mask = 0) {
   const bodyfit_model* m = p->m;
+  DevProblem dp = p->d;
+  dp.frame_flags = frame_flags;
+  dp.frame_mask = frame_mask;
   double* d_r = r_base ? r_base : p->d_r;
   int* d_comp = comp_out ? comp_out : p->d_comp;
   MeshCoef mc = p->mc;
@@ -166,7 +170,7 @@ int sweep(bodyfit_problem* p, const double* d_params, const double* d_beta, int 
     (void)hipEventRecord(ev[2], st);
     (void)hipEventRecord(ev[3], st);
   }
-  launch_frame_resjac(m->d, p->d, d_params, d_beta, d_r, want_jac ? p->d_J : nullptr, p->d_joints, mc,
+  launch_frame_resjac(m->d, dp, d_params, d_beta, d_r, want_jac ? p->d_J : nullptr, p->d_joints, mc,
                       want_jac, st);
   if (ev) (void)hipEventRecord(ev[1], st);
   if (mesh) launch_mesh(m->d, p->d, p->mc, p->d_cloud, st);
@@ -694,6 +698,7 @@ int bodyfit_internal_solve_batched_device(bodyfit_problem* p, double* frame_para
   P.prior_rows = p->lay.prior_rows_per_frame; P.row_prior = p->row_prior;
   P.shape_rows_per_frame = (p->lay.shape_rows > 0) ? m->nS : 0; P.row_shape = p->row_shape;
   P.prec = p->has_gmm ? p->gmm.prec : nullptr; P.prec_cho = p->has_gmm ? p->gmm.prec_cho : nullptr;
+  P.gmm_mean = p->has_gmm ? p->gmm.mean : nullptr; P.gmm_scale = p->has_gmm ? p->gmm.resid_scale : 0.0;
   double* d_r_new = nullptr;
   int* d_comp_new = nullptr;
   unsigned char* d_const = nullptr;
@@ -716,17 +721,25 @@ int bodyfit_internal_solve_batched_device(bodyfit_problem* p, double* frame_para
     HIP_TRY(hipMemcpy(d_const, param_constant, (size_t)npose, hipMemcpyHostToDevice));
   }
   hipStream_t st = nullptr;
+  HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+  struct StreamGuard { hipStream_t s; ~StreamGuard() { (void)hipStreamDestroy(s); } } sguard{st};
   const double* bptr = nb ? S.beta : nullptr;
   int rc = sweep(p, S.x, bptr, 1, false, st);
   if (rc) return rc;
   launch_lm_init(P, S, p->d_r, st);
   int n_sweeps = 1;
-  for (int it = 0; it < opt->max_iters; ++it) {
-    launch_lm_step(P, S, p->d_r, p->d_J, p->d_comp, d_const, it == 0 ? 1 : 0, st);
-    rc = sweep(p, S.x_new, nb ? S.beta_new : nullptr, 0, false, st, nullptr, d_r_new, d_comp_new);
-    if (rc) return rc;
+  auto iteration = [&](int first) -> int {
+    launch_lm_step(P, S, p->d_r, p->d_J, p->d_comp, d_const, first, st);
+    // candidate residuals only for frames that have a candidate; fresh Jacobians only for frames still active
+    int rc2 = sweep(p, S.x_new, nb ? S.beta_new : nullptr, 0, false, st, nullptr, d_r_new, d_comp_new, S.flags, kLmHasCand);
+    if (rc2) return rc2;
     launch_lm_accept(P, S, d_r_new, st);
-    rc = sweep(p, S.x, bptr, 1, false, st);
+    return sweep(p, S.x, bptr, 1, false, st, nullptr, nullptr, nullptr, S.flags, kLmActive);
+  };
+  // (a hipGraph replay of this ~20-launch iteration was measured slower than eager launches on ROCm 7.2:
+  //  256 frames to convergence 25.6 ms vs 23.0 ms; so the loop stays eager)
+  for (int it = 0; it < opt->max_iters; ++it) {
+    rc = iteration(it == 0 ? 1 : 0);
     if (rc) return rc;
     n_sweeps += 2;
     if ((it & 7) == 7 || it + 1 == opt->max_iters) {   // poll the number of frames still iterating

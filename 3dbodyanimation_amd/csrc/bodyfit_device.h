@@ -52,6 +52,8 @@ struct DevProblem {
   const double* R0;       // [F][9]
   double fx, fy, cx, cy;
   unsigned long long* dbg;   // diagnostic builds only (-DBODYFIT_STAMPS): per-phase s_memtime stamps
+  const int* frame_flags;    // optional [F]: frames whose bit `frame_mask` is clear are skipped (device LM)
+  int frame_mask;
 };
 
 // operands the per-frame kernel prepares for the mesh kernel
@@ -85,6 +87,8 @@ struct LmProblem {
   int shape_rows_per_frame, row_shape;    // per-frame shape prior rows
   const double* prec;         // [K][69][69] or null (L2 prior)
   const double* prec_cho;     // [K][69][69]
+  const double* gmm_mean;     // [K][69]
+  double gmm_scale;           // resid_scale of the mixture residual
 };
 
 struct LmState {              // all device pointers, one entry (or row) per frame

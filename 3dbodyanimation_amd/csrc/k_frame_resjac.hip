@@ -179,6 +179,7 @@ __global__ __launch_bounds__(kThreads) void k_frame_resjac(DevModel M, DevProble
 
   STAMP_REAL(10);
   STAMP(0);
+  if (Pb.frame_flags && !(Pb.frame_flags[f] & Pb.frame_mask)) return;   // frame already converged (device LM)
   // ---- A. small model tables, landmark weights and the frame's parameters into LDS --------------------
   if (tid < nJ) { sParent[tid] = M.parent[tid]; sAnc[tid] = M.anc_mask[tid]; }
   for (int it = tid; it < nL * kMaxLmNnz; it += kThreads) {

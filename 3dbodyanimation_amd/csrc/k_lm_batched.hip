@@ -106,18 +106,35 @@ __global__ __launch_bounds__(256) void k_lm_step(LmProblem P, LmState S, const d
 
   // ---- Jhat = sqrt(rho') [J | r], zero padded to 16 x 6 column tiles and a multiple of 4 rows -------------
   const int nrows4 = (nrows + 3) & ~3;
-  for (int i = tid; i < nrows4 * kJLd; i += 256) {
-    const int row = i / kJLd, c = i % kJLd;
-    double v = 0.0;
-    if (row < nrows && c <= n) {
-      const int k = k0 + (row >> 1);
+  if (tid < kRowsMax) {   // per-row robust weight sqrt(rho') and weighted residual (one round trip)
+    double sw = 0.0, rr = 0.0;
+    if (tid < nrows) {
+      const int k = k0 + (tid >> 1);
       const double r0 = r[2 * (size_t)k], r1 = r[2 * (size_t)k + 1];
       double rho1;
       huber_rho(P.huber, r0 * r0 + r1 * r1, &rho1);
-      const double sw = sqrt(rho1);
-      v = (c < n) ? sw * J[(size_t)(2 * k0 + row) * n + c] : sw * ((row & 1) ? r1 : r0);
+      sw = sqrt(rho1);
+      rr = sw * ((tid & 1) ? r1 : r0);
     }
-    Jh[i] = v;
+    ds[tid] = sw;                 // ds / dd are free until the solve
+    Jh[tid * kJLd + n] = rr;      // column n = rhat
+  }
+  __syncthreads();
+  {
+    // fixed trip count (kRowsMax * 88 / 256 = 22 predicated passes): all loads of J in flight together
+    double jv[22];
+#pragma unroll
+    for (int u = 0; u < 22; ++u) {
+      const int i = tid + u * 256, row = i / 88, c = i % 88;
+      jv[u] = (row < nrows && c < n) ? J[(size_t)(2 * k0 + row) * n + c] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < 22; ++u) {
+      const int i = tid + u * 256, row = i / 88, c = i % 88;
+      if (row < nrows4 && c != n) Jh[row * kJLd + c] = (row < nrows && c < n) ? ds[row] * jv[u] : 0.0;
+    }
+    for (int i = tid; i < nrows4 * (kJLd - 88); i += 256) Jh[(i / (kJLd - 88)) * kJLd + 88 + i % (kJLd - 88)] = 0.0;
+    if (tid >= nrows && tid < nrows4) Jh[tid * kJLd + n] = 0.0;
   }
   __syncthreads();
   // ---- Gram matrix on the f64 matrix cores: 21 lower tile pairs dealt to the 4 waves -----------------------
@@ -151,14 +168,28 @@ __global__ __launch_bounds__(256) void k_lm_step(LmProblem P, LmState S, const d
       const int kc = comp[f];
       const double* Pm = P.prec + (size_t)kc * D * D;       // L L^T of the selected component
       const double* L = P.prec_cho + (size_t)kc * D * D;
-      for (int e = tid; e < D * D; e += 256) {
-        const int i = e / D, j = e % D;
-        if (j <= i) M[(7 + i) * kLd + 7 + j] += bp * bp * Pm[e];
+      {
+        double pv[19];   // 69 * 69 = 4761 <= 19 * 256
+#pragma unroll
+        for (int u = 0; u < 19; ++u) {
+          const int e = tid + u * 256;
+          pv[u] = (e < D * D) ? Pm[e] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 19; ++u) {
+          const int e = tid + u * 256, i = e / D, j = e % D;
+          if (e < D * D && j <= i) M[(7 + i) * kLd + 7 + j] += bp * bp * pv[u];
+        }
       }
-      if (tid < D) {   // J^T r = beta_p L r[0:69]   (J = beta_p L^T on the top 69 rows, last row zero)
+      (void)L;
+      if (tid < D) {
+        // J^T r = beta_p L r[0:69] with r[0:69] = beta_p s L^T (x - mu)  ->  beta_p^2 s Prec (x - mu):
+        // one row of the precision matrix per thread, 69 independent loads
+        const double* xq = S.x + (size_t)f * npose + 7;
         double a = 0.0;
-        for (int k = 0; k <= tid; ++k) a += L[(size_t)tid * D + k] * rp[k];
-        M[n * kLd + 7 + tid] += bp * a;
+#pragma unroll
+        for (int k = 0; k < 69; ++k) a += (k < D) ? Pm[(size_t)tid * D + k] * (xq[k] - P.gmm_mean[(size_t)kc * D + k]) : 0.0;
+        M[n * kLd + 7 + tid] += bp * bp * P.gmm_scale * a;
       }
     } else if (tid < D) {
       M[(7 + tid) * kLd + 7 + tid] += bp * bp;
@@ -227,15 +258,27 @@ __global__ __launch_bounds__(256) void k_lm_step(LmProblem P, LmState S, const d
   bool ok = true;
   const int ty = tid >> 4, tx = tid & 15;
   for (int j = 0; j < n; ++j) {
-    const double piv = M[j * kLd + j];
-    if (!(piv > 0.0)) { ok = false; break; }     // uniform: every thread reads the same LDS word
-    const double inv = 1.0 / sqrt(piv);
+    const double piv = M[j * kLd + j];           // same LDS word for every thread: uniform branch
+    if (!(piv > 0.0)) { ok = false; break; }
+    const double rt = sqrt(piv), inv = 1.0 / rt;
+    // column j below the diagonal (the diagonal itself is finalised after the barrier: nobody reads it before)
+    for (int i = j + 1 + tid; i <= n; i += 256) M[i * kLd + j] *= inv;
     __syncthreads();
-    for (int i = j + tid; i <= n; i += 256) M[i * kLd + j] = (i == j) ? sqrt(piv) : M[i * kLd + j] * inv;
-    __syncthreads();
+    if (tid == 0) M[j * kLd + j] = rt;
+    // trailing update: thread (ty, tx) owns rows i = j+1+ty (16) and columns k = j+1+tx (16); L[.][j] in registers
+    double lk[6];
+#pragma unroll
+    for (int u = 0; u < 6; ++u) {
+      const int k = j + 1 + tx + 16 * u;
+      lk[u] = (k < n) ? M[k * kLd + j] : 0.0;
+    }
     for (int i = j + 1 + ty; i <= n; i += 16) {
       const double lij = M[i * kLd + j];
-      for (int k = j + 1 + tx; k <= i && k < n; k += 16) M[i * kLd + k] -= lij * M[k * kLd + j];
+#pragma unroll
+      for (int u = 0; u < 6; ++u) {
+        const int k = j + 1 + tx + 16 * u;
+        if (k <= i && k < n) M[i * kLd + k] -= lij * lk[u];
+      }
     }
     __syncthreads();
   }
