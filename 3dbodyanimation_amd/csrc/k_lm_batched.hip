@@ -23,7 +23,9 @@ constexpr int kN = 86;             // max unknowns per frame (76 + 10)
 constexpr int kLd = 88;            // LDS leading dimension of the (n+1) x (n+1) system
 constexpr int kRowsMax = 64;       // reprojection rows per frame handled on the device (32 keypoints)
 constexpr int kJLd = 96;           // Jhat leading dimension: 6 column tiles of 16 (86 columns + rhat + pad)
-static_assert(kRowsMax * kJLd <= kN * kLd, "Jhat must fit in the region it shares with the undamped H");
+constexpr int kMRows = 112;        // panel layout of the damped system: 96 padded unknowns + one tile row for the rhs
+constexpr int kMLd = 98;
+static_assert(kRowsMax * kJLd <= kMRows * kMLd, "Jhat must fit in the region it shares with the damped system");
 
 __device__ inline double huber_rho(double delta, double s, double* rho1) {
   const double b = delta * delta;
@@ -82,21 +84,30 @@ __global__ __launch_bounds__(256) void k_lm_init(LmProblem P, LmState S, const d
   }
 }
 
+// f64 value of lane `src` (wave-uniform lane id): two v_readlane_b32
+__device__ __forceinline__ double readlane_f64(double v, int src) {
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), src);
+  const int hi = __builtin_amdgcn_readlane((int)(b >> 32), src);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
 __global__ __launch_bounds__(256) void k_lm_step(LmProblem P, LmState S, const double* __restrict__ r,
                                                   const double* __restrict__ J, const int* __restrict__ comp,
                                                   const unsigned char* __restrict__ constant, int first_iter) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
-  double* M = sm;                          // (n+1) x kLd : damped scaled system, then its Cholesky factor
-  double* H0 = sm + (kN + 1) * kLd;        // n x kLd     : undamped unscaled H (aliases Jhat while H is built)
-  double* Jh = H0;                         // kRowsMax x kJLd
-  double* vec = H0 + kN * kLd;             // g[88], scale[88], ds[88], d[88], red[8]
+  double* M = sm;                          // kMRows x kMLd : damped scaled system (+ rhs row), factored in place
+  double* Jh = sm;                         // kRowsMax x kJLd : robustified [J | r], lives in M's region until H is built
+  double* H0 = sm + kMRows * kMLd;         // (n+1) x kLd : undamped unscaled H (row n = gradient)
+  double* vec = H0 + (kN + 1) * kLd;       // g[88], scale[88], ds[96+], d[88], red[8]
   double* g = vec;
   double* sc = vec + 88;
-  double* ds = vec + 176;
-  double* dd = vec + 264;
-  double* red = vec + 352;
+  double* ds = vec + 176;                  // 112 entries
+  double* dd = vec + 288;
+  double* red = vec + 376;
   const int f = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int n = P.ncols, npose = kFrameParams, nb = n - npose;
+  const int npad = (n + 15) & ~15, NB = npad >> 4;     // 80 / 96 unknowns padded to whole 16-column panels
   int flags = S.flags[f];
   if (!(flags & kLmActive)) {
     if (tid == 0) S.flags[f] = flags & ~kLmHasCand;
@@ -104,7 +115,7 @@ __global__ __launch_bounds__(256) void k_lm_step(LmProblem P, LmState S, const d
   }
   const int k0 = P.kp_offset[f], nrows = 2 * (P.kp_offset[f + 1] - k0);
 
-  // ---- Jhat = sqrt(rho') [J | r], zero padded to 16 x 6 column tiles and a multiple of 4 rows -------------
+  // ---- Jhat = sqrt(rho') [J | r], zero padded to 6 column tiles of 16 and a multiple of 4 rows -------------
   const int nrows4 = (nrows + 3) & ~3;
   if (tid < kRowsMax) {   // per-row robust weight sqrt(rho') and weighted residual (one round trip)
     double sw = 0.0, rr = 0.0;
@@ -116,7 +127,7 @@ __global__ __launch_bounds__(256) void k_lm_step(LmProblem P, LmState S, const d
       sw = sqrt(rho1);
       rr = sw * ((tid & 1) ? r1 : r0);
     }
-    ds[tid] = sw;                 // ds / dd are free until the solve
+    ds[tid] = sw;                 // ds is free until the solve
     Jh[tid * kJLd + n] = rr;      // column n = rhat
   }
   __syncthreads();
@@ -134,7 +145,6 @@ __global__ __launch_bounds__(256) void k_lm_step(LmProblem P, LmState S, const d
       if (row < nrows4 && c != n) Jh[row * kJLd + c] = (row < nrows && c < n) ? ds[row] * jv[u] : 0.0;
     }
     for (int i = tid; i < nrows4 * (kJLd - 88); i += 256) Jh[(i / (kJLd - 88)) * kJLd + 88 + i % (kJLd - 88)] = 0.0;
-    if (tid >= nrows && tid < nrows4) Jh[tid * kJLd + n] = 0.0;
   }
   __syncthreads();
   // ---- Gram matrix on the f64 matrix cores: 21 lower tile pairs dealt to the 4 waves -----------------------
@@ -154,7 +164,7 @@ __global__ __launch_bounds__(256) void k_lm_step(LmProblem P, LmState S, const d
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int i = 16 * ti + kk + 4 * q, j = 16 * tj + m;
-          if (i <= n && j <= n && j <= i) M[i * kLd + j] = acc[q];   // row n (= rhat column) holds g
+          if (i <= n && j < n && j <= i) H0[i * kLd + j] = acc[q];   // row n (the rhat column) is the gradient
         }
       }
   }
@@ -167,7 +177,6 @@ __global__ __launch_bounds__(256) void k_lm_step(LmProblem P, LmState S, const d
     if (P.prec) {
       const int kc = comp[f];
       const double* Pm = P.prec + (size_t)kc * D * D;       // L L^T of the selected component
-      const double* L = P.prec_cho + (size_t)kc * D * D;
       {
         double pv[19];   // 69 * 69 = 4761 <= 19 * 256
 #pragma unroll
@@ -178,10 +187,9 @@ __global__ __launch_bounds__(256) void k_lm_step(LmProblem P, LmState S, const d
 #pragma unroll
         for (int u = 0; u < 19; ++u) {
           const int e = tid + u * 256, i = e / D, j = e % D;
-          if (e < D * D && j <= i) M[(7 + i) * kLd + 7 + j] += bp * bp * pv[u];
+          if (e < D * D && j <= i) H0[(7 + i) * kLd + 7 + j] += bp * bp * pv[u];
         }
       }
-      (void)L;
       if (tid < D) {
         // J^T r = beta_p L r[0:69] with r[0:69] = beta_p s L^T (x - mu)  ->  beta_p^2 s Prec (x - mu):
         // one row of the precision matrix per thread, 69 independent loads
@@ -189,34 +197,30 @@ __global__ __launch_bounds__(256) void k_lm_step(LmProblem P, LmState S, const d
         double a = 0.0;
 #pragma unroll
         for (int k = 0; k < 69; ++k) a += (k < D) ? Pm[(size_t)tid * D + k] * (xq[k] - P.gmm_mean[(size_t)kc * D + k]) : 0.0;
-        M[n * kLd + 7 + tid] += bp * bp * P.gmm_scale * a;
+        H0[n * kLd + 7 + tid] += bp * bp * P.gmm_scale * a;
       }
     } else if (tid < D) {
-      M[(7 + tid) * kLd + 7 + tid] += bp * bp;
-      M[n * kLd + 7 + tid] += bp * rp[tid];
+      H0[(7 + tid) * kLd + 7 + tid] += bp * bp;
+      H0[n * kLd + 7 + tid] += bp * rp[tid];
     }
   }
   if (P.shape_rows_per_frame > 0 && tid >= 128 && tid - 128 < nb) {
     const int i = tid - 128;
-    M[(npose + i) * kLd + npose + i] += P.beta_shape * P.beta_shape;
-    M[n * kLd + npose + i] += P.beta_shape * r[P.row_shape + (size_t)f * P.shape_rows_per_frame + i];
+    H0[(npose + i) * kLd + npose + i] += P.beta_shape * P.beta_shape;
+    H0[n * kLd + npose + i] += P.beta_shape * r[P.row_shape + (size_t)f * P.shape_rows_per_frame + i];
   }
   __syncthreads();
-  // ---- gradient, Jacobi scaling (fixed at the first iterate), undamped copy ----------------------------------
+  // ---- gradient, Jacobi scaling (fixed at the first iterate) ----------------------------------------------------
   if (tid < n) {
-    g[tid] = M[n * kLd + tid];
-    if (first_iter) S.scale[(size_t)f * kN + tid] = 1.0 / (1.0 + sqrt(M[tid * kLd + tid]));
-    sc[tid] = first_iter ? 1.0 / (1.0 + sqrt(M[tid * kLd + tid])) : S.scale[(size_t)f * kN + tid];
-  }
-  __syncthreads();
-  for (int e = tid; e < n * n; e += 256) {
-    const int i = e / n, j = e % n;
-    H0[i * kLd + j] = (j <= i) ? M[i * kLd + j] : M[j * kLd + i];
+    g[tid] = H0[n * kLd + tid];
+    const double s0 = first_iter ? 1.0 / (1.0 + sqrt(H0[tid * kLd + tid])) : S.scale[(size_t)f * kN + tid];
+    if (first_iter) S.scale[(size_t)f * kN + tid] = s0;
+    sc[tid] = s0;
   }
   // gradient tolerance (projected on the scale bounds), Ceres gradient_tolerance = 1e-10
   double gm = 0.0;
   if (tid < n && !(tid < npose && constant && constant[tid])) {
-    double gi = g[tid];
+    double gi = H0[n * kLd + tid];
     if (tid == 0) {
       const double s0 = S.x[(size_t)f * npose];
       gi = s0 - fmin(fmax(s0 - gi, P.scale_lo), P.scale_hi);
@@ -225,7 +229,6 @@ __global__ __launch_bounds__(256) void k_lm_step(LmProblem P, LmState S, const d
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) gm = fmax(gm, __shfl_xor(gm, off, 64));
-  __syncthreads();
   if (lane == 0) red[wave] = gm;
   __syncthreads();
   gm = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
@@ -236,53 +239,109 @@ __global__ __launch_bounds__(256) void k_lm_step(LmProblem P, LmState S, const d
     }
     return;
   }
-  // ---- scaled, damped system with the right-hand side as row n ------------------------------------------------
+  // ---- scaled, damped system in panel layout: unknowns padded with identity to npad, rhs = row npad -------------
   const double radius = S.radius[f];
-  __syncthreads();
-  for (int e = tid; e < (n + 1) * n; e += 256) {
-    const int i = e / n, j = e % n;
-    if (j > i) continue;
-    const bool ci = i < npose && constant && constant[i];
-    const bool cj = j < npose && constant && constant[j];
-    double v;
-    if (i == n) v = cj ? 0.0 : -g[j] * sc[j];                 // rhs = -S g
-    else if (ci || cj) v = (i == j) ? 1.0 : 0.0;
-    else {
-      v = M[i * kLd + j] * sc[i] * sc[j];
-      if (i == j) v += fmin(fmax(v, 1e-6), 1e32) / radius;
+  for (int e = tid; e < (npad + 16) * npad; e += 256) {
+    const int i = e / npad, j = e % npad;
+    double v = 0.0;
+    if (i < n && j <= i) {
+      const bool ci = i < npose && constant && constant[i];
+      const bool cj = j < npose && constant && constant[j];
+      if (ci || cj) v = (i == j) ? 1.0 : 0.0;
+      else {
+        v = H0[i * kLd + j] * sc[i] * sc[j];
+        if (i == j) v += fmin(fmax(v, 1e-6), 1e32) / radius;
+      }
+    } else if (i < npad) {
+      v = (i == j) ? 1.0 : 0.0;                                  // identity padding keeps the system SPD
+    } else if (i == npad && j < n) {
+      v = (j < npose && constant && constant[j]) ? 0.0 : -g[j] * sc[j];   // rhs = -S g
     }
-    M[i * kLd + j] = v;
+    M[i * kMLd + j] = v;
   }
+  if (tid == 0) red[4] = 1.0;   // factorisation status
   __syncthreads();
-  // ---- Cholesky, right-looking, rhs row carried along (after column n-1 row n holds y = L^{-1} rhs) -----------
-  bool ok = true;
-  const int ty = tid >> 4, tx = tid & 15;
-  for (int j = 0; j < n; ++j) {
-    const double piv = M[j * kLd + j];           // same LDS word for every thread: uniform branch
-    if (!(piv > 0.0)) { ok = false; break; }
-    const double rt = sqrt(piv), inv = 1.0 / rt;
-    // column j below the diagonal (the diagonal itself is finalised after the barrier: nobody reads it before)
-    for (int i = j + 1 + tid; i <= n; i += 256) M[i * kLd + j] *= inv;
-    __syncthreads();
-    if (tid == 0) M[j * kLd + j] = rt;
-    // trailing update: thread (ty, tx) owns rows i = j+1+ty (16) and columns k = j+1+tx (16); L[.][j] in registers
-    double lk[6];
+  // H0 becomes the full symmetric undamped matrix (model cost change needs H d)
+  for (int e = tid; e < n * n; e += 256) {
+    const int i = e / n, j = e % n;
+    if (j > i) H0[i * kLd + j] = H0[j * kLd + i];
+  }
+
+  // ---- blocked right-looking Cholesky, 16-column panels; the rhs row rides along as one more row below ----------
+  for (int p = 0; p < NB; ++p) {
+    const int c0 = 16 * p;
+    // (a) diagonal block in registers of wave 0: lane r holds row r; column values travel by v_readlane
+    if (wave == 0) {
+      const int rr = lane & 15;
+      double a[16];
 #pragma unroll
-    for (int u = 0; u < 6; ++u) {
-      const int k = j + 1 + tx + 16 * u;
-      lk[u] = (k < n) ? M[k * kLd + j] : 0.0;
+      for (int k = 0; k < 16; ++k) a[k] = M[(c0 + rr) * kMLd + c0 + k];
+      bool okp = true;
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        const double piv = readlane_f64(a[c], c);
+        if (!(piv > 0.0)) okp = false;
+        const double rt = sqrt(piv), inv = 1.0 / rt;
+        const double l = (rr == c) ? rt : a[c] * inv;
+        a[c] = l;
+#pragma unroll
+        for (int k = c + 1; k < 16; ++k) {
+          const double lk = readlane_f64(l, k);
+          if (rr >= k) a[k] -= l * lk;
+        }
+      }
+      if (lane < 16) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
+          if (k <= rr) M[(c0 + rr) * kMLd + c0 + k] = a[k];
+      }
+      if (lane == 0 && !okp) red[4] = 0.0;
     }
-    for (int i = j + 1 + ty; i <= n; i += 16) {
-      const double lij = M[i * kLd + j];
+    __syncthreads();
+    if (red[4] == 0.0) break;
+    // (b) panel solve  X = A_below L_pp^{-T}: one row per thread (rows c0+16 .. npad incl. the rhs row)
+    {
+      const int nbelow = npad - (c0 + 16) + 1;
+      if (tid < nbelow) {
+        const int i = c0 + 16 + tid;
+        double x[16];
 #pragma unroll
-      for (int u = 0; u < 6; ++u) {
-        const int k = j + 1 + tx + 16 * u;
-        if (k <= i && k < n) M[i * kLd + k] -= lij * lk[u];
+        for (int k = 0; k < 16; ++k) x[k] = M[i * kMLd + c0 + k];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+          double v = x[c];
+#pragma unroll
+          for (int k = 0; k < c; ++k) v -= x[k] * M[(c0 + c) * kMLd + c0 + k];
+          x[c] = v / M[(c0 + c) * kMLd + c0 + c];
+        }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) M[i * kMLd + c0 + k] = x[k];
       }
     }
     __syncthreads();
+    // (c) trailing update  A[I][Kc] -= X_I X_Kc^T  on the f64 matrix cores (tiles at and below the diagonal)
+    if (p + 1 <= NB) {
+      const int m = lane & 15, kk = lane >> 4;
+      int t = 0;
+      for (int I = p + 1; I <= NB; ++I)
+        for (int Kc = p + 1; Kc <= I && Kc < NB; ++Kc, ++t) {
+          if ((t & 3) != wave) continue;
+          d4 acc;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) acc[q] = M[(16 * I + kk + 4 * q) * kMLd + 16 * Kc + m];
+#pragma unroll
+          for (int s4 = 0; s4 < 4; ++s4) {
+            const double av = -M[(16 * I + m) * kMLd + c0 + 4 * s4 + kk];
+            const double bv = M[(16 * Kc + m) * kMLd + c0 + 4 * s4 + kk];
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+          }
+#pragma unroll
+          for (int q = 0; q < 4; ++q) M[(16 * I + kk + 4 * q) * kMLd + 16 * Kc + m] = acc[q];
+        }
+    }
+    __syncthreads();
   }
-  if (!ok) {
+  if (red[4] == 0.0) {
     if (tid == 0) {
       const double dec = S.dec[f];
       const double rad = radius / dec;
@@ -296,16 +355,25 @@ __global__ __launch_bounds__(256) void k_lm_step(LmProblem P, LmState S, const d
     }
     return;
   }
-  // ---- backward substitution ds = L^{-T} y (column oriented: row j of L is contiguous) ---------------------------
-  if (tid < n) ds[tid] = M[n * kLd + tid];
-  __syncthreads();
-  for (int j = n - 1; j >= 0; --j) {
-    const double xj = ds[j] / M[j * kLd + j];
-    __syncthreads();
-    if (tid == 0) ds[j] = xj;
-    if (tid < j) ds[tid] -= M[j * kLd + tid] * xj;
-    __syncthreads();
+  // ---- backward substitution ds = L^{-T} y by wave 0 alone: two unknowns per lane, x_j broadcast by v_readlane ----
+  if (wave == 0) {
+    double d0 = M[npad * kMLd + lane];
+    double d1 = (lane + 64 < npad) ? M[npad * kMLd + lane + 64] : 0.0;
+    for (int j = npad - 1; j >= 0; --j) {
+      const double ljj = M[j * kMLd + j];
+      const double l0 = M[j * kMLd + lane];
+      const double l1 = (lane + 64 < npad) ? M[j * kMLd + lane + 64] : 0.0;
+      const double dj = (j < 64) ? readlane_f64(d0, j) : readlane_f64(d1, j - 64);
+      const double xj = dj / ljj;
+      if (lane < j) d0 -= l0 * xj;
+      if (lane == j) d0 = xj;
+      if (lane + 64 < j) d1 -= l1 * xj;
+      if (lane + 64 == j) d1 = xj;
+    }
+    ds[lane] = d0;
+    if (lane + 64 < npad) ds[lane + 64] = d1;
   }
+  __syncthreads();
   // ---- step, projection on the scale bounds, model change -dg - 1/2 d H d with the undamped H ----------------------
   const double* xf = S.x + (size_t)f * npose;
   if (tid < n) {
@@ -392,7 +460,7 @@ __global__ __launch_bounds__(256) void k_lm_accept(LmProblem P, LmState S, const
 
 }  // namespace
 
-size_t lm_step_lds_bytes() { return (size_t)((kN + 1) * kLd + kN * kLd + 360) * sizeof(double); }
+size_t lm_step_lds_bytes() { return (size_t)(kMRows * kMLd + (kN + 1) * kLd + 392) * sizeof(double); }
 
 void launch_lm_init(const LmProblem& P, const LmState& S, const double* d_r, hipStream_t s) {
   hipLaunchKernelGGL(k_lm_init, dim3(P.F), dim3(256), 0, s, P, S, d_r);
