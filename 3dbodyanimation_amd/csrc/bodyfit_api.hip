@@ -97,8 +97,6 @@ struct bodyfit_problem {
   double* d_normal = nullptr;
   int* d_comp = nullptr;
   float* d_cloud = nullptr;
-  double* d_gmm_T = nullptr;   // [F][K][72] whitened residual of every component (GMM prior only)
-  double* d_gmm_v = nullptr;   // [F][K]
   // host copies
   std::vector<int> kp_offset, kp_id, kp_frame;
   std::vector<double> kp_uv;
@@ -107,15 +105,7 @@ struct bodyfit_problem {
   bool cache_valid = false, cache_has_jac = false;
   std::vector<double> c_params, c_beta, c_r, c_J;
   std::vector<int> c_comp;
-  // priors run beside the keypoint + mesh kernels on their own stream (they only read the parameters)
-  hipStream_t side = nullptr;
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   Allocs mem;
-  ~bodyfit_problem() {
-    if (ev_fork) (void)hipEventDestroy(ev_fork);
-    if (ev_join) (void)hipEventDestroy(ev_join);
-    if (side) (void)hipStreamDestroy(side);
-  }
 };
 
 namespace {
@@ -137,8 +127,9 @@ bool chol_lower(std::vector<double>& A, int n) {
   return true;
 }
 
-// One evaluation sweep.  ev (optional, 6 events): [0] start, [1] after frame_resjac, [2]/[3] around the
-// priors on the side stream, [4] after the mesh kernel; [5] is recorded by the caller.
+// One evaluation sweep: two launches on the caller's stream.  The prior residuals are produced by extra
+// workgroups of the k_frame_resjac launch (priors_inl.h).  ev (optional): [0] start, [1] after
+// frame_resjac (+ priors), [2] after the mesh kernel.
 int sweep(bodyfit_problem* p, const double* d_params, const double* d_beta, int want_jac, bool mesh,
           hipStream_t st, hipEvent_t* ev = nullptr, double* r_base = nullptr, int* comp_out = nullptr,
           const int* frame_flags = nullptr, int frame_mask = 0) {
@@ -151,31 +142,24 @@ int sweep(bodyfit_problem* p, const double* d_params, const double* d_beta, int 
   MeshCoef mc = p->mc;
   if (!mesh) mc = MeshCoef{};
   const bodyfit_problem_desc& D = p->desc;
-  const bool priors = D.beta_pose > 0.0 || D.beta_shape > 0.0 || D.lambda_temporal > 0.0;
+  PriorArgs pa{};
+  pa.F = p->d.F; pa.nS = m->nS; pa.beta_stride = p->d.beta_stride;
+  pa.has_gmm = p->has_gmm ? 1 : 0;
+  if (p->has_gmm) pa.g = p->gmm;
+  pa.beta_pose = D.beta_pose;
+  pa.beta_shape = p->lay.shape_rows > 0 ? D.beta_shape : 0.0;
+  pa.lambda_t = D.lambda_temporal;
+  pa.n_pairs = p->n_pairs;
+  pa.beta = d_beta;
+  pa.r_prior = d_r + p->row_prior; pa.r_shape = d_r + p->row_shape; pa.r_temporal = d_r + p->row_temporal;
+  pa.comp = d_comp;
+  const bool priors = D.beta_pose > 0.0 || pa.beta_shape > 0.0 || D.lambda_temporal > 0.0;
+  pa.n_tiles = priors ? (p->d.F + 15) / 16 : 0;
   if (ev) (void)hipEventRecord(ev[0], st);
-  // the priors only read the parameters: they fork onto the side stream first.  Their kernels are made of
-  // single-wave workgroups (GMM: one per (16 frames, component)) that co-reside with the one-workgroup-per-CU
-  // kernels below instead of claiming whole CUs.
-  if (priors) {
-    (void)hipEventRecord(p->ev_fork, st);
-    (void)hipStreamWaitEvent(p->side, p->ev_fork, 0);
-    if (ev) (void)hipEventRecord(ev[2], p->side);
-    launch_priors(p->d, m->nJ, m->nS, d_params, d_beta, D.beta_pose, p->has_gmm ? &p->gmm : nullptr,
-                  p->lay.shape_rows > 0 ? D.beta_shape : 0.0, D.lambda_temporal, p->n_pairs,
-                  d_r + p->row_prior, d_r + p->row_shape, d_r + p->row_temporal, d_comp, p->d_gmm_T,
-                  p->d_gmm_v, p->side);
-    if (ev) (void)hipEventRecord(ev[3], p->side);
-    (void)hipEventRecord(p->ev_join, p->side);
-  } else if (ev) {
-    (void)hipEventRecord(ev[2], st);
-    (void)hipEventRecord(ev[3], st);
-  }
-  launch_frame_resjac(m->d, dp, d_params, d_beta, d_r, want_jac ? p->d_J : nullptr, p->d_joints, mc,
-                      want_jac, st);
+  launch_frame_resjac(m->d, dp, d_params, d_beta, d_r, want_jac ? p->d_J : nullptr, p->d_joints, mc, want_jac, pa, st);
   if (ev) (void)hipEventRecord(ev[1], st);
   if (mesh) launch_mesh(m->d, p->d, p->mc, p->d_cloud, st);
-  if (ev) (void)hipEventRecord(ev[4], st);
-  if (priors) (void)hipStreamWaitEvent(st, p->ev_join, 0);
+  if (ev) (void)hipEventRecord(ev[2], st);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(BODYFIT_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
   return BODYFIT_OK;
@@ -536,9 +520,6 @@ int bodyfit_problem_create(const bodyfit_model* m, const bodyfit_problem_desc* d
   std::vector<double> R0(desc->R0, desc->R0 + (size_t)F * 9);
   HIP_TRY(p->mem.upload(&d.R0, R0));
 
-  HIP_TRY(hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking));
-  HIP_TRY(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
-  HIP_TRY(hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming));
   HIP_TRY(p->mem.alloc(&p->d_params, (size_t)p->n_param_rows * npose));
   HIP_TRY(p->mem.alloc(&p->d_beta, (size_t)std::max(1, desc->beta_per_frame ? F * nS : nS)));
   HIP_TRY(p->mem.alloc(&p->d_r, (size_t)L.total_rows));
@@ -550,10 +531,6 @@ int bodyfit_problem_create(const bodyfit_model* m, const bodyfit_problem_desc* d
   HIP_TRY(hipMemset(p->d_r, 0, (size_t)std::max(1, L.total_rows) * sizeof(double)));
   HIP_TRY(hipMemset(p->d_comp, 0, (size_t)F * sizeof(int)));
   HIP_TRY(hipMemset(p->d_beta, 0, (size_t)std::max(1, desc->beta_per_frame ? F * nS : nS) * sizeof(double)));
-  if (p->has_gmm) {
-    HIP_TRY(p->mem.alloc(&p->d_gmm_T, (size_t)F * p->gmm.K * 72));
-    HIP_TRY(p->mem.alloc(&p->d_gmm_v, (size_t)F * p->gmm.K));
-  }
   if (desc->want_mesh) {
     const size_t nfa = (size_t)d.nFTiles * kPoseKSteps * 2 * 64 * 8;
     const size_t nba = (size_t)d.nFTiles * kShapeKSteps * 64;
@@ -654,24 +631,26 @@ int bodyfit_profile_sweep(bodyfit_problem* p, const double* d_frame_params, cons
   if (!p || !d_frame_params || !avg_ms || iters <= 0) return fail(BODYFIT_ERR_INVALID, "bad argument");
   HIP_TRY(hipSetDevice(p->m->device));
   hipStream_t st = static_cast<hipStream_t>(stream);
-  std::vector<hipEvent_t> ev((size_t)iters * 6);
+  std::vector<hipEvent_t> ev((size_t)iters * 4);
   for (auto& e : ev) HIP_TRY(hipEventCreate(&e));
   int rc = BODYFIT_OK;
   for (int it = 0; it < iters && rc == BODYFIT_OK; ++it) {
-    hipEvent_t* e = ev.data() + (size_t)it * 6;
+    hipEvent_t* e = ev.data() + (size_t)it * 4;
     rc = sweep(p, d_frame_params, d_beta, want_jacobian, p->desc.want_mesh != 0, st, e);
     if (rc == BODYFIT_OK && with_reduce) rc = bodyfit_reduce_shared_device(p, nullptr, stream);
-    (void)hipEventRecord(e[5], st);
+    (void)hipEventRecord(e[3], st);
   }
   hipError_t se = hipStreamSynchronize(st);
-  if (se == hipSuccess) se = hipStreamSynchronize(p->side);
   for (int k = 0; k < 4; ++k) avg_ms[k] = 0.0;
   if (rc == BODYFIT_OK && se == hipSuccess) {
-    const int a[4] = {0, 2, 1, 4}, b[4] = {1, 3, 4, 5};   // resjac, priors (side stream), mesh, reduce (+join)
+    // [0] frame_resjac (incl. the prior workgroups of the same launch), [1] 0 (priors are not a launch of
+    // their own), [2] mesh, [3] reduce
+    const int a[4] = {0, 0, 1, 2}, b[4] = {1, 0, 2, 3};
     for (int it = 0; it < iters; ++it)
       for (int k = 0; k < 4; ++k) {
+        if (k == 1) continue;
         float ms = 0.f;
-        (void)hipEventElapsedTime(&ms, ev[(size_t)it * 6 + a[k]], ev[(size_t)it * 6 + b[k]]);
+        (void)hipEventElapsedTime(&ms, ev[(size_t)it * 4 + a[k]], ev[(size_t)it * 4 + b[k]]);
         avg_ms[k] += ms / iters;
       }
   }

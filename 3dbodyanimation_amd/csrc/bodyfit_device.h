@@ -73,6 +73,18 @@ struct DevGmm {
   double resid_scale;
 };
 
+// prior residuals computed by extra workgroups of the k_frame_resjac launch (priors_inl.h)
+struct PriorArgs {
+  int F, nS, beta_stride, has_gmm, n_pairs, n_tiles;   // n_tiles = 0: no prior workgroups
+  double beta_pose, beta_shape, lambda_t;
+  DevGmm g;
+  const double* beta;
+  double* r_prior;
+  double* r_shape;
+  double* r_temporal;
+  int* comp;
+};
+
 // ---- device-resident LM for batches of independent frames (k_lm_batched.hip) ------------------------
 constexpr int kLmActive = 1;        // flags: frame still iterating
 constexpr int kLmHasCand = 2;       //        a candidate point awaits its residual sweep
@@ -119,11 +131,7 @@ __host__ __device__ inline float bf16_to_f32(uint16_t b) {
 // kernel launchers (defined in the .hip files)
 void launch_frame_resjac(const DevModel& M, const DevProblem& P, const double* d_params, const double* d_beta,
                          double* d_r, double* d_J, double* d_joints, const MeshCoef& mc, int want_jac,
-                         hipStream_t s);
-void launch_priors(const DevProblem& P, int nJ, int nS, const double* d_params, const double* d_beta,
-                   double beta_pose, const DevGmm* gmm /*host struct or null*/, double beta_shape,
-                   double lambda_t, int n_pairs, double* d_r_prior, double* d_r_shape, double* d_r_temporal,
-                   int* d_comp, double* d_gmm_T, double* d_gmm_v, hipStream_t s);
+                         const PriorArgs& priors, hipStream_t s);
 void launch_mesh(const DevModel& M, const DevProblem& P, const MeshCoef& mc, float* d_cloud, hipStream_t s);
 void launch_reduce_shared_ex(int K, int ncols, int npose, int nS, int total_rows, const double* d_r,
                              const double* d_J, double huber_delta, int shape_row0, int shape_rows,

@@ -16,6 +16,7 @@
 //   lanes = columns     the dense row-major [2K][ncols] panel is written with consecutive lanes on
 //                       consecutive columns (coalesced 512-B stores), keypoints dealt round-robin to waves
 #include "bodyfit_device.h"
+#include "priors_inl.h"
 
 namespace bodyfit {
 namespace {
@@ -146,8 +147,12 @@ constexpr int TAB_KPID = 96;                   // KC
 __global__ __launch_bounds__(kThreads) void k_frame_resjac(DevModel M, DevProblem Pb, const double* __restrict__ params,
                                                       const double* __restrict__ beta, double* __restrict__ r_out,
                                                       double* __restrict__ J_out, double* __restrict__ joints_out,
-                                                      MeshCoef mc, int want_jac) {
+                                                      MeshCoef mc, int want_jac, PriorArgs pa) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
+  if ((int)blockIdx.x >= Pb.F) {   // extra workgroups of the launch: prior residuals of one 16-frame tile
+    prior_block(pa, (int)blockIdx.x - Pb.F, params, sm);
+    return;
+  }
   const int f = blockIdx.x;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -635,7 +640,7 @@ __global__ __launch_bounds__(kThreads) void k_frame_resjac(DevModel M, DevProble
 
 void launch_frame_resjac(const DevModel& M, const DevProblem& P, const double* d_params, const double* d_beta,
                          double* d_r, double* d_J, double* d_joints, const MeshCoef& mc, int want_jac,
-                         hipStream_t s) {
+                         const PriorArgs& priors, hipStream_t s) {
   if (P.F <= 0) return;
   const size_t lds = (size_t)(OFF_LM + M.nL * LM_STRIDE) * sizeof(double);
   static size_t lds_granted = 48 * 1024;
@@ -644,8 +649,8 @@ void launch_frame_resjac(const DevModel& M, const DevProblem& P, const double* d
                               (int)lds);
     lds_granted = lds;
   }
-  hipLaunchKernelGGL(k_frame_resjac, dim3(P.F), dim3(kThreads), lds, s, M, P, d_params, d_beta, d_r, d_J, d_joints, mc,
-                     want_jac);
+  hipLaunchKernelGGL(k_frame_resjac, dim3(P.F + priors.n_tiles), dim3(kThreads), lds, s, M, P, d_params, d_beta, d_r,
+                     d_J, d_joints, mc, want_jac, priors);
 }
 
 }  // namespace bodyfit

@@ -1,0 +1,157 @@
+// priors_inl.h — pose prior, shape prior and temporal residuals, executed by EXTRA workgroups of the
+// k_frame_resjac launch (one per tile of 16 frames), so an evaluation sweep needs no second stream, no
+// fork/join events and no extra launches (a cross-stream fork/join was measured at ~8 us per sweep).
+//
+//   pose prior   PosePriorAAAnalytic::Evaluate (include/Sim3BA.h:263-315): L2 r = beta_p x, or the GMM
+//                max-mixture residual of ark::GaussianMixture::residual (uses at :280,288)
+//   shape prior  ShapePriorL2Analytic::Evaluate (include/Sim3BA.h:331-343): r = beta_s w
+//   temporal     Vec3DiffCost (include/MultiFrameBA.h:20-28,121-142): r = lambda (a_f - a_{f+1}) on
+//                rootT, rootAA, then joints 1..23
+// The GMM whitening  T_k = s (X - mu_k) L_k  ([16 x 69].[69 x 69] per component) is a dense contraction and
+// runs on the f64 matrix cores: the 4 waves of the workgroup take components k = wave, wave + 4, 5 column
+// tiles x 18 k-steps of v_mfma_f64_16x16x4_f64 each with the 16 frames on the MFMA row index; L_k is stored
+// in MFMA B-fragment order at upload (fully coalesced 16-byte loads, nine k-steps in flight at a time); the
+// 16 pose vectors go through LDS.  |T_k|^2 per frame is a 16-lane butterfly; the component is picked across
+// the waves through LDS (first minimum, as the sequential reference loop) and only the winner writes its rows.
+#pragma once
+#include "bodyfit_device.h"
+
+namespace bodyfit {
+
+typedef __attribute__((ext_vector_type(4))) double prior_d4;
+constexpr int kPriorTileF = 16;   // frames per prior workgroup (MFMA M)
+constexpr int kPriorNT = 5;       // column tiles of 16 (69 -> 80)
+constexpr int kPriorKS = 18;      // k-steps of 4 (69 -> 72)
+
+__device__ inline void prior_block(const PriorArgs& A, int tile, const double* __restrict__ params, double* sm) {
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int f0 = tile * kPriorTileF, F = A.F;
+  const int npose = kFrameParams, D = npose - 7;
+  double* sx = sm;                       // [16][72]
+  double* sval = sm + kPriorTileF * 72;  // [8][16]
+
+  if (A.beta_pose > 0.0 && A.r_prior) {
+    if (!A.has_gmm) {
+      for (int i = tid; i < kPriorTileF * D; i += 256) {
+        const int f = f0 + i / D, c = i % D;
+        if (f < F) A.r_prior[(size_t)f * D + c] = A.beta_pose * params[(size_t)f * npose + 7 + c];
+      }
+      if (A.comp && tid < kPriorTileF && f0 + tid < F) A.comp[f0 + tid] = 0;
+    } else {
+      const DevGmm& g = A.g;
+      const int m = lane & 15, kk = lane >> 4;  // MFMA: A[i = m][k = kk], B[k = kk][j = m]
+      {
+        // 16 x 72 pose values: fixed 5 predicated passes, all loads in flight
+        double xv[5];
+#pragma unroll
+        for (int u = 0; u < 5; ++u) {
+          const int idx = tid + u * 256, fr = idx / 72, c = idx % 72;
+          xv[u] = (idx < kPriorTileF * 72 && c < D && f0 + fr < F) ? params[(size_t)(f0 + fr) * npose + 7 + c] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 5; ++u) {
+          const int idx = tid + u * 256;
+          if (idx < kPriorTileF * 72) sx[idx] = xv[u];
+        }
+      }
+      __syncthreads();
+      prior_d4 acc[2][kPriorNT];
+      double nlw[2] = {0.0, 0.0};
+#pragma unroll
+      for (int ci = 0; ci < 2; ++ci) {
+        const int k = wave + 4 * ci;
+#pragma unroll
+        for (int nt = 0; nt < kPriorNT; ++nt) acc[ci][nt] = prior_d4{0.0, 0.0, 0.0, 0.0};
+        if (k < g.K) {
+          nlw[ci] = g.neg_log_w[k];
+          const double2* Lf = reinterpret_cast<const double2*>(g.prec_frag) + (size_t)k * kPriorKS * 3 * 64 + lane;
+#pragma unroll
+          for (int half = 0; half < 2; ++half) {
+            double2 b[9][3];
+            double mu[9];
+#pragma unroll
+            for (int s = 0; s < 9; ++s) {
+              const int ks = half * 9 + s, r = 4 * ks + kk;
+#pragma unroll
+              for (int pr = 0; pr < 3; ++pr) b[s][pr] = Lf[(size_t)(ks * 3 + pr) * 64];
+              mu[s] = (r < D) ? g.mean[(size_t)k * D + r] : 0.0;
+            }
+#pragma unroll
+            for (int s = 0; s < 9; ++s) {
+              const int r = 4 * (half * 9 + s) + kk;
+              const double a = (r < D) ? sx[m * 72 + r] - mu[s] : 0.0;
+              acc[ci][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[s][0].x, acc[ci][0], 0, 0, 0);
+              acc[ci][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[s][0].y, acc[ci][1], 0, 0, 0);
+              acc[ci][2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[s][1].x, acc[ci][2], 0, 0, 0);
+              acc[ci][3] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[s][1].y, acc[ci][3], 0, 0, 0);
+              acc[ci][4] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[s][2].x, acc[ci][4], 0, 0, 0);
+            }
+          }
+          // D layout (f64): column = lane & 15, frame row = (lane >> 4) + 4 q
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            double sacc = 0.0;
+#pragma unroll
+            for (int nt = 0; nt < kPriorNT; ++nt) {
+              acc[ci][nt][q] *= g.resid_scale;
+              sacc += acc[ci][nt][q] * acc[ci][nt][q];
+            }
+#pragma unroll
+            for (int off = 1; off < 16; off <<= 1) sacc += __shfl_xor(sacc, off, 64);
+            if (m == 0) sval[k * kPriorTileF + kk + 4 * q] = sacc + nlw[ci];
+          }
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int ci = 0; ci < 2; ++ci) {
+        const int k = wave + 4 * ci;
+        if (k >= g.K) continue;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int row = kk + 4 * q, f = f0 + row;
+          int best = 0;
+          double bv = sval[row];
+          for (int k2 = 1; k2 < g.K; ++k2) {
+            const double v2 = sval[k2 * kPriorTileF + row];
+            if (v2 < bv) { bv = v2; best = k2; }
+          }
+          if (best == k && f < F) {
+            double* o = A.r_prior + (size_t)f * (D + 1);
+#pragma unroll
+            for (int nt = 0; nt < kPriorNT; ++nt) {
+              const int c = 16 * nt + m;
+              if (c < D) o[c] = A.beta_pose * acc[ci][nt][q];
+            }
+            if (m == 0) {
+              o[D] = A.beta_pose * sqrt(nlw[ci]);
+              if (A.comp) A.comp[f] = k;
+            }
+          }
+        }
+      }
+    }
+  }
+  if (A.beta_shape > 0.0 && A.r_shape && A.beta) {
+    if (A.beta_stride > 0) {
+      for (int i = tid; i < kPriorTileF * A.nS; i += 256) {
+        const int f = f0 + i / A.nS, c = i % A.nS;
+        if (f < F) A.r_shape[(size_t)f * A.nS + c] = A.beta_shape * A.beta[(size_t)f * A.beta_stride + c];
+      }
+    } else if (tile == 0) {
+      for (int i = tid; i < A.nS; i += 256) A.r_shape[i] = A.beta_shape * A.beta[i];
+    }
+  }
+  if (A.lambda_t > 0.0 && A.r_temporal) {
+    const int T = 6 + D;
+    for (int i = tid; i < kPriorTileF * T; i += 256) {
+      const int f = f0 + i / T, c = i % T;
+      if (f < A.n_pairs) {
+        const int src = (c < 3) ? (4 + c) : (c < 6 ? (1 + (c - 3)) : (7 + (c - 6)));
+        A.r_temporal[(size_t)f * T + c] = A.lambda_t * (params[(size_t)f * npose + src] - params[(size_t)(f + 1) * npose + src]);
+      }
+    }
+  }
+}
+
+}  // namespace bodyfit

@@ -174,7 +174,7 @@ def main():
     if rank == 0:
         ms_step = dt / args.steps * 1e3
         evals_s = total_frames * args.steps / dt
-        dom = max(("mesh_blend_lbs", "frame_resjac", "priors"), key=lambda k: prof[k])
+        dom = max(("mesh_blend_lbs", "frame_resjac"), key=lambda k: prof[k])
         if dom == "mesh_blend_lbs":
             bytes_launch = B_MODEL_MESH + F * B_FRAME_MESH
         elif dom == "frame_resjac":
@@ -184,7 +184,7 @@ def main():
         traffic = None   # HBM bytes of the dominant kernel from the committed PMC passes (same workload only)
         try:
             pm = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic_c3_256.json")))
-            key = {"mesh_blend_lbs": "k_mesh_blend_lbs", "frame_resjac": "k_frame_resjac", "priors": "k_gmm_whiten"}[dom]
+            key = {"mesh_blend_lbs": "k_mesh_blend_lbs", "frame_resjac": "k_frame_resjac", "priors": "k_frame_resjac"}[dom]
             if args.workload == pm["workload"] and F == pm["frames_per_gpu"]:
                 traffic = pm["kernels"][key]["hbm_bytes"]
         except Exception:
