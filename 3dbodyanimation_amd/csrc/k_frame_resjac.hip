@@ -88,7 +88,7 @@ __device__ inline double wave_sum(double v) {
 #ifdef BODYFIT_STAMPS
 #define STAMP(i)                                                                              \
   do {                                                                                        \
-    if (Pb.dbg && (threadIdx.x & 63) == 0) {                                                  \
+    if (Pb.dbg && (threadIdx.x & 63) == 0 && threadIdx.x < 256) {                             \
       unsigned long long t_;                                                                  \
       asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");              \
       Pb.dbg[((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16 + (i)] = t_;                  \
@@ -96,7 +96,7 @@ __device__ inline double wave_sum(double v) {
   } while (0)
 #define STAMP_REAL(i)                                                                         \
   do {                                                                                        \
-    if (Pb.dbg && (threadIdx.x & 63) == 0) {                                                  \
+    if (Pb.dbg && (threadIdx.x & 63) == 0 && threadIdx.x < 256) {                             \
       unsigned long long t_;                                                                  \
       asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");          \
       Pb.dbg[((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16 + (i)] = t_;                  \
@@ -108,7 +108,7 @@ __device__ inline double wave_sum(double v) {
 #endif
 
 constexpr int KC = 32;  // keypoints staged per chunk
-constexpr int kThreads = 256;
+constexpr int kThreads = 512;   // 8 waves per frame = 2 per SIMD: the phases are latency-bound, the partner wave covers
 
 // LDS carve (doubles)
 constexpr int OFF_X = 0;                       // 88
@@ -144,7 +144,7 @@ constexpr int TAB_PARENT = 0;                  // 24
 constexpr int TAB_ANC = 24;                    // 24
 constexpr int TAB_KPID = 96;                   // KC
 
-__global__ __launch_bounds__(kThreads) void k_frame_resjac(DevModel M, DevProblem Pb, const double* __restrict__ params,
+__global__ __launch_bounds__(kThreads, 4) void k_frame_resjac(DevModel M, DevProblem Pb, const double* __restrict__ params,
                                                       const double* __restrict__ beta, double* __restrict__ r_out,
                                                       double* __restrict__ J_out, double* __restrict__ joints_out,
                                                       MeshCoef mc, int want_jac, PriorArgs pa) {
