@@ -236,3 +236,50 @@ def test_invalid_arguments_fail_loudly(api, synth, model, gpu_model):
         api.Problem(gpu_model, seq.kp_offset, bad, seq.kp_uv, seq.intr, seq.R0)
     with pytest.raises(api.BodyfitError):
         api.Problem.from_sequence(gpu_model, seq, n_cols=76, use_shape=True)
+
+
+def test_reference_keypoint_files(api, synth, model, gpu_model, oracle_mod, omodel):
+    """The reference's own data/keypoints/video1/*.json (reduced to PixelKP lists by a restated load_mp_json,
+    tests/golden/make_golden.py): 38 frames, 5 of them empty, 12-16 keypoints, the pelvis twice (quirk Q1),
+    480x270 images -> fx = fy = 432.  Ragged + empty frames through the HIP path vs the oracle, then the
+    3dba_single fit of the non-empty frames vs the dense LM."""
+    g = np.load(os.path.join(GOLD, "video1_keypoints.npz"))
+    W, H = int(g["W"]), int(g["H"])
+    f_ = 0.9 * max(W, H)
+    class S: pass
+    seq = S(); seq.kp_offset = g["kp_offset"]; seq.kp_id = g["kp_id"]; seq.kp_uv = g["kp_uv"]
+    F = len(seq.kp_offset) - 1
+    seq.intr = np.array([f_, f_, 0.5 * W, 0.5 * H]); seq.R0 = np.tile(synth.R0_DEFAULT.reshape(1, 9), (F, 1))
+    assert F == 38 and (np.diff(seq.kp_offset) == 0).sum() == 5
+    counts = np.bincount(seq.kp_id[seq.kp_offset[5]:seq.kp_offset[6]], minlength=24)
+    assert counts[0] == 2  # Q1: the pelvis keypoint is emitted twice
+    rng = np.random.default_rng(77)
+    x = random_params(rng, F, pose_sigma=0.2)
+    prob = api.Problem(gpu_model, seq.kp_offset, seq.kp_id, seq.kp_uv, seq.intr, seq.R0, n_cols=76, use_shape=False,
+                       beta_pose=20.0)
+    r, J, _ = prob.evaluate(x, None, True)
+    ro, Jo = omodel.evaluate_batch(seq, x, np.zeros(10), 76, False, True, mode=0)
+    K2 = prob.layout.reproj_rows
+    assert np.abs(r[:K2] - ro).max() < 1e-9 and np.abs(J - Jo).max() < 1e-9 * np.abs(Jo).max()
+    # fit (pose + Sim3, L2 prior 20, joints 10/11/22/23 constant) from the reference's initial state
+    from oracle import lm_dense
+    x0 = np.zeros((F, 76)); x0[:, 0] = 1.0; x0[:, 6] = 3.0
+    const = np.zeros(76, np.uint8)
+    for j in (10, 11, 22, 23):
+        const[7 + 3 * (j - 1):10 + 3 * (j - 1)] = 1
+    xf, _, summ = prob.solve(x0, None, constant=const, independent=True, max_iters=100)
+    assert all(s.usable for s in summ)
+    for f in [4, 20]:   # two non-empty frames against the dense LM
+        k0, k1 = seq.kp_offset[f], seq.kp_offset[f + 1]
+        assert k1 > k0
+        s1 = S(); s1.kp_offset = np.array([0, k1 - k0], np.int32); s1.kp_id = seq.kp_id[k0:k1]
+        s1.kp_uv = seq.kp_uv[k0:k1]; s1.intr = seq.intr; s1.R0 = seq.R0[f:f + 1]
+        xo, _, info = lm_dense.solve(omodel, s1, x0[f:f + 1], None, n_cols=76, use_shape=False, beta_pose=20.0,
+                                     max_iters=100, constant=const)
+        d_rot = np.abs(np.delete(xf[f], [0, 4, 5, 6]) - np.delete(xo[0], [0, 4, 5, 6])).max()
+        d_t = np.abs(xf[f, 4:7] / xf[f, 0] - xo[0, 4:7] / xo[0, 0]).max()
+        assert max(d_rot, d_t) < 1e-4
+        assert abs(summ[f].final_cost - info["final_cost"]) < 1e-5 * max(info["final_cost"], 1e-9)
+    # an empty frame ('[]' JSON) keeps its parameters up to the prior pull and reports a usable solution
+    e = int(np.where(np.diff(seq.kp_offset) == 0)[0][0])
+    assert summ[e].usable
