@@ -91,7 +91,7 @@ __device__ inline double wave_sum(double v) {
     if (Pb.dbg && (threadIdx.x & 63) == 0 && threadIdx.x < 256) {                             \
       unsigned long long t_;                                                                  \
       asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");              \
-      Pb.dbg[((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16 + (i)] = t_;                  \
+      Pb.dbg[((size_t)(blockIdx.x - pa.n_tiles) * 4 + (threadIdx.x >> 6)) * 16 + (i)] = t_;                  \
     }                                                                                         \
   } while (0)
 #define STAMP_REAL(i)                                                                         \
@@ -99,7 +99,7 @@ __device__ inline double wave_sum(double v) {
     if (Pb.dbg && (threadIdx.x & 63) == 0 && threadIdx.x < 256) {                             \
       unsigned long long t_;                                                                  \
       asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");          \
-      Pb.dbg[((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16 + (i)] = t_;                  \
+      Pb.dbg[((size_t)(blockIdx.x - pa.n_tiles) * 4 + (threadIdx.x >> 6)) * 16 + (i)] = t_;                  \
     }                                                                                         \
   } while (0)
 #else
@@ -149,11 +149,23 @@ __global__ __launch_bounds__(kThreads, 4) void k_frame_resjac(DevModel M, DevPro
                                                       double* __restrict__ J_out, double* __restrict__ joints_out,
                                                       MeshCoef mc, int want_jac, PriorArgs pa) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
-  if ((int)blockIdx.x >= Pb.F) {   // extra workgroups of the launch: prior residuals of one 16-frame tile
-    prior_block(pa, (int)blockIdx.x - Pb.F, params, sm);
+  if ((int)blockIdx.x < pa.n_tiles) {   // first workgroups of the launch: prior residuals of one 16-frame tile
+#ifdef BODYFIT_STAMPS
+    unsigned long long tp0 = 0;
+    if (Pb.dbg && threadIdx.x == 0) asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tp0)::"memory");
+#endif
+    prior_block(pa, (int)blockIdx.x, params, sm);   // (dispatched first so they never form the tail of the launch)
+#ifdef BODYFIT_STAMPS
+    if (Pb.dbg && threadIdx.x == 0) {
+      unsigned long long tp1;
+      asm volatile("s_waitcnt vmcnt(0)\n\ts_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tp1)::"memory");
+      Pb.dbg[((size_t)Pb.F * 4 + blockIdx.x) * 16 + 0] = tp0;
+      Pb.dbg[((size_t)Pb.F * 4 + blockIdx.x) * 16 + 1] = tp1;
+    }
+#endif
     return;
   }
-  const int f = blockIdx.x;
+  const int f = (int)blockIdx.x - pa.n_tiles;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int nJ = M.nJ, nS = M.nS, P = M.P, nL = M.nL;

@@ -283,3 +283,43 @@ def test_reference_keypoint_files(api, synth, model, gpu_model, oracle_mod, omod
     # an empty frame ('[]' JSON) keeps its parameters up to the prior pull and reports a usable solution
     e = int(np.where(np.diff(seq.kp_offset) == 0)[0][0])
     assert summ[e].usable
+
+
+def test_many_keypoints_per_frame_and_no_posedirs(api, synth, model, gpu_model, oracle_mod, omodel):
+    """(1) More than 32 keypoints in a frame exercises the keypoint-chunk loop of k_frame_resjac (and sends the
+    solve to the host loop: the device LM stages at most 32 keypoints).  (2) A model uploaded without posedirs
+    (upstream avatar applies no pose-corrective blendshapes) equals pose_blend = 0."""
+    F = 3
+    base = synth.make_sequence(model, F, seed=12)
+    rng = np.random.default_rng(5)
+    ids, uvs, offs = [], [], [0]
+    for f in range(F):
+        k0, k1 = base.kp_offset[f], base.kp_offset[f + 1]
+        rep = 3 if f == 1 else 1                      # frame 1 gets 75 keypoints (duplicates are legal: quirk Q1)
+        ids.append(np.tile(base.kp_id[k0:k1], rep))
+        uvs.append(np.tile(base.kp_uv[k0:k1], (rep, 1)) + rng.normal(scale=0.5, size=(rep * (k1 - k0), 2)))
+        offs.append(offs[-1] + rep * (k1 - k0))
+    class S: pass
+    seq = S(); seq.kp_offset = np.array(offs, np.int32); seq.kp_id = np.concatenate(ids).astype(np.int32)
+    seq.kp_uv = np.concatenate(uvs); seq.intr = base.intr; seq.R0 = base.R0
+    x = random_params(rng, F); beta = rng.normal(size=10)
+    prob = api.Problem(gpu_model, seq.kp_offset, seq.kp_id, seq.kp_uv, seq.intr, seq.R0, n_cols=86, use_shape=True)
+    r, J, _ = prob.evaluate(x, beta, True)
+    ro, Jo = omodel.evaluate_batch(seq, x, beta, 86, True, True, mode=0)
+    assert np.abs(r - ro).max() < 1e-9 and np.abs(J - Jo).max() < 1e-9 * np.abs(Jo).max()
+    pf = api.Problem(gpu_model, seq.kp_offset, seq.kp_id, seq.kp_uv, seq.intr, seq.R0, n_cols=86, use_shape=True,
+                     beta_per_frame=True, beta_pose=5.0, beta_shape=10.0)
+    with pytest.raises(api.BodyfitError):
+        pf.solve(base.init_params, np.zeros((F, 10)), independent=True, max_iters=3, solver=2)   # device loop refuses
+    xs, bs, summ = pf.solve(base.init_params, np.zeros((F, 10)), independent=True, max_iters=5)  # auto -> host loop
+    assert all(s.usable for s in summ) and summ[1].final_cost < summ[1].initial_cost
+    # (2) model without pose-corrective blendshapes
+    gm0 = api.Model(model, device=0, pose_blend_data=False)
+    p0 = api.Problem(gm0, base.kp_offset, base.kp_id, base.kp_uv, base.intr, base.R0, n_cols=86, use_shape=True,
+                     want_mesh=True)
+    r0, J0, _ = p0.evaluate(x, beta, True)
+    r1, J1 = omodel.evaluate_batch(base, x, beta, 86, True, False, mode=0)
+    assert np.abs(r0 - r1).max() < 1e-9 and np.abs(J0 - J1).max() < 1e-9 * np.abs(J1).max()
+    _, cloud = p0.forward(x, beta)
+    _, co = omodel.forward(x[1], beta, base.R0[1], pose_blend=False)
+    assert np.abs(cloud[1] - co).max() < 5e-6
