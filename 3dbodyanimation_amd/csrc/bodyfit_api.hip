@@ -311,8 +311,16 @@ int bodyfit_model_create(const bodyfit_model_desc* desc, int device, bodyfit_mod
   // mesh operands in MFMA fragment order
   {
     const int nVT = d.nVTiles;
-    std::vector<uint16_t> dirsB((size_t)nVT * 3 * kPoseKSteps * 2 * 64 * 8, 0);
-    std::vector<float> sdB((size_t)nVT * 3 * kShapeKSteps * 64, 0.0f), vtB((size_t)nVT * 3 * 32, 0.0f);
+    std::vector<uint16_t> dirsB((size_t)nVT * kBlendKSteps * 3 * 2 * 64 * 8, 0);
+    std::vector<float> vtB((size_t)nVT * 3 * 32, 0.0f);
+    auto put = [&](int vt_i, int c, int col, int k, float x) {   // 32x32x16: B[k = 16 ks + 8 h + j][col]
+      const int ks = k >> 4, hh = (k >> 3) & 1, jj = k & 7;
+      const uint16_t hi = f32_to_bf16(x);
+      const uint16_t lo = f32_to_bf16(x - bf16_to_f32(hi));
+      const size_t base = ((((size_t)vt_i * kBlendKSteps + ks) * 3 + c) * 2) * 64 * 8;
+      dirsB[base + (size_t)(hh * 32 + col) * 8 + jj] = hi;
+      dirsB[base + (size_t)64 * 8 + (size_t)(hh * 32 + col) * 8 + jj] = lo;
+    };
     std::vector<uint32_t> wIdx((size_t)nVT * 32, 0u);
     std::vector<float> wVal((size_t)nVT * 32 * 4, 0.0f);
     for (int vt_i = 0; vt_i < nVT; ++vt_i)
@@ -321,20 +329,9 @@ int bodyfit_model_create(const bodyfit_model_desc* desc, int device, bodyfit_mod
         if (v >= V) continue;
         for (int c = 0; c < 3; ++c) {
           vtB[((size_t)vt_i * 3 + c) * 32 + col] = (float)(desc->v_template[(size_t)v * 3 + c] - J0[c]);
-          for (int k = 0; k < nS; ++k) {
-            const int ks = k >> 1, hh = k & 1;  // 32x32x2: B[k = lane>>5][j = lane&31]
-            sdB[(((size_t)vt_i * 3 + c) * kShapeKSteps + ks) * 64 + hh * 32 + col] =
-                (float)(desc->shapedirs[((size_t)v * 3 + c) * nS + k] - S[(size_t)c * nS + k]);
-          }
-          for (int k = 0; k < P; ++k) {
-            const int ks = k >> 4, hh = (k >> 3) & 1, jj = k & 7;  // 32x32x16: B[k = 8h + j][col]
-            const float x = (float)desc->posedirs[((size_t)v * 3 + c) * P + k];
-            const uint16_t hi = f32_to_bf16(x);
-            const uint16_t lo = f32_to_bf16(x - bf16_to_f32(hi));
-            const size_t base = ((((size_t)vt_i * 3 + c) * kPoseKSteps + ks) * 2) * 64 * 8;
-            dirsB[base + (size_t)(hh * 32 + col) * 8 + jj] = hi;
-            dirsB[base + (size_t)64 * 8 + (size_t)(hh * 32 + col) * 8 + jj] = lo;
-          }
+          for (int k = 0; k < nS && k < kMaxShape; ++k)
+            put(vt_i, c, col, kPoseFeat + k, (float)(desc->shapedirs[((size_t)v * 3 + c) * nS + k] - S[(size_t)c * nS + k]));
+          for (int k = 0; k < P && k < kPoseFeat; ++k) put(vt_i, c, col, k, (float)desc->posedirs[((size_t)v * 3 + c) * P + k]);
         }
         int cnt = 0;
         uint32_t packed = 0;
@@ -351,7 +348,6 @@ int bodyfit_model_create(const bodyfit_model_desc* desc, int device, bodyfit_mod
         wIdx[(size_t)vt_i * 32 + col] = packed;
       }
     HIP_TRY(m->mem.upload(&d.dirsB, dirsB));
-    HIP_TRY(m->mem.upload(&d.sdB, sdB));
     HIP_TRY(m->mem.upload(&d.vtB, vtB));
     HIP_TRY(m->mem.upload(&d.wIdx, wIdx));
     HIP_TRY(m->mem.upload(&d.wVal, wVal));
@@ -532,14 +528,14 @@ int bodyfit_problem_create(const bodyfit_model* m, const bodyfit_problem_desc* d
   HIP_TRY(hipMemset(p->d_comp, 0, (size_t)F * sizeof(int)));
   HIP_TRY(hipMemset(p->d_beta, 0, (size_t)std::max(1, desc->beta_per_frame ? F * nS : nS) * sizeof(double)));
   if (desc->want_mesh) {
-    const size_t nfa = (size_t)d.nFTiles * kPoseKSteps * 2 * 64 * 8;
-    const size_t nba = (size_t)d.nFTiles * kShapeKSteps * 64;
+    const size_t nfa = (size_t)d.nFTiles * kBlendKSteps * 2 * 64 * 8;
     HIP_TRY(p->mem.alloc(&p->mc.featA, nfa));
-    HIP_TRY(p->mem.alloc(&p->mc.betaA, nba));
-    HIP_TRY(p->mem.alloc(&p->mc.skinT, (size_t)F * nJ * 12));
-    HIP_TRY(p->mem.alloc(&p->d_cloud, (size_t)F * m->V * 3));
+    const size_t nsk = (size_t)d.nFTiles * kFTile * nJ * 12;   // whole frame tiles, zero beyond F
+    HIP_TRY(p->mem.alloc(&p->mc.skinT, nsk));
+    HIP_TRY(hipMemset(p->mc.skinT, 0, nsk * sizeof(float)));
+    // frames padded to whole 32-frame tiles + one 64 x 3 float dump row: k_mesh_blend_lbs stores unconditionally
+    HIP_TRY(p->mem.alloc(&p->d_cloud, (size_t)d.nFTiles * kFTile * m->V * 3 + 64 * 3));
     HIP_TRY(hipMemset(p->mc.featA, 0, nfa * sizeof(uint16_t)));
-    HIP_TRY(hipMemset(p->mc.betaA, 0, nba * sizeof(float)));
   }
   *out = p.release();
   return BODYFIT_OK;

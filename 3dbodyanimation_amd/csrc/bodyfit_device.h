@@ -15,8 +15,8 @@ constexpr int kMeshNnz = 4;        // packed skinning weights per mesh vertex
 // mesh operand geometry (k_mesh_blend_lbs.hip)
 constexpr int kVTile = 32;         // vertices per MFMA column tile
 constexpr int kFTile = 32;         // frames per MFMA row tile
-constexpr int kPoseKSteps = 13;    // 207 -> 208 = 13 x 16 (bf16 32x32x16)
-constexpr int kShapeKSteps = 5;    // 10 = 5 x 2 (f32 32x32x2)
+constexpr int kPoseFeat = 207;     // 9 x 23 pose-corrective features
+constexpr int kBlendKSteps = 14;   // K = 207 pose features + 10 shape coefficients = 217 -> 224 = 14 x 16 (bf16 32x32x16)
 
 struct DevModel {
   int V, nJ, nS, P, nL, nLevels, nVTiles;
@@ -37,8 +37,7 @@ struct DevModel {
   const double* lm_sd;         // [nL][3][nS]   shapedirs  - S_root
   const double* lm_pd;         // [nL][3][P]
   // mesh operands (packed in MFMA fragment order at upload)
-  const uint16_t* dirsB;       // [nVTiles][3][kPoseKSteps][2 hi/lo][64][8] bf16
-  const float* sdB;            // [nVTiles][3][kShapeKSteps][64] f32
+  const uint16_t* dirsB;       // [nVTiles][kBlendKSteps][3][2 hi/lo][64][8] bf16: posedirs, then shapedirs - S_root
   const float* vtB;            // [nVTiles][3][32] f32
   const uint32_t* wIdx;        // [nVTiles*32] 4 x u8 joint ids
   const float* wVal;           // [nVTiles*32][4]
@@ -58,8 +57,7 @@ struct DevProblem {
 
 // operands the per-frame kernel prepares for the mesh kernel
 struct MeshCoef {
-  uint16_t* featA;   // [nFTiles][kPoseKSteps][2 hi/lo][64][8] bf16
-  float* betaA;      // [nFTiles][kShapeKSteps][64] f32
+  uint16_t* featA;   // [nFTiles][kBlendKSteps][2 hi/lo][64][8] bf16: pose features, then beta
   float* skinT;      // [F][nJ][12] f32: rows of [s R_root R0 A_j | s R_root R0 (P_j - A_j Jc_j) + t]
 };
 

@@ -414,7 +414,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_frame_resjac(DevModel M, DevPro
   }
   if (mc.featA) {
     const int ftile = f / kFTile, row = f % kFTile;
-    if (wave == 2 && lane < kPoseKSteps * 4) {
+    if (wave == 2 && lane < kBlendKSteps * 4) {
       const int kstep = lane >> 2, h = (lane >> 1) & 1, hl = lane & 1;
       uint32_t pk[4];
 #pragma unroll
@@ -422,18 +422,17 @@ __global__ __launch_bounds__(kThreads, 4) void k_frame_resjac(DevModel M, DevPro
         uint16_t b[2];
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-          const float x = Pb.pose_blend ? (float)sFeat[kstep * 16 + 8 * h + 2 * jj + u] : 0.0f;
+          const int k = kstep * 16 + 8 * h + 2 * jj + u;     // blend coefficient: pose feature, then beta
+          float x = 0.0f;
+          if (k < kPoseFeat) x = Pb.pose_blend ? (float)sFeat[k] : 0.0f;
+          else if (k - kPoseFeat < nS) x = (float)sbeta[k - kPoseFeat];
           const uint16_t hi = f32_to_bf16(x);
           b[u] = hl == 0 ? hi : f32_to_bf16(x - bf16_to_f32(hi));
         }
         pk[jj] = (uint32_t)b[0] | ((uint32_t)b[1] << 16);
       }
-      uint4* dst = reinterpret_cast<uint4*>(mc.featA + ((((size_t)ftile * kPoseKSteps + kstep) * 2 + hl) * 64 + (h * 32 + row)) * 8);
+      uint4* dst = reinterpret_cast<uint4*>(mc.featA + ((((size_t)ftile * kBlendKSteps + kstep) * 2 + hl) * 64 + (h * 32 + row)) * 8);
       *dst = make_uint4(pk[0], pk[1], pk[2], pk[3]);
-    }
-    if (wave == 1 && lane < 2 * kShapeKSteps) {
-      const int kstep = lane >> 1, h = lane & 1, k = 2 * kstep + h;
-      mc.betaA[((size_t)ftile * kShapeKSteps + kstep) * 64 + h * 32 + row] = (k < nS) ? (float)sbeta[k] : 0.0f;
     }
   }
   if (nL > 0 && want_jac) {

@@ -2,25 +2,23 @@
 // 24-joint linear-blend skinning, f32 out.  Replaces ark::Avatar::update()'s cloud
 // (call sites include/Sim3BA.h:371,538; include/MultiFrameBA.h:53,173; src/main_single_frame.cpp:254).
 //
-// Per workgroup: one tile of 32 vertices (MFMA N), all frames in tiles of 32 (MFMA M), K = blend
-// coefficients.  D[frame][vertex] per coordinate, accumulated in f32:
-//   template        v_template (centred on the rest root joint), added to the accumulators in the epilogue
-//   shape blend     v_mfma_f32_32x32x2_f32, K = 10 -> 5 steps, exact f32 (per-frame beta supported)
-//   pose blend      v_mfma_f32_32x32x16_bf16, K = 207 -> 13 steps, operands split hi+lo in bf16 and
-//                   three products hi.hi + hi.lo + lo.hi (relative product error <= 2^-16), 5.3x the
-//                   f32-MFMA rate
-// Data movement (the 17 MB posedirs stream is the only large read):
-//   * the vertex tile's B operands (78 KiB pose hi/lo + 1.9 KiB shape, stored in fragment order at
-//     upload) go HBM -> LDS by LDS-DMA (global_load_lds_dwordx4: 1 KiB contiguous per wave-instruction),
-//     once per workgroup, and are reused by all four waves for every frame tile;
-//   * A operands (pose-feature hi/lo, beta) come from L2 in fragment order, one 1 KiB load per k-step;
-//   * the skinning transforms of 8 frames (9 KiB, contiguous) are register-staged per wave (loads for the
-//     next 8 frames issued before the current 8 are skinned, written to LDS afterwards) and gathered by
-//     joint id with ds_read_b128; the blended vertices never touch HBM;
-//   * output rows are 384 contiguous bytes per frame (lane = vertex).
-// Eight waves per workgroup = two per SIMD, so one wave's LDS-DMA / store-retire waits (CDNA4 counts
-// stores in vmcnt) are covered by its partner's MFMA or skinning VALU work.
-// LDS: 79.9 KiB (B) + 3.75 KiB (shape) + 8 x 9 KiB (transforms) = 153.75 KiB of the CU's 160 KiB.
+// Per workgroup: one tile of 32 vertices (MFMA N); per wave: "units" of 32 frames (MFMA M) x that tile.
+//   blend     D[frame][vertex] per coordinate = [pose feature | beta] . [posedirs | shapedirs - S_root],
+//             K = 207 + 10 -> 14 k-steps of v_mfma_f32_32x32x16_bf16, both operands split hi + lo in
+//             bf16, three products hi.hi + hi.lo + lo.hi (relative product error <= 2^-16 on
+//             displacements of centimetres), f32 accumulation; the template is added in f32 afterwards
+//   skinning  per frame row: gather the vertex's <= 4 joint transforms (3x4 f32) from LDS, blend, apply,
+//             one 12-byte store per lane (lane = vertex -> 384 contiguous bytes per half-wave)
+// Software pipeline (one wave per SIMD, 4 per workgroup, up to 512 registers each): the k-loop of unit
+// n+1 and the 16 skinning rows of unit n are ONE straight-line body of 16 slots, slot s = k-step s
+// (9 MFMAs, 288 matrix-pipe cycles) + row s (about 50 vector instructions): the MFMA only holds the vector
+// issue port for 8 of its 32 cycles, so the row's VALU work runs underneath.  Everything a slot consumes was
+// requested at least one slot earlier: A fragments (L2) six k-steps ahead in a register ring, B fragments
+// (LDS) one k-step ahead, the row's 12 transform reads (LDS) one row ahead, the transforms of the next
+// 8-frame quarter (L2 -> registers -> this wave's private LDS double buffer) a whole quarter ahead.
+// Data movement: the vertex tile's B operands (84 KiB, fragment order, contiguous per tile) go
+// HBM -> LDS by LDS-DMA once per workgroup and serve every frame; nothing blended touches HBM.
+// LDS: 84 KiB (B) + 4 waves x 2 x 9 KiB (transforms) = 156 KiB of the CU's 160 KiB.
 #include "bodyfit_device.h"
 
 namespace bodyfit {
@@ -28,22 +26,27 @@ namespace {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;   // plain vector: HIP's uint4 assigns through memcpy,
+                                                                  // which keeps a staging array in scratch
 
-constexpr int kPosePieces = 3 * kPoseKSteps * 2;                 // 78 x 1 KiB
-constexpr int kPoseBytes = kPosePieces * 1024;                   // 79,872
-constexpr int kShapeFloats = 3 * kShapeKSteps * 64;              // 960 f32 = 3,840 B
-constexpr int kSkinRows = 8;                                     // frames per epilogue quarter
-constexpr int kWaves = 8;
-constexpr int kSkinBytes = kSkinRows * kMaxJoints * 48;          // 9,216
-constexpr int kLdsBytes = kPoseBytes + kShapeFloats * 4 + kWaves * kSkinBytes;   // 157,440
+constexpr int kWaves = 4;
+constexpr int kPieces = kBlendKSteps * 3 * 2;                    // 84 x 1 KiB, [ks][c][hi/lo]
+constexpr int kBBytes = kPieces * 1024;                          // 86,016
+constexpr int kRowBytes = kMaxJoints * 48;                       // one frame's 24 transforms: 1,152
+constexpr int kQuarterBytes = 8 * kRowBytes;                     // 9,216
+constexpr int kLdsBytes = kBBytes + kWaves * 2 * kQuarterBytes;  // 159,744
+constexpr int kSkinVec = kQuarterBytes / (64 * 16);              // uint4 per lane per quarter = 9
+constexpr int kAhead = 6;                                        // A-fragment ring depth, k-steps
 
 #ifdef BODYFIT_STAMPS
 #define MSTAMP(i)                                                                             \
   do {                                                                                        \
-    if (Pb.dbg && (threadIdx.x & 63) == 0) {                                                  \
-      unsigned long long t_;                                                                  \
-      asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");          \
-      Pb.dbg[((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 16 + (i)] = t_;                  \
+    if (Pb.dbg && lane == 0) {                                                                \
+      unsigned long long t_, c_;                                                              \
+      asm volatile("s_memrealtime %0\n\ts_memtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_), "=s"(c_)::"memory"); \
+      Pb.dbg[((size_t)blockIdx.x * 8 + wave) * 16 + (i)] = t_;                                \
+      Pb.dbg[((size_t)blockIdx.x * 8 + wave) * 16 + 8 + (i)] = c_;                            \
     }                                                                                         \
   } while (0)
 #else
@@ -54,186 +57,248 @@ __device__ inline void lds_dma_16(const void* g, void* l) {
   __builtin_amdgcn_global_load_lds(g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 }
 
-// One output row of the skinning epilogue.  R (compile-time) = accumulator register = frame row
-// (R & 3) + 8 (R >> 2) + 4 h of the tile; the row's 24 transforms sit at Trow in this wave's LDS slice.
+struct Lane {                    // per-lane constants of the skinning rows
+  float vt[3];                   // template (centred on the rest root joint)
+  f32x2 w2[4];                   // skinning weights, broadcast pairs
+  const unsigned char* tj[4];    // LDS address of joint i's transform in frame row 4h of buffer 0
+  unsigned out_off;              // byte offset of (frame 4h, vertex v) in the cloud
+  unsigned char* dump;           // where lanes past the last vertex store (padding behind the cloud)
+  bool v_ok;
+};
+
+// one quarter of a unit: 8 frames x 24 transforms, contiguous in HBM.  skinT is allocated (and zeroed) for whole
+// frame tiles, so the loads need no predicate (a predicated load is a branch, and a branch ends the slot's
+// scheduling region).
+__device__ __forceinline__ void skin_load(const unsigned char* skinT, int ftile, int q, int lane, u32x4 (&reg)[kSkinVec]) {
+  const unsigned char* g = skinT + ((size_t)ftile * kFTile + q * 8) * kRowBytes + lane * 16;
+#pragma unroll
+  for (int i = 0; i < kSkinVec; ++i) reg[i] = *reinterpret_cast<const u32x4*>(g + i * 1024);
+}
+__device__ __forceinline__ void skin_store(unsigned char* l, int lane, const u32x4 (&reg)[kSkinVec]) {
+#pragma unroll
+  for (int i = 0; i < kSkinVec; ++i) *reinterpret_cast<u32x4*>(l + (i * 64 + lane) * 16) = reg[i];
+}
+
+// the 12 LDS reads of row R (frame row (R & 3) + 8 (R >> 2) + 4 h of the unit) — buffer parity (R >> 2) & 1
 template <int R>
-__device__ __forceinline__ void skin_row(const f32x16 (&acc)[3], const float (&vt)[3], const unsigned char* Trow,
-                                         const int (&jo)[4], const float (&wgt)[4], float* __restrict__ o, bool live) {
-  float4 t0 = make_float4(0, 0, 0, 0), t1 = t0, t2 = t0;
+__device__ __forceinline__ void row_fetch(const Lane& L, float4 (&t)[12]) {
+  constexpr int off = ((R >> 2) & 1) * kQuarterBytes + (R & 3) * kRowBytes;
 #pragma unroll
-  for (int i = 0; i < kMeshNnz; ++i) {
-    const float4* T = reinterpret_cast<const float4*>(Trow + jo[i]);
-    const float w = wgt[i];
-    const float4 a0 = T[0], a1 = T[1], a2 = T[2];
-    t0.x += w * a0.x; t0.y += w * a0.y; t0.z += w * a0.z; t0.w += w * a0.w;
-    t1.x += w * a1.x; t1.y += w * a1.y; t1.z += w * a1.z; t1.w += w * a1.w;
-    t2.x += w * a2.x; t2.y += w * a2.y; t2.z += w * a2.z; t2.w += w * a2.w;
-  }
-  const float px = acc[0][R] + vt[0], py = acc[1][R] + vt[1], pz = acc[2][R] + vt[2];
-  if (live) {
-    o[0] = t0.x * px + t0.y * py + t0.z * pz + t0.w;
-    o[1] = t1.x * px + t1.y * py + t1.z * pz + t1.w;
-    o[2] = t2.x * px + t2.y * py + t2.z * pz + t2.w;
+  for (int i = 0; i < 4; ++i) {
+    const float4* T = reinterpret_cast<const float4*>(L.tj[i] + off);
+    t[3 * i + 0] = T[0]; t[3 * i + 1] = T[1]; t[3 * i + 2] = T[2];
   }
 }
 
-constexpr int kSkinVec = kSkinBytes / (64 * 16);   // uint4 per lane per 8-frame block = 9
-
-// issue the loads of one 8-frame block of skinning transforms (contiguous in HBM) into registers
-__device__ __forceinline__ void skin_load(const unsigned char* g, int nbytes, int lane, uint4 (&reg)[kSkinVec]) {
+// blend the four transforms, apply to the blended rest vertex, store
+template <int R>
+__device__ __forceinline__ void row_apply(const Lane& L, const float4 (&t)[12], const f32x16 (&acc)[3],
+                                          unsigned char* out_row) {
+  f32x2 b[6];
 #pragma unroll
-  for (int i = 0; i < kSkinVec; ++i) {
-    const int off = (i * 64 + lane) * 16;
-    reg[i] = (off < nbytes) ? *reinterpret_cast<const uint4*>(g + off) : make_uint4(0, 0, 0, 0);
+  for (int k = 0; k < 3; ++k) {
+    b[2 * k] = L.w2[0] * f32x2{t[k].x, t[k].y};
+    b[2 * k + 1] = L.w2[0] * f32x2{t[k].z, t[k].w};
   }
-}
-__device__ __forceinline__ void skin_store(unsigned char* l, int lane, const uint4 (&reg)[kSkinVec]) {
 #pragma unroll
-  for (int i = 0; i < kSkinVec; ++i) *reinterpret_cast<uint4*>(l + (i * 64 + lane) * 16) = reg[i];
+  for (int i = 1; i < 4; ++i)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      b[2 * k] += L.w2[i] * f32x2{t[3 * i + k].x, t[3 * i + k].y};
+      b[2 * k + 1] += L.w2[i] * f32x2{t[3 * i + k].z, t[3 * i + k].w};
+    }
+  const f32x2 pxy = {acc[0][R] + L.vt[0], acc[1][R] + L.vt[1]};
+  const f32x2 pz1 = {acc[2][R] + L.vt[2], 1.0f};
+  float o[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const f32x2 m = b[2 * k] * pxy + b[2 * k + 1] * pz1;
+    o[k] = m.x + m.y;
+  }
+  // unconditional store (a predicated one splits the slot's basic block and with it the MFMA/VALU interleave):
+  // frames past F land in the cloud's tile padding, lanes past V in the dump row
+  struct alignas(4) F3 { float x, y, z; };
+  unsigned char* dst = L.v_ok ? out_row + L.out_off : L.dump;
+  *reinterpret_cast<F3*>(dst) = F3{o[0], o[1], o[2]};
 }
 
-__global__ __launch_bounds__(64 * kWaves, 2) void k_mesh_blend_lbs(DevModel M, DevProblem Pb, MeshCoef mc,
-                                                         float* __restrict__ cloud) {
+struct Unit {            // where one unit's operands live
+  const uint4* fa;       // A fragments: featA + ftile * 14 * 2 * 64 + lane
+  int ftile;
+};
+
+// One slot of the pipeline.  kM: k-step S of unit `um` accumulates into accN; kE: row S of unit `ue` is
+// skinned from accC.
+template <int S, bool kM, bool kE>
+__device__ __forceinline__ void slot(const Lane& L, const unsigned char* sB, unsigned char* sSkin, int lane, int F, int V,
+                                     const unsigned char* skinT, unsigned char* cloud, const Unit& um, const Unit& um_next,
+                                     const Unit& ue, int ft_q1, int q_q1, int ft_q2, int q_q2, f32x16 (&accN)[3],
+                                     const f32x16 (&accC)[3], uint4 (&a)[kBlendKSteps][2], uint4 (&bq)[2][3][2],
+                                     float4 (&tq)[2][12], u32x4 (&treg)[kSkinVec]) {
+  constexpr int q = S >> 2;
+  if constexpr (kE && (S & 3) == 0) {
+    // quarter boundary: the next quarter's transforms (in registers since the previous boundary) go to
+    // the other buffer, the one after that goes in flight.  (ft_q1, q_q1) / (ft_q2, q_q2) name the quarters
+    // one / two after quarter q of unit ue; they may belong to the wave's next unit.
+    skin_store(sSkin + ((q + 1) & 1) * kQuarterBytes, lane, treg);
+    const int ft2 = (q + 2 < 4) ? ue.ftile : ft_q2;
+    skin_load(skinT, ft2, (q + 2) & 3, lane, treg);
+    (void)ft_q1; (void)q_q1; (void)q_q2;
+  }
+  if constexpr (kM && S < kBlendKSteps) {
+    constexpr int sa = S + kAhead;
+    if constexpr (sa < kBlendKSteps) {
+      a[sa][0] = um.fa[(size_t)sa * 128]; a[sa][1] = um.fa[(size_t)sa * 128 + 64];
+    } else {
+      a[sa - kBlendKSteps][0] = um_next.fa[(size_t)(sa - kBlendKSteps) * 128];
+      a[sa - kBlendKSteps][1] = um_next.fa[(size_t)(sa - kBlendKSteps) * 128 + 64];
+    }
+    constexpr int sb = (S + 1) % kBlendKSteps;       // B is the same for every unit
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const uint4* bp = reinterpret_cast<const uint4*>(sB + (size_t)((sb * 3 + c) * 2) * 1024) + lane;
+      bq[(S + 1) & 1][c][0] = bp[0];
+      bq[(S + 1) & 1][c][1] = bp[64];
+    }
+  }
+  if constexpr (kE) row_fetch<(S + 1) & 15>(L, tq[(S + 1) & 1]);
+  if constexpr (kM && S < kBlendKSteps) {
+    const bf16x8 a_hi = __builtin_bit_cast(bf16x8, a[S][0]);
+    const bf16x8 a_lo = __builtin_bit_cast(bf16x8, a[S][1]);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const bf16x8 bhi = __builtin_bit_cast(bf16x8, bq[S & 1][c][0]);
+      const bf16x8 blo = __builtin_bit_cast(bf16x8, bq[S & 1][c][1]);
+      if constexpr (S == 0) {
+        f32x16 z;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) z[r] = 0.0f;
+        accN[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, bhi, z, 0, 0, 0);
+      } else {
+        accN[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, bhi, accN[c], 0, 0, 0);
+      }
+      accN[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, blo, accN[c], 0, 0, 0);
+      accN[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo, bhi, accN[c], 0, 0, 0);
+    }
+  }
+  if constexpr (kE) {
+    const int f = ue.ftile * kFTile + q * 8 + (S & 3);               // frame of the h = 0 half
+    unsigned char* out_row = cloud + (size_t)f * V * 12;
+    row_apply<S>(L, tq[S & 1], accC, out_row);
+  }
+  if constexpr (kM && kE && S < kBlendKSteps) {
+    // issue order inside the slot: every MFMA is followed by the LDS reads and vector work that fit under it
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // DS read
+      __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);   // VALU
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+template <bool kM, bool kE>
+__device__ __forceinline__ void body(const Lane& L, const unsigned char* sB, unsigned char* sSkin, int lane, int F, int V,
+                                     const unsigned char* skinT, unsigned char* cloud, const Unit& um, const Unit& um_next,
+                                     const Unit& ue, int ft_next, f32x16 (&accN)[3], const f32x16 (&accC)[3],
+                                     uint4 (&a)[kBlendKSteps][2], uint4 (&bq)[2][3][2], float4 (&tq)[2][12],
+                                     u32x4 (&treg)[kSkinVec]) {
+#define SLOT(S) slot<S, kM, kE>(L, sB, sSkin, lane, F, V, skinT, cloud, um, um_next, ue, 0, 0, ft_next, 0, accN, accC, a, bq, tq, treg)
+  SLOT(0); SLOT(1); SLOT(2); SLOT(3); SLOT(4); SLOT(5); SLOT(6); SLOT(7);
+  SLOT(8); SLOT(9); SLOT(10); SLOT(11); SLOT(12); SLOT(13); SLOT(14); SLOT(15);
+#undef SLOT
+}
+
+__global__ __launch_bounds__(64 * kWaves, 1) void k_mesh_blend_lbs(DevModel M, DevProblem Pb, MeshCoef mc,
+                                                                   float* __restrict__ cloud_f) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int vtile = blockIdx.x;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int col = lane & 31, h = lane >> 5;
   const int v = vtile * kVTile + col;
-  const int V = M.V, nJ = M.nJ, F = Pb.F;
-  const bool pose = Pb.pose_blend && M.P > 0;
+  const int V = M.V, F = Pb.F, nFT = Pb.nFTiles;
+  unsigned char* cloud = reinterpret_cast<unsigned char*>(cloud_f);
+  const unsigned char* skinT = reinterpret_cast<const unsigned char*>(mc.skinT);
 
   MSTAMP(0);
-  unsigned char* sPose = lds;                                           // [ks][c][hl][64][16 B]
-  float* sShape = reinterpret_cast<float*>(lds + kPoseBytes);           // [c][ks][64]
-  unsigned char* sSkin = lds + kPoseBytes + kShapeFloats * 4 + wave * kSkinBytes;
+  unsigned char* sB = lds;                                             // [ks][c][hi/lo][64][16 B]
+  unsigned char* sSkin = lds + kBBytes + wave * 2 * kQuarterBytes;     // this wave's two quarter buffers
 
-  // ---- stage this vertex tile's B operands: HBM -> LDS, 1 KiB per wave-instruction -----------------
+  // ---- stage this vertex tile's B operands: HBM -> LDS, 1 KiB per wave-instruction -------------------
   {
-    const unsigned char* gp = reinterpret_cast<const unsigned char*>(M.dirsB) + (size_t)vtile * kPoseBytes;
-    if (pose) {
-      for (int p = wave; p < kPosePieces; p += kWaves) {
-        // LDS piece p = (ks, c, hl) k-step-major; global layout is [c][ks][hl]
-        const int ks = p / 6, c = (p % 6) >> 1, hl = p & 1;
-        const int gpiece = (c * kPoseKSteps + ks) * 2 + hl;
-        lds_dma_16(gp + (size_t)gpiece * 1024 + lane * 16, sPose + (size_t)p * 1024);
-      }
+    const unsigned char* gp = reinterpret_cast<const unsigned char*>(M.dirsB) + (size_t)vtile * kBBytes;
+#pragma unroll
+    for (int i = 0; i < kPieces / kWaves; ++i) {
+      const int p = i * kWaves + wave;
+      lds_dma_16(gp + (size_t)p * 1024 + lane * 16, sB + (size_t)p * 1024);
     }
-    const float* gs = M.sdB + (size_t)vtile * kShapeFloats;
-    for (int i = threadIdx.x; i < kShapeFloats; i += 64 * kWaves) sShape[i] = gs[i];
   }
-  float vt[3];
+  Lane L;
 #pragma unroll
-  for (int c = 0; c < 3; ++c) vt[c] = M.vtB[((size_t)vtile * 3 + c) * 32 + col];
-  const uint32_t widx = M.wIdx[(size_t)vtile * 32 + col];
-  const float4 wv = reinterpret_cast<const float4*>(M.wVal)[(size_t)vtile * 32 + col];
-  const float wgt[4] = {wv.x, wv.y, wv.z, wv.w};
-  int jo[4];
+  for (int c = 0; c < 3; ++c) L.vt[c] = M.vtB[((size_t)vtile * 3 + c) * 32 + col];
+  {
+    const uint32_t widx = M.wIdx[(size_t)vtile * 32 + col];
+    const float4 wv = reinterpret_cast<const float4*>(M.wVal)[(size_t)vtile * 32 + col];
+    const float wgt[4] = {wv.x, wv.y, wv.z, wv.w};
 #pragma unroll
-  for (int i = 0; i < 4; ++i) jo[i] = (int)((widx >> (8 * i)) & 0xffu) * 48;
-  const uint4* feat = reinterpret_cast<const uint4*>(mc.featA);
+    for (int i = 0; i < 4; ++i) {
+      L.w2[i] = f32x2{wgt[i], wgt[i]};
+      L.tj[i] = sSkin + 4 * h * kRowBytes + (int)((widx >> (8 * i)) & 0xffu) * 48;
+    }
+  }
+  L.out_off = (unsigned)(((size_t)4 * h * V + v) * 12);
+  L.v_ok = v < V;
+  L.dump = cloud + (size_t)nFT * kFTile * V * 12 + lane * 12;
+
+  // this wave's units: frame tiles wave, wave + 4, ...
+  const uint4* feat = reinterpret_cast<const uint4*>(mc.featA) + lane;
+  auto unit = [&](int n) {
+    const int ft = min(wave + n * kWaves, nFT - 1);                    // clamped: prefetches past the end re-read
+    return Unit{feat + (size_t)ft * kBlendKSteps * 2 * 64, ft};
+  };
+  const int n_units = (nFT - wave + kWaves - 1) / kWaves;              // may be 0
+  f32x16 accN[3], accC[3];
+  uint4 a[kBlendKSteps][2], bq[2][3][2];
+  u32x4 treg[kSkinVec];
+  float4 tq[2][12];
+  Unit u0 = unit(0);
+  if (n_units > 0) {
+#pragma unroll
+    for (int ks = 0; ks < kAhead; ++ks) { a[ks][0] = u0.fa[(size_t)ks * 128]; a[ks][1] = u0.fa[(size_t)ks * 128 + 64]; }
+    skin_load(skinT, u0.ftile, 0, lane, treg);
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   MSTAMP(1);
+  if (n_units <= 0) return;
 
-  for (int ftile = wave; ftile < Pb.nFTiles; ftile += kWaves) {
-    // first 8-frame block of skinning transforms: loads in flight across the whole MFMA section
-    const unsigned char* gskin = reinterpret_cast<const unsigned char*>(mc.skinT) + (size_t)ftile * 32 * nJ * 48;
-    const int frames_left = F - ftile * 32;
-    uint4 treg[kSkinVec];
-    skin_load(gskin, min(kSkinRows, frames_left) * nJ * 48, lane, treg);
-    // A fragments (pose-feature hi/lo, L2) run kAhead k-steps ahead of the MFMAs in a register ring
-    constexpr int kAhead = 5;
-    const uint4* fa = feat + ((size_t)ftile * kPoseKSteps * 2) * 64 + lane;
-    uint4 ahi[kPoseKSteps], alo[kPoseKSteps];
-    if (pose) {
+  // prologue: blend of unit 0, then bootstrap the transform pipeline
 #pragma unroll
-      for (int ks = 0; ks < kAhead; ++ks) { ahi[ks] = fa[(size_t)ks * 128]; alo[ks] = fa[(size_t)ks * 128 + 64]; }
-    }
-
-    f32x16 acc[3];
-#pragma unroll
-    for (int c = 0; c < 3; ++c)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[c][r] = 0.0f;   // the template is added in the epilogue (a 16-wide
-                                                       // loop-invariant C-in per coordinate costs 48 VGPRs)
-
-    // shape blend, exact f32
-#pragma unroll
-    for (int ks = 0; ks < kShapeKSteps; ++ks) {
-      const float a = mc.betaA[((size_t)ftile * kShapeKSteps + ks) * 64 + lane];
-#pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        const float b = sShape[(c * kShapeKSteps + ks) * 64 + lane];
-        acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[c], 0, 0, 0);
-      }
-    }
-    // pose blend, bf16 hi/lo split; A fragments straight from L2, B fragments from LDS
-    if (pose) {
-#pragma unroll
-      for (int ks = 0; ks < kPoseKSteps; ++ks) {
-        if (ks + kAhead < kPoseKSteps) {
-          ahi[ks + kAhead] = fa[(size_t)(ks + kAhead) * 128];
-          alo[ks + kAhead] = fa[(size_t)(ks + kAhead) * 128 + 64];
-        }
-        const bf16x8 a_hi = __builtin_bit_cast(bf16x8, ahi[ks]);
-        const bf16x8 a_lo = __builtin_bit_cast(bf16x8, alo[ks]);
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          const uint4* bp = reinterpret_cast<const uint4*>(sPose + (size_t)((ks * 3 + c) * 2) * 1024) + lane;
-          const bf16x8 bhi = __builtin_bit_cast(bf16x8, bp[0]);
-          const bf16x8 blo = __builtin_bit_cast(bf16x8, bp[64]);
-          acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, bhi, acc[c], 0, 0, 0);
-          acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, blo, acc[c], 0, 0, 0);
-          acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo, bhi, acc[c], 0, 0, 0);
-        }
-        asm volatile("" ::: "memory");   // keep the A ring at kAhead k-steps (no further hoisting: VGPR budget)
-      }
-    }
-
-    MSTAMP(2);
-    // skinning epilogue, one frame row per step (lane = vertex): accumulator register r holds frame row
-    // (r & 3) + 8 (r >> 2) + 4 h, so registers 4q..4q+3 cover rows 8q..8q+7 = one LDS-DMA'd quarter.
-    // The runtime loop + switch keeps every row's 12 transform reads in its own scheduling region
-    // (a fully unrolled epilogue hoists 192 VGPRs of reads and spills at two waves per SIMD).
-#pragma unroll 1
-    for (int r = 0; r < 16; ++r) {
-      const int q = r >> 2, rr = r & 3;
-      if (rr == 0) {
-        // this block's transforms: registers -> this wave's LDS slice; next block's loads go in flight
-        skin_store(sSkin, lane, treg);
-        if (q < 3)
-          skin_load(gskin + (size_t)(q + 1) * kSkinRows * nJ * 48,
-                    max(0, min(kSkinRows, frames_left - (q + 1) * kSkinRows)) * nJ * 48, lane, treg);
-        __builtin_amdgcn_wave_barrier();
-        if (q == 0) MSTAMP(3);
-      }
-      const int f = ftile * kFTile + q * 8 + rr + 4 * h;
-      const unsigned char* Trow = sSkin + (rr + 4 * h) * (nJ * 48);
-      float* o = cloud + ((size_t)f * V + v) * 3;
-      const bool live = f < F && v < V;
-      switch (r) {
-        case 0: skin_row<0>(acc, vt, Trow, jo, wgt, o, live); break;
-        case 1: skin_row<1>(acc, vt, Trow, jo, wgt, o, live); break;
-        case 2: skin_row<2>(acc, vt, Trow, jo, wgt, o, live); break;
-        case 3: skin_row<3>(acc, vt, Trow, jo, wgt, o, live); break;
-        case 4: skin_row<4>(acc, vt, Trow, jo, wgt, o, live); break;
-        case 5: skin_row<5>(acc, vt, Trow, jo, wgt, o, live); break;
-        case 6: skin_row<6>(acc, vt, Trow, jo, wgt, o, live); break;
-        case 7: skin_row<7>(acc, vt, Trow, jo, wgt, o, live); break;
-        case 8: skin_row<8>(acc, vt, Trow, jo, wgt, o, live); break;
-        case 9: skin_row<9>(acc, vt, Trow, jo, wgt, o, live); break;
-        case 10: skin_row<10>(acc, vt, Trow, jo, wgt, o, live); break;
-        case 11: skin_row<11>(acc, vt, Trow, jo, wgt, o, live); break;
-        case 12: skin_row<12>(acc, vt, Trow, jo, wgt, o, live); break;
-        case 13: skin_row<13>(acc, vt, Trow, jo, wgt, o, live); break;
-        case 14: skin_row<14>(acc, vt, Trow, jo, wgt, o, live); break;
-        default: skin_row<15>(acc, vt, Trow, jo, wgt, o, live); break;
-      }
-      if (rr == 3) __builtin_amdgcn_wave_barrier();   // every lane has read this block before it is overwritten
-    }
-    __builtin_amdgcn_wave_barrier();
-    MSTAMP(4);
+  for (int c = 0; c < 3; ++c) {
+    const uint4* bp = reinterpret_cast<const uint4*>(sB + (size_t)(c * 2) * 1024) + lane;
+    bq[0][c][0] = bp[0]; bq[0][c][1] = bp[64];
   }
+  {
+    const Unit u1 = unit(1);
+    body<true, false>(L, sB, sSkin, lane, F, V, skinT, cloud, u0, u1, u0, 0, accN, accC, a, bq, tq, treg);
+  }
+  skin_store(sSkin, lane, treg);                                       // quarter 0 -> buffer 0
+  skin_load(skinT, u0.ftile, 1, lane, treg);                        // quarter 1 in flight
+  row_fetch<0>(L, tq[0]);
+  MSTAMP(2);
+
+  for (int n = 0; n < n_units; ++n) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) accC[c] = accN[c];
+    const Unit ue = unit(n), um = unit(n + 1), um_next = unit(n + 2);
+    const int ft_next = um.ftile;     // clamped past the end: those quarters are staged but never read
+    if (n + 1 < n_units)
+      body<true, true>(L, sB, sSkin, lane, F, V, skinT, cloud, um, um_next, ue, ft_next, accN, accC, a, bq, tq, treg);
+    else
+      body<false, true>(L, sB, sSkin, lane, F, V, skinT, cloud, um, um_next, ue, ft_next, accN, accC, a, bq, tq, treg);
+  }
+  MSTAMP(3);
 }
 
 }  // namespace
