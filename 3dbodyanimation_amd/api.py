@@ -61,7 +61,8 @@ class FitSummary(C.Structure):
 
 class DeviceViews(C.Structure):
     _fields_ = [("residuals", C.c_void_p), ("jacobian", C.c_void_p), ("gmm_comp", C.c_void_p),
-                ("cloud", C.c_void_p), ("joints", C.c_void_p), ("normal_eq", C.c_void_p)]
+                ("cloud", C.c_void_p), ("joints", C.c_void_p), ("normal_eq", C.c_void_p),
+                ("cloud_frame_stride", C.c_longlong)]
 
 
 _lib = None

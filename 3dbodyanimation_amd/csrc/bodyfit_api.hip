@@ -333,20 +333,58 @@ int bodyfit_model_create(const bodyfit_model_desc* desc, int device, bodyfit_mod
             put(vt_i, c, col, kPoseFeat + k, (float)(desc->shapedirs[((size_t)v * 3 + c) * nS + k] - S[(size_t)c * nS + k]));
           for (int k = 0; k < P && k < kPoseFeat; ++k) put(vt_i, c, col, k, (float)desc->posedirs[((size_t)v * 3 + c) * P + k]);
         }
-        int cnt = 0;
-        uint32_t packed = 0;
-        for (int j = 0; j < nJ; ++j) {
-          const double w = desc->weights[(size_t)v * nJ + j];
-          if (w == 0.0) continue;
-          if (cnt < kMeshNnz) {
-            packed |= ((uint32_t)j) << (8 * cnt);
-            wVal[((size_t)vt_i * 32 + col) * 4 + cnt] = (float)w;
+      }
+    // Skinning weights: <= 4 (joint, weight) entries per vertex, lane = vertex.  The kernel's i-th ds_read_b128 of a row
+    // has each lane fetch 16 B of its i-th joint's transform (48-byte records), served in groups of 16 lanes; two lanes
+    // of a group collide on LDS banks exactly when their i-th joints differ by 16.  The order of a vertex's entries is
+    // free, so it is chosen (greedily, per tile) to keep "joint mod 16" unique per group and slot; unused slots take
+    // weight 0 and a joint that broadcasts or falls on a free residue.
+    const int group_of_col[32] = {0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 1, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1};
+    for (int vt_i = 0; vt_i < nVT; ++vt_i) {
+      int used[2][kMeshNnz][16];   // joint + 1 occupying residue r of (group, slot), 0 = free
+      std::memset(used, 0, sizeof(used));
+      for (int col = 0; col < 32; ++col) {
+        const int v = vt_i * 32 + col, g = group_of_col[col];
+        int js[kMeshNnz], cnt = 0;
+        double ws[kMeshNnz];
+        if (v < V)
+          for (int j = 0; j < nJ; ++j) {
+            const double w = desc->weights[(size_t)v * nJ + j];
+            if (w == 0.0) continue;
+            if (cnt < kMeshNnz) { js[cnt] = j; ws[cnt] = w; }
+            ++cnt;
           }
-          ++cnt;
+        if (cnt > kMeshNnz) { m->mesh_ok = false; cnt = kMeshNnz; }
+        int perm[kMeshNnz] = {0, 1, 2, 3}, best[kMeshNnz] = {0, 1, 2, 3}, best_cost = 1 << 30;
+        do {   // slot perm[e] receives entry e (e < cnt)
+          int cost = 0;
+          for (int e = 0; e < cnt; ++e) {
+            const int u = used[g][perm[e]][js[e] & 15];
+            cost += (u != 0 && u != js[e] + 1);
+          }
+          if (cost < best_cost) { best_cost = cost; std::copy(perm, perm + kMeshNnz, best); }
+        } while (best_cost > 0 && std::next_permutation(perm, perm + kMeshNnz));
+        int slot_j[kMeshNnz];
+        float slot_w[kMeshNnz];
+        bool filled[kMeshNnz] = {false, false, false, false};
+        for (int e = 0; e < cnt; ++e) { slot_j[best[e]] = js[e]; slot_w[best[e]] = (float)ws[e]; filled[best[e]] = true; }
+        for (int sl = 0; sl < kMeshNnz; ++sl) {
+          if (!filled[sl]) {
+            int pick = -1;
+            for (int r = 0; r < 16 && pick < 0; ++r) if (used[g][sl][r]) pick = used[g][sl][r] - 1;   // broadcast
+            slot_j[sl] = pick < 0 ? 0 : pick;
+            slot_w[sl] = 0.0f;
+          }
+          if (!used[g][sl][slot_j[sl] & 15]) used[g][sl][slot_j[sl] & 15] = slot_j[sl] + 1;
         }
-        if (cnt > kMeshNnz) m->mesh_ok = false;
+        uint32_t packed = 0;
+        for (int sl = 0; sl < kMeshNnz; ++sl) {
+          packed |= ((uint32_t)slot_j[sl]) << (8 * sl);
+          wVal[((size_t)vt_i * 32 + col) * 4 + sl] = slot_w[sl];
+        }
         wIdx[(size_t)vt_i * 32 + col] = packed;
       }
+    }
     HIP_TRY(m->mem.upload(&d.dirsB, dirsB));
     HIP_TRY(m->mem.upload(&d.vtB, vtB));
     HIP_TRY(m->mem.upload(&d.wIdx, wIdx));
@@ -470,6 +508,8 @@ int bodyfit_problem_create(const bodyfit_model* m, const bodyfit_problem_desc* d
   for (int k = 0; k < K; ++k)
     if (desc->kp_id[k] < 0 || desc->kp_id[k] >= nJ + m->nL) return fail(BODYFIT_ERR_INVALID, "keypoint id out of range");
   if (desc->gmm && desc->gmm->d.D != 3 * (nJ - 1)) return fail(BODYFIT_ERR_INVALID, "GMM dimension must be 3 (n_joints - 1)");
+  if (desc->want_mesh && (size_t)((F + kFTile - 1) / kFTile) * kFTile * m->d.nVTiles * kVTile * 12 >= ((size_t)1 << 32))
+    return fail(BODYFIT_ERR_INVALID, "mesh path: the cloud of one problem must stay below 4 GiB (split the frames)");
   if (desc->want_mesh && !m->mesh_ok)
     return fail(BODYFIT_ERR_INVALID, "mesh path needs <= 4 skinning weights per vertex");
   if (desc->want_mesh && (nJ != 24 || (m->P != 0 && m->P != 207) || nS > 10))
@@ -533,8 +573,9 @@ int bodyfit_problem_create(const bodyfit_model* m, const bodyfit_problem_desc* d
     const size_t nsk = (size_t)d.nFTiles * kFTile * nJ * 12;   // whole frame tiles, zero beyond F
     HIP_TRY(p->mem.alloc(&p->mc.skinT, nsk));
     HIP_TRY(hipMemset(p->mc.skinT, 0, nsk * sizeof(float)));
-    // frames padded to whole 32-frame tiles + one 64 x 3 float dump row: k_mesh_blend_lbs stores unconditionally
-    HIP_TRY(p->mem.alloc(&p->d_cloud, (size_t)d.nFTiles * kFTile * m->V * 3 + 64 * 3));
+    // frames padded to whole 32-frame tiles, each frame to whole 32-vertex tiles: k_mesh_blend_lbs stores
+    // unconditionally, whole 128-byte lines per half-wave
+    HIP_TRY(p->mem.alloc(&p->d_cloud, (size_t)d.nFTiles * kFTile * m->d.nVTiles * kVTile * 3));
     HIP_TRY(hipMemset(p->mc.featA, 0, nfa * sizeof(uint16_t)));
   }
   *out = p.release();
@@ -559,6 +600,7 @@ int bodyfit_problem_views(bodyfit_problem* p, bodyfit_device_views* out) {
   out->jacobian = p->d_J;
   out->gmm_comp = p->d_comp;
   out->cloud = p->d_cloud;
+  out->cloud_frame_stride = (long long)p->m->d.nVTiles * kVTile * 3;
   out->joints = p->d_joints;
   out->normal_eq = p->d_normal;
   return BODYFIT_OK;
@@ -793,8 +835,10 @@ int bodyfit_forward(bodyfit_problem* p, const double* frame_params, const double
   if (rc) return rc;
   if (joints)
     HIP_TRY(hipMemcpy(joints, p->d_joints, (size_t)p->d.F * m->nJ * 3 * sizeof(double), hipMemcpyDeviceToHost));
-  if (cloud)
-    HIP_TRY(hipMemcpy(cloud, p->d_cloud, (size_t)p->d.F * m->V * 3 * sizeof(float), hipMemcpyDeviceToHost));
+  if (cloud) {
+    const size_t row = (size_t)m->V * 3 * sizeof(float), pitch = (size_t)m->d.nVTiles * kVTile * 3 * sizeof(float);
+    HIP_TRY(hipMemcpy2D(cloud, row, p->d_cloud, pitch, row, (size_t)p->d.F, hipMemcpyDeviceToHost));
+  }
   HIP_TRY(hipDeviceSynchronize());
   return BODYFIT_OK;
 }

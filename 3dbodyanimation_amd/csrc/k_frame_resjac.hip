@@ -21,6 +21,14 @@
 namespace bodyfit {
 namespace {
 
+// Jacobian panel store, written through L2 (sc0 sc1): the panel is this kernel's largest output (34 KB per frame) and
+// nothing on the device re-reads it from this XCD's L2 before the next launch; left dirty it is flushed by the
+// end-of-kernel release, which serialises ~9 MB of write-back behind the last wave.
+__device__ __forceinline__ void store_through(double* p, double v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+
 __device__ inline void mul33(const double* A, const double* B, double* C) {  // C = A B
 #pragma unroll
   for (int r = 0; r < 3; ++r)
@@ -591,8 +599,8 @@ __global__ __launch_bounds__(kThreads, 4) void k_frame_resjac(DevModel M, DevPro
             d1 = Wm[3] * a0 + Wm[4] * a1 + Wm[5] * a2 + L[LM_PD + kc * 3 + 1];
             d2 = Wm[6] * a0 + Wm[7] * a1 + Wm[8] * a2 + L[LM_PD + kc * 3 + 2];
           }
-          J_out[(size_t)(2 * kg) * ncols + 7 + kc] = G[0] * d0 + G[1] * d1 + G[2] * d2;
-          J_out[(size_t)(2 * kg + 1) * ncols + 7 + kc] = G[3] * d0 + G[4] * d1 + G[5] * d2;
+          store_through(J_out + (size_t)(2 * kg) * ncols + 7 + kc, G[0] * d0 + G[1] * d1 + G[2] * d2);
+          store_through(J_out + (size_t)(2 * kg + 1) * ncols + 7 + kc, G[3] * d0 + G[4] * d1 + G[5] * d2);
         }
       }
       // (2) Sim3 columns (7) and shape columns (ncols - npose) per keypoint
@@ -638,8 +646,8 @@ __global__ __launch_bounds__(kThreads, 4) void k_frame_resjac(DevModel M, DevPro
           j0 = G[0] * d0 + G[1] * d1 + G[2] * d2;
           j1 = G[3] * d0 + G[4] * d1 + G[5] * d2;
         }
-        J_out[(size_t)(2 * kg) * ncols + col] = j0;
-        J_out[(size_t)(2 * kg + 1) * ncols + col] = j1;
+        store_through(J_out + (size_t)(2 * kg) * ncols + col, j0);
+        store_through(J_out + (size_t)(2 * kg + 1) * ncols + col, j1);
       }
     }
   }

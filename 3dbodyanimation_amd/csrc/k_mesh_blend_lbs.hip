@@ -7,18 +7,19 @@
 //             K = 207 + 10 -> 14 k-steps of v_mfma_f32_32x32x16_bf16, both operands split hi + lo in
 //             bf16, three products hi.hi + hi.lo + lo.hi (relative product error <= 2^-16 on
 //             displacements of centimetres), f32 accumulation; the template is added in f32 afterwards
-//   skinning  per frame row: gather the vertex's <= 4 joint transforms (3x4 f32) from LDS, blend, apply,
-//             one 12-byte store per lane (lane = vertex -> 384 contiguous bytes per half-wave)
-// Software pipeline (one wave per SIMD, 4 per workgroup, up to 512 registers each): the k-loop of unit
-// n+1 and the 16 skinning rows of unit n are ONE straight-line body of 16 slots, slot s = k-step s
-// (9 MFMAs, 288 matrix-pipe cycles) + row s (about 50 vector instructions): the MFMA only holds the vector
-// issue port for 8 of its 32 cycles, so the row's VALU work runs underneath.  Everything a slot consumes was
-// requested at least one slot earlier: A fragments (L2) six k-steps ahead in a register ring, B fragments
-// (LDS) one k-step ahead, the row's 12 transform reads (LDS) one row ahead, the transforms of the next
-// 8-frame quarter (L2 -> registers -> this wave's private LDS double buffer) a whole quarter ahead.
+//   skinning  per frame row: gather the vertex's <= 4 joint transforms (3x4 f32) from LDS, blend and apply
+//             in packed f32 (v_pk_fma_f32), one 12-byte store per lane (lane = vertex -> 384 contiguous
+//             bytes per half-wave); the blended vertices never touch HBM
+// Eight waves per workgroup = two per SIMD.  A wave issues one instruction per 4 cycles whatever its kind, so
+// the matrix pipe (288 cycles per k-step) and the vector pipe (about 35 VALU + 12 LDS reads per row) only
+// run together when they are fed by different waves: each wave alternates a blend phase and a skinning phase,
+// and its partner on the SIMD is in the other phase most of the time.  Both phases are straight-line code
+// whose operands were requested at least one step earlier: A fragments (L2) four k-steps ahead in a register
+// ring, B fragments (LDS) one k-step ahead, a row's 12 transform reads one row ahead, the next 8-frame
+// quarter of transforms (L2 -> registers -> this wave's 9 KiB LDS slice) a quarter ahead.
 // Data movement: the vertex tile's B operands (84 KiB, fragment order, contiguous per tile) go
-// HBM -> LDS by LDS-DMA once per workgroup and serve every frame; nothing blended touches HBM.
-// LDS: 84 KiB (B) + 4 waves x 2 x 9 KiB (transforms) = 156 KiB of the CU's 160 KiB.
+// HBM -> LDS by LDS-DMA once per workgroup and serve every frame.
+// LDS: 84 KiB (B) + 8 waves x 9 KiB (transforms) = 156 KiB of the CU's 160 KiB.
 #include "bodyfit_device.h"
 
 namespace bodyfit {
@@ -30,14 +31,15 @@ typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;   // plain vector: HIP's uint4 assigns through memcpy,
                                                                   // which keeps a staging array in scratch
 
-constexpr int kWaves = 4;
+constexpr int kWaves = 8;
 constexpr int kPieces = kBlendKSteps * 3 * 2;                    // 84 x 1 KiB, [ks][c][hi/lo]
 constexpr int kBBytes = kPieces * 1024;                          // 86,016
 constexpr int kRowBytes = kMaxJoints * 48;                       // one frame's 24 transforms: 1,152
 constexpr int kQuarterBytes = 8 * kRowBytes;                     // 9,216
-constexpr int kLdsBytes = kBBytes + kWaves * 2 * kQuarterBytes;  // 159,744
+constexpr int kLdsBytes = kBBytes + kWaves * kQuarterBytes;      // 159,744
 constexpr int kSkinVec = kQuarterBytes / (64 * 16);              // uint4 per lane per quarter = 9
-constexpr int kAhead = 6;                                        // A-fragment ring depth, k-steps
+constexpr int kStoreAux = 16;                                    // gfx940+ cache policy bits: 1 sc0, 2 nt, 16 sc1
+constexpr int kAhead = 4;                                        // A-fragment ring depth, k-steps
 
 #ifdef BODYFIT_STAMPS
 #define MSTAMP(i)                                                                             \
@@ -60,10 +62,8 @@ __device__ inline void lds_dma_16(const void* g, void* l) {
 struct Lane {                    // per-lane constants of the skinning rows
   float vt[3];                   // template (centred on the rest root joint)
   f32x2 w2[4];                   // skinning weights, broadcast pairs
-  const unsigned char* tj[4];    // LDS address of joint i's transform in frame row 4h of buffer 0
+  const unsigned char* tj[4];    // LDS address of joint i's transform in frame row 4h of the wave's slice
   unsigned out_off;              // byte offset of (frame 4h, vertex v) in the cloud
-  unsigned char* dump;           // where lanes past the last vertex store (padding behind the cloud)
-  bool v_ok;
 };
 
 // one quarter of a unit: 8 frames x 24 transforms, contiguous in HBM.  skinT is allocated (and zeroed) for whole
@@ -79,10 +79,10 @@ __device__ __forceinline__ void skin_store(unsigned char* l, int lane, const u32
   for (int i = 0; i < kSkinVec; ++i) *reinterpret_cast<u32x4*>(l + (i * 64 + lane) * 16) = reg[i];
 }
 
-// the 12 LDS reads of row R (frame row (R & 3) + 8 (R >> 2) + 4 h of the unit) — buffer parity (R >> 2) & 1
+// the 12 LDS reads of row R (frame row (R & 3) + 8 (R >> 2) + 4 h of the unit; the slice holds quarter R >> 2)
 template <int R>
 __device__ __forceinline__ void row_fetch(const Lane& L, float4 (&t)[12]) {
-  constexpr int off = ((R >> 2) & 1) * kQuarterBytes + (R & 3) * kRowBytes;
+  constexpr int off = (R & 3) * kRowBytes;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const float4* T = reinterpret_cast<const float4*>(L.tj[i] + off);
@@ -93,7 +93,7 @@ __device__ __forceinline__ void row_fetch(const Lane& L, float4 (&t)[12]) {
 // blend the four transforms, apply to the blended rest vertex, store
 template <int R>
 __device__ __forceinline__ void row_apply(const Lane& L, const float4 (&t)[12], const f32x16 (&acc)[3],
-                                          unsigned char* out_row) {
+                                          __amdgpu_buffer_rsrc_t out, unsigned row_off) {
   f32x2 b[6];
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
@@ -115,123 +115,102 @@ __device__ __forceinline__ void row_apply(const Lane& L, const float4 (&t)[12], 
     const f32x2 m = b[2 * k] * pxy + b[2 * k + 1] * pz1;
     o[k] = m.x + m.y;
   }
-  // unconditional store (a predicated one splits the slot's basic block and with it the MFMA/VALU interleave):
-  // frames past F land in the cloud's tile padding, lanes past V in the dump row
-  struct alignas(4) F3 { float x, y, z; };
-  unsigned char* dst = L.v_ok ? out_row + L.out_off : L.dump;
-  *reinterpret_cast<F3*>(dst) = F3{o[0], o[1], o[2]};
+  // unconditional store (a predicated one would split the step's basic block): the cloud's frame stride is padded to
+  // whole vertex tiles and its frame count to whole frame tiles, so lanes past V or F land in padding, and each
+  // half-wave writes exactly three whole 128-byte lines.  Buffer form: uniform row offset in an SGPR, lane offset in
+  // a VGPR, no address arithmetic; write-through (sc1) so that the 21 MB of output drain to HBM while the kernel
+  // runs instead of sitting dirty in L2 until the end-of-kernel release flushes them.
+  typedef __attribute__((ext_vector_type(3))) unsigned int u32x3;
+  const u32x3 pk = {__float_as_uint(o[0]), __float_as_uint(o[1]), __float_as_uint(o[2])};
+  __builtin_amdgcn_raw_buffer_store_b96(pk, out, L.out_off, row_off, kStoreAux);
 }
 
-struct Unit {            // where one unit's operands live
-  const uint4* fa;       // A fragments: featA + ftile * 14 * 2 * 64 + lane
-  int ftile;
-};
-
-// One slot of the pipeline.  kM: k-step S of unit `um` accumulates into accN; kE: row S of unit `ue` is
-// skinned from accC.
-template <int S, bool kM, bool kE>
-__device__ __forceinline__ void slot(const Lane& L, const unsigned char* sB, unsigned char* sSkin, int lane, int F, int V,
-                                     const unsigned char* skinT, unsigned char* cloud, const Unit& um, const Unit& um_next,
-                                     const Unit& ue, int ft_q1, int q_q1, int ft_q2, int q_q2, f32x16 (&accN)[3],
-                                     const f32x16 (&accC)[3], uint4 (&a)[kBlendKSteps][2], uint4 (&bq)[2][3][2],
-                                     float4 (&tq)[2][12], u32x4 (&treg)[kSkinVec]) {
-  constexpr int q = S >> 2;
-  if constexpr (kE && (S & 3) == 0) {
-    // quarter boundary: the next quarter's transforms (in registers since the previous boundary) go to
-    // the other buffer, the one after that goes in flight.  (ft_q1, q_q1) / (ft_q2, q_q2) name the quarters
-    // one / two after quarter q of unit ue; they may belong to the wave's next unit.
-    skin_store(sSkin + ((q + 1) & 1) * kQuarterBytes, lane, treg);
-    const int ft2 = (q + 2 < 4) ? ue.ftile : ft_q2;
-    skin_load(skinT, ft2, (q + 2) & 3, lane, treg);
-    (void)ft_q1; (void)q_q1; (void)q_q2;
+// ---- blend phase: k-step S of the unit whose A fragments start at fa --------------------------------------------
+template <int S>
+__device__ __forceinline__ void blend_step(const unsigned char* sB, int lane, const uint4* fa, f32x16 (&acc)[3],
+                                           uint4 (&a)[kBlendKSteps][2], uint4 (&bq)[2][3][2]) {
+  if constexpr (S + kAhead < kBlendKSteps) {
+    a[S + kAhead][0] = fa[(size_t)(S + kAhead) * 128];
+    a[S + kAhead][1] = fa[(size_t)(S + kAhead) * 128 + 64];
   }
-  if constexpr (kM && S < kBlendKSteps) {
-    constexpr int sa = S + kAhead;
-    if constexpr (sa < kBlendKSteps) {
-      a[sa][0] = um.fa[(size_t)sa * 128]; a[sa][1] = um.fa[(size_t)sa * 128 + 64];
-    } else {
-      a[sa - kBlendKSteps][0] = um_next.fa[(size_t)(sa - kBlendKSteps) * 128];
-      a[sa - kBlendKSteps][1] = um_next.fa[(size_t)(sa - kBlendKSteps) * 128 + 64];
-    }
-    constexpr int sb = (S + 1) % kBlendKSteps;       // B is the same for every unit
+  if constexpr (S + 1 < kBlendKSteps) {
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-      const uint4* bp = reinterpret_cast<const uint4*>(sB + (size_t)((sb * 3 + c) * 2) * 1024) + lane;
+      const uint4* bp = reinterpret_cast<const uint4*>(sB + (size_t)(((S + 1) * 3 + c) * 2) * 1024) + lane;
       bq[(S + 1) & 1][c][0] = bp[0];
       bq[(S + 1) & 1][c][1] = bp[64];
     }
   }
-  if constexpr (kE) row_fetch<(S + 1) & 15>(L, tq[(S + 1) & 1]);
-  if constexpr (kM && S < kBlendKSteps) {
-    const bf16x8 a_hi = __builtin_bit_cast(bf16x8, a[S][0]);
-    const bf16x8 a_lo = __builtin_bit_cast(bf16x8, a[S][1]);
+  const bf16x8 a_hi = __builtin_bit_cast(bf16x8, a[S][0]);
+  const bf16x8 a_lo = __builtin_bit_cast(bf16x8, a[S][1]);
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      const bf16x8 bhi = __builtin_bit_cast(bf16x8, bq[S & 1][c][0]);
-      const bf16x8 blo = __builtin_bit_cast(bf16x8, bq[S & 1][c][1]);
-      if constexpr (S == 0) {
-        f32x16 z;
+  for (int c = 0; c < 3; ++c) {
+    const bf16x8 bhi = __builtin_bit_cast(bf16x8, bq[S & 1][c][0]);
+    const bf16x8 blo = __builtin_bit_cast(bf16x8, bq[S & 1][c][1]);
+    if constexpr (S == 0) {
+      f32x16 z;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) z[r] = 0.0f;
-        accN[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, bhi, z, 0, 0, 0);
-      } else {
-        accN[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, bhi, accN[c], 0, 0, 0);
-      }
-      accN[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, blo, accN[c], 0, 0, 0);
-      accN[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo, bhi, accN[c], 0, 0, 0);
+      for (int r = 0; r < 16; ++r) z[r] = 0.0f;
+      acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, bhi, z, 0, 0, 0);
+    } else {
+      acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, bhi, acc[c], 0, 0, 0);
     }
+    acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, blo, acc[c], 0, 0, 0);
+    acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo, bhi, acc[c], 0, 0, 0);
   }
-  if constexpr (kE) {
-    const int f = ue.ftile * kFTile + q * 8 + (S & 3);               // frame of the h = 0 half
-    unsigned char* out_row = cloud + (size_t)f * V * 12;
-    row_apply<S>(L, tq[S & 1], accC, out_row);
-  }
-  if constexpr (kM && kE && S < kBlendKSteps) {
-    // issue order inside the slot: every MFMA is followed by the LDS reads and vector work that fit under it
+  // issue order: the next k-step's B reads and A loads go out under the first MFMAs of this one
 #pragma unroll
-    for (int i = 0; i < 9; ++i) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
-      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // DS read
-      __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);   // VALU
-    }
+  for (int i = 0; i < 3; ++i) {
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
+    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // DS read
   }
+  __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+  __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);     // VMEM read
+  __builtin_amdgcn_sched_group_barrier(0x008, 5, 0);
   __builtin_amdgcn_sched_barrier(0);
 }
 
-template <bool kM, bool kE>
-__device__ __forceinline__ void body(const Lane& L, const unsigned char* sB, unsigned char* sSkin, int lane, int F, int V,
-                                     const unsigned char* skinT, unsigned char* cloud, const Unit& um, const Unit& um_next,
-                                     const Unit& ue, int ft_next, f32x16 (&accN)[3], const f32x16 (&accC)[3],
-                                     uint4 (&a)[kBlendKSteps][2], uint4 (&bq)[2][3][2], float4 (&tq)[2][12],
-                                     u32x4 (&treg)[kSkinVec]) {
-#define SLOT(S) slot<S, kM, kE>(L, sB, sSkin, lane, F, V, skinT, cloud, um, um_next, ue, 0, 0, ft_next, 0, accN, accC, a, bq, tq, treg)
-  SLOT(0); SLOT(1); SLOT(2); SLOT(3); SLOT(4); SLOT(5); SLOT(6); SLOT(7);
-  SLOT(8); SLOT(9); SLOT(10); SLOT(11); SLOT(12); SLOT(13); SLOT(14); SLOT(15);
-#undef SLOT
+// ---- skinning phase: row S of the unit at frame tile ftile ----------------------------------------------------------
+template <int S>
+__device__ __forceinline__ void skin_step(const Lane& L, unsigned char* sSkin, int lane, unsigned stride, const unsigned char* skinT,
+                                          __amdgpu_buffer_rsrc_t cloud, int ftile, const f32x16 (&acc)[3], float4 (&tq)[2][12],
+                                          u32x4 (&treg)[kSkinVec]) {
+  constexpr int q = S >> 2;
+  if constexpr ((S & 3) == 0) {
+    // quarter boundary: every read of the previous quarter has been issued (LDS serves a wave in order), so the slice
+    // is overwritten with this quarter (in registers since the previous boundary) and the next one goes in flight
+    skin_store(sSkin, lane, treg);
+    if constexpr (q < 3) skin_load(skinT, ftile, q + 1, lane, treg);
+    row_fetch<S>(L, tq[S & 1]);
+  }
+  if constexpr ((S & 3) != 3) row_fetch<S + 1>(L, tq[(S + 1) & 1]);
+  const int f = ftile * kFTile + q * 8 + (S & 3);               // frame of the h = 0 half
+  row_apply<S>(L, tq[S & 1], acc, cloud, (unsigned)f * stride);
+  if constexpr ((S & 3) == 1 || (S & 3) == 2) __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);   // next row's reads first
+  __builtin_amdgcn_sched_barrier(0);
 }
 
-__global__ __launch_bounds__(64 * kWaves, 1) void k_mesh_blend_lbs(DevModel M, DevProblem Pb, MeshCoef mc,
+__global__ __launch_bounds__(64 * kWaves) void k_mesh_blend_lbs(DevModel M, DevProblem Pb, MeshCoef mc,
                                                                    float* __restrict__ cloud_f) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int vtile = blockIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int col = lane & 31, h = lane >> 5;
   const int v = vtile * kVTile + col;
-  const int V = M.V, F = Pb.F, nFT = Pb.nFTiles;
-  unsigned char* cloud = reinterpret_cast<unsigned char*>(cloud_f);
+  const int nFT = Pb.nFTiles;
   const unsigned char* skinT = reinterpret_cast<const unsigned char*>(mc.skinT);
 
   MSTAMP(0);
   unsigned char* sB = lds;                                             // [ks][c][hi/lo][64][16 B]
-  unsigned char* sSkin = lds + kBBytes + wave * 2 * kQuarterBytes;     // this wave's two quarter buffers
+  unsigned char* sSkin = lds + kBBytes + wave * kQuarterBytes;         // this wave's transform slice
 
   // ---- stage this vertex tile's B operands: HBM -> LDS, 1 KiB per wave-instruction -------------------
   {
     const unsigned char* gp = reinterpret_cast<const unsigned char*>(M.dirsB) + (size_t)vtile * kBBytes;
 #pragma unroll
-    for (int i = 0; i < kPieces / kWaves; ++i) {
+    for (int i = 0; i < (kPieces + kWaves - 1) / kWaves; ++i) {
       const int p = i * kWaves + wave;
-      lds_dma_16(gp + (size_t)p * 1024 + lane * 16, sB + (size_t)p * 1024);
+      if (p < kPieces) lds_dma_16(gp + (size_t)p * 1024 + lane * 16, sB + (size_t)p * 1024);
     }
   }
   Lane L;
@@ -247,64 +226,63 @@ __global__ __launch_bounds__(64 * kWaves, 1) void k_mesh_blend_lbs(DevModel M, D
       L.tj[i] = sSkin + 4 * h * kRowBytes + (int)((widx >> (8 * i)) & 0xffu) * 48;
     }
   }
-  L.out_off = (unsigned)(((size_t)4 * h * V + v) * 12);
-  L.v_ok = v < V;
-  L.dump = cloud + (size_t)nFT * kFTile * V * 12 + lane * 12;
+  const unsigned stride = (unsigned)M.nVTiles * kVTile * 12;           // bytes per frame of the cloud
+  L.out_off = 4 * h * stride + (unsigned)v * 12;
+  // raw buffer over the padded cloud (launch_mesh checks that it is < 4 GiB); 0x00020000 = gfx9 raw-buffer DATA_FORMAT
+  const __amdgpu_buffer_rsrc_t cloud =
+      __builtin_amdgcn_make_buffer_rsrc(cloud_f, 0, (int)((unsigned)nFT * kFTile * stride), 0x00020000);
 
-  // this wave's units: frame tiles wave, wave + 4, ...
+  // this wave's units: frame tiles wave, wave + 8, ...
   const uint4* feat = reinterpret_cast<const uint4*>(mc.featA) + lane;
-  auto unit = [&](int n) {
-    const int ft = min(wave + n * kWaves, nFT - 1);                    // clamped: prefetches past the end re-read
-    return Unit{feat + (size_t)ft * kBlendKSteps * 2 * 64, ft};
-  };
-  const int n_units = (nFT - wave + kWaves - 1) / kWaves;              // may be 0
-  f32x16 accN[3], accC[3];
+  f32x16 acc[3];
   uint4 a[kBlendKSteps][2], bq[2][3][2];
   u32x4 treg[kSkinVec];
   float4 tq[2][12];
-  Unit u0 = unit(0);
-  if (n_units > 0) {
+  if (wave < nFT) {
+    const uint4* fa = feat + (size_t)wave * kBlendKSteps * 2 * 64;
 #pragma unroll
-    for (int ks = 0; ks < kAhead; ++ks) { a[ks][0] = u0.fa[(size_t)ks * 128]; a[ks][1] = u0.fa[(size_t)ks * 128 + 64]; }
-    skin_load(skinT, u0.ftile, 0, lane, treg);
+    for (int ks = 0; ks < kAhead; ++ks) { a[ks][0] = fa[(size_t)ks * 128]; a[ks][1] = fa[(size_t)ks * 128 + 64]; }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   MSTAMP(1);
-  if (n_units <= 0) return;
+  // Waves w and w + 4 share a SIMD.  Left alone they run their phases in lock-step (both blending at half the matrix
+  // rate, then both skinning against each other for LDS bandwidth); with the second wave at a higher issue priority
+  // its blend finishes first and the two stay in opposite phases.
+  if (wave >= 4) __builtin_amdgcn_s_setprio(2);
 
-  // prologue: blend of unit 0, then bootstrap the transform pipeline
+  for (int ftile = wave; ftile < nFT; ftile += kWaves) {
+    const uint4* fa = feat + (size_t)ftile * kBlendKSteps * 2 * 64;
+    skin_load(skinT, ftile, 0, lane, treg);                            // quarter 0: in flight across the blend phase
 #pragma unroll
-  for (int c = 0; c < 3; ++c) {
-    const uint4* bp = reinterpret_cast<const uint4*>(sB + (size_t)(c * 2) * 1024) + lane;
-    bq[0][c][0] = bp[0]; bq[0][c][1] = bp[64];
-  }
-  {
-    const Unit u1 = unit(1);
-    body<true, false>(L, sB, sSkin, lane, F, V, skinT, cloud, u0, u1, u0, 0, accN, accC, a, bq, tq, treg);
-  }
-  skin_store(sSkin, lane, treg);                                       // quarter 0 -> buffer 0
-  skin_load(skinT, u0.ftile, 1, lane, treg);                        // quarter 1 in flight
-  row_fetch<0>(L, tq[0]);
-  MSTAMP(2);
-
-  for (int n = 0; n < n_units; ++n) {
+    for (int c = 0; c < 3; ++c) {
+      const uint4* bp = reinterpret_cast<const uint4*>(sB + (size_t)(c * 2) * 1024) + lane;
+      bq[0][c][0] = bp[0]; bq[0][c][1] = bp[64];
+    }
+#define BSTEP(S) blend_step<S>(sB, lane, fa, acc, a, bq)
+    BSTEP(0); BSTEP(1); BSTEP(2); BSTEP(3); BSTEP(4); BSTEP(5); BSTEP(6);
+    BSTEP(7); BSTEP(8); BSTEP(9); BSTEP(10); BSTEP(11); BSTEP(12); BSTEP(13);
+#undef BSTEP
+    MSTAMP(2);
+#define SSTEP(S) skin_step<S>(L, sSkin, lane, stride, skinT, cloud, ftile, acc, tq, treg)
+    SSTEP(0); SSTEP(1); SSTEP(2); SSTEP(3); SSTEP(4); SSTEP(5); SSTEP(6); SSTEP(7);
+    SSTEP(8); SSTEP(9); SSTEP(10); SSTEP(11); SSTEP(12);
+    if (ftile + kWaves < nFT) {      // next unit's first A fragments (the transform staging registers are free now)
+      const uint4* fn = feat + (size_t)(ftile + kWaves) * kBlendKSteps * 2 * 64;
 #pragma unroll
-    for (int c = 0; c < 3; ++c) accC[c] = accN[c];
-    const Unit ue = unit(n), um = unit(n + 1), um_next = unit(n + 2);
-    const int ft_next = um.ftile;     // clamped past the end: those quarters are staged but never read
-    if (n + 1 < n_units)
-      body<true, true>(L, sB, sSkin, lane, F, V, skinT, cloud, um, um_next, ue, ft_next, accN, accC, a, bq, tq, treg);
-    else
-      body<false, true>(L, sB, sSkin, lane, F, V, skinT, cloud, um, um_next, ue, ft_next, accN, accC, a, bq, tq, treg);
+      for (int ks = 0; ks < kAhead; ++ks) { a[ks][0] = fn[(size_t)ks * 128]; a[ks][1] = fn[(size_t)ks * 128 + 64]; }
+    }
+    SSTEP(13); SSTEP(14); SSTEP(15);
+#undef SSTEP
+    MSTAMP(3);
   }
-  MSTAMP(3);
 }
 
 }  // namespace
 
 void launch_mesh(const DevModel& M, const DevProblem& P, const MeshCoef& mc, float* d_cloud, hipStream_t s) {
   if (P.F <= 0) return;
+  if ((size_t)P.nFTiles * kFTile * M.nVTiles * kVTile * 12 >= ((size_t)1 << 32)) return;   // refused at problem creation
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_mesh_blend_lbs),

@@ -141,9 +141,12 @@ typedef struct bodyfit_device_views {
   double* residuals;    /* [total_rows]          */
   double* jacobian;     /* [2K][n_cols]          */
   int* gmm_comp;        /* [F]                   */
-  float* cloud;         /* [F][n_verts][3] f32, camera frame (want_mesh)          */
+  float* cloud;         /* [F][cloud_frame_stride] f32, camera frame (want_mesh): frame f's
+                           [n_verts][3] block starts at cloud + f * cloud_frame_stride          */
   double* joints;       /* [F][n_joints][3] camera-frame posed joints             */
   double* normal_eq;    /* [66] see bodyfit_reduce_shared_device                  */
+  long long cloud_frame_stride; /* floats; 3 n_verts rounded up to whole 32-vertex tiles (a multiple of
+                           128 bytes, so that every wave of the mesh kernel stores whole cache lines)     */
 } bodyfit_device_views;
 int bodyfit_problem_views(bodyfit_problem* p, bodyfit_device_views* out);
 

@@ -26,17 +26,19 @@ b = torch.from_numpy(np.tile(seq.gt_beta, (F, 1))).cuda()
 for _ in range(5):
     prob.evaluate_device(x.data_ptr(), b.data_ptr(), True, None)
 torch.cuda.synchronize()
-raw = buf.cpu().numpy()[:nblk * 8 * 16].reshape(nblk, 8, 16)[:, :4, :].astype(np.float64)
+raw = buf.cpu().numpy()[:nblk * 8 * 16].reshape(nblk, 8, 16).astype(np.float64)
 nft = (F + 31) // 32
-act = np.array([w < nft for w in range(4)])
-raw = raw[:, act, :]
+raw = raw[:, :min(8, nft), :]
 d = np.diff(raw[:, :, :4], axis=2) / 100.0   # us
-names = ["B staging (HBM->LDS) + barrier", "prologue: blend of unit 0 (14 k-steps)", "fused bodies + last unit's rows"]
-print("per-wave segment times, us (median over blocks and waves / max):")
-for i, n in enumerate(names):
-    print(f"  {n:40s} {np.median(d[:, :, i]):7.2f} {d[:, :, i].max():7.2f}")
 cyc = np.diff(raw[:, :, 8:12], axis=2)
-print("s_memtime cycles per segment (median):", np.median(cyc, axis=(0, 1)), " -> MHz:", np.median(cyc / np.maximum(d, 1e-9), axis=(0, 1)))
+names = ["B staging (HBM->LDS) + barrier", "blend phase (14 k-steps) [last unit]", "skinning phase (16 rows) [last unit]"]
+print("per-wave segment times, us (median over blocks and waves / max) and shader-clock cycles:")
+for i, n in enumerate(names):
+    print(f"  {n:40s} {np.median(d[:, :, i]):7.2f} {d[:, :, i].max():7.2f}   {np.median(cyc[:, :, i]):9.0f} cyc")
+if raw.shape[1] == 8:
+    for nm, sl in (("waves 0-3", slice(0, 4)), ("waves 4-7", slice(4, 8))):
+        t0 = raw[:, :1, 1]
+        print(f"  {nm}: blend ends {np.median(raw[:, sl, 2] - t0) / 100:6.2f} us, skinning ends {np.median(raw[:, sl, 3] - t0) / 100:6.2f} us after the barrier")
 span = raw[:, :, 3].max() - raw[:, :, 0].min()
 print("kernel span (us):", span / 100.0, " block wall median (us):", np.median(raw[:, :, 3].max(1) - raw[:, :, 0].min(1)) / 100.0)
 print("block start spread (us):", (raw[:, 0, 0].max() - raw[:, 0, 0].min()) / 100.0)
