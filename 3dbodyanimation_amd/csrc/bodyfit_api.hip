@@ -128,7 +128,8 @@ bool chol_lower(std::vector<double>& A, int n) {
 }
 
 // One evaluation sweep: two launches on the caller's stream.  The prior residuals are produced by extra
-// workgroups of the k_frame_resjac launch (priors_inl.h).  ev (optional): [0] start, [1] after
+// workgroups (priors_inl.h) of the mesh launch when the mesh is on (its vertex tiles leave 40 CUs idle), otherwise
+// of the k_frame_resjac launch.  ev (optional): [0] start, [1] after
 // frame_resjac (+ priors), [2] after the mesh kernel.
 int sweep(bodyfit_problem* p, const double* d_params, const double* d_beta, int want_jac, bool mesh,
           hipStream_t st, hipEvent_t* ev = nullptr, double* r_base = nullptr, int* comp_out = nullptr,
@@ -155,10 +156,13 @@ int sweep(bodyfit_problem* p, const double* d_params, const double* d_beta, int 
   pa.comp = d_comp;
   const bool priors = D.beta_pose > 0.0 || pa.beta_shape > 0.0 || D.lambda_temporal > 0.0;
   pa.n_tiles = priors ? (p->d.F + 15) / 16 : 0;
+  PriorArgs none = pa;
+  none.n_tiles = 0;
   if (ev) (void)hipEventRecord(ev[0], st);
-  launch_frame_resjac(m->d, dp, d_params, d_beta, d_r, want_jac ? p->d_J : nullptr, p->d_joints, mc, want_jac, pa, st);
+  launch_frame_resjac(m->d, dp, d_params, d_beta, d_r, want_jac ? p->d_J : nullptr, p->d_joints, mc, want_jac,
+                      mesh ? none : pa, st);
   if (ev) (void)hipEventRecord(ev[1], st);
-  if (mesh) launch_mesh(m->d, p->d, p->mc, p->d_cloud, st);
+  if (mesh) launch_mesh(m->d, p->d, p->mc, p->d_cloud, pa, d_params, st);
   if (ev) (void)hipEventRecord(ev[2], st);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(BODYFIT_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));

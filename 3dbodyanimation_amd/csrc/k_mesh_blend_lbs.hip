@@ -21,6 +21,7 @@
 // HBM -> LDS by LDS-DMA once per workgroup and serve every frame.
 // LDS: 84 KiB (B) + 8 waves x 9 KiB (transforms) = 156 KiB of the CU's 160 KiB.
 #include "bodyfit_device.h"
+#include "priors_inl.h"
 
 namespace bodyfit {
 namespace {
@@ -42,13 +43,14 @@ constexpr int kStoreAux = 16;                                    // gfx940+ cach
 constexpr int kAhead = 4;                                        // A-fragment ring depth, k-steps
 
 #ifdef BODYFIT_STAMPS
+constexpr size_t kStampBase = (size_t)1 << 20;   // behind k_frame_resjac's stamps in the shared diagnostic buffer
 #define MSTAMP(i)                                                                             \
   do {                                                                                        \
     if (Pb.dbg && lane == 0) {                                                                \
       unsigned long long t_, c_;                                                              \
       asm volatile("s_memrealtime %0\n\ts_memtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_), "=s"(c_)::"memory"); \
-      Pb.dbg[((size_t)blockIdx.x * 8 + wave) * 16 + (i)] = t_;                                \
-      Pb.dbg[((size_t)blockIdx.x * 8 + wave) * 16 + 8 + (i)] = c_;                            \
+      Pb.dbg[kStampBase + ((size_t)blockIdx.x * 8 + wave) * 16 + (i)] = t_;                                \
+      Pb.dbg[kStampBase + ((size_t)blockIdx.x * 8 + wave) * 16 + 8 + (i)] = c_;                            \
     }                                                                                         \
   } while (0)
 #else
@@ -191,8 +193,15 @@ __device__ __forceinline__ void skin_step(const Lane& L, unsigned char* sSkin, i
 }
 
 __global__ __launch_bounds__(64 * kWaves) void k_mesh_blend_lbs(DevModel M, DevProblem Pb, MeshCoef mc,
-                                                                   float* __restrict__ cloud_f) {
+                                                                   float* __restrict__ cloud_f, PriorArgs pa,
+                                                                   const double* __restrict__ params) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  if ((int)blockIdx.x >= M.nVTiles) {
+    // The vertex tiles occupy 216 of the 256 CUs; the sweep's prior residuals (one 16-frame tile per workgroup,
+    // priors_inl.h) ride on the idle ones instead of doubling up with k_frame_resjac's frame workgroups.
+    prior_block(pa, (int)blockIdx.x - M.nVTiles, params, reinterpret_cast<double*>(lds));
+    return;
+  }
   const int vtile = blockIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int col = lane & 31, h = lane >> 5;
@@ -280,7 +289,8 @@ __global__ __launch_bounds__(64 * kWaves) void k_mesh_blend_lbs(DevModel M, DevP
 
 }  // namespace
 
-void launch_mesh(const DevModel& M, const DevProblem& P, const MeshCoef& mc, float* d_cloud, hipStream_t s) {
+void launch_mesh(const DevModel& M, const DevProblem& P, const MeshCoef& mc, float* d_cloud, const PriorArgs& pa,
+                 const double* d_params, hipStream_t s) {
   if (P.F <= 0) return;
   if ((size_t)P.nFTiles * kFTile * M.nVTiles * kVTile * 12 >= ((size_t)1 << 32)) return;   // refused at problem creation
   static bool attr_set = false;
@@ -289,7 +299,8 @@ void launch_mesh(const DevModel& M, const DevProblem& P, const MeshCoef& mc, flo
                               hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
     attr_set = true;
   }
-  hipLaunchKernelGGL(k_mesh_blend_lbs, dim3(M.nVTiles), dim3(64 * kWaves), kLdsBytes, s, M, P, mc, d_cloud);
+  hipLaunchKernelGGL(k_mesh_blend_lbs, dim3(M.nVTiles + pa.n_tiles), dim3(64 * kWaves), kLdsBytes, s, M, P, mc, d_cloud, pa,
+                     d_params);
 }
 
 }  // namespace bodyfit

@@ -18,7 +18,8 @@ gm = api.Model(model)
 prob = api.Problem.from_sequence(gm, seq, n_cols=86, use_shape=True, beta_per_frame=True, want_mesh=True)
 lib = api.load_library()
 nblk = (6890 + 31) // 32
-buf = torch.zeros(max(F * 4, nblk * 8) * 16, dtype=torch.int64, device="cuda")
+BASE = 1 << 20
+buf = torch.zeros(BASE + nblk * 8 * 16, dtype=torch.int64, device="cuda")
 lib.bodyfit_debug_set_stamp_buffer.argtypes = [C.c_void_p, C.c_void_p]
 lib.bodyfit_debug_set_stamp_buffer(prob.h, buf.data_ptr())
 x = torch.from_numpy(seq.gt_params + 0.01).cuda()
@@ -26,7 +27,7 @@ b = torch.from_numpy(np.tile(seq.gt_beta, (F, 1))).cuda()
 for _ in range(5):
     prob.evaluate_device(x.data_ptr(), b.data_ptr(), True, None)
 torch.cuda.synchronize()
-raw = buf.cpu().numpy()[:nblk * 8 * 16].reshape(nblk, 8, 16).astype(np.float64)
+raw = buf.cpu().numpy()[BASE:BASE + nblk * 8 * 16].reshape(nblk, 8, 16).astype(np.float64)
 nft = (F + 31) // 32
 raw = raw[:, :min(8, nft), :]
 d = np.diff(raw[:, :, :4], axis=2) / 100.0   # us

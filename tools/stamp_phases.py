@@ -17,7 +17,7 @@ seq = synth.make_sequence(model, F, seed=0)
 gm = api.Model(model)
 prob = api.Problem.from_sequence(gm, seq, n_cols=86, use_shape=True, beta_per_frame=True, want_mesh=True)
 lib = api.load_library()
-buf = torch.zeros(F * 4 * 16, dtype=torch.int64, device="cuda")
+buf = torch.zeros((1 << 20) + 216 * 8 * 16, dtype=torch.int64, device="cuda")   # the mesh kernel stamps behind 1 << 20
 lib.bodyfit_debug_set_stamp_buffer.argtypes = [C.c_void_p, C.c_void_p]
 lib.bodyfit_debug_set_stamp_buffer(prob.h, buf.data_ptr())
 x = torch.from_numpy(seq.gt_params + 0.01).cuda()
@@ -25,7 +25,7 @@ b = torch.from_numpy(np.tile(seq.gt_beta, (F, 1))).cuda()
 for _ in range(5):
     prob.evaluate_device(x.data_ptr(), b.data_ptr(), True, None)
 torch.cuda.synchronize()
-raw = buf.cpu().numpy().reshape(F, 4, 16)
+raw = buf.cpu().numpy()[:F * 4 * 16].reshape(F, 4, 16)
 t = raw[:, :, :9].astype(np.float64)
 names = ["A tables", "B rodrigues/offsets", "C feat+chain walks", "C2 landmark rows", "D W/lmLBS/cam",
          "E mesh ops + lm jac terms", "F1 kp stage", "F2 jacobian sweep"]
