@@ -284,7 +284,7 @@ int bodyfit_model_create(const bodyfit_model_desc* desc, int device, bodyfit_mod
     // fixed-stride skinning weights per landmark: kMaxLmNnz slots padded with weight 0; woff[l] = count
     std::vector<int> woff(nL + 1, 0), wj((size_t)std::max(nL, 1) * kMaxLmNnz, 0);
     std::vector<double> ww((size_t)std::max(nL, 1) * kMaxLmNnz, 0.0), vt((size_t)nL * 3),
-        sd((size_t)nL * 3 * std::max(nS, 1), 0.0), pd((size_t)nL * 3 * std::max(P, 1), 0.0);
+        sd((size_t)nL * 3 * std::max(nS, 1), 0.0), pd((size_t)std::max(nL, 1) * 27 * 32, 0.0);
     for (int l = 0; l < nL; ++l) {
       const int vid = desc->landmark_vid[l];
       int cnt = 0;
@@ -301,7 +301,10 @@ int bodyfit_model_create(const bodyfit_model_desc* desc, int device, bodyfit_mod
         vt[l * 3 + a] = desc->v_template[(size_t)vid * 3 + a] - J0[a];
         for (int k = 0; k < nS; ++k)
           sd[(size_t)(l * 3 + a) * nS + k] = desc->shapedirs[((size_t)vid * 3 + a) * nS + k] - S[(size_t)a * nS + k];
-        for (int k = 0; k < P; ++k) pd[(size_t)(l * 3 + a) * P + k] = desc->posedirs[((size_t)vid * 3 + a) * P + k];
+        // [l][a * 9 + e][k - 1]: the 9 (k - 1) + e pose-feature column of joint k, joint-minor, so that the lanes of a
+        // half-wave (one joint each) read 184 contiguous bytes per (a, e)
+        for (int k = 0; k < P; ++k)
+          pd[((size_t)l * 27 + a * 9 + k % 9) * 32 + k / 9] = desc->posedirs[((size_t)vid * 3 + a) * P + k];
       }
     }
     HIP_TRY(m->mem.upload(&d.lm_woff, woff));

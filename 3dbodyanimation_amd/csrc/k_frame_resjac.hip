@@ -257,8 +257,19 @@ __global__ __launch_bounds__(kThreads, 4) void k_frame_resjac(DevModel M, DevPro
 #pragma unroll
     for (int i = 0; i < 27; ++i) sdR[tid * 27 + i] = dR[i];
   }
-  if (tid >= 64) {
-    for (int i = tid - 64; i < nJ * 3; i += kThreads - 64) {
+  if (tid >= 256 && tid - 256 < nL * 3) {
+    // landmark rest vertex before the pose blend: v_t + shapedirs . beta (10 independent loads)
+    const int row = tid - 256;
+    double sv[kMaxShape];
+#pragma unroll
+    for (int k = 0; k < kMaxShape; ++k) sv[k] = (use_shape && k < nS) ? M.lm_sd[(size_t)row * nS + k] : 0.0;
+    double acc = M.lm_vt[row];
+#pragma unroll
+    for (int k = 0; k < kMaxShape; ++k) acc += sv[k] * sbeta[min(k, nS > 0 ? nS - 1 : 0)];
+    sPart[row] = acc;
+  }
+  if (tid >= 64 && tid < 256) {
+    for (int i = tid - 64; i < nJ * 3; i += 192) {
       double o = M.offset[i], jc = M.Jc0[i];
       if (use_shape) {
         for (int k = 0; k < nS; ++k) {
@@ -279,6 +290,57 @@ __global__ __launch_bounds__(kThreads, 4) void k_frame_resjac(DevModel M, DevPro
   //     P_j      : v = o_j;        v <- R_k v + o_k        (the reference's own walk, Sim3BA.h:173-207)
   //     B_j[:,b] : v = dS_j[:,b];  v <- R_k v + dS_k[:,b]  (d P_j / d beta_b)
   //   and the landmark blend rows (wave reductions over the 207 pose-blend columns) --------------------------
+  // Landmark pose-blend terms, item = (landmark l, joint k) on lane k - 1 of half-wave l (two landmarks per wave):
+  // the 27 posedirs values pd[l][a][9 (k - 1) + e] are loaded ONCE (coalesced, joint-minor table) and serve both the
+  // blend row  v_p[l][a] = sum_k pd . vec(R_k - I)  (reduced over the half-wave's lanes, no LDS partials) and the
+  // Jacobian term  h[c][a] = pd . vec(dR_{k,c})  (parked in the landmark's LM_PD slot until phase E applies the
+  // blended rotation).  The loads are issued before the chain walks and land while those run.
+  const int lm_k = lane & 31, lm_l = 2 * wave + (lane >> 5);
+  const bool lm_blend = Pb.pose_blend && P > 0;
+  auto lm_load = [&](int l, double (&pdv)[27]) {
+    const bool on = lm_blend && l < nL && lm_k < nJ - 1;
+#pragma unroll
+    for (int ae = 0; ae < 27; ++ae) pdv[ae] = on ? M.lm_pd[((size_t)l * 27 + ae) * 32 + lm_k] : 0.0;
+  };
+  auto lm_terms = [&](int l, const double (&pdv)[27]) {
+    const int k = min(lm_k + 1, nJ - 1);
+    const bool on = l < nL && lm_k < nJ - 1;
+    double part[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+    for (int e = 0; e < 9; ++e) {
+      const double fe = sR[k * 9 + e] - ((e % 4 == 0) ? 1.0 : 0.0);
+#pragma unroll
+      for (int a = 0; a < 3; ++a) part[a] += pdv[a * 9 + e] * fe;
+    }
+    if (want_jac) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const double* d = sdR + k * 27 + c * 9;
+        double h[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+        for (int e = 0; e < 9; ++e) {
+          const double de = d[e];
+#pragma unroll
+          for (int a = 0; a < 3; ++a) h[a] += pdv[a * 9 + e] * de;
+        }
+        if (on) {
+          double* o = sLm + l * LM_STRIDE + LM_PD + (3 * (k - 1) + c) * 3;
+          o[0] = h[0]; o[1] = h[1]; o[2] = h[2];
+        }
+      }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+#pragma unroll
+      for (int off = 16; off > 0; off >>= 1) part[a] += __shfl_xor(part[a], off, 32);
+    }
+    if (on && lm_k == 0) {
+#pragma unroll
+      for (int a = 0; a < 3; ++a) sLm[l * LM_STRIDE + LM_VP + a] = sPart[l * 3 + a] + part[a];
+    }
+  };
+  double pdv0[27];
+  lm_load(lm_l, pdv0);
   for (int i = tid; i < 208; i += kThreads) {
     double v = 0.0;
     if (i < 9 * (nJ - 1)) v = sR[9 + i] - (((i % 9) % 4 == 0) ? 1.0 : 0.0);
@@ -316,40 +378,13 @@ __global__ __launch_bounds__(kThreads, 4) void k_frame_resjac(DevModel M, DevPro
     if (tid >= 16 && tid < 19) sP[tid - 16] = 0.0;
     if (tid >= 32 && tid - 32 < 3 * nS) sB[tid - 32] = 0.0;
   }
+  lm_terms(lm_l, pdv0);
+  if (nL > 16) {   // landmarks 16..31: second pass
+    double pdv1[27];
+    lm_load(lm_l + 16, pdv1);
+    lm_terms(lm_l + 16, pdv1);
+  }
   STAMP(3);
-  __syncthreads();   // sFeat complete before the landmark rows read it
-  if (nL > 0) {
-    // v_p rows: item = (row, part), 8 parts per row with stride-8 columns: every load independent,
-    // 8 consecutive threads on 64 contiguous bytes; partials meet in LDS
-    for (int it = tid; it < nL * 3 * 8; it += kThreads) {
-      const int row = it >> 3, part = it & 7;
-      double acc = 0.0;
-      if (Pb.pose_blend && P > 0) {
-        // 207 = 8 x 26 - 1: fixed trip count so all 26 loads are in flight together (a runtime-bounded
-        // loop here serialises one L2 round trip per element)
-        double pv[26];
-#pragma unroll
-        for (int u = 0; u < 26; ++u) {
-          const int i = part + 8 * u;
-          pv[u] = (i < P) ? M.lm_pd[(size_t)row * P + i] : 0.0;
-        }
-#pragma unroll
-        for (int u = 0; u < 26; ++u) acc += pv[u] * sFeat[part + 8 * u];
-      }
-      if (use_shape) {
-        double sv0 = (part < nS) ? M.lm_sd[(size_t)row * nS + part] : 0.0;
-        double sv1 = (part + 8 < nS) ? M.lm_sd[(size_t)row * nS + part + 8] : 0.0;
-        acc += sv0 * sbeta[min(part, kMaxShape - 1)] + sv1 * sbeta[min(part + 8, kMaxShape - 1)];
-      }
-      sPart[it] = acc;
-    }
-  }
-  __syncthreads();
-  if (tid < nL * 3) {
-    const double* pp = sPart + tid * 8;
-    sLm[(tid / 3) * LM_STRIDE + LM_VP + tid % 3] =
-        M.lm_vt[tid] + (((pp[0] + pp[1]) + (pp[2] + pp[3])) + ((pp[4] + pp[5]) + (pp[6] + pp[7])));
-  }
   __syncthreads();
 
   STAMP(4);
@@ -444,37 +479,18 @@ __global__ __launch_bounds__(kThreads, 4) void k_frame_resjac(DevModel M, DevPro
     }
   }
   if (nL > 0 && want_jac) {
-    // pose-blend term  Ablend . (pd[:, 9(k-1):9k] . vec(dR_{k,c}))   item = (landmark, joint k):
-    // 27 independent loads (72 contiguous bytes per row, consecutive threads on consecutive k)
-    const int nItems = nL * (nJ - 1);
-    for (int it = tid; it < nItems; it += kThreads) {
-      const int l = it / (nJ - 1), k = 1 + it % (nJ - 1);
-      double pdv[27];
-      if (Pb.pose_blend && P > 0) {
+    // pose-blend term  Ablend . (pd[:, 9(k-1):9k] . vec(dR_{k,c})): the inner products were parked in LM_PD by phase C
+    // (same lane mapping: lane k - 1 of half-wave l), the landmark's blended rotation is applied in place
+    for (int l = lm_l; l < nL; l += 16) {
+      if (lm_k < nJ - 1) {
+        const double* Ab = sLm + l * LM_STRIDE + LM_A;
 #pragma unroll
-        for (int a = 0; a < 3; ++a)
-#pragma unroll
-          for (int e = 0; e < 9; ++e) pdv[a * 9 + e] = M.lm_pd[((size_t)l * 3 + a) * P + 9 * (k - 1) + e];
-      } else {
-#pragma unroll
-        for (int e = 0; e < 27; ++e) pdv[e] = 0.0;
-      }
-      const double* Ab = sLm + l * LM_STRIDE + LM_A;
-#pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        const double* d = sdR + k * 27 + c * 9;
-        double h[3];
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-          double acc = 0;
-#pragma unroll
-          for (int e = 0; e < 9; ++e) acc += pdv[a * 9 + e] * d[e];
-          h[a] = acc;
+        for (int c = 0; c < 3; ++c) {
+          double* o = sLm + l * LM_STRIDE + LM_PD + (3 * lm_k + c) * 3;
+          double t[3];
+          mv3(Ab, o[0], o[1], o[2], t);
+          o[0] = t[0]; o[1] = t[1]; o[2] = t[2];
         }
-        double t[3];
-        mv3(Ab, h[0], h[1], h[2], t);
-        double* o = sLm + l * LM_STRIDE + LM_PD + (3 * (k - 1) + c) * 3;
-        o[0] = t[0]; o[1] = t[1]; o[2] = t[2];
       }
     }
     // shape columns  d q / d beta_k = sum_i w_i (A_j (sd_l - Sc_j) + B_j)[:, k]   item = (landmark, k)
