@@ -18,6 +18,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <limits>
@@ -33,32 +34,42 @@ namespace {
 constexpr int NP = BODYFIT_FRAME_PARAMS;
 
 // ---- small dense helpers (row-major) ------------------------------------------------------------
+// contiguous dot product, four independent partial sums (fixed association: results do not depend on the
+// compiler's vectoriser)
+inline double dot4(const double* a, const double* b, int n) {
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  int k = 0;
+  for (; k + 4 <= n; k += 4) {
+    s0 += a[k] * b[k]; s1 += a[k + 1] * b[k + 1]; s2 += a[k + 2] * b[k + 2]; s3 += a[k + 3] * b[k + 3];
+  }
+  for (; k < n; ++k) s0 += a[k] * b[k];
+  return (s0 + s1) + (s2 + s3);
+}
 bool chol_inplace(double* A, int n) {  // lower Cholesky in the lower triangle
   for (int j = 0; j < n; ++j) {
-    double d = A[j * n + j];
-    for (int k = 0; k < j; ++k) d -= A[j * n + k] * A[j * n + k];
+    double d = A[j * n + j] - dot4(A + j * n, A + j * n, j);
     if (!(d > 0.0) || !std::isfinite(d)) return false;
     d = std::sqrt(d);
     A[j * n + j] = d;
     const double inv = 1.0 / d;
-    for (int i = j + 1; i < n; ++i) {
-      double s = A[i * n + j];
-      for (int k = 0; k < j; ++k) s -= A[i * n + k] * A[j * n + k];
-      A[i * n + j] = s * inv;
-    }
+    for (int i = j + 1; i < n; ++i) A[i * n + j] = (A[i * n + j] - dot4(A + i * n, A + j * n, j)) * inv;
   }
   return true;
 }
-// X <- L^{-1} X, X is n x m
-void fwd_solve(const double* L, int n, double* X, int m) {
+// X <- L^{-1} X, X is n x m; lower_rhs: X is lower triangular on entry (and stays so), columns > i are skipped
+void fwd_solve(const double* L, int n, double* X, int m, bool lower_rhs = false) {
   for (int i = 0; i < n; ++i) {
+    const int mc = lower_rhs ? std::min(m, i + 1) : m;
+    double* Xi = X + (size_t)i * m;
     for (int k = 0; k < i; ++k) {
       const double l = L[i * n + k];
       if (l == 0.0) continue;
-      for (int c = 0; c < m; ++c) X[i * m + c] -= l * X[k * m + c];
+      const double* Xk = X + (size_t)k * m;
+      const int kc = lower_rhs ? std::min(mc, k + 1) : mc;
+      for (int c = 0; c < kc; ++c) Xi[c] -= l * Xk[c];
     }
     const double inv = 1.0 / L[i * n + i];
-    for (int c = 0; c < m; ++c) X[i * m + c] *= inv;
+    for (int c = 0; c < mc; ++c) Xi[c] *= inv;
   }
 }
 // X <- L^{-T} X
@@ -318,15 +329,18 @@ bool solve_step(const Normal& N, const std::vector<double>& scale, const unsigne
       Yf[i * m + nb] = rhs[lf * NP + i];
     }
     if (lf > 0) {
+      // Ls (block (lf, lf-1)) = diag(E) Ld^{-T} is upper triangular: row i is zero left of column i
       const double* Lp = &Ls[(size_t)(lf - 1) * NP * NP];
       const double* Yp = &Y[(size_t)(lf - 1) * NP * m];
-      for (int i = 0; i < NP; ++i)
-        for (int k = 0; k < NP; ++k) {
-          const double l = Lp[i * NP + k];
+      for (int i = 0; i < NP; ++i) {
+        const double* Li = Lp + (size_t)i * NP;
+        for (int j = 0; j <= i; ++j) Af[i * NP + j] -= dot4(Li + i, Lp + (size_t)j * NP + i, NP - i);
+        for (int k = i; k < NP; ++k) {
+          const double l = Li[k];
           if (l == 0.0) continue;
-          for (int j = 0; j <= i; ++j) Af[i * NP + j] -= l * Lp[j * NP + k];
           for (int j = 0; j < m; ++j) Yf[i * m + j] -= l * Yp[k * m + j];
         }
+      }
     }
     if (!chol_inplace(Af, NP)) return false;
     fwd_solve(Af, NP, Yf, m);
@@ -335,9 +349,9 @@ bool solve_step(const Normal& N, const std::vector<double>& scale, const unsigne
       double* Lsf = &Ls[(size_t)lf * NP * NP];
       std::vector<double> X((size_t)NP * NP, 0.0);
       for (int i = 0; i < NP; ++i) X[i * NP + i] = E[(size_t)lf * NP + i];
-      fwd_solve(Af, NP, X.data(), NP);             // X = Ld^{-1} diag(E)
+      fwd_solve(Af, NP, X.data(), NP, /*lower_rhs=*/true);   // X = Ld^{-1} diag(E), lower triangular
       for (int i = 0; i < NP; ++i)
-        for (int j = 0; j < NP; ++j) Lsf[i * NP + j] = X[j * NP + i];   // transpose
+        for (int j = i; j < NP; ++j) Lsf[i * NP + j] = X[j * NP + i];   // transpose (upper triangle; the rest stays 0)
     }
   }
   // Schur complement on beta: S = C - Yb^T Yb, rb = rhs_b - Yb^T y
@@ -473,6 +487,10 @@ extern "C" int bodyfit_solve(bodyfit_problem* p, double* frame_params, double* b
     g.cost = g.initial_cost = group_cost(c, g, r.data());
     if (!std::isfinite(g.cost)) { g.active = false; g.termination = 2; g.why = "initial cost is not finite"; }
   }
+  // BODYFIT_TIMING=1: where the host loop's wall time goes (diagnostic print at the end of the solve)
+  const bool timing = std::getenv("BODYFIT_TIMING") != nullptr;
+  double t_build = 0, t_solve = 0, t_eval_r = 0, t_eval_j = 0;
+  auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   for (int it = 0; it < opt.max_iters; ++it) {
     bool any_active = false, any_cand = false;
     xn = x; xbn = xb;
@@ -484,8 +502,10 @@ extern "C" int bodyfit_solve(bodyfit_problem* p, double* frame_params, double* b
       was_active[gi] = 1;
       const int nf = g.f1 - g.f0, n = nf * NP + nb;
       if (!normal_valid[gi]) {
+        const double t0 = timing ? now() : 0.0;
         build_normal(c, g, r.data(), J.data(), comp.data(), normals[gi]);
         normal_valid[gi] = 1;
+        if (timing && groups.size() == 1) t_build += now() - t0;
       }
       const Normal& N = normals[gi];
       if (g.scale.empty()) {   // Jacobi scaling from the first iterate
@@ -509,7 +529,10 @@ extern "C" int bodyfit_solve(bodyfit_problem* p, double* frame_params, double* b
         }
       for (int i = 0; i < nb; ++i) gmax = std::max(gmax, std::fabs(N.g[nf * NP + i]));
       if (gmax <= 1e-10) { g.active = false; g.termination = 0; g.why = "gradient tolerance"; return; }
-      if (!solve_step(N, g.scale, param_constant, g.radius, steps[gi], &model_change[gi])) {
+      const double ts0 = timing ? now() : 0.0;
+      const bool step_ok = solve_step(N, g.scale, param_constant, g.radius, steps[gi], &model_change[gi]);
+      if (timing && groups.size() == 1) t_solve += now() - ts0;
+      if (!step_ok) {
         g.radius /= g.decrease_factor; g.decrease_factor *= 2.0; ++g.n_bad; ++g.iterations;
         if (g.radius < 1e-32) { g.active = false; g.termination = 2; g.why = "trust region collapsed"; }
         return;
@@ -564,8 +587,10 @@ extern "C" int bodyfit_solve(bodyfit_problem* p, double* frame_params, double* b
     for (size_t gi = 0; gi < groups.size(); ++gi) { any_active |= was_active[gi] != 0; any_cand |= has_cand[gi] != 0; }
     if (!any_active) break;
     if (!any_cand) continue;
+    const double te0 = timing ? now() : 0.0;
     rc = bodyfit_evaluate_batch(p, xn.data(), nbeta ? xbn.data() : nullptr, rn.data(), nullptr, compn.data(), 0);
     if (rc) return rc;
+    if (timing) t_eval_r += now() - te0;
     ++n_sweeps;
     bool any_accept = false;
     for (size_t gi = 0; gi < groups.size(); ++gi) {
@@ -597,11 +622,16 @@ extern "C" int bodyfit_solve(bodyfit_problem* p, double* frame_params, double* b
         std::printf("[bodyfit] it %3d cost %.6e change %.3e rho %.3f radius %.3e\n", g.iterations, g.cost, change, rho, g.radius);
     }
     if (any_accept) {
+      const double tj0 = timing ? now() : 0.0;
       rc = bodyfit_evaluate_batch(p, x.data(), nbeta ? xb.data() : nullptr, r.data(), J.data(), comp.data(), 1);
       if (rc) return rc;
+      if (timing) t_eval_j += now() - tj0;
       ++n_sweeps;
     }
   }
+  if (timing)
+    std::fprintf(stderr, "[bodyfit timing] F=%d sweeps=%d  residual sweeps %.2f ms  jacobian sweeps %.2f ms  build_normal %.2f ms  solve_step %.2f ms\n",
+                 F, n_sweeps, t_eval_r * 1e3, t_eval_j * 1e3, t_build * 1e3, t_solve * 1e3);
   std::memcpy(frame_params, x.data(), x.size() * sizeof(double));
   if (nbeta) std::memcpy(beta, xb.data(), nbeta * sizeof(double));
   if (summaries) {
