@@ -436,7 +436,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_frame_resjac(DevModel M, DevPro
 
   STAMP(5);
   // ---- E. independent items: mesh operands + posed joints, landmark Jacobian terms ---------------------------
-  if (wave == 3 && lane < nJ) {
+  if (wave == 7 && lane < nJ) {   // (waves 6 and 7 carry no landmark items below unless the model has more than 12)
     const int jj = lane;
     double RA[9], t[3], q[3];
     mul33(Rr0, sA + jj * 9, RA);
@@ -457,7 +457,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_frame_resjac(DevModel M, DevPro
   }
   if (mc.featA) {
     const int ftile = f / kFTile, row = f % kFTile;
-    if (wave == 2 && lane < kBlendKSteps * 4) {
+    if (wave == 6 && lane < kBlendKSteps * 4) {
       const int kstep = lane >> 2, h = (lane >> 1) & 1, hl = lane & 1;
       uint32_t pk[4];
 #pragma unroll
@@ -479,17 +479,38 @@ __global__ __launch_bounds__(kThreads, 4) void k_frame_resjac(DevModel M, DevPro
     }
   }
   if (nL > 0 && want_jac) {
-    // pose-blend term  Ablend . (pd[:, 9(k-1):9k] . vec(dR_{k,c})): the inner products were parked in LM_PD by phase C
-    // (same lane mapping: lane k - 1 of half-wave l), the landmark's blended rotation is applied in place
+    // d q_l / d theta_{k,c} for landmark l, complete, left in LM_PD[l][3 (k - 1) + c] for the Jacobian sweep:
+    //   Ablend . (pd[:, 9(k-1):9k] . vec(dR_{k,c}))   the inner products were parked here by phase C (same lane mapping:
+    //                                                 lane k - 1 of half-wave l); the blended rotation is applied now
+    // + W_{k,c} . sum_{i : k is j_i or an ancestor of j_i} w_i (x_i - P_k)      the skinning term, which depends on the
+    //                                                 landmark and the joint only, not on the keypoint that uses them
     for (int l = lm_l; l < nL; l += 16) {
       if (lm_k < nJ - 1) {
-        const double* Ab = sLm + l * LM_STRIDE + LM_A;
+        const int k = lm_k + 1;
+        const double* L = sLm + l * LM_STRIDE;
+        const double* Ab = L + LM_A;
+        const int* Lj = reinterpret_cast<const int*>(L + LM_J);
+        const int nw = (int)L[LM_NW];
+        const double pk0 = sP[k * 3], pk1 = sP[k * 3 + 1], pk2 = sP[k * 3 + 2];
+        double a0 = 0, a1 = 0, a2 = 0;
+        for (int i = 0; i < nw; ++i) {
+          const int j = Lj[i];
+          if (j == k || ((sAnc[j] >> k) & 1u)) {
+            const double w = L[LM_W + i];
+            a0 += w * (L[LM_X + i * 3] - pk0);
+            a1 += w * (L[LM_X + i * 3 + 1] - pk1);
+            a2 += w * (L[LM_X + i * 3 + 2] - pk2);
+          }
+        }
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
           double* o = sLm + l * LM_STRIDE + LM_PD + (3 * lm_k + c) * 3;
+          const double* Wm = sW + (3 * lm_k + c) * 9;
           double t[3];
           mv3(Ab, o[0], o[1], o[2], t);
-          o[0] = t[0]; o[1] = t[1]; o[2] = t[2];
+          o[0] = t[0] + Wm[0] * a0 + Wm[1] * a1 + Wm[2] * a2;
+          o[1] = t[1] + Wm[3] * a0 + Wm[4] * a1 + Wm[5] * a2;
+          o[2] = t[2] + Wm[6] * a0 + Wm[7] * a1 + Wm[8] * a2;
         }
       }
     }
@@ -598,22 +619,8 @@ __global__ __launch_bounds__(kThreads, 4) void k_frame_resjac(DevModel M, DevPro
               d2 = Wm[6] * x0 + Wm[7] * x1 + Wm[8] * x2;
             }
           } else {
-            const double* L = sLm + (id - nJ) * LM_STRIDE;
-            const int* Lj = reinterpret_cast<const int*>(L + LM_J);
-            const int nw = (int)L[LM_NW];
-            double a0 = 0, a1 = 0, a2 = 0;
-            for (int i = 0; i < nw; ++i) {
-              const int j = Lj[i];
-              if (j == k || ((sAnc[j] >> k) & 1u)) {
-                const double w = L[LM_W + i];
-                a0 += w * (L[LM_X + i * 3] - pk0);
-                a1 += w * (L[LM_X + i * 3 + 1] - pk1);
-                a2 += w * (L[LM_X + i * 3 + 2] - pk2);
-              }
-            }
-            d0 = Wm[0] * a0 + Wm[1] * a1 + Wm[2] * a2 + L[LM_PD + kc * 3];
-            d1 = Wm[3] * a0 + Wm[4] * a1 + Wm[5] * a2 + L[LM_PD + kc * 3 + 1];
-            d2 = Wm[6] * a0 + Wm[7] * a1 + Wm[8] * a2 + L[LM_PD + kc * 3 + 2];
+            const double* o = sLm + (id - nJ) * LM_STRIDE + LM_PD + kc * 3;   // complete since phase E
+            d0 = o[0]; d1 = o[1]; d2 = o[2];
           }
           store_through(J_out + (size_t)(2 * kg) * ncols + 7 + kc, G[0] * d0 + G[1] * d1 + G[2] * d2);
           store_through(J_out + (size_t)(2 * kg + 1) * ncols + 7 + kc, G[3] * d0 + G[4] * d1 + G[5] * d2);
