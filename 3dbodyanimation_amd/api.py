@@ -294,7 +294,7 @@ class Problem:
         ms = np.zeros(4)
         _check(load_library().bodyfit_profile_sweep(self.h, d_params_ptr, d_beta_ptr, int(want_jacobian),
                                                     int(with_reduce), int(iters), stream, _d(ms)))
-        return dict(frame_resjac=ms[0], priors=ms[1], mesh_blend_lbs=ms[2], reduce_shared=ms[3])
+        return dict(frame_resjac=ms[0], mesh_blend_lbs=ms[2], reduce_shared=ms[3])   # priors ride on one of the two launches
 
     def views(self) -> DeviceViews:
         v = DeviceViews()

@@ -129,8 +129,8 @@ bool chol_lower(std::vector<double>& A, int n) {
 
 // One evaluation sweep: two launches on the caller's stream.  The prior residuals are produced by extra
 // workgroups (priors_inl.h) of the mesh launch when the mesh is on (its vertex tiles leave 40 CUs idle), otherwise
-// of the k_frame_resjac launch.  ev (optional): [0] start, [1] after
-// frame_resjac (+ priors), [2] after the mesh kernel.
+// of the k_frame_resjac launch.  ev (optional, 4 events): the dispatches' own begin / end timestamps,
+// [0],[1] k_frame_resjac, [2],[3] k_mesh_blend_lbs.
 int sweep(bodyfit_problem* p, const double* d_params, const double* d_beta, int want_jac, bool mesh,
           hipStream_t st, hipEvent_t* ev = nullptr, double* r_base = nullptr, int* comp_out = nullptr,
           const int* frame_flags = nullptr, int frame_mask = 0) {
@@ -158,12 +158,9 @@ int sweep(bodyfit_problem* p, const double* d_params, const double* d_beta, int 
   pa.n_tiles = priors ? (p->d.F + 15) / 16 : 0;
   PriorArgs none = pa;
   none.n_tiles = 0;
-  if (ev) (void)hipEventRecord(ev[0], st);
   launch_frame_resjac(m->d, dp, d_params, d_beta, d_r, want_jac ? p->d_J : nullptr, p->d_joints, mc, want_jac,
-                      mesh ? none : pa, st);
-  if (ev) (void)hipEventRecord(ev[1], st);
-  if (mesh) launch_mesh(m->d, p->d, p->mc, p->d_cloud, pa, d_params, st);
-  if (ev) (void)hipEventRecord(ev[2], st);
+                      mesh ? none : pa, st, ev ? ev[0] : nullptr, ev ? ev[1] : nullptr);
+  if (mesh) launch_mesh(m->d, p->d, p->mc, p->d_cloud, pa, d_params, st, ev ? ev[2] : nullptr, ev ? ev[3] : nullptr);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(BODYFIT_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
   return BODYFIT_OK;
@@ -676,28 +673,31 @@ int bodyfit_profile_sweep(bodyfit_problem* p, const double* d_frame_params, cons
   if (!p || !d_frame_params || !avg_ms || iters <= 0) return fail(BODYFIT_ERR_INVALID, "bad argument");
   HIP_TRY(hipSetDevice(p->m->device));
   hipStream_t st = static_cast<hipStream_t>(stream);
-  std::vector<hipEvent_t> ev((size_t)iters * 4);
+  // per sweep: [0],[1] begin / end of the k_frame_resjac dispatch, [2],[3] of the mesh dispatch (both taken from the
+  // dispatch's own timestamps, so they match rocprofv3's kernel durations), [4],[5] around the reduction launches
+  const bool mesh = p->desc.want_mesh != 0;
+  std::vector<hipEvent_t> ev((size_t)iters * 6);
   for (auto& e : ev) HIP_TRY(hipEventCreate(&e));
   int rc = BODYFIT_OK;
   for (int it = 0; it < iters && rc == BODYFIT_OK; ++it) {
-    hipEvent_t* e = ev.data() + (size_t)it * 4;
-    rc = sweep(p, d_frame_params, d_beta, want_jacobian, p->desc.want_mesh != 0, st, e);
-    if (rc == BODYFIT_OK && with_reduce) rc = bodyfit_reduce_shared_device(p, nullptr, stream);
-    (void)hipEventRecord(e[3], st);
+    hipEvent_t* e = ev.data() + (size_t)it * 6;
+    rc = sweep(p, d_frame_params, d_beta, want_jacobian, mesh, st, e);
+    if (rc == BODYFIT_OK && with_reduce) {
+      (void)hipEventRecord(e[4], st);
+      rc = bodyfit_reduce_shared_device(p, nullptr, stream);
+      (void)hipEventRecord(e[5], st);
+    }
   }
   hipError_t se = hipStreamSynchronize(st);
   for (int k = 0; k < 4; ++k) avg_ms[k] = 0.0;
   if (rc == BODYFIT_OK && se == hipSuccess) {
-    // [0] frame_resjac (incl. the prior workgroups of the same launch), [1] 0 (priors are not a launch of
-    // their own), [2] mesh, [3] reduce
-    const int a[4] = {0, 0, 1, 2}, b[4] = {1, 0, 2, 3};
-    for (int it = 0; it < iters; ++it)
-      for (int k = 0; k < 4; ++k) {
-        if (k == 1) continue;
-        float ms = 0.f;
-        (void)hipEventElapsedTime(&ms, ev[(size_t)it * 4 + a[k]], ev[(size_t)it * 4 + b[k]]);
-        avg_ms[k] += ms / iters;
-      }
+    for (int it = 0; it < iters; ++it) {
+      hipEvent_t* e = ev.data() + (size_t)it * 6;
+      float ms = 0.f;
+      (void)hipEventElapsedTime(&ms, e[0], e[1]); avg_ms[0] += ms / iters;
+      if (mesh) { (void)hipEventElapsedTime(&ms, e[2], e[3]); avg_ms[2] += ms / iters; }
+      if (with_reduce) { (void)hipEventElapsedTime(&ms, e[4], e[5]); avg_ms[3] += ms / iters; }
+    }
   }
   for (auto& e : ev) (void)hipEventDestroy(e);
   if (se != hipSuccess) return fail(BODYFIT_ERR_HIP, std::string("profile sync: ") + hipGetErrorString(se));

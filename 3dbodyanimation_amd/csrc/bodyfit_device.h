@@ -129,9 +129,10 @@ __host__ __device__ inline float bf16_to_f32(uint16_t b) {
 // kernel launchers (defined in the .hip files)
 void launch_frame_resjac(const DevModel& M, const DevProblem& P, const double* d_params, const double* d_beta,
                          double* d_r, double* d_J, double* d_joints, const MeshCoef& mc, int want_jac,
-                         const PriorArgs& priors, hipStream_t s);
+                         const PriorArgs& priors, hipStream_t s, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 void launch_mesh(const DevModel& M, const DevProblem& P, const MeshCoef& mc, float* d_cloud, const PriorArgs& pa,
-                 const double* d_params, hipStream_t s);
+                 const double* d_params, hipStream_t s, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
+// (ev_start / ev_stop: optional events that take the dispatch's own begin / end timestamps, hipExtLaunchKernelGGL)
 void launch_reduce_shared_ex(int K, int ncols, int npose, int nS, int total_rows, const double* d_r,
                              const double* d_J, double huber_delta, int shape_row0, int shape_rows,
                              double beta_shape, double* d_partials, double* d_out66, hipStream_t s);

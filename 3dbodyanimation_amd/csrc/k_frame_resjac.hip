@@ -15,6 +15,8 @@
 //                       landmark per wave at a time)
 //   lanes = columns     the dense row-major [2K][ncols] panel is written with consecutive lanes on
 //                       consecutive columns (coalesced 512-B stores), keypoints dealt round-robin to waves
+#include <hip/hip_ext.h>
+
 #include "bodyfit_device.h"
 #include "priors_inl.h"
 
@@ -682,7 +684,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_frame_resjac(DevModel M, DevPro
 
 void launch_frame_resjac(const DevModel& M, const DevProblem& P, const double* d_params, const double* d_beta,
                          double* d_r, double* d_J, double* d_joints, const MeshCoef& mc, int want_jac,
-                         const PriorArgs& priors, hipStream_t s) {
+                         const PriorArgs& priors, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop) {
   if (P.F <= 0) return;
   const size_t lds = (size_t)(OFF_LM + M.nL * LM_STRIDE) * sizeof(double);
   static size_t lds_granted = 48 * 1024;
@@ -691,8 +693,8 @@ void launch_frame_resjac(const DevModel& M, const DevProblem& P, const double* d
                               (int)lds);
     lds_granted = lds;
   }
-  hipLaunchKernelGGL(k_frame_resjac, dim3(P.F + priors.n_tiles), dim3(kThreads), lds, s, M, P, d_params, d_beta, d_r,
-                     d_J, d_joints, mc, want_jac, priors);
+  hipExtLaunchKernelGGL(k_frame_resjac, dim3(P.F + priors.n_tiles), dim3(kThreads), lds, s, ev_start, ev_stop, 0, M, P,
+                        d_params, d_beta, d_r, d_J, d_joints, mc, want_jac, priors);
 }
 
 }  // namespace bodyfit

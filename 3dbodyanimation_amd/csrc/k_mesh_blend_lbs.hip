@@ -20,6 +20,8 @@
 // Data movement: the vertex tile's B operands (84 KiB, fragment order, contiguous per tile) go
 // HBM -> LDS by LDS-DMA once per workgroup and serve every frame.
 // LDS: 84 KiB (B) + 8 waves x 9 KiB (transforms) = 156 KiB of the CU's 160 KiB.
+#include <hip/hip_ext.h>
+
 #include "bodyfit_device.h"
 #include "priors_inl.h"
 
@@ -290,7 +292,7 @@ __global__ __launch_bounds__(64 * kWaves) void k_mesh_blend_lbs(DevModel M, DevP
 }  // namespace
 
 void launch_mesh(const DevModel& M, const DevProblem& P, const MeshCoef& mc, float* d_cloud, const PriorArgs& pa,
-                 const double* d_params, hipStream_t s) {
+                 const double* d_params, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop) {
   if (P.F <= 0) return;
   if ((size_t)P.nFTiles * kFTile * M.nVTiles * kVTile * 12 >= ((size_t)1 << 32)) return;   // refused at problem creation
   static bool attr_set = false;
@@ -299,8 +301,8 @@ void launch_mesh(const DevModel& M, const DevProblem& P, const MeshCoef& mc, flo
                               hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
     attr_set = true;
   }
-  hipLaunchKernelGGL(k_mesh_blend_lbs, dim3(M.nVTiles + pa.n_tiles), dim3(64 * kWaves), kLdsBytes, s, M, P, mc, d_cloud, pa,
-                     d_params);
+  hipExtLaunchKernelGGL(k_mesh_blend_lbs, dim3(M.nVTiles + pa.n_tiles), dim3(64 * kWaves), kLdsBytes, s, ev_start, ev_stop,
+                        0, M, P, mc, d_cloud, pa, d_params);
 }
 
 }  // namespace bodyfit
