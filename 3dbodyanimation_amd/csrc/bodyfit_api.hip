@@ -97,6 +97,7 @@ struct bodyfit_problem {
   double* d_normal = nullptr;
   int* d_comp = nullptr;
   float* d_cloud = nullptr;
+  double* d_frame_normal = nullptr;   // [F][87][88] per-frame normal-equation panels (window solver), on first use
   // host copies
   std::vector<int> kp_offset, kp_id, kp_frame;
   std::vector<double> kp_uv;
@@ -651,6 +652,32 @@ int bodyfit_evaluate_batch(bodyfit_problem* p, const double* frame_params, const
   if (residuals) std::memcpy(residuals, p->c_r.data(), p->c_r.size() * sizeof(double));
   if (jacobian && wj) std::memcpy(jacobian, p->c_J.data(), p->c_J.size() * sizeof(double));
   if (gmm_comp) std::memcpy(gmm_comp, p->c_comp.data(), p->c_comp.size() * sizeof(int));
+  return BODYFIT_OK;
+}
+
+int bodyfit_internal_frame_normals(bodyfit_problem* p, const double* frame_params, const double* beta, double* residuals,
+                                   int* gmm_comp, double* H) {
+  if (!p || !frame_params || !residuals || !H) return fail(BODYFIT_ERR_INVALID, "null argument");
+  const bodyfit_model* m = p->m;
+  const int npose = 7 + 3 * (m->nJ - 1), F = p->d.F;
+  const bool has_beta = p->lay.n_cols > npose;
+  HIP_TRY(hipSetDevice(m->device));
+  std::lock_guard<std::mutex> lock(p->mu);
+  p->cache_valid = false;
+  const size_t npar = (size_t)p->n_param_rows * npose;
+  const size_t nbeta = has_beta ? (size_t)(p->desc.beta_per_frame ? F * m->nS : m->nS) : 0;
+  const size_t nH = (size_t)F * kNormalRows * kNormalLd;
+  if (!p->d_frame_normal) HIP_TRY(p->mem.alloc(&p->d_frame_normal, nH));
+  HIP_TRY(hipMemcpyAsync(p->d_params, frame_params, npar * sizeof(double), hipMemcpyHostToDevice, nullptr));
+  if (nbeta) HIP_TRY(hipMemcpyAsync(p->d_beta, beta, nbeta * sizeof(double), hipMemcpyHostToDevice, nullptr));
+  int rc = sweep(p, p->d_params, has_beta ? p->d_beta : nullptr, 1, false, nullptr);
+  if (rc) return rc;
+  launch_frame_normal(F, p->lay.n_cols, p->d.kp_offset, p->desc.huber_delta, p->d_r, p->d_J, p->d_frame_normal, nullptr);
+  HIP_TRY(hipMemcpyAsync(residuals, p->d_r, (size_t)p->lay.total_rows * sizeof(double), hipMemcpyDeviceToHost, nullptr));
+  if (gmm_comp) HIP_TRY(hipMemcpyAsync(gmm_comp, p->d_comp, (size_t)F * sizeof(int), hipMemcpyDeviceToHost, nullptr));
+  HIP_TRY(hipMemcpyAsync(H, p->d_frame_normal, nH * sizeof(double), hipMemcpyDeviceToHost, nullptr));
+  HIP_TRY(hipStreamSynchronize(nullptr));
+  HIP_TRY(hipGetLastError());
   return BODYFIT_OK;
 }
 

@@ -179,7 +179,9 @@ struct Normal {
   std::vector<double> g;   // [nf*NP + nb] gradient J^T r
 };
 
-void build_normal(const Ctx& c, const Group& g, const double* r, const double* J, const int* comp, Normal& N) {
+// Hblk (optional): the reprojection part built on the device, [F][87][88] lower panels (k_frame_normal); J is then unused
+void build_normal(const Ctx& c, const Group& g, const double* r, const double* J, const int* comp, Normal& N,
+                  const double* Hblk = nullptr) {
   const int nf = g.f1 - g.f0, nb = c.nb, ncols = c.lay.n_cols, D = NP - 7;
   N.nf = nf; N.nb = nb;
   N.A.assign((size_t)nf * NP * NP, 0.0);
@@ -193,7 +195,20 @@ void build_normal(const Ctx& c, const Group& g, const double* r, const double* J
     double* B = &N.B[(size_t)lf * NP * std::max(nb, 1)];
     double* gf = &N.g[(size_t)lf * NP];
     double* gb = &N.g[(size_t)nf * NP];
-    for (int k = c.kp_off[f]; k < c.kp_off[f + 1]; ++k) {
+    if (Hblk) {
+      const double* H = Hblk + (size_t)f * 87 * 88;
+      for (int i = 0; i < NP; ++i) {
+        for (int j = 0; j <= i; ++j) A[i * NP + j] += H[i * 88 + j];   // (+=: the previous frame's temporal pair is already in)
+        gf[i] += H[ncols * 88 + i];
+      }
+      for (int ib = 0; ib < nb; ++ib) {
+        const double* Hr = H + (size_t)(NP + ib) * 88;
+        for (int j = 0; j < NP; ++j) B[j * nb + ib] += Hr[j];
+        for (int jb = 0; jb <= ib; ++jb) N.C[ib * nb + jb] += Hr[NP + jb];
+        gb[ib] += H[ncols * 88 + NP + ib];
+      }
+    }
+    for (int k = c.kp_off[f]; !Hblk && k < c.kp_off[f + 1]; ++k) {
       const double r0 = r[2 * k], r1 = r[2 * k + 1];
       double rho1;
       huber_rho(c.huber, r0 * r0 + r1 * r1, &rho1);
@@ -469,10 +484,19 @@ extern "C" int bodyfit_solve(bodyfit_problem* p, double* frame_params, double* b
   std::vector<double> x(frame_params, frame_params + (size_t)F * NP), xb(nbeta);
   if (nbeta) std::memcpy(xb.data(), beta, nbeta * sizeof(double));
   std::vector<double> r((size_t)c.lay.total_rows), rn((size_t)c.lay.total_rows);
-  std::vector<double> J((size_t)c.lay.reproj_rows * c.lay.n_cols);
+  // normal equations: the reprojection part comes from the device as per-frame panels (k_frame_normal) whenever the
+  // frames fit its 64-row staging; otherwise J is copied back and the Gram products are formed here
+  const bool device_normals = view.max_kp_per_frame <= 32 && std::getenv("BODYFIT_HOST_NORMALS") == nullptr;
+  std::vector<double> J(device_normals ? 0 : (size_t)c.lay.reproj_rows * c.lay.n_cols);
+  std::vector<double> Hblk(device_normals ? (size_t)F * 87 * 88 : 0);
   std::vector<int> comp(F, 0), compn(F, 0);
   std::vector<double> xn(x), xbn(xb);
-  int rc = bodyfit_evaluate_batch(p, x.data(), nbeta ? xb.data() : nullptr, r.data(), J.data(), comp.data(), 1);
+  auto eval_full = [&]() -> int {
+    return device_normals
+               ? bodyfit_internal_frame_normals(p, x.data(), nbeta ? xb.data() : nullptr, r.data(), comp.data(), Hblk.data())
+               : bodyfit_evaluate_batch(p, x.data(), nbeta ? xb.data() : nullptr, r.data(), J.data(), comp.data(), 1);
+  };
+  int rc = eval_full();
   if (rc) return rc;
   int n_sweeps = 1;
   std::vector<Normal> normals(groups.size());
@@ -503,7 +527,7 @@ extern "C" int bodyfit_solve(bodyfit_problem* p, double* frame_params, double* b
       const int nf = g.f1 - g.f0, n = nf * NP + nb;
       if (!normal_valid[gi]) {
         const double t0 = timing ? now() : 0.0;
-        build_normal(c, g, r.data(), J.data(), comp.data(), normals[gi]);
+        build_normal(c, g, r.data(), J.data(), comp.data(), normals[gi], device_normals ? Hblk.data() : nullptr);
         normal_valid[gi] = 1;
         if (timing && groups.size() == 1) t_build += now() - t0;
       }
@@ -623,7 +647,7 @@ extern "C" int bodyfit_solve(bodyfit_problem* p, double* frame_params, double* b
     }
     if (any_accept) {
       const double tj0 = timing ? now() : 0.0;
-      rc = bodyfit_evaluate_batch(p, x.data(), nbeta ? xb.data() : nullptr, r.data(), J.data(), comp.data(), 1);
+      rc = eval_full();
       if (rc) return rc;
       if (timing) t_eval_j += now() - tj0;
       ++n_sweeps;

@@ -412,6 +412,69 @@ __global__ __launch_bounds__(256) void k_lm_step(LmProblem P, LmState S, const d
   }
 }
 
+// Reprojection part of one frame's normal equations for the window solver (host_solver.cpp): the robustified Gram
+// matrix of [J_f | r_f] — A_f (76 x 76), B_f (76 x nb), this frame's share of C (nb x nb), and the gradient in row n —
+// on the f64 matrix cores, lower triangle of an (n + 1) x kLd panel per frame.  The host adds the prior / temporal
+// blocks (constant Jacobians) and runs the block-tridiagonal factorisation; it no longer needs J itself
+// ("normal equations built on device").
+__global__ __launch_bounds__(256) void k_frame_normal(int F, int n, const int* __restrict__ kp_offset, double huber,
+                                                       const double* __restrict__ r, const double* __restrict__ J,
+                                                       double* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  double* Jh = sm;                         // kRowsMax x kJLd : robustified [J | r]
+  double* ds = sm + kRowsMax * kJLd;       // per-row sqrt(rho')
+  const int f = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int k0 = kp_offset[f], nrows = 2 * (kp_offset[f + 1] - k0);
+  const int nrows4 = (nrows + 3) & ~3;
+  if (tid < kRowsMax) {
+    double sw = 0.0, rr = 0.0;
+    if (tid < nrows) {
+      const int k = k0 + (tid >> 1);
+      const double r0 = r[2 * (size_t)k], r1 = r[2 * (size_t)k + 1];
+      double rho1;
+      huber_rho(huber, r0 * r0 + r1 * r1, &rho1);
+      sw = sqrt(rho1);
+      rr = sw * ((tid & 1) ? r1 : r0);
+    }
+    ds[tid] = sw;
+    Jh[tid * kJLd + n] = rr;
+  }
+  __syncthreads();
+  {
+    double jv[22];
+#pragma unroll
+    for (int u = 0; u < 22; ++u) {
+      const int i = tid + u * 256, row = i / 88, c = i % 88;
+      jv[u] = (row < nrows && c < n) ? J[(size_t)(2 * k0 + row) * n + c] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < 22; ++u) {
+      const int i = tid + u * 256, row = i / 88, c = i % 88;
+      if (row < nrows4 && c != n) Jh[row * kJLd + c] = (row < nrows && c < n) ? ds[row] * jv[u] : 0.0;
+    }
+    for (int i = tid; i < nrows4 * (kJLd - 88); i += 256) Jh[(i / (kJLd - 88)) * kJLd + 88 + i % (kJLd - 88)] = 0.0;
+  }
+  __syncthreads();
+  double* H = out + (size_t)f * (kN + 1) * kLd;
+  const int m = lane & 15, kk = lane >> 4;
+  int pair = 0;
+  for (int ti = 0; ti < 6; ++ti)
+    for (int tj = 0; tj <= ti; ++tj, ++pair) {
+      if ((pair & 3) != wave) continue;
+      d4 acc = {0.0, 0.0, 0.0, 0.0};
+      for (int s = 0; s < nrows4 / 4; ++s) {
+        const double a = Jh[(4 * s + kk) * kJLd + 16 * ti + m];
+        const double b = Jh[(4 * s + kk) * kJLd + 16 * tj + m];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int i = 16 * ti + kk + 4 * q, j = 16 * tj + m;
+        if (i <= n && j < n && j <= i) H[i * kLd + j] = acc[q];
+      }
+    }
+}
+
 // candidate bookkeeping for frames without a candidate: x_new = x so the residual sweep stays well defined
 __global__ __launch_bounds__(128) void k_lm_fill(LmProblem P, LmState S) {
   const int f = blockIdx.x, tid = threadIdx.x;
@@ -478,6 +541,18 @@ void launch_lm_step(const LmProblem& P, const LmState& S, const double* d_r, con
 }
 void launch_lm_accept(const LmProblem& P, const LmState& S, const double* d_r_new, hipStream_t s) {
   hipLaunchKernelGGL(k_lm_accept, dim3(P.F), dim3(256), 0, s, P, S, d_r_new);
+}
+
+void launch_frame_normal(int F, int n, const int* d_kp_offset, double huber, const double* d_r, const double* d_J,
+                         double* d_out, hipStream_t s) {
+  if (F <= 0) return;
+  const size_t lds = (size_t)(kRowsMax * kJLd + kRowsMax) * sizeof(double);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_frame_normal), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(k_frame_normal, dim3(F), dim3(256), lds, s, F, n, d_kp_offset, huber, d_r, d_J, d_out);
 }
 
 }  // namespace bodyfit
