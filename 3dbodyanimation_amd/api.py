@@ -110,6 +110,7 @@ def load_library():
     lib.bodyfit_solve.argtypes = [C.c_void_p, _dp, _dp, C.POINTER(C.c_ubyte), C.c_int, C.POINTER(FitOptions),
                                   C.POINTER(FitSummary), C.c_int]
     lib.bodyfit_forward.argtypes = [C.c_void_p, _dp, _dp, _dp, _fp]
+    lib.bodyfit_writeback_batch.argtypes = [C.c_void_p, _dp, _dp, _dp, _dp, _fp, _dp]
     lib.bodyfit_evaluate_block.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(_dp), _dp, C.POINTER(_dp)]
     _lib = lib
     return lib
@@ -308,6 +309,17 @@ class Problem:
         _check(load_library().bodyfit_forward(self.h, _d(x), _d(b), _d(joints),
                                               cloud.ctypes.data_as(_fp) if cloud is not None else None))
         return joints, cloud
+
+    def writeback(self, frame_params, beta=None, want_cloud=False):
+        """The reference's post-solve write-back for every frame, on the device (bodyfit_writeback_batch):
+        R0' = R(rootAA) R0, update() without the Sim3 scale, mean pixel error of the FK keypoints."""
+        x = _c64(frame_params); b = _c64(beta) if beta is not None else None
+        F = self.n_frames
+        r0 = np.empty((F, 3, 3)); joints = np.empty((F, self.model.n_joints, 3)); px = np.empty(F)
+        cloud = np.empty((F, self.model.n_verts, 3), np.float32) if want_cloud else None
+        _check(load_library().bodyfit_writeback_batch(self.h, _d(x), _d(b), _d(r0), _d(joints),
+                                                      cloud.ctypes.data_as(_fp) if cloud is not None else None, _d(px)))
+        return dict(R0=r0, joints=joints, cloud=cloud, mean_px=px)
 
     def solve(self, frame_params, beta=None, constant=None, independent=False, max_iters=100, scale_bounds=(0.3, 3.0),
               verbose=False, solver=0):

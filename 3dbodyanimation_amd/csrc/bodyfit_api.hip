@@ -97,7 +97,8 @@ struct bodyfit_problem {
   double* d_normal = nullptr;
   int* d_comp = nullptr;
   float* d_cloud = nullptr;
-  double* d_frame_normal = nullptr;   // [F][87][88] per-frame normal-equation panels (window solver), on first use
+  double* d_frame_normal = nullptr;
+  double* d_writeback = nullptr;      // [F][76] update parameters + [F][9] R0' + [F] mean pixel error, on first use   // [F][87][88] per-frame normal-equation panels (window solver), on first use
   // host copies
   std::vector<int> kp_offset, kp_id, kp_frame;
   std::vector<double> kp_uv;
@@ -134,9 +135,10 @@ bool chol_lower(std::vector<double>& A, int n) {
 // [0],[1] k_frame_resjac, [2],[3] k_mesh_blend_lbs.
 int sweep(bodyfit_problem* p, const double* d_params, const double* d_beta, int want_jac, bool mesh,
           hipStream_t st, hipEvent_t* ev = nullptr, double* r_base = nullptr, int* comp_out = nullptr,
-          const int* frame_flags = nullptr, int frame_mask = 0) {
+          const int* frame_flags = nullptr, int frame_mask = 0, const double* R0_override = nullptr) {
   const bodyfit_model* m = p->m;
   DevProblem dp = p->d;
+  if (R0_override) dp.R0 = R0_override;
   dp.frame_flags = frame_flags;
   dp.frame_mask = frame_mask;
   double* d_r = r_base ? r_base : p->d_r;
@@ -850,6 +852,43 @@ int bodyfit_debug_set_stamp_buffer(bodyfit_problem* p, unsigned long long* d_buf
   return BODYFIT_OK;
 }
 #endif
+
+int bodyfit_writeback_batch(bodyfit_problem* p, const double* frame_params, const double* beta, double* R0_out,
+                            double* joints, float* cloud, double* mean_px) {
+  if (!p || !frame_params) return fail(BODYFIT_ERR_INVALID, "null argument");
+  const bodyfit_model* m = p->m;
+  const int npose = 7 + 3 * (m->nJ - 1), F = p->d.F;
+  const bool has_beta = p->lay.n_cols > npose;
+  if (cloud && !p->desc.want_mesh) return fail(BODYFIT_ERR_INVALID, "problem was created without want_mesh");
+  HIP_TRY(hipSetDevice(m->device));
+  std::lock_guard<std::mutex> lock(p->mu);
+  p->cache_valid = false;
+  const size_t npar = (size_t)p->n_param_rows * npose;
+  const size_t nbeta = (has_beta && beta) ? (size_t)(p->desc.beta_per_frame ? F * m->nS : m->nS) : 0;
+  if (!p->d_writeback) HIP_TRY(p->mem.alloc(&p->d_writeback, (size_t)p->n_param_rows * npose + (size_t)F * 10));
+  double* d_upd = p->d_writeback;
+  double* d_R0n = d_upd + (size_t)p->n_param_rows * npose;
+  double* d_px = d_R0n + (size_t)F * 9;
+  HIP_TRY(hipMemcpyAsync(p->d_params, frame_params, npar * sizeof(double), hipMemcpyHostToDevice, nullptr));
+  if (nbeta) HIP_TRY(hipMemcpyAsync(p->d_beta, beta, nbeta * sizeof(double), hipMemcpyHostToDevice, nullptr));
+  launch_writeback_prepare(F, npose, p->d_params, p->d.R0, d_upd, d_R0n, nullptr);
+  int rc = sweep(p, d_upd, nbeta ? p->d_beta : nullptr, 0, p->desc.want_mesh != 0, nullptr, nullptr, nullptr, nullptr,
+                 nullptr, 0, d_R0n);
+  if (rc) return rc;
+  launch_mean_pixel_error(F, m->nJ, p->d.kp_offset, p->d.kp_id, p->d.kp_uv, p->d_joints, p->d.fx, p->d.fy, p->d.cx,
+                          p->d.cy, d_px, nullptr);
+  if (R0_out) HIP_TRY(hipMemcpyAsync(R0_out, d_R0n, (size_t)F * 9 * sizeof(double), hipMemcpyDeviceToHost, nullptr));
+  if (mean_px) HIP_TRY(hipMemcpyAsync(mean_px, d_px, (size_t)F * sizeof(double), hipMemcpyDeviceToHost, nullptr));
+  if (joints)
+    HIP_TRY(hipMemcpyAsync(joints, p->d_joints, (size_t)F * m->nJ * 3 * sizeof(double), hipMemcpyDeviceToHost, nullptr));
+  if (cloud) {
+    const size_t row = (size_t)m->V * 3 * sizeof(float), pitch = (size_t)m->d.nVTiles * kVTile * 3 * sizeof(float);
+    HIP_TRY(hipMemcpy2DAsync(cloud, row, p->d_cloud, pitch, row, (size_t)F, hipMemcpyDeviceToHost, nullptr));
+  }
+  HIP_TRY(hipStreamSynchronize(nullptr));
+  HIP_TRY(hipGetLastError());
+  return BODYFIT_OK;
+}
 
 int bodyfit_forward(bodyfit_problem* p, const double* frame_params, const double* beta, double* joints,
                     float* cloud) {

@@ -140,6 +140,10 @@ void launch_reduce_shared_ex(int K, int ncols, int npose, int nS, int total_rows
                              const double* d_J, double huber_delta, int shape_row0, int shape_rows,
                              double beta_shape, double* d_partials, double* d_out66, hipStream_t s);
 int reduce_partials_doubles();
+void launch_writeback_prepare(int F, int npose, const double* d_params, const double* d_R0, double* d_params_upd,
+                              double* d_R0_new, hipStream_t s);
+void launch_mean_pixel_error(int F, int nJ, const int* d_kp_offset, const int* d_kp_id, const double* d_kp_uv,
+                             const double* d_joints, double fx, double fy, double cx, double cy, double* d_out, hipStream_t s);
 void launch_regress(int nJ, int V, int ncol, const double* d_reg, const double* d_x, double* d_out, hipStream_t s);
 
 }  // namespace bodyfit

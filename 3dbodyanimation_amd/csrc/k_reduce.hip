@@ -154,4 +154,63 @@ void launch_regress(int nJ, int V, int ncol, const double* d_reg, const double* 
   hipLaunchKernelGGL(k_regress, dim3(nJ, ncol), dim3(256), 0, s, V, ncol, d_reg, d_x, d_out);
 }
 
+
+// ---- post-solve write-back (include/MultiFrameBA.h:154-174, include/Sim3BA.h:481-505) -----------------------------
+namespace {
+// R0' = R(rootAA) R0 (left-multiplied, so it compounds over repeated solves: quirk Q8); update parameters
+// [1, 0 0 0, rootT, jointAA]: the Sim3 scale is dropped by the write-back (quirk Q5).
+__global__ __launch_bounds__(64) void k_writeback_prepare(int F, int npose, const double* __restrict__ params,
+                                                          const double* __restrict__ R0, double* __restrict__ params_upd,
+                                                          double* __restrict__ R0_new) {
+  const int f = blockIdx.x * 64 + threadIdx.x;
+  if (f >= F) return;
+  const double* x = params + (size_t)f * npose;
+  double* y = params_upd + (size_t)f * npose;
+  const double ax = x[1], ay = x[2], az = x[3];
+  const double th = sqrt(ax * ax + ay * ay + az * az);
+  double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  if (th > 1e-12) {   // Eigen::AngleAxisd(theta, aa / theta).toRotationMatrix()
+    const double kx = ax / th, ky = ay / th, kz = az / th, c = cos(th), s = sin(th), v = 1.0 - c;
+    R[0] = c + kx * kx * v;      R[1] = kx * ky * v - kz * s; R[2] = kx * kz * v + ky * s;
+    R[3] = ky * kx * v + kz * s; R[4] = c + ky * ky * v;      R[5] = ky * kz * v - kx * s;
+    R[6] = kz * kx * v - ky * s; R[7] = kz * ky * v + kx * s; R[8] = c + kz * kz * v;
+  }
+  const double* A = R0 + (size_t)f * 9;
+  double* B = R0_new + (size_t)f * 9;
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) B[i * 3 + j] = R[i * 3] * A[j] + R[i * 3 + 1] * A[3 + j] + R[i * 3 + 2] * A[6 + j];
+  y[0] = 1.0; y[1] = 0.0; y[2] = 0.0; y[3] = 0.0;
+  for (int i = 4; i < npose; ++i) y[i] = x[i];
+}
+// mean_pixel_error (include/Utils.h:102-115) of every frame against its own posed joints; keypoints that are not FK
+// joints (vertex landmarks, which the reference does not have) are left out of the mean; no keypoints -> 0.
+__global__ __launch_bounds__(64) void k_mean_pixel_error(int F, int nJ, const int* __restrict__ kp_offset,
+                                                         const int* __restrict__ kp_id, const double* __restrict__ kp_uv,
+                                                         const double* __restrict__ joints, double fx, double fy, double cx,
+                                                         double cy, double* __restrict__ out) {
+  const int f = blockIdx.x, lane = threadIdx.x;
+  double sum = 0.0, cnt = 0.0;
+  for (int k = kp_offset[f] + lane; k < kp_offset[f + 1]; k += 64) {
+    const int id = kp_id[k];
+    if (id >= nJ) continue;
+    const double* X = joints + ((size_t)f * nJ + id) * 3;
+    const double u = fx * X[0] / X[2] + cx, v = fy * X[1] / X[2] + cy;
+    const double du = u - kp_uv[2 * (size_t)k], dv = v - kp_uv[2 * (size_t)k + 1];
+    sum += sqrt(du * du + dv * dv);
+    cnt += 1.0;
+  }
+  for (int off = 32; off > 0; off >>= 1) { sum += __shfl_xor(sum, off, 64); cnt += __shfl_xor(cnt, off, 64); }
+  if (lane == 0) out[f] = cnt > 0.0 ? sum / cnt : 0.0;
+}
+}  // namespace
+
+void launch_writeback_prepare(int F, int npose, const double* d_params, const double* d_R0, double* d_params_upd,
+                              double* d_R0_new, hipStream_t s) {
+  if (F > 0) hipLaunchKernelGGL(k_writeback_prepare, dim3((F + 63) / 64), dim3(64), 0, s, F, npose, d_params, d_R0, d_params_upd, d_R0_new);
+}
+void launch_mean_pixel_error(int F, int nJ, const int* d_kp_offset, const int* d_kp_id, const double* d_kp_uv,
+                             const double* d_joints, double fx, double fy, double cx, double cy, double* d_out, hipStream_t s) {
+  if (F > 0) hipLaunchKernelGGL(k_mean_pixel_error, dim3(F), dim3(64), 0, s, F, nJ, d_kp_offset, d_kp_id, d_kp_uv, d_joints, fx, fy, cx, cy, d_out);
+}
+
 }  // namespace bodyfit

@@ -122,22 +122,16 @@ def intrinsics(W: int, H: int) -> np.ndarray:
     return synth.camera_intrinsics(W, H)
 
 
-def _mean_pixel_error(ids, uv, joints, intr) -> float:
-    fk = ids < joints.shape[0]                        # mean_pixel_error indexes jointPos by jid (include/Utils.h:109)
-    if not fk.any():
-        return 0.0
-    return api.mean_pixel_error(ids[fk], uv[fk], joints, intr)
-
-
-def _updated_joints(gpu_model, r0, t, joint_aa, beta):
-    """Avatar::update() after the write-back: r[0] = r0, p = t, no scale (quirk Q5)."""
+def _updated(gpu_model, kps, intr, r0, t, joint_aa, beta):
+    """Avatar::update() + mean_pixel_error for frames whose write-back already happened (r[0] = r0, p = t, each with its
+    own beta copy), on the device: bodyfit_writeback_batch with a zero root angle-axis."""
     F = r0.shape[0]
+    off, kid, uv = kps
     x = np.zeros((F, 76)); x[:, 0] = 1.0; x[:, 4:7] = t; x[:, 7:] = joint_aa
-    off = np.arange(F + 1, dtype=np.int32)            # one placeholder keypoint per frame, only the forward pass is used
-    p = api.Problem(gpu_model, off, np.zeros(F, np.int32), np.zeros((F, 2)), [1, 1, 0, 0], r0.reshape(F, 9), n_cols=86,
-                    use_shape=True, beta_per_frame=(np.ndim(beta) == 2))
-    joints, _ = p.forward(x, beta, want_cloud=False)
-    return joints
+    p = api.Problem(gpu_model, off, kid, uv, intr, r0.reshape(F, 9), n_cols=86, use_shape=True,
+                    beta_per_frame=(np.ndim(beta) == 2))
+    wb = p.writeback(x, beta)
+    return wb["joints"], wb["mean_px"]
 
 
 def _subsequence(seq, ids):
@@ -175,12 +169,9 @@ def run_single(gpu_model, seq: KeypointSequence, intr, max_iters=100, beta_pose=
     x, beta, summ = prob.solve(x0, np.zeros((n, 10)) if shape_block else None, constant=const, independent=True,
                                max_iters=max_iters)
     ms = (time.perf_counter() - t0) * 1e3 / n
-    r0_new = np.stack([synth.rodrigues(x[f, 1:4]) @ R0[f].reshape(3, 3) for f in range(n)])
-    joints = _updated_joints(gpu_model, r0_new, x[:, 4:7], x[:, 7:], beta if beta is not None else np.zeros(10))
-    rows = []
-    for k, f in enumerate(keep):
-        ids, puv = seq.frame(f)
-        rows.append((f, _mean_pixel_error(ids, puv, joints[k], intr), ms))
+    wb = prob.writeback(x, beta)       # R0' = R(rootAA) R0, update() without the scale (Q5), mean pixel error: on the device
+    r0_new = wb["R0"]
+    rows = [(f, float(wb["mean_px"][k]), ms) for k, f in enumerate(keep)]
     _write_log(out_dir, rows)
     return dict(frames=keep, params=x, beta=beta, r0=r0_new, log=rows, summaries=summ)
 
@@ -214,10 +205,9 @@ def run_multi(gpu_model, seq: KeypointSequence, intr, max_iters_s1=1000, skip=10
     _, b1, s1 = solve(anchors, poses[anchors].copy(), w[anchors[0]].copy(), beta_shape, max_iters_s1)   # Q7: copy
     w[anchors[0]] = b1
     ms_anchor = (time.perf_counter() - t0) * 1e3
-    ja = _updated_joints(gpu_model, r0[anchors], t[anchors], jaa[anchors], w[anchors])   # each avatar's own w (:141-147)
-    for k, f in enumerate(anchors):
-        ids, uv = seq.frame(f)
-        rows.append((f, _mean_pixel_error(ids, uv, ja[k], intr), ms_anchor / len(anchors)))
+    _, px = _updated(gpu_model, _subsequence(seq, anchors), intr, r0[anchors], t[anchors], jaa[anchors], w[anchors])
+    for k, f in enumerate(anchors):                                 # each avatar's own w (:141-147)
+        rows.append((f, float(px[k]), ms_anchor / len(anchors)))
     w[:] = w[0]                                                     # share the shape among all avatars (:154)
     # ---- stage 2: sliding windows -----------------------------------------------------------------------------
     stride = wsize - overlap
@@ -229,10 +219,9 @@ def run_multi(gpu_model, seq: KeypointSequence, intr, max_iters_s1=1000, skip=10
         w[s] = bw
         poses[ids] = x
         ms_win = (time.perf_counter() - t0) * 1e3
-        jw = _updated_joints(gpu_model, r0[ids], t[ids], jaa[ids], w[ids])
+        _, px = _updated(gpu_model, _subsequence(seq, ids), intr, r0[ids], t[ids], jaa[ids], w[ids])
         for k, f in enumerate(ids):
-            a, b = seq.frame(f)
-            rows.append((f, _mean_pixel_error(a, b, jw[k], intr), ms_win / (e - s)))
+            rows.append((f, float(px[k]), ms_win / (e - s)))
     _write_log(out_dir, rows)
     return dict(poses=poses, r0=r0, t=t, joint_aa=jaa, w=w, log=rows, stage1=s1[0])
 

@@ -176,6 +176,17 @@ int bodyfit_evaluate_block(bodyfit_problem* p, int kind, int index, const double
 int bodyfit_forward(bodyfit_problem* p, const double* frame_params, const double* beta,
                     double* joints, float* cloud);
 
+/* The post-solve write-back of a whole solve on the device: for every frame
+ *   r[0] <- R(rootAA) r[0]  (left-multiplied, so it compounds over repeated solves),  p <- rootT,
+ *   r[j] <- R(jointAA[j]),  Avatar::update()  (the Sim3 scale is dropped),
+ * as OptimizeMultiFrame / OptimizePose*Reprojection do per frame on the host (include/MultiFrameBA.h:154-174,
+ * include/Sim3BA.h:481-505), followed by mean_pixel_error (include/Utils.h:102-115) of the frame's FK-joint
+ * keypoints against the updated joints (0 for a frame without any).
+ * Outputs, each optional: R0_out [F][9] row-major, joints [F][nJ][3], cloud [F][V][3] (needs want_mesh; the posed
+ * cloud also stays resident, see bodyfit_problem_views), mean_px [F].                                      */
+int bodyfit_writeback_batch(bodyfit_problem* p, const double* frame_params, const double* beta, double* R0_out,
+                            double* joints, float* cloud, double* mean_px);
+
 /* include/Utils.h:102-115 on the joints of bodyfit_forward (no Sim3 scale: pass scale = 1). */
 double bodyfit_mean_pixel_error(int n_kp, const int* jid, const double* uv, const double* joints,
                                 double fx, double fy, double cx, double cy);

@@ -144,6 +144,41 @@ class Avatar {  // ark::Avatar stand-in: w (shape), p (root position), r (local 
     bodyfit_problem_destroy(pr);
     check(rc);
   }
+
+  // update() of many avatars of one model in ONE device pass (each with its own w, p, r): what the write-back loops of
+  // OptimizeMultiFrame and the drivers do frame by frame (include/MultiFrameBA.h:154-174, src/main_multi_frame.cpp:146)
+  static void update_batch(const std::vector<Avatar*>& avs, bool with_cloud = true) {
+    const int F = (int)avs.size();
+    if (F == 0) return;
+    const AvatarModel& model = avs[0]->model;
+    const int nJ = model.numJoints(), nS = model.numShapeKeys();
+    std::vector<int> off(F + 1, 0);
+    std::vector<double> R0((size_t)F * 9), x((size_t)F * BODYFIT_FRAME_PARAMS, 0.0), w((size_t)F * nS);
+    for (int f = 0; f < F; ++f) {
+      std::copy(avs[f]->r[0].begin(), avs[f]->r[0].end(), R0.begin() + (size_t)f * 9);
+      double* xf = &x[(size_t)f * BODYFIT_FRAME_PARAMS];
+      xf[0] = 1.0; xf[4] = avs[f]->p[0]; xf[5] = avs[f]->p[1]; xf[6] = avs[f]->p[2];
+      for (int j = 1; j < nJ; ++j) MatrixToAngleAxis(avs[f]->r[j], &xf[7 + 3 * (j - 1)]);
+      std::copy(avs[f]->w.begin(), avs[f]->w.end(), w.begin() + (size_t)f * nS);
+    }
+    bodyfit_problem_desc d{};
+    d.n_frames = F; d.kp_offset = off.data(); d.n_cols = BODYFIT_FRAME_PARAMS + nS;
+    d.use_shape = 1; d.beta_per_frame = 1; d.pose_blend = 1; d.R0 = R0.data(); d.want_mesh = with_cloud ? 1 : 0;
+    d.huber_delta = 3.0;
+    bodyfit_problem* pr = nullptr;
+    check(bodyfit_problem_create(model.handle(), &d, &pr));
+    std::vector<double> joints((size_t)F * nJ * 3);
+    std::vector<float> clouds(with_cloud ? (size_t)F * model.numPoints() * 3 : 0);
+    const int rc = bodyfit_forward(pr, x.data(), w.data(), joints.data(), with_cloud ? clouds.data() : nullptr);
+    bodyfit_problem_destroy(pr);
+    check(rc);
+    for (int f = 0; f < F; ++f) {
+      avs[f]->jointPos.assign(joints.begin() + (size_t)f * nJ * 3, joints.begin() + (size_t)(f + 1) * nJ * 3);
+      if (with_cloud)
+        avs[f]->cloud.assign(clouds.begin() + (size_t)f * model.numPoints() * 3,
+                             clouds.begin() + (size_t)(f + 1) * model.numPoints() * 3);
+    }
+  }
 };
 
 namespace detail {
@@ -280,8 +315,8 @@ inline std::pair<bool, std::string> OptimizeMultiFrame(
     avatars[f]->r[0] = Mul(AngleAxisToMatrix(poses[f].rootAA), avatars[f]->r[0]);
     avatars[f]->p = {poses[f].rootT[0], poses[f].rootT[1], poses[f].rootT[2]};
     for (int j = 1; j < nJ; ++j) avatars[f]->r[j] = AngleAxisToMatrix(poses[f].jointAA[j].data());
-    avatars[f]->update();
   }
+  Avatar::update_batch(avatars);                               // every avatar's update(), one device pass
   return {sum.usable != 0, detail::report(sum)};
 }
 

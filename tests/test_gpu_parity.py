@@ -323,3 +323,28 @@ def test_many_keypoints_per_frame_and_no_posedirs(api, synth, model, gpu_model, 
     _, cloud = p0.forward(x, beta)
     _, co = omodel.forward(x[1], beta, base.R0[1], pose_blend=False)
     assert np.abs(cloud[1] - co).max() < 5e-6
+
+
+@pytest.mark.gpu
+def test_writeback_batch_matches_host_composition(api, synth, model, gpu_model, omodel):
+    """bodyfit_writeback_batch against the same steps done on the host: R0' = R(rootAA) R0, forward with
+    s = 1 / zero root angle-axis through the oracle, mean_pixel_error over the FK keypoints; frames without keypoints -> 0."""
+    F = 9
+    seq = synth.make_sequence(model, F, seed=21, ragged=True)
+    rng = np.random.default_rng(5)
+    x = random_params(rng, F, pose_sigma=0.3)
+    beta = rng.normal(size=10) * 0.5
+    prob = api.Problem.from_sequence(gpu_model, seq, n_cols=86, use_shape=True, want_mesh=True)
+    wb = prob.writeback(x, beta, want_cloud=True)
+    for f in range(F):
+        R0n = synth.rodrigues(x[f, 1:4]) @ seq.R0[f].reshape(3, 3)
+        assert np.abs(wb["R0"][f] - R0n).max() < 1e-12
+        xu = x[f].copy(); xu[0] = 1.0; xu[1:4] = 0.0
+        jo, co = omodel.forward(xu, beta, R0n)
+        assert np.abs(wb["joints"][f] - jo).max() < 1e-9
+        assert np.abs(wb["cloud"][f] - co).max() < 5e-6
+        k0, k1 = seq.kp_offset[f], seq.kp_offset[f + 1]
+        ids, uv = seq.kp_id[k0:k1], seq.kp_uv[k0:k1]
+        fk = ids < 24
+        want = api.mean_pixel_error(ids[fk], uv[fk], jo, seq.intr) if fk.any() else 0.0
+        assert abs(wb["mean_px"][f] - want) < 1e-8 * max(1.0, want)
