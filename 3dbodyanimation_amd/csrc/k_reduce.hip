@@ -10,13 +10,16 @@
 //     robustified [J_beta | r] rows on the f64 matrix cores; two deterministic stages (per-wave partials,
 //     then one workgroup summing them in fixed order), no atomics.
 // (2) k_regress: out[j][c] = sum_v reg[j][v] x[v][c]  (initialJointPos, jointShapeReg) by wave reductions.
+#include <algorithm>
+
 #include "bodyfit_device.h"
 
 namespace bodyfit {
 namespace {
 
 typedef __attribute__((ext_vector_type(4))) double d4;
-constexpr int kRedWaves = 512;      // stage-1 wavefronts (one per workgroup)
+constexpr int kRedWavesMax = 4096;  // stage-1 wavefronts (one per workgroup), sized by the launch: 16 MFMA steps each
+constexpr int kRedSteps = 16;       // 4-row MFMA steps per stage-1 wave: all their loads are in flight together
 constexpr int kPartial = 256 + 2;   // 16x16 Gram tile + [huber cost, plain cost] per stage-1 wave
 
 __device__ inline double wave_sum64(double v) {
@@ -38,29 +41,37 @@ __global__ __launch_bounds__(64) void k_reduce_stage1(int K, int ncols, int npos
   const double d2 = delta * delta;
   const int nrows = 2 * K;
   const int steps = (nrows + 3) / 4;
-  const int per = (steps + nw - 1) / nw;
+  const int per = (steps + nw - 1) / nw;                      // <= kRedSteps unless the launch was capped
   const int s0 = w * per, s1 = min(steps, s0 + per);
   d4 acc = {0.0, 0.0, 0.0, 0.0};
   double hub = 0.0;
   if (has_beta) {
-    for (int sb = s0; sb < s1; sb += 4) {
-      double v[4];
+    for (int sb = s0; sb < s1; sb += kRedSteps) {
+      // kRedSteps independent steps: residual pair + Jacobian entry of each are requested before any is used (a
+      // runtime-bounded loop of dependent round trips is what made this kernel 10x slower than its traffic)
+      double rr0[kRedSteps], rr1[kRedSteps], jv[kRedSteps];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {   // four independent steps: their loads are in flight together
+      for (int u = 0; u < kRedSteps; ++u) {
         const int row = 4 * (sb + u) + kk;
-        v[u] = 0.0;
-        if (sb + u < s1 && row < nrows) {
-          const int k = row >> 1;
-          const double r0 = r[2 * (size_t)k], r1 = r[2 * (size_t)k + 1];
-          const double sq = r0 * r0 + r1 * r1;
-          const double rho1 = (delta > 0.0 && sq > d2) ? delta / sqrt(sq) : 1.0;
-          const double sw = sqrt(rho1);
-          if (col < nS) v[u] = sw * J[(size_t)row * ncols + npose + col];
-          else if (col == 10) v[u] = sw * ((row & 1) ? r1 : r0);
-        }
+        const bool on = sb + u < s1 && row < nrows;
+        const int k = on ? (row >> 1) : 0;
+        rr0[u] = on ? r[2 * (size_t)k] : 0.0;
+        rr1[u] = on ? r[2 * (size_t)k + 1] : 0.0;
+        jv[u] = (on && col < nS) ? J[(size_t)row * ncols + npose + col] : 0.0;
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(v[u], v[u], acc, 0, 0, 0);
+      for (int u = 0; u < kRedSteps; ++u) {
+        const int row = 4 * (sb + u) + kk;
+        const double sq = rr0[u] * rr0[u] + rr1[u] * rr1[u];
+        const double rho1 = (delta > 0.0 && sq > d2) ? delta / sqrt(sq) : 1.0;
+        const double sw = sqrt(rho1);
+        double v = 0.0;
+        if (sb + u < s1 && row < nrows) {
+          if (col < nS) v = sw * jv[u];
+          else if (col == 10) v = sw * ((row & 1) ? rr1[u] : rr0[u]);
+        }
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(v, v, acc, 0, 0, 0);
+      }
     }
   }
   // Huber cost of the keypoints and plain least squares of the remaining rows: lanes over rows
@@ -76,7 +87,13 @@ __global__ __launch_bounds__(64) void k_reduce_stage1(int K, int ncols, int npos
     const int rper = (rows + nw - 1) / nw;
     const int q0 = nrows + w * rper, q1 = min(total_rows, q0 + rper);
     double pl = 0.0;
-    for (int q = q0 + lane; q < q1; q += 64) pl += 0.5 * r[q] * r[q];
+    for (int q = q0 + lane; q < q1; q += 4 * 64) {   // four loads in flight per pass
+      double v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = (q + 64 * u < q1) ? r[q + 64 * u] : 0.0;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) pl += 0.5 * v[u] * v[u];
+    }
     hub = wave_sum64(hub);
     pl = wave_sum64(pl);
     if (lane == 0) { partials[(size_t)w * kPartial + 256] = hub; partials[(size_t)w * kPartial + 257] = pl; }
@@ -87,30 +104,41 @@ __global__ __launch_bounds__(64) void k_reduce_stage1(int K, int ncols, int npos
 }
 
 // Stage 2: fixed-order sum of the per-wave partials (deterministic), then pack [cost, g(10), upper H(55)].
+// 16 slices per entry; a slice's partials are requested in fixed-trip batches of 16 (all in flight), because a
+// runtime-bounded loop of loads pays one L2 round trip per iteration.
+constexpr int kSlices = 16;
 __global__ __launch_bounds__(1024) void k_reduce_stage2(int nw, const double* __restrict__ partials, int shape_row0,
                                                          int shape_rows, double beta_shape,
                                                          const double* __restrict__ r, double* __restrict__ out) {
-  __shared__ double sred[4][kPartial];
+  __shared__ double sred[kSlices][kPartial];
   const int tid = threadIdx.x;
-  for (int idx = tid; idx < 4 * kPartial; idx += 1024) {
+  for (int idx = tid; idx < kSlices * kPartial; idx += 1024) {
     const int slice = idx / kPartial, e = idx % kPartial;
-    double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // eight loads in flight per pass, summed in a fixed order
-    for (int w0 = slice; w0 < nw; w0 += 32) {
+    double tot = 0.0;
+    for (int w0 = slice; w0 < nw; w0 += kSlices * 16) {
+      double a[16];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int w = w0 + 4 * u;
-        a[u] += (w < nw) ? partials[(size_t)w * kPartial + e] : 0.0;
+      for (int u = 0; u < 16; ++u) {
+        const int w = w0 + kSlices * u;
+        a[u] = (w < nw) ? partials[(size_t)w * kPartial + e] : 0.0;
       }
+      tot += (((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]))) +
+             (((a[8] + a[9]) + (a[10] + a[11])) + ((a[12] + a[13]) + (a[14] + a[15])));
     }
-    sred[slice][e] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+    sred[slice][e] = tot;
   }
   __syncthreads();
   if (tid < 66) {
-    auto G = [&](int i, int j) { return (sred[0][i * 16 + j] + sred[1][i * 16 + j]) + (sred[2][i * 16 + j] + sred[3][i * 16 + j]); };
+    auto T = [&](int e) {
+      double v = 0.0;
+#pragma unroll
+      for (int sl = 0; sl < kSlices; ++sl) v += sred[sl][e];
+      return v;
+    };
+    auto G = [&](int i, int j) { return T(i * 16 + j); };
     double v;
     if (tid == 0) {
-      v = (sred[0][256] + sred[1][256]) + (sred[2][256] + sred[3][256]) +
-          (sred[0][257] + sred[1][257]) + (sred[2][257] + sred[3][257]);
+      v = T(256) + T(257);
     } else if (tid < 11) {
       v = G(tid - 1, 10);
       if (tid - 1 < shape_rows) v += beta_shape * r[shape_row0 + tid - 1];     // shared shape prior, J = beta_s I
@@ -121,6 +149,36 @@ __global__ __launch_bounds__(1024) void k_reduce_stage2(int nw, const double* __
       if (rem == 0 && row < shape_rows) v += beta_shape * beta_shape;
     }
     out[tid] = v;
+  }
+}
+
+// Stage 2a (large problems only): the same fixed-order sum spread over 17 workgroups (16 entries each, 64 slices per
+// entry, one batch of loads per thread for up to 1024 stage-1 waves); the totals go through partials[0..kPartial) of a
+// second buffer and k_reduce_stage2 then packs them with nw = 1.
+__global__ __launch_bounds__(1024) void k_reduce_stage2a(int nw, const double* __restrict__ partials,
+                                                          double* __restrict__ totals) {
+  __shared__ double sred[64][17];
+  const int tid = threadIdx.x, el = tid & 15, slice = tid >> 4;
+  const int e = blockIdx.x * 16 + el;
+  double tot = 0.0;
+  if (e < kPartial) {
+    for (int w0 = slice; w0 < nw; w0 += 64 * 16) {
+      double a[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const int w = w0 + 64 * u;
+        a[u] = (w < nw) ? partials[(size_t)w * kPartial + e] : 0.0;
+      }
+      tot += (((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]))) +
+             (((a[8] + a[9]) + (a[10] + a[11])) + ((a[12] + a[13]) + (a[14] + a[15])));
+    }
+  }
+  sred[slice][el] = tot;
+  __syncthreads();
+  if (tid < 16 && e < kPartial) {
+    double v = 0.0;
+    for (int sl = 0; sl < 64; ++sl) v += sred[sl][tid];
+    totals[e] = v;
   }
 }
 
@@ -139,15 +197,24 @@ __global__ __launch_bounds__(256) void k_regress(int V, int ncol, const double* 
 
 }  // namespace
 
-int reduce_partials_doubles() { return kRedWaves * kPartial; }
+int reduce_partials_doubles() { return (kRedWavesMax + 1) * kPartial; }   // + one row of totals (stage 2a)
 
 void launch_reduce_shared_ex(int K, int ncols, int npose, int nS, int total_rows, const double* d_r,
                              const double* d_J, double huber_delta, int shape_row0, int shape_rows,
                              double beta_shape, double* d_partials, double* d_out66, hipStream_t s) {
-  hipLaunchKernelGGL(k_reduce_stage1, dim3(kRedWaves), dim3(64), 0, s, K, ncols, npose, nS, total_rows, d_r, d_J,
+  const int steps = (2 * K + 3) / 4;
+  const int nw = std::min(kRedWavesMax, std::max(64, (steps + kRedSteps - 1) / kRedSteps));
+  hipLaunchKernelGGL(k_reduce_stage1, dim3(nw), dim3(64), 0, s, K, ncols, npose, nS, total_rows, d_r, d_J,
                      huber_delta, d_partials);
-  hipLaunchKernelGGL(k_reduce_stage2, dim3(1), dim3(1024), 0, s, kRedWaves, d_partials, shape_row0, shape_rows,
-                     beta_shape, d_r, d_out66);
+  if (nw > 256) {   // many partials: sum them on 17 workgroups first (a single workgroup pays ~20 serial L2 round trips)
+    double* totals = d_partials + (size_t)kRedWavesMax * kPartial;
+    hipLaunchKernelGGL(k_reduce_stage2a, dim3((kPartial + 15) / 16), dim3(1024), 0, s, nw, d_partials, totals);
+    hipLaunchKernelGGL(k_reduce_stage2, dim3(1), dim3(1024), 0, s, 1, totals, shape_row0, shape_rows, beta_shape, d_r,
+                       d_out66);
+  } else {
+    hipLaunchKernelGGL(k_reduce_stage2, dim3(1), dim3(1024), 0, s, nw, d_partials, shape_row0, shape_rows, beta_shape,
+                       d_r, d_out66);
+  }
 }
 
 void launch_regress(int nJ, int V, int ncol, const double* d_reg, const double* d_x, double* d_out, hipStream_t s) {
