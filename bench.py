@@ -92,10 +92,14 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    # rehearsal switches (tests only): BENCH_SHARE_DEVICE0=1 puts every rank on cuda:0 and BENCH_BACKEND=gloo replaces
+    # RCCL, so the N > 1 code path can be exercised on a one-GPU box; the driver's runs use neither
+    if os.environ.get("BENCH_SHARE_DEVICE0"):
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(os.environ.get("BENCH_BACKEND", "nccl"), rank=rank, world_size=world)
 
     api = importlib.import_module("3dbodyanimation_amd.api")
     synth = importlib.import_module("3dbodyanimation_amd.synth")

@@ -1,0 +1,45 @@
+"""bench.py keeps the driver's contract: one JSON line with the agreed keys at N = 1, and the N > 1 launch form
+(torch.distributed.run, one rank per GPU) runs end to end -- rehearsed on the one-GPU box with both ranks on cuda:0 and
+gloo in place of RCCL (BENCH_SHARE_DEVICE0 / BENCH_BACKEND, switches the driver never sets)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+        "dtype", "data", "config", "roofline"}
+
+
+def _last_json(out):
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    assert lines, out[-2000:]
+    return json.loads(lines[-1])
+
+
+@pytest.mark.gpu
+def test_bench_single_gpu_line():
+    out = subprocess.run([sys.executable, "bench.py", "--steps", "10", "--warmup", "3", "--no-cpu-baseline"], cwd=ROOT,
+                         capture_output=True, text=True, timeout=300)
+    d = _last_json(out.stdout)
+    assert KEYS <= set(d), sorted(KEYS - set(d))
+    assert d["n_gpus"] == 1 and d["steps"] == 10 and d["warmup"] == 3 and d["vs_baseline"] is None
+    assert d["unit"] == "evals/s" and d["value"] > 1e5 and d["scaling"] == "weak" and "workload" in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert abs(d["value"] - d["config"]["frames_per_gpu"] / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("workload,scaling", [("c3", "weak"), ("c5", "strong")])
+def test_bench_two_ranks_rehearsal(workload, scaling):
+    env = dict(os.environ, BENCH_SHARE_DEVICE0="1", BENCH_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29541", "bench.py", "--gpus", "2", "--steps", "5", "--warmup", "2", "--workload", workload,
+           "--no-cpu-baseline"] + (["--window", "128"] if workload == "c5" else [])
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = _last_json(out.stdout)
+    assert d["n_gpus"] == 2 and d["scaling"] == scaling and d["value"] > 0
