@@ -16,6 +16,9 @@
 #include "bodyfit_device.h"
 
 namespace bodyfit {
+#ifdef BODYFIT_STAMPS
+__device__ unsigned long long* g_lm_dbg = nullptr;   // diagnostic builds only: per-frame s_memtime stamps of k_lm_step
+#endif
 namespace {
 
 typedef __attribute__((ext_vector_type(4))) double d4;
@@ -26,6 +29,19 @@ constexpr int kJLd = 96;           // Jhat leading dimension: 6 column tiles of 
 constexpr int kMRows = 112;        // panel layout of the damped system: 96 padded unknowns + one tile row for the rhs
 constexpr int kMLd = 98;
 static_assert(kRowsMax * kJLd <= kMRows * kMLd, "Jhat must fit in the region it shares with the damped system");
+
+#ifdef BODYFIT_STAMPS
+#define LSTAMP(i)                                                                                   \
+  do {                                                                                              \
+    if (g_lm_dbg && threadIdx.x == 0) {                                                             \
+      unsigned long long t_;                                                                        \
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                    \
+      g_lm_dbg[(size_t)blockIdx.x * 16 + (i)] = t_;                                                 \
+    }                                                                                               \
+  } while (0)
+#else
+#define LSTAMP(i)
+#endif
 
 __device__ inline double huber_rho(double delta, double s, double* rho1) {
   const double b = delta * delta;
@@ -105,6 +121,7 @@ __global__ __launch_bounds__(256) void k_lm_step(LmProblem P, LmState S, const d
   double* ds = vec + 176;                  // 112 entries
   double* dd = vec + 288;
   double* red = vec + 376;
+  double* invd = vec + 384;                // 112 entries: 1 / L_jj of the factor
   const int f = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int n = P.ncols, npose = kFrameParams, nb = n - npose;
   const int npad = (n + 15) & ~15, NB = npad >> 4;     // 80 / 96 unknowns padded to whole 16-column panels
@@ -114,6 +131,7 @@ __global__ __launch_bounds__(256) void k_lm_step(LmProblem P, LmState S, const d
     return;
   }
   const int k0 = P.kp_offset[f], nrows = 2 * (P.kp_offset[f + 1] - k0);
+  LSTAMP(0);
 
   // ---- Jhat = sqrt(rho') [J | r], zero padded to 6 column tiles of 16 and a multiple of 4 rows -------------
   const int nrows4 = (nrows + 3) & ~3;
@@ -147,6 +165,7 @@ __global__ __launch_bounds__(256) void k_lm_step(LmProblem P, LmState S, const d
     for (int i = tid; i < nrows4 * (kJLd - 88); i += 256) Jh[(i / (kJLd - 88)) * kJLd + 88 + i % (kJLd - 88)] = 0.0;
   }
   __syncthreads();
+  LSTAMP(1);
   // ---- Gram matrix on the f64 matrix cores: 21 lower tile pairs dealt to the 4 waves -----------------------
   {
     const int m = lane & 15, kk = lane >> 4;
@@ -155,10 +174,18 @@ __global__ __launch_bounds__(256) void k_lm_step(LmProblem P, LmState S, const d
       for (int tj = 0; tj <= ti; ++tj, ++pair) {
         if ((pair & 3) != wave) continue;
         d4 acc = {0.0, 0.0, 0.0, 0.0};
-        for (int s = 0; s < nrows4 / 4; ++s) {
-          const double a = Jh[(4 * s + kk) * kJLd + 16 * ti + m];
-          const double b = Jh[(4 * s + kk) * kJLd + 16 * tj + m];
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+        const int nsteps = nrows4 / 4;
+        for (int s0 = 0; s0 < nsteps; s0 += 8) {      // eight k-steps per batch: their 16 LDS reads are in flight together
+          double av[8], bv[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const bool on = s0 + u < nsteps;
+            const int row = on ? 4 * (s0 + u) + kk : 0;
+            av[u] = on ? Jh[row * kJLd + 16 * ti + m] : 0.0;
+            bv[u] = on ? Jh[row * kJLd + 16 * tj + m] : 0.0;
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], acc, 0, 0, 0);
         }
         // D: column = lane & 15 (B side, tile tj), row = (lane >> 4) + 4 q (A side, tile ti)
 #pragma unroll
@@ -169,6 +196,7 @@ __global__ __launch_bounds__(256) void k_lm_step(LmProblem P, LmState S, const d
       }
   }
   __syncthreads();
+  LSTAMP(2);
   // ---- priors: pose prior on the 69 joint columns, shape prior on beta ---------------------------------------
   const int D = npose - 7;
   if (P.prior_rows > 0) {
@@ -210,6 +238,7 @@ __global__ __launch_bounds__(256) void k_lm_step(LmProblem P, LmState S, const d
     H0[n * kLd + npose + i] += P.beta_shape * r[P.row_shape + (size_t)f * P.shape_rows_per_frame + i];
   }
   __syncthreads();
+  LSTAMP(3);
   // ---- gradient, Jacobi scaling (fixed at the first iterate) ----------------------------------------------------
   if (tid < n) {
     g[tid] = H0[n * kLd + tid];
@@ -241,23 +270,30 @@ __global__ __launch_bounds__(256) void k_lm_step(LmProblem P, LmState S, const d
   }
   // ---- scaled, damped system in panel layout: unknowns padded with identity to npad, rhs = row npad -------------
   const double radius = S.radius[f];
-  for (int e = tid; e < (npad + 16) * npad; e += 256) {
-    const int i = e / npad, j = e % npad;
-    double v = 0.0;
-    if (i < n && j <= i) {
-      const bool ci = i < npose && constant && constant[i];
-      const bool cj = j < npose && constant && constant[j];
-      if (ci || cj) v = (i == j) ? 1.0 : 0.0;
-      else {
-        v = H0[i * kLd + j] * sc[i] * sc[j];
-        if (i == j) v += fmin(fmax(v, 1e-6), 1e32) / radius;
+  const double inv_radius = 1.0 / radius;
+  for (int ii = 0; ii < (kMRows + 7) / 8; ++ii) {           // 32 columns x 8 rows per pass, no integer division
+    const int i = (tid >> 5) + 8 * ii;
+    if (i >= npad + 16) continue;
+    const bool ci = i < npose && constant && constant[i];
+#pragma unroll
+    for (int jj = 0; jj < 3; ++jj) {
+      const int j = (tid & 31) + 32 * jj;
+      if (j >= npad) continue;
+      double v = 0.0;
+      if (i < n && j <= i) {
+        const bool cj = j < npose && constant && constant[j];
+        if (ci || cj) v = (i == j) ? 1.0 : 0.0;
+        else {
+          v = H0[i * kLd + j] * sc[i] * sc[j];
+          if (i == j) v += fmin(fmax(v, 1e-6), 1e32) * inv_radius;
+        }
+      } else if (i < npad) {
+        v = (i == j) ? 1.0 : 0.0;                                  // identity padding keeps the system SPD
+      } else if (i == npad && j < n) {
+        v = (j < npose && constant && constant[j]) ? 0.0 : -g[j] * sc[j];   // rhs = -S g
       }
-    } else if (i < npad) {
-      v = (i == j) ? 1.0 : 0.0;                                  // identity padding keeps the system SPD
-    } else if (i == npad && j < n) {
-      v = (j < npose && constant && constant[j]) ? 0.0 : -g[j] * sc[j];   // rhs = -S g
+      M[i * kMLd + j] = v;
     }
-    M[i * kMLd + j] = v;
   }
   if (tid == 0) red[4] = 1.0;   // factorisation status
   __syncthreads();
@@ -267,6 +303,7 @@ __global__ __launch_bounds__(256) void k_lm_step(LmProblem P, LmState S, const d
     if (j > i) H0[i * kLd + j] = H0[j * kLd + i];
   }
 
+  LSTAMP(4);
   // ---- blocked right-looking Cholesky, 16-column panels; the rhs row rides along as one more row below ----------
   for (int p = 0; p < NB; ++p) {
     const int c0 = 16 * p;
@@ -281,7 +318,13 @@ __global__ __launch_bounds__(256) void k_lm_step(LmProblem P, LmState S, const d
       for (int c = 0; c < 16; ++c) {
         const double piv = readlane_f64(a[c], c);
         if (!(piv > 0.0)) okp = false;
-        const double rt = sqrt(piv), inv = 1.0 / rt;
+        // 1 / sqrt(piv): hardware estimate + two Newton steps (full f64 precision for the normal range the damped,
+        // Jacobi-scaled pivots live in) instead of a software sqrt and a software division on the serial path
+        double inv = __builtin_amdgcn_rsq(piv);
+        inv = inv * (1.5 - 0.5 * piv * inv * inv);
+        inv = inv * (1.5 - 0.5 * piv * inv * inv);
+        const double rt = piv * inv;
+        if (lane == 0) invd[c0 + c] = inv;            // 1 / L_cc: the panel solve and the back substitution multiply
         const double l = (rr == c) ? rt : a[c] * inv;
         a[c] = l;
 #pragma unroll
@@ -312,7 +355,7 @@ __global__ __launch_bounds__(256) void k_lm_step(LmProblem P, LmState S, const d
           double v = x[c];
 #pragma unroll
           for (int k = 0; k < c; ++k) v -= x[k] * M[(c0 + c) * kMLd + c0 + k];
-          x[c] = v / M[(c0 + c) * kMLd + c0 + c];
+          x[c] = v * invd[c0 + c];
         }
 #pragma unroll
         for (int k = 0; k < 16; ++k) M[i * kMLd + c0 + k] = x[k];
@@ -355,25 +398,38 @@ __global__ __launch_bounds__(256) void k_lm_step(LmProblem P, LmState S, const d
     }
     return;
   }
+  LSTAMP(5);
   // ---- backward substitution ds = L^{-T} y by wave 0 alone: two unknowns per lane, x_j broadcast by v_readlane ----
   if (wave == 0) {
     double d0 = M[npad * kMLd + lane];
     double d1 = (lane + 64 < npad) ? M[npad * kMLd + lane + 64] : 0.0;
-    for (int j = npad - 1; j >= 0; --j) {
-      const double ljj = M[j * kMLd + j];
-      const double l0 = M[j * kMLd + lane];
-      const double l1 = (lane + 64 < npad) ? M[j * kMLd + lane + 64] : 0.0;
-      const double dj = (j < 64) ? readlane_f64(d0, j) : readlane_f64(d1, j - 64);
-      const double xj = dj / ljj;
-      if (lane < j) d0 -= l0 * xj;
-      if (lane == j) d0 = xj;
-      if (lane + 64 < j) d1 -= l1 * xj;
-      if (lane + 64 == j) d1 = xj;
+    // npad is a multiple of 16: four columns per pass, their factor rows and pivots are read before the dependent
+    // chain (fma -> readlane -> mul) starts, so LDS latency stays off it
+    for (int j4 = npad - 1; j4 >= 0; j4 -= 4) {
+      double ij[4], r0[4], r1[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int j = j4 - u;
+        ij[u] = invd[j];
+        r0[u] = M[j * kMLd + lane];
+        r1[u] = (lane + 64 < npad) ? M[j * kMLd + lane + 64] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int j = j4 - u;
+        const double dj = (j < 64) ? readlane_f64(d0, j) : readlane_f64(d1, j - 64);
+        const double xj = dj * ij[u];
+        if (lane < j) d0 -= r0[u] * xj;
+        if (lane == j) d0 = xj;
+        if (lane + 64 < j) d1 -= r1[u] * xj;
+        if (lane + 64 == j) d1 = xj;
+      }
     }
     ds[lane] = d0;
     if (lane + 64 < npad) ds[lane + 64] = d1;
   }
   __syncthreads();
+  LSTAMP(6);
   // ---- step, projection on the scale bounds, model change -dg - 1/2 d H d with the undamped H ----------------------
   const double* xf = S.x + (size_t)f * npose;
   if (tid < n) {
@@ -410,6 +466,7 @@ __global__ __launch_bounds__(256) void k_lm_step(LmProblem P, LmState S, const d
     S.model[f] = model;
     S.flags[f] = flags | kLmHasCand;
   }
+  LSTAMP(7);
 }
 
 // Reprojection part of one frame's normal equations for the window solver (host_solver.cpp): the robustified Gram
@@ -523,7 +580,7 @@ __global__ __launch_bounds__(256) void k_lm_accept(LmProblem P, LmState S, const
 
 }  // namespace
 
-size_t lm_step_lds_bytes() { return (size_t)(kMRows * kMLd + (kN + 1) * kLd + 392) * sizeof(double); }
+size_t lm_step_lds_bytes() { return (size_t)(kMRows * kMLd + (kN + 1) * kLd + 504) * sizeof(double); }
 
 void launch_lm_init(const LmProblem& P, const LmState& S, const double* d_r, hipStream_t s) {
   hipLaunchKernelGGL(k_lm_init, dim3(P.F), dim3(256), 0, s, P, S, d_r);
@@ -556,3 +613,9 @@ void launch_frame_normal(int F, int n, const int* d_kp_offset, double huber, con
 }
 
 }  // namespace bodyfit
+
+#ifdef BODYFIT_STAMPS
+extern "C" int bodyfit_debug_set_lm_stamp_buffer(unsigned long long* d_buf) {
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(bodyfit::g_lm_dbg), &d_buf, sizeof(d_buf));
+}
+#endif
