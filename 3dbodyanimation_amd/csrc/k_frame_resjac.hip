@@ -348,33 +348,36 @@ __global__ __launch_bounds__(kThreads, 4) void k_frame_resjac(DevModel M, DevPro
     if (i < 9 * (nJ - 1)) v = sR[9 + i] - (((i % 9) % 4 == 0) ? 1.0 : 0.0);
     sFeat[i] = v;
   }
+  // chain walk of one item up the kinematic chain (kind 0: column sel of A_j, 1: P_j, 2: column sel of B_j)
+  auto walk = [&](int kind, int j, int sel) {
+    double v0, v1, v2;
+    if (kind == 0) { v0 = sR[j * 9 + sel]; v1 = sR[j * 9 + 3 + sel]; v2 = sR[j * 9 + 6 + sel]; }
+    else if (kind == 1) { v0 = sO[j * 3]; v1 = sO[j * 3 + 1]; v2 = sO[j * 3 + 2]; }
+    else {
+      v0 = sDS[(j * 3 + 0) * nS + sel]; v1 = sDS[(j * 3 + 1) * nS + sel]; v2 = sDS[(j * 3 + 2) * nS + sel];
+    }
+    for (int k = sParent[j]; k > 0; k = sParent[k]) {
+      const double* R = sR + k * 9;
+      double t0 = R[0] * v0 + R[1] * v1 + R[2] * v2;
+      double t1 = R[3] * v0 + R[4] * v1 + R[5] * v2;
+      double t2 = R[6] * v0 + R[7] * v1 + R[8] * v2;
+      if (kind == 1) { t0 += sO[k * 3]; t1 += sO[k * 3 + 1]; t2 += sO[k * 3 + 2]; }
+      else if (kind == 2) {
+        t0 += sDS[(k * 3 + 0) * nS + sel]; t1 += sDS[(k * 3 + 1) * nS + sel]; t2 += sDS[(k * 3 + 2) * nS + sel];
+      }
+      v0 = t0; v1 = t1; v2 = t2;
+    }
+    if (kind == 0) { sA[j * 9 + sel] = v0; sA[j * 9 + 3 + sel] = v1; sA[j * 9 + 6 + sel] = v2; }
+    else if (kind == 1) { sP[j * 3] = v0; sP[j * 3 + 1] = v1; sP[j * 3 + 2] = v2; }
+    else { sB[(j * 3 + 0) * nS + sel] = v0; sB[(j * 3 + 1) * nS + sel] = v1; sB[(j * 3 + 2) * nS + sel] = v2; }
+  };
   {
-    const int nA = 3 * (nJ - 1), nP = nJ - 1, nB = (use_shape && want_jac) ? nS * (nJ - 1) : 0;
-    for (int it = tid; it < nA + nP + nB; it += kThreads) {
-      int j, kind, sel;
-      if (it < nA) { kind = 0; j = 1 + it / 3; sel = it % 3; }
-      else if (it < nA + nP) { kind = 1; j = 1 + (it - nA); sel = 0; }
-      else { kind = 2; j = 1 + (it - nA - nP) / nS; sel = (it - nA - nP) % nS; }
-      double v0, v1, v2;
-      if (kind == 0) { v0 = sR[j * 9 + sel]; v1 = sR[j * 9 + 3 + sel]; v2 = sR[j * 9 + 6 + sel]; }
-      else if (kind == 1) { v0 = sO[j * 3]; v1 = sO[j * 3 + 1]; v2 = sO[j * 3 + 2]; }
-      else {
-        v0 = sDS[(j * 3 + 0) * nS + sel]; v1 = sDS[(j * 3 + 1) * nS + sel]; v2 = sDS[(j * 3 + 2) * nS + sel];
-      }
-      for (int k = sParent[j]; k > 0; k = sParent[k]) {
-        const double* R = sR + k * 9;
-        double t0 = R[0] * v0 + R[1] * v1 + R[2] * v2;
-        double t1 = R[3] * v0 + R[4] * v1 + R[5] * v2;
-        double t2 = R[6] * v0 + R[7] * v1 + R[8] * v2;
-        if (kind == 1) { t0 += sO[k * 3]; t1 += sO[k * 3 + 1]; t2 += sO[k * 3 + 2]; }
-        else if (kind == 2) {
-          t0 += sDS[(k * 3 + 0) * nS + sel]; t1 += sDS[(k * 3 + 1) * nS + sel]; t2 += sDS[(k * 3 + 2) * nS + sel];
-        }
-        v0 = t0; v1 = t1; v2 = t2;
-      }
-      if (kind == 0) { sA[j * 9 + sel] = v0; sA[j * 9 + 3 + sel] = v1; sA[j * 9 + 6 + sel] = v2; }
-      else if (kind == 1) { sP[j * 3] = v0; sP[j * 3 + 1] = v1; sP[j * 3 + 2] = v2; }
-      else { sB[(j * 3 + 0) * nS + sel] = v0; sB[(j * 3 + 1) * nS + sel] = v1; sB[(j * 3 + 2) * nS + sel] = v2; }
+    // A_j columns and P_j (92 items) on waves 6-7, beside the landmark items of waves 0-5 (two landmarks per wave);
+    // the 230 B_j columns nothing needs before phase E are walked in phase D, where most threads are idle
+    const int nA = 3 * (nJ - 1), nP = nJ - 1;
+    for (int it = tid - 384; it >= 0 && it < nA + nP; it += 128) {
+      if (it < nA) walk(0, 1 + it / 3, it % 3);
+      else walk(1, 1 + (it - nA), 0);
     }
     if (tid < 9) sA[tid] = (tid % 4 == 0) ? 1.0 : 0.0;       // root: A_0 = I, P_0 = 0, B_0 = 0
     if (tid >= 16 && tid < 19) sP[tid - 16] = 0.0;
@@ -390,7 +393,11 @@ __global__ __launch_bounds__(kThreads, 4) void k_frame_resjac(DevModel M, DevPro
   __syncthreads();
 
   STAMP(4);
-  // ---- D. wave 0-1: W_{k,c} = A_p (dR_{k,c} R_k^T) A_p^T ; wave 2: landmark LBS ; wave 3: camera matrices ----
+  // ---- D. wave 0-1: W_{k,c} = A_p (dR_{k,c} R_k^T) A_p^T ; wave 2: landmark LBS ; wave 3: camera matrices ;
+  //         waves 4-7: B_j columns (d P_j / d beta) ----
+  if (use_shape && want_jac) {
+    for (int it = tid - 256; it >= 0 && it < nS * (nJ - 1); it += 256) walk(2, 1 + it / nS, it % nS);
+  }
   if (want_jac && tid < 3 * (nJ - 1)) {
     const int k = 1 + tid / 3, c = tid % 3, p = sParent[k];
     double T1[9], T2[9], Wm[9];
