@@ -280,6 +280,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_frame_resjac(DevModel M, DevPro
         }
       }
       sO[i] = (i < 3) ? 0.0 : o;
+      if (i < 3) sPart[100 + i] = o;     // the root keypoint's own q = offset_0 + S_0 beta (include/Sim3BA.h:142-170)
       sJc[i] = jc;
     }
   }
@@ -566,14 +567,9 @@ __global__ __launch_bounds__(kThreads, 4) void k_frame_resjac(DevModel M, DevPro
       double q[3];
       if (id < nJ) {
         if (id == 0 || sParent[id] < 0) {
-          // include/Sim3BA.h:142-170 without a chain: q = offset + S_id beta (no parent term)
+          // include/Sim3BA.h:142-170 without a chain: q = offset + S_id beta (no parent term), staged in phase B
 #pragma unroll
-          for (int a = 0; a < 3; ++a) {
-            double v = M.offset[id * 3 + a];
-            if (use_shape)
-              for (int k = 0; k < nS; ++k) v += sDS[(id * 3 + a) * nS + k] * sbeta[k];
-            q[a] = v;
-          }
+          for (int a = 0; a < 3; ++a) q[a] = sPart[100 + a];
         } else {
 #pragma unroll
           for (int a = 0; a < 3; ++a) q[a] = sP[id * 3 + a];
