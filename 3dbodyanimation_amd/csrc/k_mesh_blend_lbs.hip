@@ -190,7 +190,13 @@ __device__ __forceinline__ void skin_step(const Lane& L, unsigned char* sSkin, i
   if constexpr ((S & 3) != 3) row_fetch<S + 1>(L, tq[(S + 1) & 1]);
   const int f = ftile * kFTile + q * 8 + (S & 3);               // frame of the h = 0 half
   row_apply<S>(L, tq[S & 1], acc, cloud, (unsigned)f * stride);
-  if constexpr ((S & 3) == 1 || (S & 3) == 2) __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);   // next row's reads first
+  if constexpr ((S & 3) == 1 || (S & 3) == 2) {
+    // issue order of the row: the NEXT row's 12 transform reads first (a whole row of VALU work ahead of their use),
+    // then this row's arithmetic, then the store.  (One group alone does not pin a position; the sequence does.)
+    __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);   // DS read
+    __builtin_amdgcn_sched_group_barrier(0x002, 64, 0);   // VALU
+    __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);    // VMEM write
+  }
   __builtin_amdgcn_sched_barrier(0);
 }
 
