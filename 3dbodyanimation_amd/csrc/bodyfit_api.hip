@@ -98,7 +98,10 @@ struct bodyfit_problem {
   int* d_comp = nullptr;
   float* d_cloud = nullptr;
   double* d_frame_normal = nullptr;
-  double* d_writeback = nullptr;      // [F][76] update parameters + [F][9] R0' + [F] mean pixel error, on first use   // [F][87][88] per-frame normal-equation panels (window solver), on first use
+  double* d_writeback = nullptr;
+  double* d_frame_partials = nullptr; // [F][258] per-frame beta partials written by k_frame_resjac (shared-beta problems)
+  int partials_tiles = 0;             // prior tiles that added their plain-cost rows behind the frame rows
+  bool partials_fresh = false;        // the last sweep produced them (want_jac)      // [F][76] update parameters + [F][9] R0' + [F] mean pixel error, on first use   // [F][87][88] per-frame normal-equation panels (window solver), on first use
   // host copies
   std::vector<int> kp_offset, kp_id, kp_frame;
   std::vector<double> kp_uv;
@@ -139,6 +142,9 @@ int sweep(bodyfit_problem* p, const double* d_params, const double* d_beta, int 
   const bodyfit_model* m = p->m;
   DevProblem dp = p->d;
   if (R0_override) dp.R0 = R0_override;
+  dp.beta_partials = (want_jac && !frame_flags) ? p->d_frame_partials : nullptr;
+  dp.huber = p->desc.huber_delta;
+  p->partials_fresh = dp.beta_partials != nullptr;
   dp.frame_flags = frame_flags;
   dp.frame_mask = frame_mask;
   double* d_r = r_base ? r_base : p->d_r;
@@ -159,6 +165,8 @@ int sweep(bodyfit_problem* p, const double* d_params, const double* d_beta, int 
   pa.comp = d_comp;
   const bool priors = D.beta_pose > 0.0 || pa.beta_shape > 0.0 || D.lambda_temporal > 0.0;
   pa.n_tiles = priors ? (p->d.F + 15) / 16 : 0;
+  pa.plain_cost = dp.beta_partials ? dp.beta_partials + (size_t)p->d.F * kReducePartial : nullptr;
+  p->partials_tiles = dp.beta_partials ? pa.n_tiles : 0;
   PriorArgs none = pa;
   none.n_tiles = 0;
   launch_frame_resjac(m->d, dp, d_params, d_beta, d_r, want_jac ? p->d_J : nullptr, p->d_joints, mc, want_jac,
@@ -570,6 +578,11 @@ int bodyfit_problem_create(const bodyfit_model* m, const bodyfit_problem_desc* d
   HIP_TRY(p->mem.alloc(&p->d_joints, (size_t)F * nJ * 3));
   HIP_TRY(p->mem.alloc(&p->d_comp, (size_t)F));
   HIP_TRY(p->mem.alloc(&p->d_partials, (size_t)reduce_partials_doubles()));
+  if (L.n_cols > npose && !desc->beta_per_frame && nS == kMaxShape) {
+    const size_t nfp = (size_t)(F + (F + 15) / 16) * kReducePartial;   // one row per frame + one per prior tile
+    HIP_TRY(p->mem.alloc(&p->d_frame_partials, nfp));
+    HIP_TRY(hipMemset(p->d_frame_partials, 0, nfp * sizeof(double)));
+  }
   HIP_TRY(p->mem.alloc(&p->d_normal, (size_t)66));
   HIP_TRY(hipMemset(p->d_r, 0, (size_t)std::max(1, L.total_rows) * sizeof(double)));
   HIP_TRY(hipMemset(p->d_comp, 0, (size_t)F * sizeof(int)));
@@ -688,9 +701,17 @@ int bodyfit_reduce_shared_device(bodyfit_problem* p, double* d_out66, void* stre
   HIP_TRY(hipSetDevice(p->m->device));
   const int npose = 7 + 3 * (p->m->nJ - 1);
   const int shared_shape_rows = (!p->desc.beta_per_frame) ? p->lay.shape_rows : 0;
-  launch_reduce_shared_ex(p->lay.n_keypoints, p->lay.n_cols, npose, p->m->nS, p->lay.total_rows, p->d_r, p->d_J,
-                          p->desc.huber_delta, p->row_shape, shared_shape_rows, p->desc.beta_shape, p->d_partials,
-                          d_out66 ? d_out66 : p->d_normal, static_cast<hipStream_t>(stream));
+  if (p->d_frame_partials && p->partials_fresh) {
+    // the sweep's k_frame_resjac already reduced every frame's reprojection rows: sum the per-frame partials and the
+    // prior / temporal rows, pack
+    launch_reduce_frames(p->d.F + p->partials_tiles, 0, 0, p->d_r, p->row_shape, shared_shape_rows,
+                         p->desc.beta_shape, p->d_frame_partials, p->d_partials, d_out66 ? d_out66 : p->d_normal,
+                         static_cast<hipStream_t>(stream));
+  } else {
+    launch_reduce_shared_ex(p->lay.n_keypoints, p->lay.n_cols, npose, p->m->nS, p->lay.total_rows, p->d_r, p->d_J,
+                            p->desc.huber_delta, p->row_shape, shared_shape_rows, p->desc.beta_shape, p->d_partials,
+                            d_out66 ? d_out66 : p->d_normal, static_cast<hipStream_t>(stream));
+  }
   HIP_TRY(hipGetLastError());
   return BODYFIT_OK;
 }

@@ -53,6 +53,10 @@ struct DevProblem {
   unsigned long long* dbg;   // diagnostic builds only (-DBODYFIT_STAMPS): per-phase s_memtime stamps
   const int* frame_flags;    // optional [F]: frames whose bit `frame_mask` is clear are skipped (device LM)
   int frame_mask;
+  // shared-beta reduction folded into k_frame_resjac: per frame [cost, g_beta, upper H_bb] of the robustified
+  // reprojection rows, in k_reduce's 258-entry partial layout (null: not produced)
+  double* beta_partials;
+  double huber;
 };
 
 // operands the per-frame kernel prepares for the mesh kernel
@@ -72,6 +76,8 @@ struct DevGmm {
 };
 
 // prior residuals computed by extra workgroups of the k_frame_resjac launch (priors_inl.h)
+constexpr int kReducePartial = 258;   // entries per reduction partial: 16 x 16 Gram tile (H_bb upper + g_beta in column 10), huber cost, plain cost
+
 struct PriorArgs {
   int F, nS, beta_stride, has_gmm, n_pairs, n_tiles;   // n_tiles = 0: no prior workgroups
   double beta_pose, beta_shape, lambda_t;
@@ -81,6 +87,7 @@ struct PriorArgs {
   double* r_shape;
   double* r_temporal;
   int* comp;
+  double* plain_cost;   // optional [n_tiles][258]: entry 257 of row `tile` receives the tile's 1/2 sum r^2 (folded reduction)
 };
 
 // ---- device-resident LM for batches of independent frames (k_lm_batched.hip) ------------------------
@@ -140,6 +147,9 @@ void launch_reduce_shared_ex(int K, int ncols, int npose, int nS, int total_rows
                              const double* d_J, double huber_delta, int shape_row0, int shape_rows,
                              double beta_shape, double* d_partials, double* d_out66, hipStream_t s);
 int reduce_partials_doubles();
+void launch_reduce_frames(int F, int rows_begin, int total_rows, const double* d_r, int shape_row0, int shape_rows,
+                          double beta_shape, const double* d_frame_partials, double* d_scratch, double* d_out66,
+                          hipStream_t s);
 void launch_writeback_prepare(int F, int npose, const double* d_params, const double* d_R0, double* d_params_upd,
                               double* d_R0_new, hipStream_t s);
 void launch_mean_pixel_error(int F, int nJ, const int* d_kp_offset, const int* d_kp_id, const double* d_kp_uv,

@@ -554,6 +554,11 @@ __global__ __launch_bounds__(kThreads, 4) void k_frame_resjac(DevModel M, DevPro
   // ---- F. keypoints of this frame, KC at a time: stage per-keypoint data, then the flat (keypoint, column)
   //         sweep over all 256 threads (consecutive threads on consecutive columns of the row-major panel) ------
   const int k_begin = Pb.kp_offset[f], k_end = Pb.kp_offset[f + 1];
+  const bool fold = Pb.beta_partials != nullptr && want_jac && ncols > npose && nS == kMaxShape;
+  double* sJb = sdR;            // [2 KC][10] d r / d beta of the chunk; dR is dead after phase D
+  double fold_acc = 0.0;
+  typedef __attribute__((ext_vector_type(4))) double fold_d4;
+  fold_d4 fold_gram = {0.0, 0.0, 0.0, 0.0};
   for (int kc0 = k_begin; kc0 < k_end; kc0 += KC) {
     const int nk = min(KC, k_end - kc0);
     __syncthreads();   // phase E results visible / previous chunk's staging consumed
@@ -582,8 +587,18 @@ __global__ __launch_bounds__(kThreads, 4) void k_frame_resjac(DevModel M, DevPro
       mv3(Rr0, q[0], q[1], q[2], z);                     // include/Sim3BA.h:210-216
       const double X0 = s * z[0] + sx[4], X1 = s * z[1] + sx[5], X2 = s * z[2] + sx[6];  // :217-219
       const double iz = 1.0 / X2;                        // :222-223, Z unguarded as in the reference
-      r_out[2 * (size_t)kg] = Pb.fx * X0 * iz + Pb.cx - u_obs;
-      r_out[2 * (size_t)kg + 1] = Pb.fy * X1 * iz + Pb.cy - v_obs;
+      const double res0 = Pb.fx * X0 * iz + Pb.cx - u_obs, res1 = Pb.fy * X1 * iz + Pb.cy - v_obs;
+      r_out[2 * (size_t)kg] = res0;
+      r_out[2 * (size_t)kg + 1] = res1;
+      if (fold) {   // kept for the folded beta reduction (the observation in sKpUv was consumed above; sFeat is dead)
+        const double sq = res0 * res0 + res1 * res1, d2 = Pb.huber * Pb.huber;
+        const bool outl = Pb.huber > 0.0 && sq > d2;
+        const double rt = sqrt(sq);
+        sKpUv[2 * tid] = res0;
+        sKpUv[2 * tid + 1] = res1;
+        sFeat[tid] = outl ? sqrt(Pb.huber / rt) : 1.0;                // sqrt(rho')
+        sFeat[KC + tid] = 0.5 * (outl ? 2.0 * Pb.huber * rt - d2 : sq);   // 1/2 rho
+      }
       double* kp = sKp + tid * 18;
       const double dpi[6] = {Pb.fx * iz, 0.0, -Pb.fx * X0 * iz * iz, 0.0, Pb.fy * iz, -Pb.fy * X1 * iz * iz};
 #pragma unroll
@@ -676,7 +691,41 @@ __global__ __launch_bounds__(kThreads, 4) void k_frame_resjac(DevModel M, DevPro
         }
         store_through(J_out + (size_t)(2 * kg) * ncols + col, j0);
         store_through(J_out + (size_t)(2 * kg + 1) * ncols + col, j1);
+        if (fold && c >= 7) { sJb[(2 * kk) * kMaxShape + c - 7] = j0; sJb[(2 * kk + 1) * kMaxShape + c - 7] = j1; }
       }
+    }
+    if (fold) {
+      // shared-beta reduction of this frame (k_reduce.hip's definition): the Gram matrix of the robustified rows
+      // [sqrt(rho') J_beta | sqrt(rho') r] holds H_bb (upper 10 x 10) and g_beta (column 10); 4 rows per
+      // v_mfma_f64_16x16x4_f64 with the same register as A and B operand, wave 0 only; the cost by one lane of wave 1
+      __syncthreads();
+      if (wave == 0) {
+        const int col = lane & 15, kq = lane >> 4;
+        for (int s0 = 0; s0 < (2 * nk + 3) / 4; s0 += 4) {   // four steps per pass: their LDS reads are in flight together
+          double vv[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int row = 4 * (s0 + u) + kq;
+            const bool on = row < 2 * nk;
+            const double sw = on ? sFeat[row >> 1] : 0.0;
+            const double x = (on && col < nS) ? sJb[row * kMaxShape + col] : ((on && col == 10) ? sKpUv[row] : 0.0);
+            vv[u] = sw * x;
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) fold_gram = __builtin_amdgcn_mfma_f64_16x16x4f64(vv[u], vv[u], fold_gram, 0, 0, 0);
+        }
+      } else if (tid == 64) {
+        for (int kk = 0; kk < nk; ++kk) fold_acc += sFeat[KC + kk];
+      }
+    }
+  }
+  if (fold) {
+    double* out = Pb.beta_partials + (size_t)f * kReducePartial;
+    if (wave == 0) {     // D layout (f64 16x16): column = lane & 15, row = (lane >> 4) + 4 q
+#pragma unroll
+      for (int q = 0; q < 4; ++q) out[((lane >> 4) + 4 * q) * 16 + (lane & 15)] = fold_gram[q];
+    } else if (tid == 64) {
+      out[256] = fold_acc;
     }
   }
   STAMP(8);

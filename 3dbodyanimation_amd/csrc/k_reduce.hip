@@ -155,12 +155,26 @@ __global__ __launch_bounds__(1024) void k_reduce_stage2(int nw, const double* __
 // Stage 2a (large problems only): the same fixed-order sum spread over 17 workgroups (16 entries each, 64 slices per
 // entry, one batch of loads per thread for up to 1024 stage-1 waves); the totals go through partials[0..kPartial) of a
 // second buffer and k_reduce_stage2 then packs them with nw = 1.
+// rows_begin < rows_end (folded path only): the last workgroup's threads that own no entry also sum 1/2 r^2 over the
+// non-reprojection rows [rows_begin, rows_end) into entry 257.
 __global__ __launch_bounds__(1024) void k_reduce_stage2a(int nw, const double* __restrict__ partials,
-                                                          double* __restrict__ totals) {
+                                                          double* __restrict__ totals, const double* __restrict__ r,
+                                                          int rows_begin, int rows_end) {
   __shared__ double sred[64][17];
   const int tid = threadIdx.x, el = tid & 15, slice = tid >> 4;
   const int e = blockIdx.x * 16 + el;
   double tot = 0.0;
+  if (rows_begin < rows_end && e >= kPartial) {
+    // 14 idle entry columns x 64 slices = 896 threads over the rows, 8 loads in flight per pass
+    const int t = (el - (kPartial & 15)) * 64 + slice;
+    for (int q = rows_begin + t; q < rows_end; q += 896 * 8) {
+      double v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = (q + 896 * u < rows_end) ? r[q + 896 * u] : 0.0;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) tot += 0.5 * v[u] * v[u];
+    }
+  }
   if (e < kPartial) {
     for (int w0 = slice; w0 < nw; w0 += 64 * 16) {
       double a[16];
@@ -178,6 +192,9 @@ __global__ __launch_bounds__(1024) void k_reduce_stage2a(int nw, const double* _
   if (tid < 16 && e < kPartial) {
     double v = 0.0;
     for (int sl = 0; sl < 64; ++sl) v += sred[sl][tid];
+    if (e == 257 && rows_begin < rows_end)
+      for (int c = (kPartial & 15); c < 16; ++c)
+        for (int sl = 0; sl < 64; ++sl) v += sred[sl][c];
     totals[e] = v;
   }
 }
@@ -208,7 +225,7 @@ void launch_reduce_shared_ex(int K, int ncols, int npose, int nS, int total_rows
                      huber_delta, d_partials);
   if (nw > 256) {   // many partials: sum them on 17 workgroups first (a single workgroup pays ~20 serial L2 round trips)
     double* totals = d_partials + (size_t)kRedWavesMax * kPartial;
-    hipLaunchKernelGGL(k_reduce_stage2a, dim3((kPartial + 15) / 16), dim3(1024), 0, s, nw, d_partials, totals);
+    hipLaunchKernelGGL(k_reduce_stage2a, dim3((kPartial + 15) / 16), dim3(1024), 0, s, nw, d_partials, totals, d_r, 0, 0);
     hipLaunchKernelGGL(k_reduce_stage2, dim3(1), dim3(1024), 0, s, 1, totals, shape_row0, shape_rows, beta_shape, d_r,
                        d_out66);
   } else {
@@ -217,6 +234,17 @@ void launch_reduce_shared_ex(int K, int ncols, int npose, int nS, int total_rows
   }
 }
 
+// Folded path: k_frame_resjac already left one partial per frame (d_frame_partials, [F][258], entries it does not own
+// stay zero from allocation); sum them and the plain rows on 17 workgroups, then pack.
+void launch_reduce_frames(int F, int rows_begin, int total_rows, const double* d_r, int shape_row0, int shape_rows,
+                          double beta_shape, const double* d_frame_partials, double* d_scratch, double* d_out66,
+                          hipStream_t s) {
+  static_assert(kPartial == kReducePartial, "partial layout");
+  hipLaunchKernelGGL(k_reduce_stage2a, dim3((kPartial + 15) / 16), dim3(1024), 0, s, F, d_frame_partials, d_scratch, d_r,
+                     rows_begin, total_rows);
+  hipLaunchKernelGGL(k_reduce_stage2, dim3(1), dim3(1024), 0, s, 1, d_scratch, shape_row0, shape_rows, beta_shape, d_r,
+                     d_out66);
+}
 void launch_regress(int nJ, int V, int ncol, const double* d_reg, const double* d_x, double* d_out, hipStream_t s) {
   hipLaunchKernelGGL(k_regress, dim3(nJ, ncol), dim3(256), 0, s, V, ncol, d_reg, d_x, d_out);
 }

@@ -31,12 +31,13 @@ __device__ inline void prior_block(const PriorArgs& A, int tile, const double* _
   const int npose = kFrameParams, D = npose - 7;
   double* sx = sm;                       // [16][72]
   double* sval = sm + kPriorTileF * 72;  // [8][16]
+  double pcost = 0.0;                    // 1/2 sum of squares of the rows this thread writes (folded shared-beta reduction)
 
   if (A.beta_pose > 0.0 && A.r_prior) {
     if (!A.has_gmm) {
       for (int i = tid; i < kPriorTileF * D; i += NT) {
         const int f = f0 + i / D, c = i % D;
-        if (f < F) A.r_prior[(size_t)f * D + c] = A.beta_pose * params[(size_t)f * npose + 7 + c];
+        if (f < F) { const double v = A.beta_pose * params[(size_t)f * npose + 7 + c]; A.r_prior[(size_t)f * D + c] = v; pcost += 0.5 * v * v; }
       }
       if (A.comp && tid < kPriorTileF && f0 + tid < F) A.comp[f0 + tid] = 0;
     } else {
@@ -117,10 +118,11 @@ __device__ inline void prior_block(const PriorArgs& A, int tile, const double* _
 #pragma unroll
             for (int nt = 0; nt < kPriorNT; ++nt) {
               const int c = 16 * nt + m;
-              if (c < D) o[c] = A.beta_pose * acc[nt][q];
+              if (c < D) { const double v = A.beta_pose * acc[nt][q]; o[c] = v; pcost += 0.5 * v * v; }
             }
             if (m == 0) {
-              o[D] = A.beta_pose * sqrt(nlw);
+              const double v = A.beta_pose * sqrt(nlw);
+              o[D] = v; pcost += 0.5 * v * v;
               if (A.comp) A.comp[f] = k;
             }
           }
@@ -132,10 +134,10 @@ __device__ inline void prior_block(const PriorArgs& A, int tile, const double* _
     if (A.beta_stride > 0) {
       for (int i = tid; i < kPriorTileF * A.nS; i += NT) {
         const int f = f0 + i / A.nS, c = i % A.nS;
-        if (f < F) A.r_shape[(size_t)f * A.nS + c] = A.beta_shape * A.beta[(size_t)f * A.beta_stride + c];
+        if (f < F) { const double v = A.beta_shape * A.beta[(size_t)f * A.beta_stride + c]; A.r_shape[(size_t)f * A.nS + c] = v; pcost += 0.5 * v * v; }
       }
     } else if (tile == 0) {
-      for (int i = tid; i < A.nS; i += NT) A.r_shape[i] = A.beta_shape * A.beta[i];
+      for (int i = tid; i < A.nS; i += NT) { const double v = A.beta_shape * A.beta[i]; A.r_shape[i] = v; pcost += 0.5 * v * v; }
     }
   }
   if (A.lambda_t > 0.0 && A.r_temporal) {
@@ -144,8 +146,21 @@ __device__ inline void prior_block(const PriorArgs& A, int tile, const double* _
       const int f = f0 + i / T, c = i % T;
       if (f < A.n_pairs) {
         const int src = (c < 3) ? (4 + c) : (c < 6 ? (1 + (c - 3)) : (7 + (c - 6)));
-        A.r_temporal[(size_t)f * T + c] = A.lambda_t * (params[(size_t)f * npose + src] - params[(size_t)(f + 1) * npose + src]);
+        const double v = A.lambda_t * (params[(size_t)f * npose + src] - params[(size_t)(f + 1) * npose + src]);
+        A.r_temporal[(size_t)f * T + c] = v; pcost += 0.5 * v * v;
       }
+    }
+  }
+  if (A.plain_cost) {   // this tile's share of 1/2 |r|^2 over the prior / shape / temporal rows, fixed-order block sum
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) pcost += __shfl_xor(pcost, off, 64);
+    __syncthreads();
+    if (lane == 0) sval[wave] = pcost;
+    __syncthreads();
+    if (tid == 0) {
+      double v = 0.0;
+      for (int w = 0; w < NT / 64; ++w) v += sval[w];
+      A.plain_cost[(size_t)tile * kReducePartial + 257] = v;
     }
   }
 }
