@@ -1,20 +1,31 @@
-// k_frame_resjac.hip — per-frame keypoint residuals + analytic Jacobian, f64, one 4-wave workgroup per frame.
+// k_frame_resjac.hip — per-frame keypoint residuals + analytic Jacobian, f64, one 8-wave workgroup per frame.
 //
 // Replaces, for every reprojection block of a frame at once, what the reference evaluates through
 // ceres::DynamicAutoDiffCostFunction<ReprojCost[Shape]> (include/Sim3BA.h:34-88,126-227,420,581;
 // include/MultiFrameBA.h:85-102): 22 dual-number passes per 2-residual block become one closed-form
-// Jacobian.  The same wave also prepares the operands of the mesh kernel (pose-feature fragments in
-// bf16 hi/lo, shape coefficients, 24 skinning transforms) so the two kernels share one Rodrigues pass.
+// Jacobian.  The same workgroup also prepares the operands of the mesh kernel (blend-coefficient fragments in
+// bf16 hi/lo, 24 skinning transforms) so the two kernels share one Rodrigues pass, and, for shared-beta problems,
+// its frame's share of the [cost, g_beta, H_bb] reduction.
 //
-// Work layout (256 threads = 4 CDNA4 wavefronts per frame, one per SIMD of the CU; phases separated by
-// workgroup barriers, all intermediate state in LDS):
-//   lanes = joints      Rodrigues R_j, dR_j/da (both branches of Ceres' AngleAxisRotatePoint)
-//   lanes = (joint,e)   level-synchronous kinematic chain A_j, P_j, dP_j/dbeta, staged in LDS
-//   lanes = (k,c)       W_{k,c} = A_par(k) dR_{k,c} R_k^T A_par(k)^T  (d x / d a_{k,c} = W (x - P_k))
-//   wave reductions     landmark blend rows  v_p = v_t + sd.beta + pd.feat   (coalesced 512-B reads, one
-//                       landmark per wave at a time)
-//   lanes = columns     the dense row-major [2K][ncols] panel is written with consecutive lanes on
-//                       consecutive columns (coalesced 512-B stores), keypoints dealt round-robin to waves
+// Work layout (512 threads = 8 wavefronts per frame, two per SIMD; <= 128 VGPRs so that two workgroups share a CU at
+// large frame counts; phases separated by workgroup barriers, all intermediate state in LDS, about 73 KB).  At one
+// frame per CU the kernel is a latency chain, so every phase is organised around having its loads in flight together
+// (fixed-trip predicated batches; a runtime-bounded loop of loads pays one L2 round trip per iteration) and around
+// keeping all eight waves busy:
+//   A  model tables, landmark weights, the frame's parameters -> LDS
+//   B  wave 0: Rodrigues R_j, dR_j/da (both branches of Ceres' AngleAxisRotatePoint) | waves 1-3: chain offsets
+//      o_j(beta), centred rest joints | wave 4: landmark rest vertices
+//   C  waves 6-7: A_j columns and P_j as independent 3-vector walks up the kinematic chain | waves 0-5: landmark
+//      items (landmark l, joint k) on lane k - 1 of half-wave l: the landmark's 27 posedirs values are read ONCE
+//      (joint-minor table, coalesced) and give the blend row (half-wave shuffle reduction) and the Jacobian inner
+//      products pd . vec(dR_{k,c})
+//   D  W_{k,c} = A_par(k) dR_{k,c} R_k^T A_par(k)^T (d x / d a_{k,c} = W (x - P_k)) | landmark LBS | camera matrices |
+//      waves 4-7: B_j columns (d P_j / d beta)
+//   E  mesh operands and posed joints (waves 6-7) | complete landmark terms d q_l / d theta_{k,c} per (landmark, joint)
+//      and d q_l / d beta
+//   F  per chunk of 32 keypoints: keypoint stage (projection, residuals, d pi), then the Jacobian sweep with
+//      thread = column (W_{k,c} and P_k in registers), consecutive threads on consecutive columns of the dense
+//      row-major [2K][ncols] panel, written through L2; then (shared beta only) the frame's Gram partial on wave 0
 #include <hip/hip_ext.h>
 
 #include "bodyfit_device.h"
