@@ -95,3 +95,21 @@ def test_noise_free_recovery_regression(api, synth, model, gpu_model):
     K = prob.layout.n_keypoints
     assert np.abs(r[:2 * K]).max() < 0.3
     assert all(s.usable for s in summ)
+
+
+@pytest.mark.gpu
+def test_window_solve_device_normals_match_host_normals(api, synth, model, gpu_model, monkeypatch):
+    """The window LM with the reprojection normal-equation panels built on the device (k_frame_normal) against the
+    same solve forming them on the host from the copied-back Jacobian (BODYFIT_HOST_NORMALS): same iterates up to
+    summation order."""
+    F = 12
+    seq = synth.make_sequence(model, F, seed=31)
+    kw = dict(n_cols=86, use_shape=True, beta_pose=5.0, beta_shape=25.0, lambda_temporal=3.0)
+    prob = api.Problem.from_sequence(gpu_model, seq, **kw)
+    x1, b1, s1 = prob.solve(seq.init_params, np.zeros(10), independent=False, max_iters=25, scale_bounds=(-1e300, 1e300))
+    monkeypatch.setenv("BODYFIT_HOST_NORMALS", "1")
+    prob2 = api.Problem.from_sequence(gpu_model, seq, **kw)
+    x2, b2, s2 = prob2.solve(seq.init_params, np.zeros(10), independent=False, max_iters=25, scale_bounds=(-1e300, 1e300))
+    assert s1[0].iterations == s2[0].iterations
+    assert abs(s1[0].final_cost - s2[0].final_cost) < 1e-9 * s2[0].final_cost
+    assert np.abs(x1[:, 1:] - x2[:, 1:]).max() < 1e-6 and np.abs(b1 - b2).max() < 1e-6
