@@ -126,8 +126,15 @@ __global__ __launch_bounds__(256) void k_lm_step(LmProblem P, LmState S, const d
   const int n = P.ncols, npose = kFrameParams, nb = n - npose;
   const int npad = (n + 15) & ~15, NB = npad >> 4;     // 80 / 96 unknowns padded to whole 16-column panels
   int flags = S.flags[f];
+  // frames that leave without a candidate still hand the residual sweep (its prior workgroups read every frame) a
+  // well-defined point: x_new = x
+  auto no_candidate = [&]() {
+    if (tid < npose) S.x_new[(size_t)f * npose + tid] = S.x[(size_t)f * npose + tid];
+    else if (tid < n) S.beta_new[(size_t)f * nb + tid - npose] = S.beta[(size_t)f * nb + tid - npose];
+  };
   if (!(flags & kLmActive)) {
     if (tid == 0) S.flags[f] = flags & ~kLmHasCand;
+    no_candidate();
     return;
   }
   const int k0 = P.kp_offset[f], nrows = 2 * (P.kp_offset[f + 1] - k0);
@@ -266,6 +273,7 @@ __global__ __launch_bounds__(256) void k_lm_step(LmProblem P, LmState S, const d
       S.flags[f] = (flags & ~(kLmActive | kLmHasCand | kLmTermMask));   // termination 0: convergence
       atomicSub(S.active_count, 1);
     }
+    no_candidate();
     return;
   }
   // ---- scaled, damped system in panel layout: unknowns padded with identity to npad, rhs = row npad -------------
@@ -396,6 +404,7 @@ __global__ __launch_bounds__(256) void k_lm_step(LmProblem P, LmState S, const d
       if (rad < 1e-32) { fl = (fl & ~(kLmActive | kLmTermMask)) | (2 << kLmTermShift); atomicSub(S.active_count, 1); }
       S.flags[f] = fl;
     }
+    no_candidate();
     return;
   }
   LSTAMP(5);
@@ -458,6 +467,7 @@ __global__ __launch_bounds__(256) void k_lm_step(LmProblem P, LmState S, const d
       S.flags[f] = (flags & ~(kLmActive | kLmHasCand | kLmTermMask));
       atomicSub(S.active_count, 1);
     }
+    no_candidate();
     return;
   }
   if (tid < npose) S.x_new[(size_t)f * npose + tid] = xf[tid] + dd[tid];
@@ -532,15 +542,6 @@ __global__ __launch_bounds__(256) void k_frame_normal(int F, int n, const int* _
     }
 }
 
-// candidate bookkeeping for frames without a candidate: x_new = x so the residual sweep stays well defined
-__global__ __launch_bounds__(128) void k_lm_fill(LmProblem P, LmState S) {
-  const int f = blockIdx.x, tid = threadIdx.x;
-  if (S.flags[f] & kLmHasCand) return;
-  const int npose = kFrameParams, nb = P.ncols - npose;
-  if (tid < npose) S.x_new[(size_t)f * npose + tid] = S.x[(size_t)f * npose + tid];
-  else if (tid - npose < nb) S.beta_new[(size_t)f * nb + tid - npose] = S.beta[(size_t)f * nb + tid - npose];
-}
-
 __global__ __launch_bounds__(256) void k_lm_accept(LmProblem P, LmState S, const double* __restrict__ r_new) {
   __shared__ double red[4];
   const int f = blockIdx.x, tid = threadIdx.x;
@@ -594,7 +595,6 @@ void launch_lm_step(const LmProblem& P, const LmState& S, const double* d_r, con
     attr = true;
   }
   hipLaunchKernelGGL(k_lm_step, dim3(P.F), dim3(256), lds, s, P, S, d_r, d_J, d_comp, d_constant, first_iter);
-  hipLaunchKernelGGL(k_lm_fill, dim3(P.F), dim3(128), 0, s, P, S);
 }
 void launch_lm_accept(const LmProblem& P, const LmState& S, const double* d_r_new, hipStream_t s) {
   hipLaunchKernelGGL(k_lm_accept, dim3(P.F), dim3(256), 0, s, P, S, d_r_new);
