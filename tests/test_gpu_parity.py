@@ -116,7 +116,7 @@ def test_derived_tables_match(gpu_model, omodel):
     assert np.abs(J0 - J0o).max() < 1e-13 and np.abs(S - So).max() < 1e-13 and np.abs(off - offo).max() < 1e-13
 
 
-@pytest.mark.parametrize("F", [1, 33, 256])
+@pytest.mark.parametrize("F", [1, 33, 256, 300, 1024])   # 300 / 1024: several 32-frame units per wave
 def test_mesh_forward_matches_oracle(api, synth, model, gpu_model, omodel, F):
     seq = synth.make_sequence(model, F, seed=3)
     rng = np.random.default_rng(31)
@@ -125,7 +125,7 @@ def test_mesh_forward_matches_oracle(api, synth, model, gpu_model, omodel, F):
     beta = rng.normal(size=(F, 10))
     prob = api.Problem.from_sequence(gpu_model, seq, n_cols=86, use_shape=True, beta_per_frame=True, want_mesh=True)
     joints, cloud = prob.forward(x, beta)
-    check = sorted(set([0, F // 2, F - 1]))
+    check = sorted(set([0, F // 2, F - 1, min(F - 1, 257), min(F - 1, 288), (3 * F) // 4]))
     worst = 0.0
     for f in check:
         jo, co = omodel.forward(x[f], beta[f], seq.R0[f])
