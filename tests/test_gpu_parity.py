@@ -348,3 +348,28 @@ def test_writeback_batch_matches_host_composition(api, synth, model, gpu_model, 
         fk = ids < 24
         want = api.mean_pixel_error(ids[fk], uv[fk], jo, seq.intr) if fk.any() else 0.0
         assert abs(wb["mean_px"][f] - want) < 1e-8 * max(1.0, want)
+
+
+@pytest.mark.gpu
+def test_large_batch_equals_small_batches(api, synth, model, gpu_model):
+    """Size-independent property at a full-size batch (1024 frames, two workgroups per CU): every frame's residuals and
+    Jacobian are bit-identical to the same frame evaluated in a 40-frame problem."""
+    F = 1024
+    seq = synth.make_sequence(model, F, seed=5)
+    rng = np.random.default_rng(9)
+    x = random_params(rng, F, pose_sigma=0.2)
+    beta = rng.normal(size=(F, 10)) * 0.5
+    prob = api.Problem.from_sequence(gpu_model, seq, n_cols=86, use_shape=True, beta_per_frame=True, beta_pose=20.0,
+                                     beta_shape=30.0)
+    r, J, _ = prob.evaluate(x, beta, True)
+    K2 = prob.layout.reproj_rows
+    for f0 in (0, 492, F - 40):
+        sl = slice(f0, f0 + 40)
+        k0, k1 = seq.kp_offset[f0], seq.kp_offset[f0 + 40]
+        sub = api.Problem(gpu_model, seq.kp_offset[f0:f0 + 41] - k0, seq.kp_id[k0:k1], seq.kp_uv[k0:k1], seq.intr, seq.R0[sl],
+                          n_cols=86, use_shape=True, beta_per_frame=True, beta_pose=20.0, beta_shape=30.0)
+        rs, Js, _ = sub.evaluate(x[sl], beta[sl], True)
+        assert np.array_equal(rs[:2 * (k1 - k0)], r[2 * k0:2 * k1])
+        assert np.array_equal(Js, J[2 * k0:2 * k1])
+        npr = prob.layout.prior_rows_per_frame
+        assert np.array_equal(rs[2 * (k1 - k0):2 * (k1 - k0) + 40 * npr], r[K2 + f0 * npr:K2 + (f0 + 40) * npr])
