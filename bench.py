@@ -196,6 +196,13 @@ def main():
             a = alg[k] / (prof[k] * 1e-3) / 1e9
             kernels[k] = {"achieved": a, "frac": a / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": alg[k],
                           "avg_launch_ms": prof[k], "traffic": pm["kernels"][pmc_name[k]]["hbm_bytes"] if pm else None}
+        # matrix-pipe view of the mesh kernel: the blend contraction is 2 x 20670 x 217 flop per frame; it is
+        # executed as three bf16 products per k-step on v_mfma_f32_32x32x16_bf16 (216 tiles x 14 k-steps x 9 MFMAs per 32 frames)
+        alg_flop = 2.0 * 20670 * 217 * F
+        exe_flop = 216 * ((F + 31) // 32) * 14 * 9 * 2.0 * 32 * 32 * 16
+        kernels["mesh_blend_lbs"]["mfma"] = {
+            "algorithmic_TFLOPs": alg_flop / (prof["mesh_blend_lbs"] * 1e-3) / 1e12, "f32_mfma_peak_TFLOPs": 157.3,
+            "executed_bf16_TFLOPs": exe_flop / (prof["mesh_blend_lbs"] * 1e-3) / 1e12, "bf16_dense_peak_TFLOPs": 2500.0}
         dom = max(alg, key=lambda k: prof[k])
         bytes_launch, ach, traffic = alg[dom], kernels[dom]["achieved"], kernels[dom]["traffic"]
         whole = (B_MODEL_ALL + F * B_FRAME_ALL) / (ms_step * 1e-3) / 1e9
