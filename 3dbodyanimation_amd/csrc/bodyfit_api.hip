@@ -138,7 +138,8 @@ bool chol_lower(std::vector<double>& A, int n) {
 // [0],[1] k_frame_resjac, [2],[3] k_mesh_blend_lbs.
 int sweep(bodyfit_problem* p, const double* d_params, const double* d_beta, int want_jac, bool mesh,
           hipStream_t st, hipEvent_t* ev = nullptr, double* r_base = nullptr, int* comp_out = nullptr,
-          const int* frame_flags = nullptr, int frame_mask = 0, const double* R0_override = nullptr) {
+          const int* frame_flags = nullptr, int frame_mask = 0, const double* R0_override = nullptr,
+          bool skip_priors = false) {
   const bodyfit_model* m = p->m;
   DevProblem dp = p->d;
   if (R0_override) dp.R0 = R0_override;
@@ -164,7 +165,7 @@ int sweep(bodyfit_problem* p, const double* d_params, const double* d_beta, int 
   pa.r_prior = d_r + p->row_prior; pa.r_shape = d_r + p->row_shape; pa.r_temporal = d_r + p->row_temporal;
   pa.comp = d_comp;
   const bool priors = D.beta_pose > 0.0 || pa.beta_shape > 0.0 || D.lambda_temporal > 0.0;
-  pa.n_tiles = priors ? (p->d.F + 15) / 16 : 0;
+  pa.n_tiles = (priors && !skip_priors) ? (p->d.F + 15) / 16 : 0;
   pa.plain_cost = dp.beta_partials ? dp.beta_partials + (size_t)p->d.F * kReducePartial : nullptr;
   p->partials_tiles = dp.beta_partials ? pa.n_tiles : 0;
   PriorArgs none = pa;
@@ -807,8 +808,9 @@ int bodyfit_internal_solve_batched_device(bodyfit_problem* p, double* frame_para
     // candidate residuals only for frames that have a candidate; fresh Jacobians only for frames still active
     int rc2 = sweep(p, S.x_new, nb ? S.beta_new : nullptr, 0, false, st, nullptr, d_r_new, d_comp_new, S.flags, kLmHasCand);
     if (rc2) return rc2;
-    launch_lm_accept(P, S, d_r_new, st);
-    return sweep(p, S.x, bptr, 1, false, st, nullptr, nullptr, nullptr, S.flags, kLmActive);
+    launch_lm_accept(P, S, d_r_new, p->d_r, d_comp_new, p->d_comp, st);
+    // (prior rows of accepted frames were carried over by k_lm_accept: no prior workgroups on this sweep)
+    return sweep(p, S.x, bptr, 1, false, st, nullptr, nullptr, nullptr, S.flags, kLmActive, nullptr, /*skip_priors=*/true);
   };
   // (a hipGraph replay of this ~20-launch iteration was measured slower than eager launches on ROCm 7.2:
   //  256 frames to convergence 25.6 ms vs 23.0 ms; so the loop stays eager)

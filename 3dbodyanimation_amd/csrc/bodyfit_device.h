@@ -119,7 +119,8 @@ size_t lm_step_lds_bytes();
 void launch_lm_init(const LmProblem& P, const LmState& S, const double* d_r, hipStream_t s);
 void launch_lm_step(const LmProblem& P, const LmState& S, const double* d_r, const double* d_J, const int* d_comp,
                     const unsigned char* d_constant, int first_iter, hipStream_t s);
-void launch_lm_accept(const LmProblem& P, const LmState& S, const double* d_r_new, hipStream_t s);
+void launch_lm_accept(const LmProblem& P, const LmState& S, const double* d_r_new, double* d_r_cur, const int* d_comp_new,
+                      int* d_comp_cur, hipStream_t s);
 constexpr int kNormalRows = 87, kNormalLd = 88;   // per-frame normal-equation panel of k_frame_normal: (n + 1) x 88, lower
 void launch_frame_normal(int F, int n, const int* d_kp_offset, double huber, const double* d_r, const double* d_J,
                          double* d_out, hipStream_t s);

@@ -542,7 +542,9 @@ __global__ __launch_bounds__(256) void k_frame_normal(int F, int n, const int* _
     }
 }
 
-__global__ __launch_bounds__(256) void k_lm_accept(LmProblem P, LmState S, const double* __restrict__ r_new) {
+__global__ __launch_bounds__(256) void k_lm_accept(LmProblem P, LmState S, const double* __restrict__ r_new,
+                                                    double* __restrict__ r_cur, const int* __restrict__ comp_new,
+                                                    int* __restrict__ comp_cur) {
   __shared__ double red[4];
   const int f = blockIdx.x, tid = threadIdx.x;
   const int flags = S.flags[f];
@@ -556,6 +558,18 @@ __global__ __launch_bounds__(256) void k_lm_accept(LmProblem P, LmState S, const
   if (accept) {
     if (tid < npose) S.x[(size_t)f * npose + tid] = S.x_new[(size_t)f * npose + tid];
     else if (tid - npose < nb) S.beta[(size_t)f * nb + tid - npose] = S.beta_new[(size_t)f * nb + tid - npose];
+    // the prior rows (and the GMM component) at the accepted point were computed by the residual sweep: they become
+    // the current ones here, so the Jacobian sweep that follows launches no prior workgroups
+    if (r_cur) {
+      if (tid < P.prior_rows) {
+        const size_t o = P.row_prior + (size_t)f * P.prior_rows + tid;
+        r_cur[o] = r_new[o];
+      } else if (tid >= 128 && tid - 128 < P.shape_rows_per_frame) {
+        const size_t o = P.row_shape + (size_t)f * P.shape_rows_per_frame + tid - 128;
+        r_cur[o] = r_new[o];
+      }
+      if (tid == 255 && comp_cur && comp_new) comp_cur[f] = comp_new[f];
+    }
   }
   if (tid == 0) {
     int fl = flags & ~kLmHasCand;
@@ -596,8 +610,9 @@ void launch_lm_step(const LmProblem& P, const LmState& S, const double* d_r, con
   }
   hipLaunchKernelGGL(k_lm_step, dim3(P.F), dim3(256), lds, s, P, S, d_r, d_J, d_comp, d_constant, first_iter);
 }
-void launch_lm_accept(const LmProblem& P, const LmState& S, const double* d_r_new, hipStream_t s) {
-  hipLaunchKernelGGL(k_lm_accept, dim3(P.F), dim3(256), 0, s, P, S, d_r_new);
+void launch_lm_accept(const LmProblem& P, const LmState& S, const double* d_r_new, double* d_r_cur, const int* d_comp_new,
+                      int* d_comp_cur, hipStream_t s) {
+  hipLaunchKernelGGL(k_lm_accept, dim3(P.F), dim3(256), 0, s, P, S, d_r_new, d_r_cur, d_comp_new, d_comp_cur);
 }
 
 void launch_frame_normal(int F, int n, const int* d_kp_offset, double huber, const double* d_r, const double* d_J,
