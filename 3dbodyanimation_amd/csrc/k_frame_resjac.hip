@@ -109,18 +109,18 @@ __device__ inline double wave_sum(double v) {
 #ifdef BODYFIT_STAMPS
 #define STAMP(i)                                                                              \
   do {                                                                                        \
-    if (Pb.dbg && (threadIdx.x & 63) == 0 && threadIdx.x < 256) {                             \
+    if (Pb.dbg && (threadIdx.x & 63) == 0) {                                                  \
       unsigned long long t_;                                                                  \
       asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");              \
-      Pb.dbg[((size_t)(blockIdx.x - pa.n_tiles) * 4 + (threadIdx.x >> 6)) * 16 + (i)] = t_;                  \
+      Pb.dbg[((size_t)(blockIdx.x - pa.n_tiles) * 8 + (threadIdx.x >> 6)) * 16 + (i)] = t_;                  \
     }                                                                                         \
   } while (0)
 #define STAMP_REAL(i)                                                                         \
   do {                                                                                        \
-    if (Pb.dbg && (threadIdx.x & 63) == 0 && threadIdx.x < 256) {                             \
+    if (Pb.dbg && (threadIdx.x & 63) == 0) {                                                  \
       unsigned long long t_;                                                                  \
       asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");          \
-      Pb.dbg[((size_t)(blockIdx.x - pa.n_tiles) * 4 + (threadIdx.x >> 6)) * 16 + (i)] = t_;                  \
+      Pb.dbg[((size_t)(blockIdx.x - pa.n_tiles) * 8 + (threadIdx.x >> 6)) * 16 + (i)] = t_;                  \
     }                                                                                         \
   } while (0)
 #else
@@ -180,8 +180,8 @@ __global__ __launch_bounds__(kThreads, 4) void k_frame_resjac(DevModel M, DevPro
     if (Pb.dbg && threadIdx.x == 0) {
       unsigned long long tp1;
       asm volatile("s_waitcnt vmcnt(0)\n\ts_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tp1)::"memory");
-      Pb.dbg[((size_t)Pb.F * 4 + blockIdx.x) * 16 + 0] = tp0;
-      Pb.dbg[((size_t)Pb.F * 4 + blockIdx.x) * 16 + 1] = tp1;
+      Pb.dbg[((size_t)Pb.F * 8 + blockIdx.x) * 16 + 0] = tp0;
+      Pb.dbg[((size_t)Pb.F * 8 + blockIdx.x) * 16 + 1] = tp1;
     }
 #endif
     return;

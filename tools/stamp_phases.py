@@ -25,12 +25,12 @@ b = torch.from_numpy(np.tile(seq.gt_beta, (F, 1))).cuda()
 for _ in range(5):
     prob.evaluate_device(x.data_ptr(), b.data_ptr(), True, None)
 torch.cuda.synchronize()
-raw = buf.cpu().numpy()[:F * 4 * 16].reshape(F, 4, 16)
+raw = buf.cpu().numpy()[:F * 8 * 16].reshape(F, 8, 16)
 t = raw[:, :, :9].astype(np.float64)
 names = ["A tables", "B rodrigues/offsets", "C feat+chain walks", "C2 landmark rows", "D W/lmLBS/cam",
          "E mesh ops + lm jac terms", "F1 kp stage", "F2 jacobian sweep"]
-d = np.diff(t, axis=2)  # [F,4,8]
-print("phase durations in shader cycles (median over blocks; per wave 0..3):")
+d = np.diff(t, axis=2)  # [F,8,8]
+print("phase durations in shader cycles (median over blocks; per wave 0..7):")
 for i, n in enumerate(names):
     print(f"  {n:28s}", np.median(d[:, :, i], axis=0).astype(int), " max-wave median:", int(np.median(d[:, :, i].max(1))))
 tot = t[:, :, 8].max(1) - t[:, :, 0].min(1)
