@@ -8,7 +8,7 @@
 typedef __attribute__((ext_vector_type(3))) unsigned int u32x3;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
-template <int AUX, bool X4>
+template <int AUX, bool X4, bool TILE_MAJOR = false>
 __global__ __launch_bounds__(512) void k_store(float* cloud, int F, int nVT, unsigned long long* stamps, int spin) {
   const int vtile = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const unsigned stride = (unsigned)nVT * 32 * 12;
@@ -25,9 +25,14 @@ __global__ __launch_bounds__(512) void k_store(float* cloud, int F, int nVT, uns
         u32x4 v = {__float_as_uint(acc), 1u, 2u, 3u};
         __builtin_amdgcn_raw_buffer_store_b128(v, rs, off % ((unsigned)F * stride - 16), 0, AUX);
       } else {
-        const unsigned off = 4 * (lane >> 5) * stride + (unsigned)(vtile * 32 + (lane & 31)) * 12;
         u32x3 v = {__float_as_uint(acc), 1u, 2u};
-        __builtin_amdgcn_raw_buffer_store_b96(v, rs, off, (unsigned)f * stride, AUX);
+        if (TILE_MAJOR) {   // cloud as [vtile][frame][32][3]: a workgroup's stores cover one contiguous region
+          const unsigned off = ((unsigned)vtile * (unsigned)F + (unsigned)f + 4 * (lane >> 5)) * 384 + (lane & 31) * 12;
+          __builtin_amdgcn_raw_buffer_store_b96(v, rs, off, 0, AUX);
+        } else {
+          const unsigned off = 4 * (lane >> 5) * stride + (unsigned)(vtile * 32 + (lane & 31)) * 12;
+          __builtin_amdgcn_raw_buffer_store_b96(v, rs, off, (unsigned)f * stride, AUX);
+        }
       }
     }
   }
@@ -37,13 +42,13 @@ __global__ __launch_bounds__(512) void k_store(float* cloud, int F, int nVT, uns
   }
 }
 
-template <int AUX, bool X4>
+template <int AUX, bool X4, bool TM = false>
 void run(const char* name, float* d, int F, int nVT, unsigned long long* ds, int spin) {
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  for (int i = 0; i < 5; ++i) hipLaunchKernelGGL((k_store<AUX, X4>), dim3(nVT), dim3(512), 0, 0, d, F, nVT, ds, spin);
+  for (int i = 0; i < 5; ++i) hipLaunchKernelGGL((k_store<AUX, X4, TM>), dim3(nVT), dim3(512), 0, 0, d, F, nVT, ds, spin);
   hipDeviceSynchronize();
   hipEventRecord(e0);
-  for (int i = 0; i < 20; ++i) hipLaunchKernelGGL((k_store<AUX, X4>), dim3(nVT), dim3(512), 0, 0, d, F, nVT, ds, spin);
+  for (int i = 0; i < 20; ++i) hipLaunchKernelGGL((k_store<AUX, X4, TM>), dim3(nVT), dim3(512), 0, 0, d, F, nVT, ds, spin);
   hipEventRecord(e1); hipEventSynchronize(e1);
   float ms; hipEventElapsedTime(&ms, e0, e1);
   std::vector<unsigned long long> h(nVT * 8 * 2);
@@ -59,12 +64,14 @@ int main() {
   const int F = 256, nVT = 216;
   float* d; hipMalloc(&d, (size_t)F * nVT * 32 * 12 * 2);
   unsigned long long* ds; hipMalloc(&ds, nVT * 8 * 2 * 8);
-  for (int spin : {0, 200}) {
+  for (int spin : {0, 20}) {
     run<0, false>("dwordx3 plain", d, F, nVT, ds, spin);
     run<16, false>("dwordx3 sc1", d, F, nVT, ds, spin);
     run<2, false>("dwordx3 nt", d, F, nVT, ds, spin);
     run<0, true>("dwordx4 contiguous plain", d, F, nVT, ds, spin);
     run<16, true>("dwordx4 contiguous sc1", d, F, nVT, ds, spin);
+    run<0, false, true>("dwordx3 tile-major plain", d, F, nVT, ds, spin);
+    run<16, false, true>("dwordx3 tile-major sc1", d, F, nVT, ds, spin);
   }
   return 0;
 }
