@@ -219,7 +219,7 @@ def forward_numpy(model: SynthModel, x: np.ndarray, beta: np.ndarray, R0: np.nda
     joints = Pj @ M.T + t
     if vids is None:
         vids = np.arange(model.n_verts)
-    vids = np.asarray(vids)
+    vids = np.asarray(vids, dtype=np.int64)
     vp = model.v_template[vids] - Jb[0] + model.shapedirs[vids] @ b
     if pose_blend:
         feat = np.concatenate([(Rl[j] - np.eye(3)).reshape(-1) for j in range(1, nJ)])

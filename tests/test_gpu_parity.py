@@ -373,3 +373,38 @@ def test_large_batch_equals_small_batches(api, synth, model, gpu_model):
         assert np.array_equal(Js, J[2 * k0:2 * k1])
         npr = prob.layout.prior_rows_per_frame
         assert np.array_equal(rs[2 * (k1 - k0):2 * (k1 - k0) + 40 * npr], r[K2 + f0 * npr:K2 + (f0 + 40) * npr])
+
+
+@pytest.mark.gpu
+def test_small_model_variants(api, synth, oracle_mod):
+    """Generality of the kernels beyond the SMPL sizes the bench uses: 6 shape directions, a 2048-vertex mesh (64 full
+    tiles), no landmarks, a 3-component GMM; residuals, Jacobian and mesh against the oracle."""
+    import dataclasses
+    base = synth.make_model(3, n_verts=2048, n_landmarks=0)
+    m = dataclasses.replace(base, shapedirs=base.shapedirs[:, :, :6].copy()).finalize()
+    assert m.n_shape == 6 and len(m.landmark_vid) == 0
+    gm = api.Model(m)
+    om = oracle_mod.OracleModel(m)
+    F = 20
+    seq = synth.make_sequence(m, F, seed=8, kp_ids=[i for i in synth.BODY25_IDS if i < 24])
+    rng = np.random.default_rng(12)
+    x = random_params(rng, F, pose_sigma=0.25)
+    beta = rng.normal(size=6) * 0.7
+    w, mu, cov = synth.make_gmm(5, n_comp=3)
+    gmm = api.Gmm(w, mu, cov)
+    prob = api.Problem.from_sequence(gm, seq, n_cols=76 + 6, use_shape=True, beta_pose=3.0, gmm=gmm, beta_shape=2.0,
+                                     lambda_temporal=1.5, want_mesh=True)
+    r, J, comp = prob.evaluate(x, beta, True)
+    ro, Jo = om.evaluate_batch(seq, x, beta, 82, True, True, mode=0)
+    K2 = prob.layout.reproj_rows
+    assert np.abs(r[:K2] - ro).max() < 1e-9 and np.abs(J - Jo).max() < 1e-9 * max(1.0, np.abs(Jo).max())
+    og = oracle_mod.OracleGmm(w, mu, cov)
+    for f in (0, F - 1):
+        rp, kc = og.residual(x[f, 7:])
+        assert kc == comp[f]
+        assert np.abs(r[K2 + f * 70:K2 + (f + 1) * 70] - 3.0 * rp).max() < 1e-9
+    joints, cloud = prob.forward(x, beta)
+    for f in (0, 7, F - 1):
+        jo, co = om.forward(x[f], beta, seq.R0[f])
+        assert np.abs(joints[f] - jo).max() < 1e-11
+        assert np.abs(cloud[f] - co).max() < 5e-6
