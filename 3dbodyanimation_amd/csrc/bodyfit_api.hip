@@ -697,6 +697,16 @@ int bodyfit_internal_frame_normals(bodyfit_problem* p, const double* frame_param
   return BODYFIT_OK;
 }
 
+int bodyfit_frame_normals(bodyfit_problem* p, const double* frame_params, const double* beta, double* residuals,
+                          int* gmm_comp, double* normals) {
+  if (p) {
+    int maxk = 0;
+    for (int f = 0; f < p->d.F; ++f) maxk = std::max(maxk, p->kp_offset[f + 1] - p->kp_offset[f]);
+    if (maxk > 32) return fail(BODYFIT_ERR_INVALID, "bodyfit_frame_normals: at most 32 keypoints per frame");
+  }
+  return bodyfit_internal_frame_normals(p, frame_params, beta, residuals, gmm_comp, normals);
+}
+
 int bodyfit_reduce_shared_device(bodyfit_problem* p, double* d_out66, void* stream) {
   if (!p) return fail(BODYFIT_ERR_INVALID, "null argument");
   HIP_TRY(hipSetDevice(p->m->device));

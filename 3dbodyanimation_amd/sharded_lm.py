@@ -1,0 +1,345 @@
+"""Frame-sharded Levenberg-Marquardt for one multi-frame window (second half).
+
+OptimizeMultiFrame's normal equations are block tridiagonal in the frames (76 x 76 diagonal blocks, DIAGONAL coupling
+blocks -lambda^2 from the temporal links) with a 10-wide arrow border for the shared beta
+(include/MultiFrameBA.h:64-142).  With the frames sharded over ranks (sharded.shard_range) the LM step is solved by
+substructuring, exactly (same iterates as the single-process solve up to rounding):
+  * interface unknowns: the first frame of every rank r >= 1, plus beta; everything else is interior to one rank;
+  * each rank factors its interior chain (block-tridiagonal Cholesky) against the right-hand sides
+    [coupling to its own interface frame | coupling to the next rank's interface frame | beta columns | rhs]
+    and contributes the Schur complement  -K_SI T^-1 [K_IS | rhs_I]  (162 x 163 doubles);
+  * the contributions are all-gathered, every rank assembles and solves the same small interface system
+    (76 (N - 1) + 10 unknowns), then back-substitutes its interior.
+Collectives per LM iteration: one all-reduce of [cost, g_beta, H_bb] per evaluation (the 66-double buffer of
+sharded.ShardedWindow, here with the full 10 x 10 block), one all-gather of the interface contributions, one all-gather of
+the step.  Parameters stay replicated on every rank, as the halo scheme of the evaluator assumes.
+The LM itself (Jacobi scaling from the first iterate, damping by the clamped scaled diagonal over the radius, step
+quality, radius update, the three Ceres tolerances) is host_solver.cpp's, i.e. Ceres 1.14's defaults.
+
+The local evaluator is injected:
+    normals(x_local [n,76], beta [10]) -> (huber_cost, panels [n, 87, 88])     k_frame_normal's layout: lower triangle of
+                                                                              J^T rho' J over [frame 76 | beta 10], row 86 = gradient
+    cost(x_local, beta) -> huber_cost
+HipNormals drives libbodyfit.so; the tests use the CPU oracle.
+"""
+from __future__ import annotations
+
+import numpy as np
+import scipy.linalg as sla
+
+from . import sharded
+
+NP_, NB = 76, 10
+T_IDX = np.arange(1, NP_)          # parameters linked by the temporal rows: everything but the scale
+
+
+def _sym_from_lower(L):
+    return np.tril(L) + np.tril(L, -1).T
+
+
+class ShardedLM:
+    def __init__(self, n_frames, local, beta_pose, beta_shape, lambda_t, dist=None, rank=0, world=1, max_iters=100,
+                 verbose=False):
+        assert n_frames >= world, "every rank needs at least one frame"
+        self.F, self.local, self.dist, self.rank, self.world = n_frames, local, dist, rank, world
+        self.bp, self.bs, self.lam = beta_pose, beta_shape, lambda_t
+        self.f0, self.f1 = sharded.shard_range(n_frames, world, rank)
+        self.first = [sharded.shard_range(n_frames, world, r)[0] for r in range(world)]   # interface frames: first[1:]
+        self.max_iters, self.verbose = max_iters, verbose
+
+    # ---- collectives ---------------------------------------------------------------------------------------------
+    def _sum(self, v):
+        if self.world == 1:
+            return v
+        import torch
+        t = torch.from_numpy(np.ascontiguousarray(v, dtype=np.float64))
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return t.numpy()
+
+    def _max(self, s):
+        if self.world == 1:
+            return s
+        import torch
+        t = torch.tensor([s], dtype=torch.float64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t[0])
+
+    def _gather(self, v):
+        """all_gather of equally sized float64 vectors -> [world, len]"""
+        if self.world == 1:
+            return v[None]
+        import torch
+        t = torch.from_numpy(np.ascontiguousarray(v, dtype=np.float64))
+        out = [torch.empty_like(t) for _ in range(self.world)]
+        self.dist.all_gather(out, t)
+        return np.stack([o.numpy() for o in out])
+
+    # ---- evaluation ----------------------------------------------------------------------------------------------
+    def _prior_cost(self, x, beta):
+        c = 0.5 * self.bp ** 2 * (x[self.f0:self.f1, 7:] ** 2).sum()
+        if self.lam > 0:
+            for f in range(self.f0, min(self.f1, self.F - 1)):         # pairs (f, f+1) owned by f's rank
+                c += 0.5 * self.lam ** 2 * ((x[f, T_IDX] - x[f + 1, T_IDX]) ** 2).sum()
+        if self.rank == 0:
+            c += 0.5 * self.bs ** 2 * (beta ** 2).sum()
+        return c
+
+    def cost(self, x, beta):
+        return float(self._sum(np.array([self.local.cost(x[self.f0:self.f1], beta) + self._prior_cost(x, beta)]))[0])
+
+    def blocks(self, x, beta):
+        """Normal-equation blocks of the local frames at (x, beta): reprojection part from the evaluator, prior and
+        temporal blocks added analytically (constant Jacobians).  beta block and cost all-reduced."""
+        n = self.f1 - self.f0
+        hub, P = self.local.normals(x[self.f0:self.f1], beta)
+        A = np.zeros((n, NP_, NP_)); B = np.zeros((n, NP_, NB)); g = np.zeros((n, NP_))
+        C = np.zeros((NB, NB)); gb = np.zeros(NB)
+        for l in range(n):
+            f = self.f0 + l
+            A[l] = _sym_from_lower(P[l, :NP_, :NP_])
+            B[l] = P[l, NP_:NP_ + NB, :NP_].T
+            g[l] = P[l, NP_ + NB, :NP_]
+            C += _sym_from_lower(P[l, NP_:NP_ + NB, NP_:NP_ + NB])
+            gb += P[l, NP_ + NB, NP_:NP_ + NB]
+            A[l][np.arange(7, NP_), np.arange(7, NP_)] += self.bp ** 2
+            g[l][7:] += self.bp ** 2 * x[f, 7:]
+            if self.lam > 0:
+                for nbf in (f - 1, f + 1):
+                    if 0 <= nbf < self.F:
+                        A[l][T_IDX, T_IDX] += self.lam ** 2
+                        g[l][T_IDX] += self.lam ** 2 * (x[f, T_IDX] - x[nbf, T_IDX])
+        if self.rank == 0:
+            C += self.bs ** 2 * np.eye(NB)
+            gb += self.bs ** 2 * beta
+        red = self._sum(np.concatenate([[hub + self._prior_cost(x, beta)], gb, C.ravel()]))
+        return dict(cost=float(red[0]), A=A, B=B, g=g, gb=red[1:1 + NB].copy(), C=red[1 + NB:].reshape(NB, NB).copy())
+
+    # ---- one LM step: substructured solve of the damped, Jacobi-scaled system ------------------------------------------------
+    @staticmethod
+    def _chain_solve(M, e, W):
+        """Block-tridiagonal SPD system: diagonal blocks M[i] (76 x 76), couplings diag(e[i]) between i and i+1;
+        right-hand sides W[i] (76 x m).  Returns the solution blocks, or None when a block is not positive definite."""
+        n = len(M)
+        Lc, Ls, Y = [None] * n, [None] * n, [None] * n
+        for i in range(n):
+            Mi, Wi = M[i], W[i]
+            if i > 0:
+                Mi = Mi - Ls[i - 1] @ Ls[i - 1].T
+                Wi = Wi - Ls[i - 1] @ Y[i - 1]
+            try:
+                Lc[i] = np.linalg.cholesky(Mi)
+            except np.linalg.LinAlgError:
+                return None
+            Y[i] = sla.solve_triangular(Lc[i], Wi, lower=True)
+            if i + 1 < n:
+                Ls[i] = sla.solve_triangular(Lc[i], np.diag(e[i]), lower=True).T      # diag(e) L^-T
+        Z = [None] * n
+        for i in range(n - 1, -1, -1):
+            Yi = Y[i] if i + 1 == n else Y[i] - Ls[i].T @ Z[i + 1]
+            Z[i] = sla.solve_triangular(Lc[i], Yi, lower=True, trans="T")
+        return Z
+
+    def step(self, blk, scale, scale_b, radius):
+        """Returns (d [F,76], d_beta [10], model_change) or None when the factorisation fails anywhere."""
+        n, N = self.f1 - self.f0, self.world
+        s = scale[self.f0:self.f1]
+        M = blk["A"] * s[:, :, None] * s[:, None, :]
+        for l in range(n):
+            dg = np.clip(np.diag(M[l]), 1e-6, 1e32)
+            M[l][np.arange(NP_), np.arange(NP_)] += dg / radius
+        Bh = blk["B"] * s[:, :, None] * scale_b[None, None, :]
+        rhs = -blk["g"] * s
+
+        def coupling(f):      # between global frames f and f + 1 (scaled); zero on the scale parameter
+            e = np.zeros(NP_)
+            if self.lam > 0 and 0 <= f < self.F - 1:
+                e[T_IDX] = -self.lam ** 2 * scale[f, T_IDX] * scale[f + 1, T_IDX]
+            return e
+
+        has_if = self.rank >= 1                                  # this rank's first frame is an interface unknown
+        i0 = 1 if has_if else 0                                  # first interior frame (local index)
+        ni = n - i0
+        has_right = self.rank < N - 1
+        # ---- interior elimination -> contribution on [left interface | right interface | beta] ----------------------------
+        m = 2 * NP_ + NB + 1
+        G = np.zeros((2 * NP_ + NB, m))
+        direct = np.zeros(NP_)                                   # interface-to-interface coupling when there is no interior
+        Z = None
+        if ni > 0:
+            W = []
+            for i in range(ni):
+                Wi = np.zeros((NP_, m))
+                if i == 0 and has_if:
+                    Wi[:, :NP_] = np.diag(coupling(self.f0))                     # to this rank's interface frame
+                if i == ni - 1 and has_right:
+                    Wi[:, NP_:2 * NP_] = np.diag(coupling(self.f1 - 1))          # to the next rank's interface frame
+                Wi[:, 2 * NP_:2 * NP_ + NB] = Bh[i0 + i]
+                Wi[:, -1] = rhs[i0 + i]
+                W.append(Wi)
+            e_int = [coupling(self.f0 + i0 + i) for i in range(ni - 1)]
+            Z = self._chain_solve([M[i0 + i] for i in range(ni)], e_int, W)
+            ok = Z is not None
+            if ok:
+                for i in range(ni):
+                    G -= W[i][:, :2 * NP_ + NB].T @ Z[i]
+        else:
+            ok = True
+            if has_right:
+                direct = coupling(self.f0)
+        ok = self._max(0.0 if ok else 1.0) == 0.0
+        if not ok:
+            return None
+        # ---- interface system, identical on every rank --------------------------------------------------------------------
+        mine = np.zeros(NP_ * NP_ + NP_ * NB + NP_)
+        if has_if:
+            mine = np.concatenate([M[0].ravel(), Bh[0].ravel(), rhs[0]])
+        allv = self._gather(np.concatenate([mine, G.ravel(), direct]))
+        nI = N - 1
+        K = np.zeros((nI * NP_ + NB, nI * NP_ + NB)); rh = np.zeros(nI * NP_ + NB)
+        bsl = slice(nI * NP_, nI * NP_ + NB)
+        Cs = blk["C"] * np.outer(scale_b, scale_b)
+        Cs[np.arange(NB), np.arange(NB)] += np.clip(np.diag(Cs), 1e-6, 1e32) / radius
+        K[bsl, bsl] = Cs
+        rh[bsl] = -blk["gb"] * scale_b
+        o_m, o_b, o_r = 0, NP_ * NP_, NP_ * NP_ + NP_ * NB
+        o_g = o_r + NP_
+        for r in range(N):
+            v = allv[r]
+            sl_l = slice((r - 1) * NP_, r * NP_) if r >= 1 else None
+            sl_r = slice(r * NP_, (r + 1) * NP_) if r < N - 1 else None
+            if r >= 1:
+                K[sl_l, sl_l] += v[o_m:o_b].reshape(NP_, NP_)
+                K[sl_l, bsl] += v[o_b:o_r].reshape(NP_, NB)
+                K[bsl, sl_l] += v[o_b:o_r].reshape(NP_, NB).T
+                rh[sl_l] += v[o_r:o_g]
+            Gr = v[o_g:o_g + (2 * NP_ + NB) * m].reshape(2 * NP_ + NB, m)
+            dr = v[o_g + (2 * NP_ + NB) * m:]
+            parts = [(sl_l, slice(0, NP_)), (sl_r, slice(NP_, 2 * NP_)), (bsl, slice(2 * NP_, 2 * NP_ + NB))]
+            for (ga, la) in parts:
+                if ga is None:
+                    continue
+                rh[ga] += Gr[la, -1]
+                for (gb_, lb) in parts:
+                    if gb_ is not None:
+                        K[ga, gb_] += Gr[la, lb]
+            if sl_l is not None and sl_r is not None:
+                K[sl_l, sl_r] += np.diag(dr); K[sl_r, sl_l] += np.diag(dr)
+        try:
+            cf = sla.cho_factor(K, lower=True)
+        except np.linalg.LinAlgError:
+            return None
+        y = sla.cho_solve(cf, rh)
+        db_s = y[bsl]
+        x_l = y[(self.rank - 1) * NP_:self.rank * NP_] if has_if else np.zeros(NP_)
+        x_r = y[self.rank * NP_:(self.rank + 1) * NP_] if has_right else np.zeros(NP_)
+        ds = np.zeros((n, NP_))
+        if has_if:
+            ds[0] = x_l
+        for i in range(ni):
+            ds[i0 + i] = Z[i][:, -1] - Z[i][:, :NP_] @ x_l - Z[i][:, NP_:2 * NP_] @ x_r - Z[i][:, 2 * NP_:2 * NP_ + NB] @ db_s
+        d_loc = ds * s
+        d = self._gather(np.concatenate([d_loc.ravel(), np.zeros((self._max_local() - n) * NP_)]))
+        d_all = np.zeros((self.F, NP_))
+        for r in range(N):
+            a, b = sharded.shard_range(self.F, N, r)
+            d_all[a:b] = d[r][:(b - a) * NP_].reshape(b - a, NP_)
+        db = db_s * scale_b
+        # model change -d^T g - 1/2 d^T H d with the undamped, unscaled blocks
+        mc = 0.0
+        for l in range(n):
+            f = self.f0 + l
+            dl = d_all[f]
+            hd = blk["A"][l] @ dl + 2.0 * blk["B"][l] @ db
+            if self.lam > 0 and f + 1 < self.F:
+                hd[T_IDX] += 2.0 * (-self.lam ** 2) * d_all[f + 1, T_IDX]
+            mc += -dl @ blk["g"][l] - 0.5 * dl @ hd
+        if self.rank == 0:
+            mc += -db @ blk["gb"] - 0.5 * db @ blk["C"] @ db
+        return d_all, db, float(self._sum(np.array([mc]))[0])
+
+    def _max_local(self):
+        return max(b - a for a, b in (sharded.shard_range(self.F, self.world, r) for r in range(self.world)))
+
+    # ---- the loop ----------------------------------------------------------------------------------------------------
+    def solve(self, x0, beta0):
+        x, beta = np.array(x0, float), np.array(beta0, float)
+        blk = self.blocks(x, beta)
+        info = dict(initial_cost=blk["cost"], iterations=0, n_ok=0, n_bad=0, termination=1)
+        radius, dec = 1e4, 2.0
+        n = self.f1 - self.f0
+        s_loc = 1.0 / (1.0 + np.sqrt(np.stack([np.diag(blk["A"][l]) for l in range(n)]))) if n else np.zeros((0, NP_))
+        sg = self._gather(np.concatenate([s_loc.ravel(), np.zeros((self._max_local() - n) * NP_)]))
+        scale = np.zeros((self.F, NP_))
+        for r in range(self.world):
+            a, b = sharded.shard_range(self.F, self.world, r)
+            scale[a:b] = sg[r][:(b - a) * NP_].reshape(b - a, NP_)
+        scale_b = 1.0 / (1.0 + np.sqrt(np.diag(blk["C"])))
+        for _ in range(self.max_iters):
+            gmax = self._max(max(np.abs(blk["g"]).max() if n else 0.0, np.abs(blk["gb"]).max()))
+            if gmax <= 1e-10:
+                info["termination"] = 0; break
+            st = self.step(blk, scale, scale_b, radius)
+            if st is None:
+                radius /= dec; dec *= 2; info["n_bad"] += 1; info["iterations"] += 1
+                if radius < 1e-32:
+                    info["termination"] = 2; break
+                continue
+            d, db, model = st
+            if np.sqrt((d ** 2).sum() + (db ** 2).sum()) <= 1e-8 * (np.sqrt((x ** 2).sum() + (beta ** 2).sum()) + 1e-8):
+                info["termination"] = 0; break
+            xn, bn = x + d, beta + db
+            new_cost = self.cost(xn, bn)
+            info["iterations"] += 1
+            change = blk["cost"] - new_cost
+            rho = change / model if model != 0 else -1.0
+            if np.isfinite(new_cost) and model > 0 and rho > 1e-3:
+                old = blk["cost"]
+                x, beta = xn, bn
+                blk = self.blocks(x, beta)
+                radius = min(1e16, radius / max(1.0 / 3.0, 1.0 - (2 * rho - 1) ** 3)); dec = 2.0
+                info["n_ok"] += 1
+                if self.verbose and self.rank == 0:
+                    print(f"[sharded-lm] it {info['iterations']} cost {blk['cost']:.6e} rho {rho:.3f} radius {radius:.2e}")
+                if abs(change) < 1e-6 * old:
+                    info["termination"] = 0; break
+            else:
+                radius /= dec; dec *= 2; info["n_bad"] += 1
+                if radius < 1e-32:
+                    info["termination"] = 2; break
+        info["final_cost"] = blk["cost"]
+        return x, beta, info
+
+
+class HipNormals:
+    """Local evaluator on one MI355X: the shard's frames as an api.Problem without priors (ShardedLM adds them), sweep +
+    k_frame_normal through bodyfit_frame_normals."""
+
+    def __init__(self, api, gpu_model, seq_slice):
+        import ctypes as C
+        self.api, self.C = api, C
+        self.prob = api.Problem(gpu_model, seq_slice["kp_offset"], seq_slice["kp_id"], seq_slice["kp_uv"], seq_slice["intr"],
+                                seq_slice["R0"], n_cols=86, use_shape=True)
+        self.lib = api.load_library()
+        dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int)
+        self.lib.bodyfit_frame_normals.argtypes = [C.c_void_p, dp, dp, dp, ip, dp]
+        self.n = self.prob.n_frames
+        self.K = self.prob.layout.n_keypoints
+
+    def _huber(self, r):
+        s = (r[:2 * self.K].reshape(-1, 2) ** 2).sum(1)
+        return 0.5 * np.where(s > 9.0, 6.0 * np.sqrt(s) - 9.0, s).sum()
+
+    def normals(self, x_local, beta):
+        C = self.C
+        x = np.ascontiguousarray(x_local, dtype=np.float64); b = np.ascontiguousarray(beta, dtype=np.float64)
+        r = np.empty(self.prob.layout.total_rows); H = np.empty((self.n, 87, 88))
+        dp = C.POINTER(C.c_double)
+        rc = self.lib.bodyfit_frame_normals(self.prob.h, x.ctypes.data_as(dp), b.ctypes.data_as(dp), r.ctypes.data_as(dp),
+                                                     None, H.ctypes.data_as(dp))
+        if rc:
+            raise self.api.BodyfitError(self.lib.bodyfit_last_error().decode())
+        return self._huber(r), H
+
+    def cost(self, x_local, beta):
+        r, _, _ = self.prob.evaluate(x_local, beta, False)
+        return self._huber(r)

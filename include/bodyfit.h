@@ -219,6 +219,15 @@ int bodyfit_solve(bodyfit_problem* p, double* frame_params, double* beta, const 
                   int independent_frames, const bodyfit_fit_options* options, bodyfit_fit_summary* summaries,
                   int n_summaries);
 
+/* Normal equations of the reprojection blocks, built on the device (window solvers: bodyfit_solve's host loop,
+ * 3dbodyanimation_amd/sharded_lm.py): evaluate at (frame_params, beta) and return the residual vector [total_rows], the
+ * GMM components [F] (may be NULL) and, per frame, the lower triangle of J^T rho' J over its n_cols columns with the
+ * gradient J^T rho' r in row n_cols, as a [F][87][88] row-major panel (HuberLoss weights rho' applied per keypoint,
+ * include/MultiFrameBA.h:64,102).  Prior and temporal blocks have constant Jacobians and are left to the caller.
+ * Needs <= 32 keypoints per frame.                                                                        */
+int bodyfit_frame_normals(bodyfit_problem* p, const double* frame_params, const double* beta, double* residuals,
+                          int* gmm_comp, double* normals);
+
 const char* bodyfit_last_error(void);
 int bodyfit_device_count(void);
 
