@@ -408,3 +408,33 @@ def test_small_model_variants(api, synth, oracle_mod):
         jo, co = om.forward(x[f], beta, seq.R0[f])
         assert np.abs(joints[f] - jo).max() < 1e-11
         assert np.abs(cloud[f] - co).max() < 5e-6
+
+
+@pytest.mark.gpu
+def test_sweeps_are_deterministic(api, synth, model, gpu_model):
+    """Race / ordering check: 40 evaluations of the same inputs give bit-identical residuals, Jacobian, mesh and
+    shared-beta reduction (fixed-order sums everywhere, no atomics on the data path)."""
+    import torch
+    F = 96
+    seq = synth.make_sequence(model, F, seed=13)
+    rng = np.random.default_rng(3)
+    x = random_params(rng, F, pose_sigma=0.3)
+    beta = rng.normal(size=10) * 0.5
+    w, mu, cov = synth.make_gmm(0)
+    prob = api.Problem.from_sequence(gpu_model, seq, n_cols=86, use_shape=True, beta_pose=4.0, gmm=api.Gmm(w, mu, cov),
+                                     beta_shape=20.0, lambda_temporal=2.0, want_mesh=True)
+    dx = torch.from_numpy(x).cuda(); db = torch.from_numpy(beta).cuda()
+    out = torch.zeros(66, dtype=torch.float64, device="cuda")
+    def snapshot():
+        prob.evaluate_device(dx.data_ptr(), db.data_ptr(), True, None)
+        prob.reduce_shared_device(out.data_ptr(), None)
+        torch.cuda.synchronize()
+        r, J, comp = prob.evaluate(x, beta, True)          # same point through the host-pointer path (copies r, J back)
+        joints, cloud = prob.forward(x, beta)
+        return r.copy(), J.copy(), comp.copy(), cloud.copy(), out.cpu().numpy().copy()
+
+    ref = snapshot()
+    for _ in range(40):
+        cur = snapshot()
+        for a, b in zip(ref, cur):
+            assert np.array_equal(a, b)
