@@ -60,43 +60,42 @@ __device__ inline void mv3(const double* A, double x0, double x1, double x2, dou
   for (int r = 0; r < 3; ++r) y[r] = A[r * 3] * x0 + A[r * 3 + 1] * x1 + A[r * 3 + 2] * x2;
 }
 
-// R(a) and dR/da_c.  theta^2 <= DBL_EPSILON: R = I + [a]x, dR_c = [e_c]x (the first-order branch).
-__device__ void rodrigues_grad(double a0, double a1, double a2, double* R, double* dR) {
+// R(a) and dR/da_k for ONE k (0..2).  theta^2 <= DBL_EPSILON: R = I + [a]x, dR_k = [e_k]x (the first-order branch).
+// One sincos of the half angle gives sin, cos and 1 - cos of theta (st = 2 s c, ct = 1 - 2 s^2, 1 - ct = 2 s^2 without
+// cancellation).  Three lanes per joint each take one k, so the trigonometry (the long part) is the only serial piece.
+__device__ void rodrigues_grad_k(double a0, double a1, double a2, int k, double* R, double* dRk) {
   const double th2 = a0 * a0 + a1 * a1 + a2 * a2;
   if (th2 > 2.220446049250313e-16) {
     const double th = sqrt(th2), ith = 1.0 / th;
-    double st, ct;
-    sincos(th, &st, &ct);
-    const double sh = sin(0.5 * th);
-    const double omc = 2.0 * sh * sh;
+    double sh, ch;
+    sincos(0.5 * th, &sh, &ch);
+    const double st = 2.0 * sh * ch, omc = 2.0 * sh * sh, ct = 1.0 - omc;
     const double w[3] = {a0 * ith, a1 * ith, a2 * ith};
     const double K[9] = {0, -w[2], w[1], w[2], 0, -w[0], -w[1], w[0], 0};
 #pragma unroll
     for (int r = 0; r < 3; ++r)
 #pragma unroll
       for (int c = 0; c < 3; ++c) R[r * 3 + c] = (r == c ? ct : 0.0) + st * K[r * 3 + c] + omc * w[r] * w[c];
+    const double wk = (k == 0) ? w[0] : (k == 1 ? w[1] : w[2]);
+    double dw[3];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      double dw[3];
+    for (int i = 0; i < 3; ++i) dw[i] = ((i == k ? 1.0 : 0.0) - w[i] * wk) * ith;
+    const double dK[9] = {0, -dw[2], dw[1], dw[2], 0, -dw[0], -dw[1], dw[0], 0};
 #pragma unroll
-      for (int i = 0; i < 3; ++i) dw[i] = ((i == k ? 1.0 : 0.0) - w[i] * w[k]) * ith;
-      const double dK[9] = {0, -dw[2], dw[1], dw[2], 0, -dw[0], -dw[1], dw[0], 0};
+    for (int r = 0; r < 3; ++r)
 #pragma unroll
-      for (int r = 0; r < 3; ++r)
-#pragma unroll
-        for (int c = 0; c < 3; ++c)
-          dR[k * 9 + r * 3 + c] = (r == c ? -st * w[k] : 0.0) + ct * w[k] * K[r * 3 + c] + st * dK[r * 3 + c] +
-                                  st * w[k] * w[r] * w[c] + omc * (dw[r] * w[c] + w[r] * dw[c]);
-    }
+      for (int c = 0; c < 3; ++c)
+        dRk[r * 3 + c] = (r == c ? -st * wk : 0.0) + ct * wk * K[r * 3 + c] + st * dK[r * 3 + c] +
+                         st * wk * w[r] * w[c] + omc * (dw[r] * w[c] + w[r] * dw[c]);
   } else {
     R[0] = 1; R[1] = -a2; R[2] = a1;
     R[3] = a2; R[4] = 1; R[5] = -a0;
     R[6] = -a1; R[7] = a0; R[8] = 1;
 #pragma unroll
-    for (int i = 0; i < 27; ++i) dR[i] = 0.0;
-    dR[0 * 9 + 5] = -1; dR[0 * 9 + 7] = 1;   // [e_x]x
-    dR[1 * 9 + 2] = 1;  dR[1 * 9 + 6] = -1;  // [e_y]x
-    dR[2 * 9 + 1] = -1; dR[2 * 9 + 3] = 1;   // [e_z]x
+    for (int i = 0; i < 9; ++i) dRk[i] = 0.0;
+    if (k == 0) { dRk[5] = -1; dRk[7] = 1; }        // [e_x]x
+    else if (k == 1) { dRk[2] = 1; dRk[6] = -1; }   // [e_y]x
+    else { dRk[1] = -1; dRk[3] = 1; }               // [e_z]x
   }
 }
 
@@ -261,14 +260,17 @@ __global__ __launch_bounds__(kThreads, 4) void k_frame_resjac(DevModel M, DevPro
   STAMP(1);
   // ---- B. wave 0: Rodrigues + gradient per joint (joint 0 = root angle-axis);
   //         waves 1-3: chain offsets o_j(beta) (include/Sim3BA.h:142-170,179-205), centred rest joints ------
-  if (tid < nJ) {
-    const double* aa = (tid == 0) ? (sx + 1) : (sx + 7 + 3 * (tid - 1));
-    double R[9], dR[27];
-    rodrigues_grad(aa[0], aa[1], aa[2], R, dR);
+  if (tid < 3 * nJ) {     // (joint, k): wave 0 and a few lanes of wave 1
+    const int jj = tid / 3, k = tid - 3 * jj;
+    const double* aa = (jj == 0) ? (sx + 1) : (sx + 7 + 3 * (jj - 1));
+    double R[9], dRk[9];
+    rodrigues_grad_k(aa[0], aa[1], aa[2], k, R, dRk);
+    if (k == 0) {
 #pragma unroll
-    for (int i = 0; i < 9; ++i) sR[tid * 9 + i] = R[i];
+      for (int i = 0; i < 9; ++i) sR[jj * 9 + i] = R[i];
+    }
 #pragma unroll
-    for (int i = 0; i < 27; ++i) sdR[tid * 27 + i] = dR[i];
+    for (int i = 0; i < 9; ++i) sdR[jj * 27 + k * 9 + i] = dRk[i];
   }
   if (tid >= 256 && tid - 256 < nL * 3) {
     // landmark rest vertex before the pose blend: v_t + shapedirs . beta (10 independent loads)
@@ -281,8 +283,8 @@ __global__ __launch_bounds__(kThreads, 4) void k_frame_resjac(DevModel M, DevPro
     for (int k = 0; k < kMaxShape; ++k) acc += sv[k] * sbeta[min(k, nS > 0 ? nS - 1 : 0)];
     sPart[row] = acc;
   }
-  if (tid >= 64 && tid < 256) {
-    for (int i = tid - 64; i < nJ * 3; i += 192) {
+  if (tid >= 128 && tid < 256) {
+    for (int i = tid - 128; i < nJ * 3; i += 128) {
       double o = M.offset[i], jc = M.Jc0[i];
       if (use_shape) {
         for (int k = 0; k < nS; ++k) {
