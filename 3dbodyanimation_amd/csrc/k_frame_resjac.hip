@@ -565,7 +565,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_frame_resjac(DevModel M, DevPro
 
   STAMP(6);
   // ---- F. keypoints of this frame, KC at a time: stage per-keypoint data, then the flat (keypoint, column)
-  //         sweep over all 256 threads (consecutive threads on consecutive columns of the row-major panel) ------
+  //         sweep over all 512 threads (consecutive threads on consecutive columns of the row-major panel) ------
   const int k_begin = Pb.kp_offset[f], k_end = Pb.kp_offset[f + 1];
   const bool fold = Pb.beta_partials != nullptr && want_jac && ncols > npose && nS == kMaxShape;
   double* sJb = sdR;            // [2 KC][10] d r / d beta of the chunk; dR is dead after phase D
@@ -631,7 +631,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_frame_resjac(DevModel M, DevPro
       //     all keypoints of the group; consecutive threads write consecutive columns of a row; the
       //     FK / landmark branch is uniform across the threads of a group.
       const int njc = npose - 7;
-      const int ngrp = kThreads / njc;                      // 3 groups of 69 columns
+      const int ngrp = kThreads / njc;                      // 7 groups of 69 columns
       if (tid < ngrp * njc) {
         const int g = tid / njc, kc = tid - g * njc, k = 1 + kc / 3;
         double Wm[9];
