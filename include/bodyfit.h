@@ -25,9 +25,16 @@
  *   bodyfit_forward            ark::Avatar::update() (include/Sim3BA.h:371,538;
  *                              include/MultiFrameBA.h:53,173; src/main_single_frame.cpp:213,254)
  *   bodyfit_mean_pixel_error   mean_pixel_error (include/Utils.h:102-115)
- *   bodyfit_optimize_*         OptimizePoseReprojection / OptimizePoseShapeReprojection
- *                              (include/Sim3BA.h:348-358,515-525), OptimizeMultiFrame
- *                              (include/MultiFrameBA.h:33-43)
+ *   bodyfit_writeback_batch    the post-solve write-back loops (include/MultiFrameBA.h:154-174,
+ *                              include/Sim3BA.h:481-505) + mean_pixel_error, for all frames at once
+ *   bodyfit_reduce_shared_device  the shared shape block of OptimizeMultiFrame (include/MultiFrameBA.h:67-68)
+ *                              reduced per GPU for frame-sharded solves
+ *   bodyfit_frame_normals      per-frame normal equations of the reprojection blocks (what DENSE_QR
+ *                              factors, include/MultiFrameBA.h:145-151), for structured window solvers
+ *   bodyfit_solve              ceres::Solve as configured by OptimizePoseReprojection /
+ *                              OptimizePoseShapeReprojection (include/Sim3BA.h:472-479,641-647) and
+ *                              OptimizeMultiFrame (include/MultiFrameBA.h:144-151); the three functions
+ *                              themselves are mirrored in include/bodyfit.hpp
  */
 #ifndef BODYFIT_H_
 #define BODYFIT_H_
