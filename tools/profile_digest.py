@@ -41,3 +41,23 @@ out = {
 }
 json.dump(out, open(f"profiles/{tag}_pmc_traffic.json", "w"), indent=1)
 print(json.dumps({k: v["hbm_bytes"] for k, v in kern.items()}))
+# SQ counter passes -> mean per launch and kernel
+sq = defaultdict(dict)
+for path in glob.glob(f"{src}/pmc_sq*/**/*counter_collection.csv", recursive=True):
+    vals = defaultdict(lambda: defaultdict(list))
+    for row in csv.DictReader(open(path)):
+        m = re.search(r"k_[a-z0-9_]+", row["Kernel_Name"])
+        if m:
+            vals[m.group(0)][row["Counter_Name"]].append(float(row["Counter_Value"]))
+    for k, cs in vals.items():
+        for c, v in cs.items():
+            sq[k][c] = round(sum(v) / len(v), 1)
+if sq:
+    for k, d in sq.items():
+        if d.get("SQ_BUSY_CYCLES") and "SQ_VALU_MFMA_BUSY_CYCLES" in d:
+            d["mfma_busy_over_sq_busy"] = round(d["SQ_VALU_MFMA_BUSY_CYCLES"] / d["SQ_BUSY_CYCLES"], 4)
+        if d.get("SQ_LDS_IDX_ACTIVE") and "SQ_LDS_BANK_CONFLICT" in d:
+            d["lds_conflict_share"] = round(d["SQ_LDS_BANK_CONFLICT"] / d["SQ_LDS_IDX_ACTIVE"], 4)
+    json.dump({"source": "rocprofv3 --pmc <three SQ counters per pass> -- python3 bench.py --no-cpu-baseline --steps 5 --warmup 2",
+               "note": "sums over all shader engines / CUs per launch, as rocprofv3 reports them", "kernels": sq},
+              open(f"profiles/{tag}_pmc_sq.json", "w"), indent=1)
