@@ -1,0 +1,30 @@
+"""Soak: 24,000 sweeps over four batch sizes (outputs finite and bit-stable) and 30 batched solves; run on the GPU box."""
+import importlib, os, sys, time
+import numpy as np
+sys.path.insert(0, os.getcwd())
+api = importlib.import_module("3dbodyanimation_amd.api"); synth = importlib.import_module("3dbodyanimation_amd.synth")
+import torch
+model = synth.make_model(0); gm = api.Model(model)
+w, mu, cov = synth.make_gmm(0); gmm = api.Gmm(w, mu, cov)
+t0 = time.time()
+for F in (1, 31, 256, 777):
+    seq = synth.make_sequence(model, F, seed=F, ragged=True)
+    prob = api.Problem.from_sequence(gm, seq, n_cols=86, use_shape=True, beta_per_frame=True, beta_pose=20.0, gmm=gmm, beta_shape=30.0, want_mesh=True)
+    x = torch.from_numpy(seq.gt_params + 0.01).cuda(); b = torch.from_numpy(np.tile(seq.gt_beta, (F, 1))).cuda()
+    r0 = None
+    for i in range(6000):
+        prob.evaluate_device(x.data_ptr(), b.data_ptr(), True, None)
+        if i % 2000 == 0:
+            torch.cuda.synchronize()
+            r, J, _ = prob.evaluate(seq.gt_params + 0.01, np.tile(seq.gt_beta, (F, 1)), True)
+            assert np.isfinite(r).all() and np.isfinite(J).all()
+            if r0 is None: r0 = r.copy()
+            assert np.array_equal(r0, r)
+    torch.cuda.synchronize()
+    print("F", F, "ok", round(time.time() - t0, 1), "s", flush=True)
+for rep in range(30):
+    seq = synth.make_sequence(model, 64, seed=100 + rep)
+    prob = api.Problem.from_sequence(gm, seq, n_cols=86, use_shape=True, beta_per_frame=True, beta_pose=20.0, gmm=gmm, beta_shape=30.0)
+    xs, bs, s = prob.solve(seq.init_params, np.zeros((64, 10)), independent=True, max_iters=60)
+    assert all(q.usable for q in s) and np.isfinite(xs).all()
+print("solves ok", round(time.time() - t0, 1), "s")
