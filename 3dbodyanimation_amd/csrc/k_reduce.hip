@@ -240,6 +240,11 @@ void launch_reduce_frames(int F, int rows_begin, int total_rows, const double* d
                           double beta_shape, const double* d_frame_partials, double* d_scratch, double* d_out66,
                           hipStream_t s) {
   static_assert(kPartial == kReducePartial, "partial layout");
+  if (F <= 256 && rows_begin >= total_rows) {   // small shard: one workgroup sums the partials (one batch of loads) and packs
+    hipLaunchKernelGGL(k_reduce_stage2, dim3(1), dim3(1024), 0, s, F, d_frame_partials, shape_row0, shape_rows, beta_shape,
+                       d_r, d_out66);
+    return;
+  }
   hipLaunchKernelGGL(k_reduce_stage2a, dim3((kPartial + 15) / 16), dim3(1024), 0, s, F, d_frame_partials, d_scratch, d_r,
                      rows_begin, total_rows);
   hipLaunchKernelGGL(k_reduce_stage2, dim3(1), dim3(1024), 0, s, 1, d_scratch, shape_row0, shape_rows, beta_shape, d_r,
