@@ -147,8 +147,9 @@ constexpr int OFF_TAB = OFF_KP + KC * 18;      // int tables (as 4-byte words): 
 constexpr int OFF_KPUV = OFF_TAB + 64;         // KC*2 observed pixels of the first keypoint chunk
 constexpr int OFF_DS = OFF_KPUV + 2 * KC;      // 24*3*10  S_j - S_par(j)
 constexpr int OFF_SC = OFF_DS + 720;           // 24*3*10  S_j - S_0
-constexpr int OFF_PART = OFF_SC + 720;         // landmark blend-row partial sums: kMaxLandmarks*3*8
-constexpr int OFF_LM = OFF_PART + kMaxLandmarks * 3 * 8;   // landmarks: nL * LM_STRIDE
+constexpr int OFF_PART = OFF_SC + 720;         // landmark rest vertices [<= 96], root keypoint offset [100..102]
+constexpr int OFF_T = OFF_PART + 128;          // 24*3*10  T_j = B_j - A_j Sc_j (landmark shape columns)
+constexpr int OFF_LM = OFF_T + 720;            // landmarks: nL * LM_STRIDE, then their shapedirs rows nL * 3 * 10
 constexpr int LM_VP = 0;                       // 3
 constexpr int LM_Q = 3;                        // 3
 constexpr int LM_A = 6;                        // 9  blended rotation
@@ -210,9 +211,12 @@ __global__ __launch_bounds__(kThreads, 4) void k_frame_resjac(DevModel M, DevPro
   double* sSc = sm + OFF_SC;
   double* sPart = sm + OFF_PART;
   double* sLm = sm + OFF_LM;
+  double* sT = sm + OFF_T;
+  double* sLmSd = sLm + nL * LM_STRIDE;          // [nL][3][nS] shapedirs - S_root of the landmark vertices
   int* sParent = sTab + TAB_PARENT;
   unsigned* sAnc = reinterpret_cast<unsigned*>(sTab + TAB_ANC);
   int* sKpId = sTab + TAB_KPID;
+  unsigned* sKpAnc = reinterpret_cast<unsigned*>(sTab + 48);   // [KC] ancestor mask of each staged keypoint's joint
 
   STAMP_REAL(10);
   STAMP(0);
@@ -227,6 +231,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_frame_resjac(DevModel M, DevPro
     reinterpret_cast<int*>(L + LM_J)[i] = M.lm_wj[it];
     if (i == 0) L[LM_NW] = (double)M.lm_woff[l];   // weight count
   }
+  for (int it = tid; it < nL * 3 * nS; it += kThreads) sLmSd[it] = M.lm_sd[it];
   {
     // 720 = 24 x 3 x 10 doubles each: fixed 3 predicated passes so all six loads are in flight together
     double t0[3], t1[3];
@@ -277,7 +282,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_frame_resjac(DevModel M, DevPro
     const int row = tid - 256;
     double sv[kMaxShape];
 #pragma unroll
-    for (int k = 0; k < kMaxShape; ++k) sv[k] = (use_shape && k < nS) ? M.lm_sd[(size_t)row * nS + k] : 0.0;
+    for (int k = 0; k < kMaxShape; ++k) sv[k] = (use_shape && k < nS) ? sLmSd[row * nS + k] : 0.0;
     double acc = M.lm_vt[row];
 #pragma unroll
     for (int k = 0; k < kMaxShape; ++k) acc += sv[k] * sbeta[min(k, nS > 0 ? nS - 1 : 0)];
@@ -383,7 +388,13 @@ __global__ __launch_bounds__(kThreads, 4) void k_frame_resjac(DevModel M, DevPro
     }
     if (kind == 0) { sA[j * 9 + sel] = v0; sA[j * 9 + 3 + sel] = v1; sA[j * 9 + 6 + sel] = v2; }
     else if (kind == 1) { sP[j * 3] = v0; sP[j * 3 + 1] = v1; sP[j * 3 + 2] = v2; }
-    else { sB[(j * 3 + 0) * nS + sel] = v0; sB[(j * 3 + 1) * nS + sel] = v1; sB[(j * 3 + 2) * nS + sel] = v2; }
+    else {
+      sB[(j * 3 + 0) * nS + sel] = v0; sB[(j * 3 + 1) * nS + sel] = v1; sB[(j * 3 + 2) * nS + sel] = v2;
+      // T_j[:, sel] = B_j[:, sel] - A_j Sc_j[:, sel]: what a skinning weight on joint j adds to d q_l / d beta_sel
+      double c[3];
+      mv3(sA + j * 9, sSc[(j * 3 + 0) * nS + sel], sSc[(j * 3 + 1) * nS + sel], sSc[(j * 3 + 2) * nS + sel], c);
+      sT[(j * 3 + 0) * nS + sel] = v0 - c[0]; sT[(j * 3 + 1) * nS + sel] = v1 - c[1]; sT[(j * 3 + 2) * nS + sel] = v2 - c[2];
+    }
   };
   {
     // A_j columns and P_j (92 items) on waves 6-7, beside the landmark items of waves 0-5 (two landmarks per wave);
@@ -395,7 +406,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_frame_resjac(DevModel M, DevPro
     }
     if (tid < 9) sA[tid] = (tid % 4 == 0) ? 1.0 : 0.0;       // root: A_0 = I, P_0 = 0, B_0 = 0
     if (tid >= 16 && tid < 19) sP[tid - 16] = 0.0;
-    if (tid >= 32 && tid - 32 < 3 * nS) sB[tid - 32] = 0.0;
+    if (tid >= 32 && tid - 32 < 3 * nS) { sB[tid - 32] = 0.0; sT[tid - 32] = 0.0; }
   }
   lm_terms(lm_l, pdv0);
   if (nL > 16) {   // landmarks 16..31: second pass
@@ -411,6 +422,31 @@ __global__ __launch_bounds__(kThreads, 4) void k_frame_resjac(DevModel M, DevPro
   //         waves 4-7: B_j columns (d P_j / d beta) ----
   if (use_shape && want_jac) {
     for (int it = tid - 256; it >= 0 && it < nS * (nJ - 1); it += 256) walk(2, 1 + it / nS, it % nS);
+  }
+  // blend-coefficient fragments of the mesh kernel (pose features from phase C, beta): nothing in this phase's way
+  if (mc.featA) {
+    const int ftile = f / kFTile, row = f % kFTile;
+    if (wave == 3 && lane >= 8 && lane - 8 < kBlendKSteps * 4) {   // wave 3 only has the camera matrices in this phase
+      const int wl = lane - 8;
+      const int kstep = wl >> 2, h = (wl >> 1) & 1, hl = wl & 1;
+      uint32_t pk[4];
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        uint16_t b[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int k = kstep * 16 + 8 * h + 2 * jj + u;     // blend coefficient: pose feature, then beta
+          float x = 0.0f;
+          if (k < kPoseFeat) x = Pb.pose_blend ? (float)sFeat[k] : 0.0f;
+          else if (k - kPoseFeat < nS) x = (float)sbeta[k - kPoseFeat];
+          const uint16_t hi = f32_to_bf16(x);
+          b[u] = hl == 0 ? hi : f32_to_bf16(x - bf16_to_f32(hi));
+        }
+        pk[jj] = (uint32_t)b[0] | ((uint32_t)b[1] << 16);
+      }
+      uint4* dst = reinterpret_cast<uint4*>(mc.featA + ((((size_t)ftile * kBlendKSteps + kstep) * 2 + hl) * 64 + (h * 32 + row)) * 8);
+      *dst = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+    }
   }
   if (want_jac && tid < 3 * (nJ - 1)) {
     const int k = 1 + tid / 3, c = tid % 3, p = sParent[k];
@@ -478,29 +514,6 @@ __global__ __launch_bounds__(kThreads, 4) void k_frame_resjac(DevModel M, DevPro
       for (int r = 0; r < 3; ++r) joints_out[((size_t)f * nJ + jj) * 3 + r] = s * t[r] + sx[4 + r];
     }
   }
-  if (mc.featA) {
-    const int ftile = f / kFTile, row = f % kFTile;
-    if (wave == 6 && lane < kBlendKSteps * 4) {
-      const int kstep = lane >> 2, h = (lane >> 1) & 1, hl = lane & 1;
-      uint32_t pk[4];
-#pragma unroll
-      for (int jj = 0; jj < 4; ++jj) {
-        uint16_t b[2];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const int k = kstep * 16 + 8 * h + 2 * jj + u;     // blend coefficient: pose feature, then beta
-          float x = 0.0f;
-          if (k < kPoseFeat) x = Pb.pose_blend ? (float)sFeat[k] : 0.0f;
-          else if (k - kPoseFeat < nS) x = (float)sbeta[k - kPoseFeat];
-          const uint16_t hi = f32_to_bf16(x);
-          b[u] = hl == 0 ? hi : f32_to_bf16(x - bf16_to_f32(hi));
-        }
-        pk[jj] = (uint32_t)b[0] | ((uint32_t)b[1] << 16);
-      }
-      uint4* dst = reinterpret_cast<uint4*>(mc.featA + ((((size_t)ftile * kBlendKSteps + kstep) * 2 + hl) * 64 + (h * 32 + row)) * 8);
-      *dst = make_uint4(pk[0], pk[1], pk[2], pk[3]);
-    }
-  }
   if (nL > 0 && want_jac) {
     // d q_l / d theta_{k,c} for landmark l, complete, left in LM_PD[l][3 (k - 1) + c] for the Jacobian sweep:
     //   Ablend . (pd[:, 9(k-1):9k] . vec(dR_{k,c}))   the inner products were parked here by phase C (same lane mapping:
@@ -537,28 +550,23 @@ __global__ __launch_bounds__(kThreads, 4) void k_frame_resjac(DevModel M, DevPro
         }
       }
     }
-    // shape columns  d q / d beta_k = sum_i w_i (A_j (sd_l - Sc_j) + B_j)[:, k]   item = (landmark, k)
+    // shape columns  d q / d beta_k = sum_i w_i (A_j (sd_l - Sc_j) + B_j)[:, k] = Ablend sd_l[:, k] + sum_i w_i T_j[:, k]
+    // item = (landmark, k); sd_l staged in LDS since phase A, T_j since phase D
     if (use_shape) {
       for (int it = kThreads - 1 - tid; it < nL * nS; it += kThreads) {
         const int l = it / nS, k = it % nS;
         const double* L = sLm + l * LM_STRIDE;
         const int* Lj = reinterpret_cast<const int*>(L + LM_J);
-        const int nw = (int)L[LM_NW];
-        const double s0 = M.lm_sd[(size_t)(l * 3 + 0) * nS + k], s1 = M.lm_sd[(size_t)(l * 3 + 1) * nS + k],
-                     s2 = M.lm_sd[(size_t)(l * 3 + 2) * nS + k];
-        double d0 = 0, d1 = 0, d2 = 0;
-        for (int i = 0; i < nw; ++i) {
+        double d[3];
+        mv3(L + LM_A, sLmSd[(l * 3 + 0) * nS + k], sLmSd[(l * 3 + 1) * nS + k], sLmSd[(l * 3 + 2) * nS + k], d);
+#pragma unroll
+        for (int i = 0; i < kMaxLmNnz; ++i) {      // fixed stride, padded with weight 0 (joint 0)
           const int j = Lj[i];
           const double w = L[LM_W + i];
-          double t[3];
-          mv3(sA + j * 9, s0 - sSc[(j * 3 + 0) * nS + k], s1 - sSc[(j * 3 + 1) * nS + k],
-              s2 - sSc[(j * 3 + 2) * nS + k], t);
-          d0 += w * (t[0] + sB[(j * 3 + 0) * nS + k]);
-          d1 += w * (t[1] + sB[(j * 3 + 1) * nS + k]);
-          d2 += w * (t[2] + sB[(j * 3 + 2) * nS + k]);
+          d[0] += w * sT[(j * 3 + 0) * nS + k]; d[1] += w * sT[(j * 3 + 1) * nS + k]; d[2] += w * sT[(j * 3 + 2) * nS + k];
         }
         double* o = sLm + l * LM_STRIDE + LM_BETA + k * 3;
-        o[0] = d0; o[1] = d1; o[2] = d2;
+        o[0] = d[0]; o[1] = d[1]; o[2] = d[2];
       }
     }
   }
@@ -582,6 +590,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_frame_resjac(DevModel M, DevPro
       const double u_obs = first ? sKpUv[2 * tid] : Pb.kp_uv[2 * (size_t)kg];
       const double v_obs = first ? sKpUv[2 * tid + 1] : Pb.kp_uv[2 * (size_t)kg + 1];
       sKpId[tid] = id;
+      sKpAnc[tid] = (id < nJ) ? sAnc[id] : 0u;    // the Jacobian sweep reads id and mask in one LDS round trip
       double q[3];
       if (id < nJ) {
         if (id == 0 || sParent[id] < 0) {
@@ -641,11 +650,12 @@ __global__ __launch_bounds__(kThreads, 4) void k_frame_resjac(DevModel M, DevPro
         for (int kk = g; kk < nk; kk += ngrp) {
           const int kg = kc0 + kk;
           const int id = sKpId[kk];
+          const unsigned am = sKpAnc[kk];
           const double* kp = sKp + kk * 18;
           const double* G = kp + 12;
           double d0 = 0.0, d1 = 0.0, d2 = 0.0;
           if (id < nJ) {
-            if ((sAnc[id] >> k) & 1u) {
+            if ((am >> k) & 1u) {
               const double x0 = kp[0] - pk0, x1 = kp[1] - pk1, x2 = kp[2] - pk2;
               d0 = Wm[0] * x0 + Wm[1] * x1 + Wm[2] * x2;
               d1 = Wm[3] * x0 + Wm[4] * x1 + Wm[5] * x2;
@@ -751,7 +761,7 @@ void launch_frame_resjac(const DevModel& M, const DevProblem& P, const double* d
                          double* d_r, double* d_J, double* d_joints, const MeshCoef& mc, int want_jac,
                          const PriorArgs& priors, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop) {
   if (P.F <= 0) return;
-  const size_t lds = (size_t)(OFF_LM + M.nL * LM_STRIDE) * sizeof(double);
+  const size_t lds = (size_t)(OFF_LM + M.nL * (LM_STRIDE + 3 * kMaxShape)) * sizeof(double);
   static size_t lds_granted = 48 * 1024;
   if (lds > lds_granted) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_frame_resjac), hipFuncAttributeMaxDynamicSharedMemorySize,
