@@ -19,10 +19,11 @@
 //      items (landmark l, joint k) on lane k - 1 of half-wave l: the landmark's 27 posedirs values are read ONCE
 //      (joint-minor table, coalesced) and give the blend row (half-wave shuffle reduction) and the Jacobian inner
 //      products pd . vec(dR_{k,c})
-//   D  W_{k,c} = A_par(k) dR_{k,c} R_k^T A_par(k)^T (d x / d a_{k,c} = W (x - P_k)) | landmark LBS | camera matrices |
-//      waves 4-7: B_j columns (d P_j / d beta)
-//   E  mesh operands and posed joints (waves 6-7) | complete landmark terms d q_l / d theta_{k,c} per (landmark, joint)
-//      and d q_l / d beta
+//   D  W_{k,c} = A_par(k) dR_{k,c} R_k^T A_par(k)^T (d x / d a_{k,c} = W (x - P_k)) | landmark LBS | camera matrices and
+//      the mesh kernel's blend-coefficient fragments (wave 3) | waves 4-7: B_j columns (d P_j / d beta) and
+//      T_j = B_j - A_j Sc_j
+//   E  skinning transforms and posed joints (wave 7) | complete landmark terms d q_l / d theta_{k,c} per (landmark,
+//      joint) and d q_l / d beta = Ablend sd_l + sum_i w_i T_{j_i}
 //   F  per chunk of 32 keypoints: keypoint stage (projection, residuals, d pi), then the Jacobian sweep with
 //      thread = column (W_{k,c} and P_k in registers), consecutive threads on consecutive columns of the dense
 //      row-major [2K][ncols] panel, written through L2; then (shared beta only) the frame's Gram partial on wave 0
