@@ -108,7 +108,19 @@ __device__ __forceinline__ double readlane_f64(double v, int src) {
   return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 
-__global__ __launch_bounds__(256) void k_lm_step(LmProblem P, LmState S, const double* __restrict__ r,
+constexpr int kStepThreads = 512, kStepWaves = 8;
+__device__ inline double block_sum8(double v, double* red, int tid) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  __syncthreads();
+  if ((tid & 63) == 0) red[tid >> 6] = v;
+  __syncthreads();
+  return ((red[0] + red[1]) + (red[2] + red[3])) + ((red[4] + red[5]) + (red[6] + red[7]));
+}
+
+// k_lm_step runs 512 threads = two waves per SIMD: its serial parts (diagonal blocks, back substitution) belong to wave 0,
+// every other part is spread over all eight waves so that LDS and L2 latency of one wave is covered by its neighbour.
+__global__ __launch_bounds__(kStepThreads) void k_lm_step(LmProblem P, LmState S, const double* __restrict__ r,
                                                   const double* __restrict__ J, const int* __restrict__ comp,
                                                   const unsigned char* __restrict__ constant, int first_iter) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
@@ -121,7 +133,7 @@ __global__ __launch_bounds__(256) void k_lm_step(LmProblem P, LmState S, const d
   double* ds = vec + 176;                  // 112 entries
   double* dd = vec + 288;
   double* red = vec + 376;
-  double* invd = vec + 384;                // 112 entries: 1 / L_jj of the factor
+  double* invd = vec + 392;                // 112 entries: 1 / L_jj of the factor (red holds 8 wave partials + a status word)
   const int f = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int n = P.ncols, npose = kFrameParams, nb = n - npose;
   const int npad = (n + 15) & ~15, NB = npad >> 4;     // 80 / 96 unknowns padded to whole 16-column panels
@@ -157,19 +169,19 @@ __global__ __launch_bounds__(256) void k_lm_step(LmProblem P, LmState S, const d
   }
   __syncthreads();
   {
-    // fixed trip count (kRowsMax * 88 / 256 = 22 predicated passes): all loads of J in flight together
-    double jv[22];
+    // fixed trip count (kRowsMax * 88 / 512 = 11 predicated passes): all loads of J in flight together
+    double jv[11];
 #pragma unroll
-    for (int u = 0; u < 22; ++u) {
-      const int i = tid + u * 256, row = i / 88, c = i % 88;
+    for (int u = 0; u < 11; ++u) {
+      const int i = tid + u * kStepThreads, row = i / 88, c = i % 88;
       jv[u] = (row < nrows && c < n) ? J[(size_t)(2 * k0 + row) * n + c] : 0.0;
     }
 #pragma unroll
-    for (int u = 0; u < 22; ++u) {
-      const int i = tid + u * 256, row = i / 88, c = i % 88;
+    for (int u = 0; u < 11; ++u) {
+      const int i = tid + u * kStepThreads, row = i / 88, c = i % 88;
       if (row < nrows4 && c != n) Jh[row * kJLd + c] = (row < nrows && c < n) ? ds[row] * jv[u] : 0.0;
     }
-    for (int i = tid; i < nrows4 * (kJLd - 88); i += 256) Jh[(i / (kJLd - 88)) * kJLd + 88 + i % (kJLd - 88)] = 0.0;
+    for (int i = tid; i < nrows4 * (kJLd - 88); i += kStepThreads) Jh[(i / (kJLd - 88)) * kJLd + 88 + i % (kJLd - 88)] = 0.0;
   }
   __syncthreads();
   LSTAMP(1);
@@ -179,7 +191,7 @@ __global__ __launch_bounds__(256) void k_lm_step(LmProblem P, LmState S, const d
     int pair = 0;
     for (int ti = 0; ti < 6; ++ti)
       for (int tj = 0; tj <= ti; ++tj, ++pair) {
-        if ((pair & 3) != wave) continue;
+        if (pair % kStepWaves != wave) continue;
         d4 acc = {0.0, 0.0, 0.0, 0.0};
         const int nsteps = nrows4 / 4;
         for (int s0 = 0; s0 < nsteps; s0 += 8) {      // eight k-steps per batch: their 16 LDS reads are in flight together
@@ -213,15 +225,15 @@ __global__ __launch_bounds__(256) void k_lm_step(LmProblem P, LmState S, const d
       const int kc = comp[f];
       const double* Pm = P.prec + (size_t)kc * D * D;       // L L^T of the selected component
       {
-        double pv[19];   // 69 * 69 = 4761 <= 19 * 256
+        double pv[10];   // 69 * 69 = 4761 <= 10 * 512
 #pragma unroll
-        for (int u = 0; u < 19; ++u) {
-          const int e = tid + u * 256;
+        for (int u = 0; u < 10; ++u) {
+          const int e = tid + u * kStepThreads;
           pv[u] = (e < D * D) ? Pm[e] : 0.0;
         }
 #pragma unroll
-        for (int u = 0; u < 19; ++u) {
-          const int e = tid + u * 256, i = e / D, j = e % D;
+        for (int u = 0; u < 10; ++u) {
+          const int e = tid + u * kStepThreads, i = e / D, j = e % D;
           if (e < D * D && j <= i) H0[(7 + i) * kLd + 7 + j] += bp * bp * pv[u];
         }
       }
@@ -267,7 +279,7 @@ __global__ __launch_bounds__(256) void k_lm_step(LmProblem P, LmState S, const d
   for (int off = 32; off > 0; off >>= 1) gm = fmax(gm, __shfl_xor(gm, off, 64));
   if (lane == 0) red[wave] = gm;
   __syncthreads();
-  gm = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+  gm = fmax(fmax(fmax(red[0], red[1]), fmax(red[2], red[3])), fmax(fmax(red[4], red[5]), fmax(red[6], red[7])));
   if (gm <= 1e-10) {
     if (tid == 0) {
       S.flags[f] = (flags & ~(kLmActive | kLmHasCand | kLmTermMask));   // termination 0: convergence
@@ -279,8 +291,8 @@ __global__ __launch_bounds__(256) void k_lm_step(LmProblem P, LmState S, const d
   // ---- scaled, damped system in panel layout: unknowns padded with identity to npad, rhs = row npad -------------
   const double radius = S.radius[f];
   const double inv_radius = 1.0 / radius;
-  for (int ii = 0; ii < (kMRows + 7) / 8; ++ii) {           // 32 columns x 8 rows per pass, no integer division
-    const int i = (tid >> 5) + 8 * ii;
+  for (int ii = 0; ii < (kMRows + 15) / 16; ++ii) {         // 32 columns x 16 rows per pass, no integer division
+    const int i = (tid >> 5) + 16 * ii;
     if (i >= npad + 16) continue;
     const bool ci = i < npose && constant && constant[i];
 #pragma unroll
@@ -303,10 +315,10 @@ __global__ __launch_bounds__(256) void k_lm_step(LmProblem P, LmState S, const d
       M[i * kMLd + j] = v;
     }
   }
-  if (tid == 0) red[4] = 1.0;   // factorisation status
+  if (tid == 0) red[8] = 1.0;   // factorisation status
   __syncthreads();
   // H0 becomes the full symmetric undamped matrix (model cost change needs H d)
-  for (int e = tid; e < n * n; e += 256) {
+  for (int e = tid; e < n * n; e += kStepThreads) {
     const int i = e / n, j = e % n;
     if (j > i) H0[i * kLd + j] = H0[j * kLd + i];
   }
@@ -346,10 +358,10 @@ __global__ __launch_bounds__(256) void k_lm_step(LmProblem P, LmState S, const d
         for (int k = 0; k < 16; ++k)
           if (k <= rr) M[(c0 + rr) * kMLd + c0 + k] = a[k];
       }
-      if (lane == 0 && !okp) red[4] = 0.0;
+      if (lane == 0 && !okp) red[8] = 0.0;
     }
     __syncthreads();
-    if (red[4] == 0.0) break;
+    if (red[8] == 0.0) break;
     // (b) panel solve  X = A_below L_pp^{-T}: one row per thread (rows c0+16 .. npad incl. the rhs row)
     {
       const int nbelow = npad - (c0 + 16) + 1;
@@ -376,7 +388,7 @@ __global__ __launch_bounds__(256) void k_lm_step(LmProblem P, LmState S, const d
       int t = 0;
       for (int I = p + 1; I <= NB; ++I)
         for (int Kc = p + 1; Kc <= I && Kc < NB; ++Kc, ++t) {
-          if ((t & 3) != wave) continue;
+          if (t % kStepWaves != wave) continue;
           d4 acc;
 #pragma unroll
           for (int q = 0; q < 4; ++q) acc[q] = M[(16 * I + kk + 4 * q) * kMLd + 16 * Kc + m];
@@ -392,7 +404,7 @@ __global__ __launch_bounds__(256) void k_lm_step(LmProblem P, LmState S, const d
     }
     __syncthreads();
   }
-  if (red[4] == 0.0) {
+  if (red[8] == 0.0) {
     if (tid == 0) {
       const double dec = S.dec[f];
       const double rad = radius / dec;
@@ -459,9 +471,9 @@ __global__ __launch_bounds__(256) void k_lm_step(LmProblem P, LmState S, const d
     const double xv = (tid < npose) ? xf[tid] : S.beta[(size_t)f * nb + tid - npose];
     xn = xv * xv;
   }
-  const double model = block_sum(part, red, tid);
-  const double dnorm = sqrt(block_sum(dn, red, tid));
-  const double xnorm = sqrt(block_sum(xn, red, tid));
+  const double model = block_sum8(part, red, tid);
+  const double dnorm = sqrt(block_sum8(dn, red, tid));
+  const double xnorm = sqrt(block_sum8(xn, red, tid));
   if (dnorm <= 1e-8 * (xnorm + 1e-8)) {      // Ceres parameter_tolerance
     if (tid == 0) {
       S.flags[f] = (flags & ~(kLmActive | kLmHasCand | kLmTermMask));
@@ -484,7 +496,7 @@ __global__ __launch_bounds__(256) void k_lm_step(LmProblem P, LmState S, const d
 // on the f64 matrix cores, lower triangle of an (n + 1) x kLd panel per frame.  The host adds the prior / temporal
 // blocks (constant Jacobians) and runs the block-tridiagonal factorisation; it no longer needs J itself
 // ("normal equations built on device").
-__global__ __launch_bounds__(256) void k_frame_normal(int F, int n, const int* __restrict__ kp_offset, double huber,
+__global__ __launch_bounds__(kStepThreads) void k_frame_normal(int F, int n, const int* __restrict__ kp_offset, double huber,
                                                        const double* __restrict__ r, const double* __restrict__ J,
                                                        double* __restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
@@ -508,18 +520,18 @@ __global__ __launch_bounds__(256) void k_frame_normal(int F, int n, const int* _
   }
   __syncthreads();
   {
-    double jv[22];
+    double jv[11];
 #pragma unroll
-    for (int u = 0; u < 22; ++u) {
-      const int i = tid + u * 256, row = i / 88, c = i % 88;
+    for (int u = 0; u < 11; ++u) {
+      const int i = tid + u * kStepThreads, row = i / 88, c = i % 88;
       jv[u] = (row < nrows && c < n) ? J[(size_t)(2 * k0 + row) * n + c] : 0.0;
     }
 #pragma unroll
-    for (int u = 0; u < 22; ++u) {
-      const int i = tid + u * 256, row = i / 88, c = i % 88;
+    for (int u = 0; u < 11; ++u) {
+      const int i = tid + u * kStepThreads, row = i / 88, c = i % 88;
       if (row < nrows4 && c != n) Jh[row * kJLd + c] = (row < nrows && c < n) ? ds[row] * jv[u] : 0.0;
     }
-    for (int i = tid; i < nrows4 * (kJLd - 88); i += 256) Jh[(i / (kJLd - 88)) * kJLd + 88 + i % (kJLd - 88)] = 0.0;
+    for (int i = tid; i < nrows4 * (kJLd - 88); i += kStepThreads) Jh[(i / (kJLd - 88)) * kJLd + 88 + i % (kJLd - 88)] = 0.0;
   }
   __syncthreads();
   double* H = out + (size_t)f * (kN + 1) * kLd;
@@ -527,7 +539,7 @@ __global__ __launch_bounds__(256) void k_frame_normal(int F, int n, const int* _
   int pair = 0;
   for (int ti = 0; ti < 6; ++ti)
     for (int tj = 0; tj <= ti; ++tj, ++pair) {
-      if ((pair & 3) != wave) continue;
+      if (pair % kStepWaves != wave) continue;
       d4 acc = {0.0, 0.0, 0.0, 0.0};
       for (int s = 0; s < nrows4 / 4; ++s) {
         const double a = Jh[(4 * s + kk) * kJLd + 16 * ti + m];
@@ -595,7 +607,7 @@ __global__ __launch_bounds__(256) void k_lm_accept(LmProblem P, LmState S, const
 
 }  // namespace
 
-size_t lm_step_lds_bytes() { return (size_t)(kMRows * kMLd + (kN + 1) * kLd + 504) * sizeof(double); }
+size_t lm_step_lds_bytes() { return (size_t)(kMRows * kMLd + (kN + 1) * kLd + 512) * sizeof(double); }
 
 void launch_lm_init(const LmProblem& P, const LmState& S, const double* d_r, hipStream_t s) {
   hipLaunchKernelGGL(k_lm_init, dim3(P.F), dim3(256), 0, s, P, S, d_r);
@@ -608,7 +620,7 @@ void launch_lm_step(const LmProblem& P, const LmState& S, const double* d_r, con
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_lm_step), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr = true;
   }
-  hipLaunchKernelGGL(k_lm_step, dim3(P.F), dim3(256), lds, s, P, S, d_r, d_J, d_comp, d_constant, first_iter);
+  hipLaunchKernelGGL(k_lm_step, dim3(P.F), dim3(kStepThreads), lds, s, P, S, d_r, d_J, d_comp, d_constant, first_iter);
 }
 void launch_lm_accept(const LmProblem& P, const LmState& S, const double* d_r_new, double* d_r_cur, const int* d_comp_new,
                       int* d_comp_cur, hipStream_t s) {
@@ -624,7 +636,7 @@ void launch_frame_normal(int F, int n, const int* d_kp_offset, double huber, con
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_frame_normal), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL(k_frame_normal, dim3(F), dim3(256), lds, s, F, n, d_kp_offset, huber, d_r, d_J, d_out);
+  hipLaunchKernelGGL(k_frame_normal, dim3(F), dim3(kStepThreads), lds, s, F, n, d_kp_offset, huber, d_r, d_J, d_out);
 }
 
 }  // namespace bodyfit
