@@ -39,8 +39,12 @@ static_assert(kRowsMax * kJLd <= kMRows * kMLd, "Jhat must fit in the region it 
       g_lm_dbg[(size_t)blockIdx.x * 16 + (i)] = t_;                                                 \
     }                                                                                               \
   } while (0)
+#define LTIME(var) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory")
+#define LACC(i, dt) do { if (g_lm_dbg && threadIdx.x == 0) g_lm_dbg[(size_t)blockIdx.x * 16 + (i)] += (dt); } while (0)
 #else
 #define LSTAMP(i)
+#define LTIME(var)
+#define LACC(i, dt)
 #endif
 
 __device__ inline double huber_rho(double delta, double s, double* rho1) {
@@ -324,9 +328,12 @@ __global__ __launch_bounds__(kStepThreads) void k_lm_step(LmProblem P, LmState S
   }
 
   LSTAMP(4);
+  if (tid >= n && tid < npad) invd[tid] = 1.0;       // padded unknowns: unit pivots
   // ---- blocked right-looking Cholesky, 16-column panels; the rhs row rides along as one more row below ----------
   for (int p = 0; p < NB; ++p) {
     const int c0 = 16 * p;
+    unsigned long long ta0 = 0, ta1 = 0, ta2 = 0, ta3 = 0;
+    LTIME(ta0);
     // (a) diagonal block in registers of wave 0: lane r holds row r; column values travel by v_readlane
     if (wave == 0) {
       const int rr = lane & 15;
@@ -336,6 +343,7 @@ __global__ __launch_bounds__(kStepThreads) void k_lm_step(LmProblem P, LmState S
       bool okp = true;
 #pragma unroll
       for (int c = 0; c < 16; ++c) {
+        if (c0 + c >= n) continue;                    // identity padding: nothing to factor, nothing to update (uniform branch)
         const double piv = readlane_f64(a[c], c);
         if (!(piv > 0.0)) okp = false;
         // 1 / sqrt(piv): hardware estimate + two Newton steps (full f64 precision for the normal range the damped,
@@ -361,6 +369,7 @@ __global__ __launch_bounds__(kStepThreads) void k_lm_step(LmProblem P, LmState S
       if (lane == 0 && !okp) red[8] = 0.0;
     }
     __syncthreads();
+    LTIME(ta1);
     if (red[8] == 0.0) break;
     // (b) panel solve  X = A_below L_pp^{-T}: one row per thread (rows c0+16 .. npad incl. the rhs row)
     {
@@ -382,6 +391,7 @@ __global__ __launch_bounds__(kStepThreads) void k_lm_step(LmProblem P, LmState S
       }
     }
     __syncthreads();
+    LTIME(ta2);
     // (c) trailing update  A[I][Kc] -= X_I X_Kc^T  on the f64 matrix cores (tiles at and below the diagonal)
     if (p + 1 <= NB) {
       const int m = lane & 15, kk = lane >> 4;
@@ -403,6 +413,9 @@ __global__ __launch_bounds__(kStepThreads) void k_lm_step(LmProblem P, LmState S
         }
     }
     __syncthreads();
+    LTIME(ta3);
+    LACC(8, ta1 - ta0); LACC(9, ta2 - ta1); LACC(10, ta3 - ta2);
+    (void)ta0; (void)ta1; (void)ta2; (void)ta3;
   }
   if (red[8] == 0.0) {
     if (tid == 0) {
@@ -426,7 +439,7 @@ __global__ __launch_bounds__(kStepThreads) void k_lm_step(LmProblem P, LmState S
     double d1 = (lane + 64 < npad) ? M[npad * kMLd + lane + 64] : 0.0;
     // npad is a multiple of 16: four columns per pass, their factor rows and pivots are read before the dependent
     // chain (fma -> readlane -> mul) starts, so LDS latency stays off it
-    for (int j4 = npad - 1; j4 >= 0; j4 -= 4) {
+    for (int j4 = ((n + 3) & ~3) - 1; j4 >= 0; j4 -= 4) {   // padded unknowns stay 0 (zero right-hand side, unit pivots)
       double ij[4], r0[4], r1[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {

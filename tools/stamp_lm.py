@@ -23,6 +23,7 @@ buf = torch.zeros(F * 16, dtype=torch.int64, device="cuda")
 lib.bodyfit_debug_set_lm_stamp_buffer.argtypes = [C.c_void_p]
 assert lib.bodyfit_debug_set_lm_stamp_buffer(buf.data_ptr()) == 0
 x, b, s = prob.solve(seq.init_params, np.zeros((F, 10)), independent=True, max_iters=6)
+
 torch.cuda.synchronize()
 raw = buf.cpu().numpy().reshape(F, 16).astype(np.float64)
 ok = raw[:, 7] > raw[:, 0]
@@ -33,3 +34,5 @@ print(f"k_lm_step phases, shader cycles (median over {ok.sum()} frames of the la
 for i, n in enumerate(names):
     print(f"  {n:36s} {np.median(d[:, i]):9.0f}")
 print("  total", np.median(raw[ok, 7] - raw[ok, 0]))
+print("  Cholesky parts summed over the solve's iterations / iterations: (a) diagonal blocks, (b) panel solves, (c) trailing updates:",
+      np.median(raw[ok, 8:11], axis=0) / max(1, int(max(q.iterations for q in s))))
