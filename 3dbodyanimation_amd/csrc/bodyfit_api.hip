@@ -98,6 +98,8 @@ struct bodyfit_problem {
   int* d_comp = nullptr;
   float* d_cloud = nullptr;
   double* d_frame_normal = nullptr;
+  unsigned char* lm_pool = nullptr;    // device LM state of bodyfit_solve, one allocation kept across solves
+  hipStream_t lm_stream = nullptr;
   double* d_writeback = nullptr;
   double* d_frame_partials = nullptr; // [F][258] per-frame beta partials written by k_frame_resjac (shared-beta problems)
   int partials_tiles = 0;             // prior tiles that added their plain-cost rows behind the frame rows
@@ -606,6 +608,7 @@ int bodyfit_problem_create(const bodyfit_model* m, const bodyfit_problem_desc* d
 void bodyfit_problem_destroy(bodyfit_problem* p) {
   if (!p) return;
   (void)hipSetDevice(p->m->device);
+  if (p->lm_stream) (void)hipStreamDestroy(p->lm_stream);
   delete p;
 }
 
@@ -774,7 +777,6 @@ int bodyfit_internal_solve_batched_device(bodyfit_problem* p, double* frame_para
   HIP_TRY(hipSetDevice(m->device));
   std::lock_guard<std::mutex> lock(p->mu);
   p->cache_valid = false;
-  Allocs tmp;
   LmState S{};
   LmProblem P{};
   P.F = F; P.ncols = n; P.kp_offset = p->d.kp_offset;
@@ -787,27 +789,37 @@ int bodyfit_internal_solve_batched_device(bodyfit_problem* p, double* frame_para
   double* d_r_new = nullptr;
   int* d_comp_new = nullptr;
   unsigned char* d_const = nullptr;
-  HIP_TRY(tmp.alloc(&S.x, (size_t)F * npose));
-  HIP_TRY(tmp.alloc(&S.beta, (size_t)F * std::max(nb, 1)));
-  HIP_TRY(tmp.alloc(&S.x_new, (size_t)F * npose));
-  HIP_TRY(tmp.alloc(&S.beta_new, (size_t)F * std::max(nb, 1)));
-  HIP_TRY(tmp.alloc(&S.radius, (size_t)F)); HIP_TRY(tmp.alloc(&S.dec, (size_t)F)); HIP_TRY(tmp.alloc(&S.cost, (size_t)F));
-  HIP_TRY(tmp.alloc(&S.initial_cost, (size_t)F)); HIP_TRY(tmp.alloc(&S.model, (size_t)F));
-  HIP_TRY(tmp.alloc(&S.scale, (size_t)F * 86));
-  HIP_TRY(tmp.alloc(&S.flags, (size_t)F)); HIP_TRY(tmp.alloc(&S.iters, (size_t)F)); HIP_TRY(tmp.alloc(&S.n_ok, (size_t)F));
-  HIP_TRY(tmp.alloc(&S.n_bad, (size_t)F)); HIP_TRY(tmp.alloc(&S.active_count, (size_t)1));
-  HIP_TRY(tmp.alloc(&d_r_new, (size_t)p->lay.total_rows));
-  HIP_TRY(tmp.alloc(&d_comp_new, (size_t)F));
-  HIP_TRY(hipMemset(S.active_count, 0, sizeof(int)));
-  HIP_TRY(hipMemcpy(S.x, frame_params, (size_t)F * npose * sizeof(double), hipMemcpyHostToDevice));
-  if (nb) HIP_TRY(hipMemcpy(S.beta, beta, (size_t)F * nb * sizeof(double), hipMemcpyHostToDevice));
-  if (param_constant) {
-    HIP_TRY(tmp.alloc(&d_const, (size_t)npose));
-    HIP_TRY(hipMemcpy(d_const, param_constant, (size_t)npose, hipMemcpyHostToDevice));
+  {
+    // one pooled allocation (sizes depend on the problem only), made on the first solve and reused: seventeen
+    // hipMalloc / hipFree pairs per solve were a quarter of a single-frame fit
+    const size_t nbb = (size_t)std::max(nb, 1);
+    size_t off = 0;
+    auto take = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+    const size_t o_x = take((size_t)F * npose * 8), o_b = take((size_t)F * nbb * 8), o_xn = take((size_t)F * npose * 8),
+                 o_bn = take((size_t)F * nbb * 8), o_rad = take((size_t)F * 8), o_dec = take((size_t)F * 8),
+                 o_cost = take((size_t)F * 8), o_ic = take((size_t)F * 8), o_model = take((size_t)F * 8),
+                 o_scale = take((size_t)F * 86 * 8), o_flags = take((size_t)F * 4), o_iters = take((size_t)F * 4),
+                 o_ok = take((size_t)F * 4), o_bad = take((size_t)F * 4), o_act = take(4),
+                 o_rn = take((size_t)std::max(1, p->lay.total_rows) * 8), o_cn = take((size_t)F * 4), o_const = take((size_t)npose);
+    if (!p->lm_pool) HIP_TRY(p->mem.alloc(&p->lm_pool, off));
+    unsigned char* B = p->lm_pool;
+    S.x = reinterpret_cast<double*>(B + o_x); S.beta = reinterpret_cast<double*>(B + o_b);
+    S.x_new = reinterpret_cast<double*>(B + o_xn); S.beta_new = reinterpret_cast<double*>(B + o_bn);
+    S.radius = reinterpret_cast<double*>(B + o_rad); S.dec = reinterpret_cast<double*>(B + o_dec);
+    S.cost = reinterpret_cast<double*>(B + o_cost); S.initial_cost = reinterpret_cast<double*>(B + o_ic);
+    S.model = reinterpret_cast<double*>(B + o_model); S.scale = reinterpret_cast<double*>(B + o_scale);
+    S.flags = reinterpret_cast<int*>(B + o_flags); S.iters = reinterpret_cast<int*>(B + o_iters);
+    S.n_ok = reinterpret_cast<int*>(B + o_ok); S.n_bad = reinterpret_cast<int*>(B + o_bad);
+    S.active_count = reinterpret_cast<int*>(B + o_act);
+    d_r_new = reinterpret_cast<double*>(B + o_rn); d_comp_new = reinterpret_cast<int*>(B + o_cn);
+    if (param_constant) d_const = B + o_const;
   }
-  hipStream_t st = nullptr;
-  HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-  struct StreamGuard { hipStream_t s; ~StreamGuard() { (void)hipStreamDestroy(s); } } sguard{st};
+  if (!p->lm_stream) HIP_TRY(hipStreamCreateWithFlags(&p->lm_stream, hipStreamNonBlocking));
+  hipStream_t st = p->lm_stream;
+  HIP_TRY(hipMemsetAsync(S.active_count, 0, sizeof(int), st));
+  HIP_TRY(hipMemcpyAsync(S.x, frame_params, (size_t)F * npose * sizeof(double), hipMemcpyHostToDevice, st));
+  if (nb) HIP_TRY(hipMemcpyAsync(S.beta, beta, (size_t)F * nb * sizeof(double), hipMemcpyHostToDevice, st));
+  if (param_constant) HIP_TRY(hipMemcpyAsync(d_const, param_constant, (size_t)npose, hipMemcpyHostToDevice, st));
   const double* bptr = nb ? S.beta : nullptr;
   int rc = sweep(p, S.x, bptr, 1, false, st);
   if (rc) return rc;
