@@ -59,6 +59,11 @@ class FitSummary(C.Structure):
                 ("final_cost", C.c_double)]
 
 
+class _OverlayDesc(C.Structure):
+    _fields_ = [("device", C.c_int), ("n_vertices", C.c_int), ("n_faces", C.c_int), ("faces", C.POINTER(C.c_int32)),
+                ("width", C.c_int), ("height", C.c_int), ("max_frames", C.c_int)]
+
+
 class DeviceViews(C.Structure):
     _fields_ = [("residuals", C.c_void_p), ("jacobian", C.c_void_p), ("gmm_comp", C.c_void_p),
                 ("cloud", C.c_void_p), ("joints", C.c_void_p), ("normal_eq", C.c_void_p),
@@ -112,6 +117,19 @@ def load_library():
     lib.bodyfit_forward.argtypes = [C.c_void_p, _dp, _dp, _dp, _fp]
     lib.bodyfit_writeback_batch.argtypes = [C.c_void_p, _dp, _dp, _dp, _dp, _fp, _dp]
     lib.bodyfit_evaluate_block.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(_dp), _dp, C.POINTER(_dp)]
+    _u8p = C.POINTER(C.c_uint8)
+    _i32p = C.POINTER(C.c_int32)
+    lib.bodyfit_overlay_create.argtypes = [C.POINTER(_OverlayDesc), C.POINTER(C.c_void_p)]
+    lib.bodyfit_overlay_destroy.argtypes = [C.c_void_p]
+    lib.bodyfit_overlay_destroy.restype = None
+    lib.bodyfit_overlay_render_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_int, C.c_void_p,
+                                                  C.c_size_t, C.c_size_t, C.c_double, C.c_double, C.c_double,
+                                                  C.c_double, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    lib.bodyfit_overlay_render.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_int, _u8p, C.c_size_t,
+                                           C.c_size_t, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int,
+                                           C.c_int]
+    lib.bodyfit_overlay_drawlist.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), _i32p, _i32p, _i32p]
+    lib.bodyfit_overlay_last_timing.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
     _lib = lib
     return lib
 
@@ -359,6 +377,83 @@ class Problem:
             self.close()
         except Exception:
             pass
+
+
+class Overlay:
+    """Mesh overlay on the device: smpl::render::renderSMPLMesh (include/RenderSMPLMesh.h:16-110) for a batch of
+    frames.  `faces` are the model's triangles (AvatarModel::mesh, src/main_single_frame.cpp:185-188)."""
+
+    def __init__(self, faces, n_vertices: int, width: int, height: int, max_frames: int = 1, device: int = 0):
+        self.faces = _c32i(faces).reshape(-1, 3)
+        self.n_vertices, self.width, self.height, self.max_frames = int(n_vertices), int(width), int(height), int(max_frames)
+        d = _OverlayDesc(device, self.n_vertices, self.faces.shape[0], self.faces.ctypes.data_as(C.POINTER(C.c_int32)),
+                         self.width, self.height, self.max_frames)
+        h = C.c_void_p()
+        _check(load_library().bodyfit_overlay_create(C.byref(d), C.byref(h)))
+        self.h = h
+
+    def render(self, cloud, images, intr, fill=True, backface_cull=True, wireframe=False):
+        """cloud [F][V][3] float32 or float64 (camera coordinates), images [F][H][W][3] uint8, modified in place."""
+        cloud = np.asarray(cloud)
+        if cloud.dtype != np.float32:
+            cloud = np.ascontiguousarray(cloud, dtype=np.float64)
+        cloud = np.ascontiguousarray(cloud).reshape(-1, self.n_vertices, 3)
+        F = cloud.shape[0]
+        if not (isinstance(images, np.ndarray) and images.dtype == np.uint8 and images.flags.c_contiguous
+                and images.size == F * self.height * self.width * 3):
+            raise BodyfitError("Overlay.render: images must be a C-contiguous uint8 array [F][H][W][3]")
+        _check(load_library().bodyfit_overlay_render(
+            self.h, cloud.ctypes.data_as(C.c_void_p), int(cloud.dtype == np.float64), self.n_vertices * 3, F,
+            images.ctypes.data_as(C.POINTER(C.c_uint8)), self.width * 3, self.width * 3 * self.height,
+            float(intr[0]), float(intr[1]), float(intr[2]), float(intr[3]), int(fill), int(backface_cull), int(wireframe)))
+        return images
+
+    def render_device(self, d_cloud_ptr: int, cloud_is_f64: bool, cloud_frame_stride: int, n_frames: int, d_images_ptr: int,
+                      intr, row_stride=None, frame_stride=None, fill=True, backface_cull=True, stream=None):
+        rs = self.width * 3 if row_stride is None else int(row_stride)
+        fs = rs * self.height if frame_stride is None else int(frame_stride)
+        _check(load_library().bodyfit_overlay_render_device(
+            self.h, d_cloud_ptr, int(cloud_is_f64), int(cloud_frame_stride), int(n_frames), d_images_ptr, rs, fs,
+            float(intr[0]), float(intr[1]), float(intr[2]), float(intr[3]), int(fill), int(backface_cull), 0, stream))
+
+    def drawlist(self, frame: int = 0):
+        nf = self.faces.shape[0]
+        face = np.zeros(nf, np.int32); pts = np.zeros((nf, 6), np.int32); gray = np.zeros(nf, np.int32)
+        n = C.c_int(0)
+        p32 = C.POINTER(C.c_int32)
+        _check(load_library().bodyfit_overlay_drawlist(self.h, int(frame), C.byref(n), face.ctypes.data_as(p32),
+                                                       pts.ctypes.data_as(p32), gray.ctypes.data_as(p32)))
+        return face[:n.value], pts[:n.value], gray[:n.value]
+
+    def last_timing(self):
+        ms = (C.c_float * 4)()
+        _check(load_library().bodyfit_overlay_last_timing(self.h, ms))
+        return dict(faces=ms[0], order=ms[1], binning=ms[2], tiles=ms[3])
+
+    def close(self):
+        if getattr(self, "h", None):
+            load_library().bodyfit_overlay_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def renderSMPLMesh(cloud, faces, img, fx, fy, cx, cy, fill=True, backface_cull=True, wireframe=False, device=0):
+    """include/RenderSMPLMesh.h:16-24, one frame: cloud [V][3] (or the reference's 3xV, column-major), img HxWx3 uint8
+    drawn in place."""
+    cloud = np.asarray(cloud)
+    if cloud.ndim == 2 and cloud.shape[0] == 3 and cloud.shape[1] != 3:
+        cloud = cloud.T
+    ov = Overlay(faces, cloud.shape[0], img.shape[1], img.shape[0], 1, device)
+    try:
+        ov.render(cloud[None], img.reshape(1, *img.shape), (fx, fy, cx, cy), fill, backface_cull, wireframe)
+    finally:
+        ov.close()
+    return img
 
 
 def mean_pixel_error(jid, uv, joints, intr) -> float:

@@ -1,0 +1,855 @@
+// Mesh overlay on the device: the batched replacement of smpl::render::renderSMPLMesh
+// (/root/reference/include/RenderSMPLMesh.h:16-110).  Declared in include/bodyfit.h (bodyfit_overlay_*).
+//
+// The reference draws the triangles of one frame one after the other (painter's order) with OpenCV's
+// anti-aliased convex fill, so a pixel's final value is a fold over the triangles that touch it, in draw order.
+// That fold is kept, and made parallel over pixels instead:
+//
+//   k_ov_faces        one thread per (frame, face): projection, cull, shade, depth key, integer corners
+//                     (RenderSMPLMesh.h:36-88)
+//   k_ov_sort_chunks  one workgroup per 8192 faces of a frame: bitonic sort of (depth key, face) in LDS
+//   k_ov_rank         rank of every face in the frame's draw order (own position + binary searches in the
+//                     other chunks); the face records are scattered into draw order (:91-92)
+//   k_ov_bin_count / k_ov_scan{1,2,3} / k_ov_bin_fill
+//                     16x16-pixel tiles: which ranks touch which tile (bounding box + the AA fringe)
+//   k_ov_tiles        one workgroup per non-empty tile, one thread per pixel: the tile's ranks are put in order
+//                     through an LDS bitmap, 32 triangles at a time are set up (clipLine / LineAA / FillConvexPoly
+//                     state, closed form per row and column) by 128 threads, and every pixel folds them in order
+//                     (:95-104)
+//
+// Scan conversion is integer work (16.16 fixed point); the face stage is a short f64 chain compiled without
+// contraction so that it matches the C restatement bit for bit.  Everything is HBM/latency-bound byte work: no MFMA.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdint>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/bodyfit.h"
+#include "solver_view.h"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+constexpr int kTile = 16;               // pixels per tile side; one thread per pixel
+constexpr int kChunk = 8192;            // faces per LDS sort
+constexpr int kSortThreads = 1024;
+constexpr int kMaxFaces = 65536;        // LDS bitmap of the tile kernel
+constexpr int kGroup = 32;              // triangles set up per round of the tile kernel
+constexpr int kListCap = 2048;          // ordered ranks held in LDS per pass
+constexpr int kFringe = 2;              // pixels around a triangle's bounding box the AA lines can touch
+constexpr int XY_SHIFT = 16;
+constexpr int XY_ONE = 1 << XY_SHIFT;
+constexpr unsigned long long kDeadKey = ~0ull;
+
+// drawing.cpp tables [recalled, see oracle/overlay_oracle.c]
+__constant__ unsigned char cFilter[64] = {
+    168, 177, 185, 194, 202, 210, 218, 224, 231, 236, 241, 246, 249, 252, 254, 254,
+    254, 254, 252, 249, 246, 241, 236, 231, 224, 218, 210, 202, 194, 185, 177, 168,
+    158, 149, 140, 131, 122, 114, 105, 97,  89,  82,  75,  68,  62,  56,  50,  45,
+    40,  36,  32,  28,  25,  22,  19,  16,  14,  12,  11,  9,   8,   7,   5,   5};
+__constant__ unsigned char cSlopeCorr[32] = {181, 181, 181, 182, 182, 183, 184, 185, 187, 188, 190,
+                                             192, 194, 196, 198, 201, 203, 206, 209, 211, 214, 218,
+                                             221, 224, 227, 231, 235, 238, 242, 246, 250, 254};
+
+struct OvFace {      // 32 bytes
+  int px[3], py[3];
+  int gray;          // -1: not drawn
+  int face;
+};
+
+struct OvLine {      // one anti-aliased edge after clipping, closed form along its major axis
+  long long m0, step;
+  int c0, E;         // first major coordinate, last step index (steps 0..E)
+  int flags;         // bit 0 drawn, bit 1 x-major
+  unsigned short ep[9];
+  unsigned short pad;
+};
+
+struct OvFill {      // the two edge walkers of FillConvexPoly, at most two linear pieces each
+  long long xs[2][2], dx[2][2];
+  int ys[2][2];      // first row of the piece (second piece: INT_MAX when absent)
+  int y0, y1;        // rows drawn: y0..y1 (empty when y1 < y0)
+  int gray;
+  int bx0, by0, bx1, by1;   // bounding box + fringe (quick reject)
+};
+
+__device__ __forceinline__ int round_to_int(float f) {
+  const float r = roundf(f);
+  if (!(r > -2147483648.0f)) return r != r ? 0 : INT32_MIN;
+  if (r >= 2147483648.0f) return INT32_MAX;
+  return (int)r;
+}
+
+// ---- faces --------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void k_ov_faces(const T* __restrict__ cloud, size_t frame_stride,
+                                                  const int* __restrict__ faces, int nF, int nV, double fx, double fy,
+                                                  double cx, double cy, int cull, OvFace* __restrict__ out,
+                                                  unsigned long long* __restrict__ keys) {
+  const int f = blockIdx.x * 256 + threadIdx.x;
+  const int frame = blockIdx.y;
+  if (f >= nF) return;
+  const T* c = cloud + (size_t)frame * frame_stride;
+  const int id[3] = {faces[3 * f], faces[3 * f + 1], faces[3 * f + 2]};
+  double v[3][3];
+  bool ok = true;
+  int px[3], py[3];
+  for (int k = 0; k < 3; ++k) {
+    v[k][0] = (double)c[3 * (size_t)id[k]];
+    v[k][1] = (double)c[3 * (size_t)id[k] + 1];
+    v[k][2] = (double)c[3 * (size_t)id[k] + 2];
+    if (v[k][2] <= 1e-6) ok = false;                     // RenderSMPLMesh.h:42
+    const float u = (float)(fx * v[k][0] / v[k][2] + cx);   // :43-44
+    const float w = (float)(fy * v[k][1] / v[k][2] + cy);
+    px[k] = round_to_int(u);                             // :79-84
+    py[k] = round_to_int(w);
+  }
+  OvFace o;
+  o.face = f;
+  o.gray = -1;
+  unsigned long long key = kDeadKey;
+  for (int k = 0; k < 3; ++k) { o.px[k] = px[k]; o.py[k] = py[k]; }
+  if (ok) {
+    const double e1[3] = {v[1][0] - v[0][0], v[1][1] - v[0][1], v[1][2] - v[0][2]};
+    const double e2[3] = {v[2][0] - v[0][0], v[2][1] - v[0][1], v[2][2] - v[0][2]};
+    const double n[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
+    if (!(cull && n[2] >= 0.0)) {                        // :65
+      const double ctr[3] = {(v[0][0] + v[1][0] + v[2][0]) / 3.0, (v[0][1] + v[1][1] + v[2][1]) / 3.0,
+                             (v[0][2] + v[1][2] + v[2][2]) / 3.0};
+      double w[3] = {-ctr[0], -ctr[1], -ctr[2]};
+      const double w2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
+      if (w2 > 0.0) { const double s = sqrt(w2); w[0] /= s; w[1] /= s; w[2] /= s; }
+      double m[3] = {n[0], n[1], n[2]};
+      const double m2 = m[0] * m[0] + m[1] * m[1] + m[2] * m[2];
+      if (m2 > 0.0) { const double s = sqrt(m2); m[0] /= s; m[1] /= s; m[2] /= s; }
+      double shade = m[0] * w[0] + m[1] * w[1] + m[2] * w[2];   // :70
+      shade = shade < 0.0 ? 0.0 : (shade > 1.0 ? 1.0 : shade);
+      const double g = round(220 * shade);                 // :99
+      int gi = g != g ? 0 : (int)g;
+      o.gray = gi < 0 ? 0 : (gi > 255 ? 255 : gi);
+      const double depth = (v[0][2] + v[1][2] + v[2][2]) / 3.0;   // :74, > 0 for a valid face
+      // far to near: larger depth first.  depth > 0, so its bit pattern orders like the value.
+      key = ~(unsigned long long)__double_as_longlong(depth);
+      if (key == kDeadKey) key = kDeadKey - 1;
+    }
+  }
+  out[(size_t)frame * nF + f] = o;
+  keys[(size_t)frame * nF + f] = key;
+}
+
+// ---- draw order ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool key_less(unsigned long long ka, unsigned ia, unsigned long long kb, unsigned ib) {
+  return ka < kb || (ka == kb && ia < ib);
+}
+
+__global__ __launch_bounds__(kSortThreads) void k_ov_sort_chunks(const unsigned long long* __restrict__ keys, int nF,
+                                                                 int nChunks, unsigned long long* __restrict__ skey,
+                                                                 unsigned* __restrict__ sidx) {
+  extern __shared__ unsigned long long sm[];
+  unsigned long long* k = sm;
+  unsigned* ix = reinterpret_cast<unsigned*>(sm + kChunk);
+  const int chunk = blockIdx.x, frame = blockIdx.y;
+  const int base = chunk * kChunk;
+  for (int i = threadIdx.x; i < kChunk; i += kSortThreads) {
+    const int f = base + i;
+    k[i] = f < nF ? keys[(size_t)frame * nF + f] : kDeadKey;
+    ix[i] = f < nF ? (unsigned)f : 0xFFFFFFFFu;
+  }
+  __syncthreads();
+  for (int size = 2; size <= kChunk; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int t = threadIdx.x; t < kChunk / 2; t += kSortThreads) {
+        const int lo = ((t & ~(stride - 1)) << 1) | (t & (stride - 1));
+        const int hi = lo | stride;
+        const bool up = (lo & size) == 0;
+        const unsigned long long ka = k[lo], kb = k[hi];
+        const unsigned ia = ix[lo], ib = ix[hi];
+        const bool swap = up ? key_less(kb, ib, ka, ia) : key_less(ka, ia, kb, ib);
+        if (swap) { k[lo] = kb; k[hi] = ka; ix[lo] = ib; ix[hi] = ia; }
+      }
+      __syncthreads();
+    }
+  }
+  const size_t o = ((size_t)frame * nChunks + chunk) * kChunk;
+  for (int i = threadIdx.x; i < kChunk; i += kSortThreads) { skey[o + i] = k[i]; sidx[o + i] = ix[i]; }
+}
+
+__global__ __launch_bounds__(256) void k_ov_rank(const unsigned long long* __restrict__ skey,
+                                                 const unsigned* __restrict__ sidx, int nF, int nChunks,
+                                                 const OvFace* __restrict__ in, OvFace* __restrict__ sorted,
+                                                 int* __restrict__ n_alive) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  const int frame = blockIdx.y;
+  if (e >= nChunks * kChunk) return;
+  const size_t fo = (size_t)frame * nChunks * kChunk;
+  const unsigned idx = sidx[fo + e];
+  if (idx == 0xFFFFFFFFu) return;          // padding of the last chunk
+  const unsigned long long key = skey[fo + e];
+  const int c = e / kChunk;
+  int rank = e - c * kChunk;
+  for (int o = 0; o < nChunks; ++o) {
+    if (o == c) continue;
+    const unsigned long long* ok = skey + fo + (size_t)o * kChunk;
+    const unsigned* oi = sidx + fo + (size_t)o * kChunk;
+    int lo = 0, hi = kChunk;             // first position whose (key, idx) is not less than mine
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (key_less(ok[mid], oi[mid], key, idx)) lo = mid + 1; else hi = mid;
+    }
+    rank += lo;
+  }
+  sorted[(size_t)frame * nF + rank] = in[(size_t)frame * nF + idx];
+  if (key != kDeadKey) atomicAdd(&n_alive[frame], 1);
+}
+
+// ---- binning ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool tile_range(const OvFace& o, int W, int H, int tilesX, int tilesY, int& tx0, int& ty0,
+                                           int& tx1, int& ty1) {
+  long long x0 = min(o.px[0], min(o.px[1], o.px[2])), x1 = max(o.px[0], max(o.px[1], o.px[2]));
+  long long y0 = min(o.py[0], min(o.py[1], o.py[2])), y1 = max(o.py[0], max(o.py[1], o.py[2]));
+  x0 -= kFringe; y0 -= kFringe; x1 += kFringe; y1 += kFringe;
+  if (x1 < 0 || y1 < 0 || x0 >= W || y0 >= H) return false;
+  x0 = max(x0, 0ll); y0 = max(y0, 0ll); x1 = min(x1, (long long)W - 1); y1 = min(y1, (long long)H - 1);
+  tx0 = (int)x0 / kTile; ty0 = (int)y0 / kTile; tx1 = (int)x1 / kTile; ty1 = (int)y1 / kTile;
+  return true;
+}
+
+template <bool kFillPass>
+__global__ __launch_bounds__(256) void k_ov_bin(const OvFace* __restrict__ sorted, int nF, int W, int H, int tilesX,
+                                                int tilesY, unsigned* __restrict__ count,
+                                                const unsigned* __restrict__ offset, unsigned* __restrict__ entries) {
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  const int frame = blockIdx.y;
+  if (r >= nF) return;
+  const OvFace o = sorted[(size_t)frame * nF + r];
+  if (o.gray < 0) return;
+  int tx0, ty0, tx1, ty1;
+  if (!tile_range(o, W, H, tilesX, tilesY, tx0, ty0, tx1, ty1)) return;
+  const size_t tb = (size_t)frame * tilesX * tilesY;
+  for (int ty = ty0; ty <= ty1; ++ty)
+    for (int tx = tx0; tx <= tx1; ++tx) {
+      const size_t t = tb + (size_t)ty * tilesX + tx;
+      if (kFillPass) {
+        const unsigned slot = atomicSub(&count[t], 1u) - 1u;   // the count pass left the tile's total here
+        entries[offset[t] + slot] = (unsigned)r;
+      } else {
+        atomicAdd(&count[t], 1u);
+      }
+    }
+}
+
+// exclusive scan of the tile counts in three small launches: block sums, their scan, offsets + compaction
+constexpr int kScanBlock = 1024;   // tiles per block (256 threads x 4)
+
+__global__ __launch_bounds__(256) void k_ov_scan1(const unsigned* __restrict__ count, size_t n,
+                                                  unsigned* __restrict__ blockSum) {
+  __shared__ unsigned red[4];
+  const size_t i0 = (size_t)blockIdx.x * kScanBlock + threadIdx.x * 4;
+  unsigned s = 0;
+  for (int k = 0; k < 4; ++k) if (i0 + k < n) s += count[i0 + k];
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) blockSum[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(1024) void k_ov_scan2(unsigned* __restrict__ blockSum, int nBlocks,
+                                                   unsigned* __restrict__ totals /* [0] entries */) {
+  __shared__ unsigned part[1024];
+  const int per = (nBlocks + 1023) / 1024;
+  const int b0 = threadIdx.x * per;
+  unsigned s = 0;
+  for (int k = 0; k < per; ++k) if (b0 + k < nBlocks) s += blockSum[b0 + k];
+  part[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 1; o < 1024; o <<= 1) {
+    const unsigned v = threadIdx.x >= o ? part[threadIdx.x - o] : 0;
+    __syncthreads();
+    part[threadIdx.x] += v;
+    __syncthreads();
+  }
+  unsigned run = part[threadIdx.x] - s;   // exclusive
+  for (int k = 0; k < per; ++k)
+    if (b0 + k < nBlocks) { const unsigned v = blockSum[b0 + k]; blockSum[b0 + k] = run; run += v; }
+  if (threadIdx.x == 1023) totals[0] = part[1023];
+}
+
+__global__ __launch_bounds__(256) void k_ov_scan3(const unsigned* __restrict__ count, size_t n,
+                                                  const unsigned* __restrict__ blockBase, unsigned* __restrict__ offset,
+                                                  unsigned* __restrict__ active, unsigned* __restrict__ totals) {
+  __shared__ unsigned part[256];
+  const size_t i0 = (size_t)blockIdx.x * kScanBlock + threadIdx.x * 4;
+  unsigned c[4], s = 0;
+  for (int k = 0; k < 4; ++k) { c[k] = i0 + k < n ? count[i0 + k] : 0; s += c[k]; }
+  part[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 1; o < 256; o <<= 1) {
+    const unsigned v = threadIdx.x >= o ? part[threadIdx.x - o] : 0;
+    __syncthreads();
+    part[threadIdx.x] += v;
+    __syncthreads();
+  }
+  unsigned run = blockBase[blockIdx.x] + part[threadIdx.x] - s;
+  for (int k = 0; k < 4; ++k)
+    if (i0 + k < n) {
+      offset[i0 + k] = run;
+      run += c[k];
+      if (c[k]) active[atomicAdd(&totals[1], 1u)] = (unsigned)(i0 + k);
+    }
+}
+
+// ---- triangle set-up (one lane per edge / per fill) ---------------------------------------------------------
+struct Pt { long long x, y; };
+
+// cv::clipLine(Size2l, Point2l&, Point2l&)
+__device__ bool clip_line(long long width, long long height, Pt& p1, Pt& p2) {
+  const long long right = width - 1, bottom = height - 1;
+  long long x1 = p1.x, y1 = p1.y, x2 = p2.x, y2 = p2.y;
+  int c1 = (x1 < 0) + (x1 > right) * 2 + (y1 < 0) * 4 + (y1 > bottom) * 8;
+  int c2 = (x2 < 0) + (x2 > right) * 2 + (y2 < 0) * 4 + (y2 > bottom) * 8;
+  if ((c1 & c2) == 0 && (c1 | c2) != 0) {
+    long long a;
+    if (c1 & 12) {
+      a = c1 < 8 ? 0 : bottom;
+      x1 += (long long)((double)(a - y1) * (double)(x2 - x1) / (double)(y2 - y1));
+      y1 = a;
+      c1 = (x1 < 0) + (x1 > right) * 2;
+    }
+    if (c2 & 12) {
+      a = c2 < 8 ? 0 : bottom;
+      x2 += (long long)((double)(a - y2) * (double)(x2 - x1) / (double)(y2 - y1));
+      y2 = a;
+      c2 = (x2 < 0) + (x2 > right) * 2;
+    }
+    if ((c1 & c2) == 0 && (c1 | c2) != 0) {
+      if (c1) {
+        a = c1 == 1 ? 0 : right;
+        y1 += (long long)((double)(a - x1) * (double)(y2 - y1) / (double)(x2 - x1));
+        x1 = a;
+        c1 = 0;
+      }
+      if (c2) {
+        a = c2 == 1 ? 0 : right;
+        y2 += (long long)((double)(a - x2) * (double)(y2 - y1) / (double)(x2 - x1));
+        x2 = a;
+        c2 = 0;
+      }
+    }
+  }
+  p1.x = x1; p1.y = y1; p2.x = x2; p2.y = y2;
+  return (c1 | c2) == 0;
+}
+
+// drawing.cpp LineAA up to its pixel loop: the loop itself becomes a closed form in the step index
+__device__ void setup_line(OvLine& L, int xa, int ya, int xb, int yb, int W, int H) {
+  Pt pt1{(long long)xa * XY_ONE, (long long)ya * XY_ONE}, pt2{(long long)xb * XY_ONE, (long long)yb * XY_ONE};
+  L.flags = 0;
+  if (!clip_line((long long)W << XY_SHIFT, (long long)H << XY_SHIFT, pt1, pt2)) return;
+  long long dx = pt2.x - pt1.x, dy = pt2.y - pt1.y;
+  long long j = dx < 0 ? -1 : 0, i = dy < 0 ? -1 : 0;
+  const long long ax = (dx ^ j) - j, ay = (dy ^ i) - i;
+  long long step;
+  int slope, ecount;
+  if (ax > ay) {
+    dy = (dy ^ j) - j;
+    if (j) { const Pt t = pt1; pt1 = pt2; pt2 = t; }
+    step = (dy * XY_ONE) / (ax | 1);
+    pt2.x += XY_ONE;
+    ecount = (int)((pt2.x >> XY_SHIFT) - (pt1.x >> XY_SHIFT));
+    j = -(pt1.x & (XY_ONE - 1));
+    pt1.y += ((step * j) >> XY_SHIFT) + (XY_ONE >> 1);
+    slope = (int)((step >> (XY_SHIFT - 5)) & 0x3f);
+    slope ^= (step < 0 ? 0x3f : 0);
+    i = (pt1.x >> (XY_SHIFT - 7)) & 0x78;
+    j = (pt2.x >> (XY_SHIFT - 7)) & 0x78;
+    L.flags = 3;
+    L.c0 = (int)(pt1.x >> XY_SHIFT);
+    L.m0 = pt1.y;
+  } else {
+    dx = (dx ^ i) - i;
+    if (i) { const Pt t = pt1; pt1 = pt2; pt2 = t; }
+    step = (dx * XY_ONE) / (ay | 1);
+    pt2.y += XY_ONE;
+    ecount = (int)((pt2.y >> XY_SHIFT) - (pt1.y >> XY_SHIFT));
+    j = -(pt1.y & (XY_ONE - 1));
+    pt1.x += ((step * j) >> XY_SHIFT) + (XY_ONE >> 1);
+    slope = (int)((step >> (XY_SHIFT - 5)) & 0x3f);
+    slope ^= (step < 0 ? 0x3f : 0);
+    i = (pt1.y >> (XY_SHIFT - 7)) & 0x78;
+    j = (pt2.y >> (XY_SHIFT - 7)) & 0x78;
+    L.flags = 1;
+    L.c0 = (int)(pt1.y >> XY_SHIFT);
+    L.m0 = pt1.x;
+  }
+  L.step = step;
+  L.E = ecount;
+  slope = (slope & 0x20) ? 0x100 : cSlopeCorr[slope];
+  const int t0 = slope << 7;
+  const int t1 = ((0x78 - (int)i) | 4) * slope;
+  const int t2 = ((int)j | 4) * slope;
+  L.ep[0] = 0;
+  L.ep[8] = (unsigned short)slope;
+  L.ep[1] = L.ep[3] = (unsigned short)(((((int)(j - i) & 0x78) | 4) * slope >> 8) & 0x1ff);
+  L.ep[2] = (unsigned short)((t1 >> 8) & 0x1ff);
+  L.ep[4] = (unsigned short)((((((int)(j - i) + 0x80) | 4) * slope) >> 8) & 0x1ff);
+  L.ep[5] = (unsigned short)(((t1 + t0) >> 8) & 0x1ff);
+  L.ep[6] = (unsigned short)((t2 >> 8) & 0x1ff);
+  L.ep[7] = (unsigned short)(((t2 + t0) >> 8) & 0x1ff);
+}
+
+// drawing.cpp FillConvexPoly (LINE_AA, shift 0, three points): the row loop only changes state at vertex rows, so
+// the same state machine is run from event row to event row and every walker piece is kept as (first row, x, dx)
+__device__ void setup_fill(OvFill& Fl, const OvFace& o, int W, int H) {
+  const int vx[3] = {o.px[0], o.px[1], o.px[2]}, vy[3] = {o.py[0], o.py[1], o.py[2]};
+  int imin = 0;
+  long long xmin = vx[0], xmax = vx[0], ymin = vy[0], ymax = vy[0];
+  for (int i = 0; i < 3; ++i) {
+    if (vy[i] < ymin) { ymin = vy[i]; imin = i; }
+    if (vy[i] > ymax) ymax = vy[i];
+    if (vx[i] > xmax) xmax = vx[i];
+    if (vx[i] < xmin) xmin = vx[i];
+  }
+  Fl.gray = o.gray;
+  Fl.bx0 = (int)max(xmin - kFringe, (long long)INT32_MIN); Fl.bx1 = (int)min(xmax + kFringe, (long long)INT32_MAX);
+  Fl.by0 = (int)max(ymin - kFringe, (long long)INT32_MIN); Fl.by1 = (int)min(ymax + kFringe, (long long)INT32_MAX);
+  Fl.y0 = 0; Fl.y1 = -1;
+  for (int w = 0; w < 2; ++w) {
+    Fl.ys[w][0] = (int)ymin; Fl.xs[w][0] = -XY_ONE; Fl.dx[w][0] = 0;
+    Fl.ys[w][1] = INT32_MAX; Fl.xs[w][1] = 0; Fl.dx[w][1] = 0;
+  }
+  if (xmax < 0 || ymax < 0 || xmin >= W || ymin >= H) return;
+  if (ymax > H - 1) ymax = H - 1;
+  int edges = 3;
+  int idxs[2] = {imin, imin}, di[2] = {1, 2}, ye[2] = {(int)ymin, (int)ymin}, npiece[2] = {0, 0};
+  int y = (int)ymin;
+  int y_end = (int)ymax;
+  for (;;) {
+    // an event row: (y < ymax || y == ymin) holds here by construction
+    for (int i = 0; i < 2; ++i) {
+      if (y >= ye[i]) {
+        int idx0 = idxs[i];
+        int idx = idx0 + di[i];
+        if (idx >= 3) idx -= 3;
+        for (; edges-- > 0;) {
+          const int ty = vy[idx];
+          if (ty > y) {
+            const long long xs = (long long)vx[idx0] * XY_ONE, xe = (long long)vx[idx] * XY_ONE;
+            ye[i] = ty;
+            const int p = min(npiece[i], 1);
+            Fl.ys[i][p] = y;
+            Fl.xs[i][p] = xs;
+            Fl.dx[i][p] = ((xe - xs) * 2 + (ty - y)) / (2 * (long long)(ty - y));
+            npiece[i] = p + 1;
+            idxs[i] = idx;
+            break;
+          }
+          idx0 = idx;
+          idx += di[i];
+          if (idx >= 3) idx -= 3;
+        }
+      }
+    }
+    if (edges < 0) { y_end = y - 1; break; }
+    const int next = min(ye[0], ye[1]);       // > y: every walker that was due has moved on (or edges < 0 above)
+    if (next <= y || next >= (int)ymax) break;   // no further update row before the last one
+    y = next;
+  }
+  Fl.y0 = max((int)ymin, 0);
+  Fl.y1 = y_end;
+}
+
+// ---- tiles --------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void blend2(int& v, int col, int a) {   // ICV_PUT_POINT, applied twice
+  v += ((col - v) * a + 127) >> 8;
+  v += ((col - v) * a + 127) >> 8;
+}
+
+__global__ __launch_bounds__(256) void k_ov_tiles(const OvFace* __restrict__ sorted, int nF, int W, int H, int tilesX,
+                                                  int tilesY, const unsigned* __restrict__ offset,
+                                                  const unsigned* __restrict__ entries,
+                                                  const unsigned* __restrict__ active,
+                                                  const unsigned* __restrict__ totals, unsigned char* __restrict__ images,
+                                                  size_t row_stride, size_t frame_stride) {
+  extern __shared__ unsigned char smem[];
+  const int nWords = (nF + 31) >> 5;
+  unsigned* bitmap = reinterpret_cast<unsigned*>(smem);                 // [nWords]
+  unsigned* wordPos = bitmap + nWords;                                  // [nWords] ordinal of the word's first bit
+  unsigned* list = wordPos + nWords;                                    // [kListCap]
+  OvLine* lines = reinterpret_cast<OvLine*>(list + kListCap);           // [kGroup][3]
+  OvFill* fills = reinterpret_cast<OvFill*>(lines + kGroup * 3);        // [kGroup]
+  unsigned* scan = reinterpret_cast<unsigned*>(fills + kGroup);         // [256]
+  unsigned char* filt = reinterpret_cast<unsigned char*>(scan + 256);   // [64]
+  const int tid = threadIdx.x;
+  if (tid < 64) filt[tid] = cFilter[tid];
+  const unsigned nActive = totals[1];
+  const int tilesPerFrame = tilesX * tilesY;
+  // 4 waves = 4 quadrants of 8x8 pixels: a triangle's bounding box is tested per wave
+  const int wave = tid >> 6, lane = tid & 63;
+  const int lx = (wave & 1) * 8 + (lane & 7), ly = (wave >> 1) * 8 + (lane >> 3);
+  const int per = (nWords + 255) / 256;
+
+  for (unsigned a = blockIdx.x; a < nActive; a += gridDim.x) {
+    const unsigned t = active[a];
+    const int frame = (int)(t / tilesPerFrame);
+    const int tt = (int)(t - (unsigned)frame * tilesPerFrame);
+    const int tx = tt % tilesX, ty = tt / tilesX;
+    const unsigned e0 = offset[t], e1 = offset[t + 1];
+    const OvFace* fs = sorted + (size_t)frame * nF;
+    const int px = tx * kTile + lx, py = ty * kTile + ly;
+    const bool inside = px < W && py < H;
+    unsigned char* pix = images + (size_t)frame * frame_stride + (size_t)py * row_stride + (size_t)px * 3;
+    int c0 = 0, c1 = 0, c2 = 0;
+    if (inside) { c0 = pix[0]; c1 = pix[1]; c2 = pix[2]; }
+    const int wx0 = tx * kTile + (wave & 1) * 8, wy0 = ty * kTile + (wave >> 1) * 8;
+
+    __syncthreads();   // previous tile's LDS is no longer read
+    for (int w = tid; w < nWords; w += 256) bitmap[w] = 0;
+    __syncthreads();
+    for (unsigned e = e0 + tid; e < e1; e += 256) {
+      const unsigned r = entries[e];
+      atomicOr(&bitmap[r >> 5], 1u << (r & 31));
+    }
+    __syncthreads();
+    {   // ordinal of every word's first set bit: block scan over `per` words per thread
+      unsigned s = 0;
+      for (int k = 0; k < per; ++k) { const int w = tid * per + k; if (w < nWords) s += __popc(bitmap[w]); }
+      scan[tid] = s;
+      __syncthreads();
+      for (int o = 1; o < 256; o <<= 1) {
+        const unsigned v = tid >= o ? scan[tid - o] : 0;
+        __syncthreads();
+        scan[tid] += v;
+        __syncthreads();
+      }
+      unsigned run = scan[tid] - s;
+      for (int k = 0; k < per; ++k) {
+        const int w = tid * per + k;
+        if (w < nWords) { wordPos[w] = run; run += __popc(bitmap[w]); }
+      }
+    }
+    __syncthreads();
+    const unsigned nList = e1 - e0;
+    for (unsigned pass0 = 0; pass0 < nList; pass0 += kListCap) {
+      // ranks with ordinal in [pass0, pass0 + kListCap), ascending
+      for (int w = tid; w < nWords; w += 256) {
+        unsigned bits = bitmap[w], pos = wordPos[w];
+        while (bits) {
+          const int b = __ffs(bits) - 1;
+          bits &= bits - 1;
+          if (pos >= pass0 && pos < pass0 + kListCap) list[pos - pass0] = (unsigned)(w * 32 + b);
+          ++pos;
+        }
+      }
+      __syncthreads();
+      const unsigned nPass = min((unsigned)kListCap, nList - pass0);
+      for (unsigned g0 = 0; g0 < nPass; g0 += kGroup) {
+        const int ng = (int)min((unsigned)kGroup, nPass - g0);
+        // set-up: threads 0..95 one edge each, threads 128..159 one fill each
+        if (tid < kGroup * 3) {
+          const int fi = tid / 3, li = tid - fi * 3;
+          if (fi < ng) {
+            const OvFace o = fs[list[g0 + fi]];
+            // FillConvexPoly draws p0 = v[2] -> v[0], v[0] -> v[1], v[1] -> v[2]
+            const int ia = li == 0 ? 2 : li - 1, ib = li;
+            setup_line(lines[fi * 3 + li], o.px[ia], o.py[ia], o.px[ib], o.py[ib], W, H);
+          }
+        } else if (tid >= 128 && tid < 128 + kGroup) {
+          const int fi = tid - 128;
+          if (fi < ng) setup_fill(fills[fi], fs[list[g0 + fi]], W, H);
+        }
+        __syncthreads();
+        for (int fi = 0; fi < ng; ++fi) {
+          const OvFill& Fl = fills[fi];
+          // wave-uniform reject: the wave's 8x8 pixels against the triangle's box + fringe
+          if (Fl.bx1 < wx0 || Fl.bx0 > wx0 + 7 || Fl.by1 < wy0 || Fl.by0 > wy0 + 7) continue;
+          const int g = Fl.gray;
+#pragma unroll
+          for (int li = 0; li < 3; ++li) {
+            const OvLine& L = lines[fi * 3 + li];
+            if (!(L.flags & 1)) continue;
+            const bool xm = (L.flags & 2) != 0;
+            const int major = xm ? px : py, minor = xm ? py : px;
+            const int k = major - L.c0;
+            if ((unsigned)k <= (unsigned)L.E && L.E >= 0) {
+              const long long m = L.m0 + (long long)k * L.step;
+              const int d = minor - ((int)(m >> XY_SHIFT) - 1);
+              if ((unsigned)d < 3u) {
+                const int dist = (int)((m >> (XY_SHIFT - 5)) & 31);
+                const int f = d == 0 ? filt[dist + 32] : (d == 1 ? filt[dist] : filt[63 - dist]);
+                const int ep = L.ep[min(k, 2) * 3 + min(L.E - k, 2)];
+                const int al = (ep * f >> 8) & 0xff;
+                blend2(c0, g, al); blend2(c1, g, al); blend2(c2, g, al);
+              }
+            }
+          }
+          if (py >= Fl.y0 && py <= Fl.y1) {
+            const int p0 = py >= Fl.ys[0][1] ? 1 : 0, p1 = py >= Fl.ys[1][1] ? 1 : 0;
+            long long xa = Fl.xs[0][p0] + Fl.dx[0][p0] * (long long)(py - Fl.ys[0][p0]);
+            long long xb = Fl.xs[1][p1] + Fl.dx[1][p1] * (long long)(py - Fl.ys[1][p1]);
+            if (xa > xb) { const long long tmp = xa; xa = xb; xb = tmp; }
+            const int xx1 = (int)((xa + (XY_ONE - 1)) >> XY_SHIFT), xx2 = (int)(xb >> XY_SHIFT);
+            if (px >= xx1 && px <= xx2) { c0 = g; c1 = g; c2 = g; }
+          }
+        }
+        __syncthreads();
+      }
+    }
+    if (inside) { pix[0] = (unsigned char)c0; pix[1] = (unsigned char)c1; pix[2] = (unsigned char)c2; }
+  }
+}
+
+size_t tile_lds_bytes(int nF) {
+  const int nWords = (nF + 31) >> 5;
+  return (size_t)nWords * 8 + kListCap * 4 + sizeof(OvLine) * kGroup * 3 + sizeof(OvFill) * kGroup + 256 * 4 + 64;
+}
+
+#define OV_TRY(expr)                                                                                          \
+  do {                                                                                                        \
+    hipError_t e_ = (expr);                                                                                   \
+    if (e_ != hipSuccess)                                                                                     \
+      return bodyfit_internal_fail(BODYFIT_ERR_HIP, (std::string(#expr) + ": " + hipGetErrorString(e_)).c_str()); \
+  } while (0)
+
+}  // namespace
+
+struct bodyfit_overlay {
+  int device = 0, nV = 0, nF = 0, W = 0, H = 0, maxFrames = 0;
+  int tilesX = 0, tilesY = 0, nChunks = 0;
+  int* d_faces = nullptr;
+  OvFace *d_tmp = nullptr, *d_sorted = nullptr;
+  unsigned long long *d_key = nullptr, *d_skey = nullptr;
+  unsigned *d_sidx = nullptr, *d_count = nullptr, *d_offset = nullptr, *d_blockSum = nullptr, *d_active = nullptr,
+           *d_totals = nullptr, *d_entries = nullptr;
+  int* d_alive = nullptr;
+  size_t entriesCap = 0;
+  void* d_cloud = nullptr;          // staging of the host form
+  size_t cloudCap = 0;
+  unsigned char* d_images = nullptr;
+  size_t imagesCap = 0;
+  int lastFrames = 0;
+  hipEvent_t ev[5] = {};
+  bool timed = false;
+  std::vector<void*> owned;
+  template <typename T>
+  hipError_t alloc(T** p, size_t n) {
+    void* q = nullptr;
+    hipError_t e = hipMalloc(&q, std::max<size_t>(n, 1) * sizeof(T));
+    if (e == hipSuccess) { owned.push_back(q); *p = static_cast<T*>(q); }
+    return e;
+  }
+  ~bodyfit_overlay() {
+    for (void* q : owned) (void)hipFree(q);
+    if (d_entries) (void)hipFree(d_entries);
+    if (d_cloud) (void)hipFree(d_cloud);
+    if (d_images) (void)hipFree(d_images);
+    for (auto& e : ev) if (e) (void)hipEventDestroy(e);
+  }
+};
+
+extern "C" {
+
+int bodyfit_overlay_create(const bodyfit_overlay_desc* desc, bodyfit_overlay** out) {
+  if (!desc || !out || !desc->faces) return bodyfit_internal_fail(BODYFIT_ERR_INVALID, "bodyfit_overlay_create: null argument");
+  if (desc->n_faces < 1 || desc->n_faces > kMaxFaces || desc->n_vertices < 1 || desc->width < 1 || desc->height < 1 ||
+      desc->max_frames < 1 || desc->width > 32768 || desc->height > 32768)
+    return bodyfit_internal_fail(BODYFIT_ERR_INVALID, "bodyfit_overlay_create: sizes out of range (n_faces <= 65536)");
+  for (int i = 0; i < desc->n_faces * 3; ++i)
+    if (desc->faces[i] < 0 || desc->faces[i] >= desc->n_vertices)
+      return bodyfit_internal_fail(BODYFIT_ERR_INVALID, "bodyfit_overlay_create: face refers to a vertex out of range");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || desc->device < 0 || desc->device >= ndev)
+    return bodyfit_internal_fail(BODYFIT_ERR_HIP, "bodyfit_overlay_create: no such HIP device (there is no CPU path)");
+  OV_TRY(hipSetDevice(desc->device));
+  auto* ov = new bodyfit_overlay;
+  ov->device = desc->device; ov->nV = desc->n_vertices; ov->nF = desc->n_faces; ov->W = desc->width; ov->H = desc->height;
+  ov->maxFrames = desc->max_frames;
+  ov->tilesX = (ov->W + kTile - 1) / kTile; ov->tilesY = (ov->H + kTile - 1) / kTile;
+  ov->nChunks = (ov->nF + kChunk - 1) / kChunk;
+  const size_t F = ov->maxFrames, nT = F * ov->tilesX * ov->tilesY;
+  const size_t nBlocks = (nT + 1 + kScanBlock - 1) / kScanBlock;
+  hipError_t e = hipSuccess;
+  auto chk = [&](hipError_t r) { if (e == hipSuccess) e = r; };
+  chk(ov->alloc(&ov->d_faces, (size_t)ov->nF * 3));
+  chk(ov->alloc(&ov->d_tmp, F * ov->nF));
+  chk(ov->alloc(&ov->d_sorted, F * ov->nF));
+  chk(ov->alloc(&ov->d_key, F * ov->nF));
+  chk(ov->alloc(&ov->d_skey, F * ov->nChunks * kChunk));
+  chk(ov->alloc(&ov->d_sidx, F * ov->nChunks * kChunk));
+  chk(ov->alloc(&ov->d_count, nT + 1));
+  chk(ov->alloc(&ov->d_offset, nT + 1));
+  chk(ov->alloc(&ov->d_blockSum, nBlocks));
+  chk(ov->alloc(&ov->d_active, nT));
+  chk(ov->alloc(&ov->d_totals, 4));
+  chk(ov->alloc(&ov->d_alive, F));
+  if (e == hipSuccess) e = hipMemcpy(ov->d_faces, desc->faces, (size_t)ov->nF * 3 * sizeof(int), hipMemcpyHostToDevice);
+  for (auto& evn : ov->ev) if (e == hipSuccess) e = hipEventCreate(&evn);
+  if (e == hipSuccess)
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_ov_sort_chunks), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            kChunk * 12);
+  if (e != hipSuccess) {
+    delete ov;
+    return bodyfit_internal_fail(BODYFIT_ERR_HIP, (std::string("bodyfit_overlay_create: ") + hipGetErrorString(e)).c_str());
+  }
+  *out = ov;
+  return BODYFIT_OK;
+}
+
+void bodyfit_overlay_destroy(bodyfit_overlay* ov) {
+  if (!ov) return;
+  (void)hipSetDevice(ov->device);
+  delete ov;
+}
+
+int bodyfit_overlay_render_device(bodyfit_overlay* ov, const void* d_cloud, int cloud_is_f64,
+                                  size_t cloud_frame_stride_elems, int n_frames, uint8_t* d_images, size_t row_stride,
+                                  size_t frame_stride, double fx, double fy, double cx, double cy, int fill,
+                                  int backface_cull, int wireframe, void* stream) {
+  if (!ov || !d_cloud || !d_images) return bodyfit_internal_fail(BODYFIT_ERR_INVALID, "bodyfit_overlay_render: null argument");
+  if (wireframe) return bodyfit_internal_fail(BODYFIT_ERR_INVALID, "bodyfit_overlay_render: wireframe is not supported");
+  if (n_frames < 1 || n_frames > ov->maxFrames)
+    return bodyfit_internal_fail(BODYFIT_ERR_INVALID, "bodyfit_overlay_render: n_frames exceeds max_frames");
+  if (cloud_frame_stride_elems < (size_t)ov->nV * 3 || row_stride < (size_t)ov->W * 3 ||
+      (n_frames > 1 && frame_stride < row_stride * (size_t)ov->H))
+    return bodyfit_internal_fail(BODYFIT_ERR_INVALID, "bodyfit_overlay_render: strides smaller than the data");
+  OV_TRY(hipSetDevice(ov->device));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int F = n_frames, nF = ov->nF;
+  const size_t nT = (size_t)F * ov->tilesX * ov->tilesY;
+  // the scan runs over nT + 1 counts (the last one is zero), so that offset[nT] is the total
+  const int nBlocks = (int)((nT + 1 + kScanBlock - 1) / kScanBlock);
+  ov->lastFrames = F;
+  ov->timed = false;
+  OV_TRY(hipEventRecord(ov->ev[0], st));
+  {
+    dim3 grid((nF + 255) / 256, F);
+    if (cloud_is_f64)
+      hipLaunchKernelGGL(k_ov_faces<double>, grid, dim3(256), 0, st, static_cast<const double*>(d_cloud),
+                         cloud_frame_stride_elems, ov->d_faces, nF, ov->nV, fx, fy, cx, cy, backface_cull, ov->d_tmp,
+                         ov->d_key);
+    else
+      hipLaunchKernelGGL(k_ov_faces<float>, grid, dim3(256), 0, st, static_cast<const float*>(d_cloud),
+                         cloud_frame_stride_elems, ov->d_faces, nF, ov->nV, fx, fy, cx, cy, backface_cull, ov->d_tmp,
+                         ov->d_key);
+  }
+  OV_TRY(hipEventRecord(ov->ev[1], st));
+  OV_TRY(hipMemsetAsync(ov->d_alive, 0, sizeof(int) * F, st));
+  hipLaunchKernelGGL(k_ov_sort_chunks, dim3(ov->nChunks, F), dim3(kSortThreads), kChunk * 12, st, ov->d_key, nF,
+                     ov->nChunks, ov->d_skey, ov->d_sidx);
+  hipLaunchKernelGGL(k_ov_rank, dim3((ov->nChunks * kChunk + 255) / 256, F), dim3(256), 0, st, ov->d_skey, ov->d_sidx, nF,
+                     ov->nChunks, ov->d_tmp, ov->d_sorted, ov->d_alive);
+  OV_TRY(hipEventRecord(ov->ev[2], st));
+  if (!fill) {   // wireframe is off too: the reference draws nothing (RenderSMPLMesh.h:97,106)
+    OV_TRY(hipEventRecord(ov->ev[3], st));
+    OV_TRY(hipEventRecord(ov->ev[4], st));
+    OV_TRY(hipGetLastError());
+    ov->timed = true;
+    return BODYFIT_OK;
+  }
+  OV_TRY(hipMemsetAsync(ov->d_count, 0, sizeof(unsigned) * (nT + 1), st));
+  OV_TRY(hipMemsetAsync(ov->d_totals, 0, sizeof(unsigned) * 4, st));
+  hipLaunchKernelGGL(k_ov_bin<false>, dim3((nF + 255) / 256, F), dim3(256), 0, st, ov->d_sorted, nF, ov->W, ov->H,
+                     ov->tilesX, ov->tilesY, ov->d_count, ov->d_offset, ov->d_entries);
+  hipLaunchKernelGGL(k_ov_scan1, dim3(nBlocks), dim3(256), 0, st, ov->d_count, nT + 1, ov->d_blockSum);
+  hipLaunchKernelGGL(k_ov_scan2, dim3(1), dim3(1024), 0, st, ov->d_blockSum, nBlocks, ov->d_totals);
+  hipLaunchKernelGGL(k_ov_scan3, dim3(nBlocks), dim3(256), 0, st, ov->d_count, nT + 1, ov->d_blockSum, ov->d_offset,
+                     ov->d_active, ov->d_totals);
+  unsigned totals[2] = {0, 0};
+  OV_TRY(hipMemcpyAsync(totals, ov->d_totals, sizeof(totals), hipMemcpyDeviceToHost, st));
+  OV_TRY(hipStreamSynchronize(st));
+  if (totals[0] > ov->entriesCap) {
+    if (ov->d_entries) OV_TRY(hipFree(ov->d_entries));
+    ov->d_entries = nullptr;
+    ov->entriesCap = (size_t)totals[0] + totals[0] / 4 + 1024;
+    void* q = nullptr;
+    OV_TRY(hipMalloc(&q, ov->entriesCap * sizeof(unsigned)));
+    ov->d_entries = static_cast<unsigned*>(q);
+  }
+  if (totals[0]) {
+    hipLaunchKernelGGL(k_ov_bin<true>, dim3((nF + 255) / 256, F), dim3(256), 0, st, ov->d_sorted, nF, ov->W, ov->H,
+                       ov->tilesX, ov->tilesY, ov->d_count, ov->d_offset, ov->d_entries);
+  }
+  OV_TRY(hipEventRecord(ov->ev[3], st));
+  if (totals[1]) {
+    const int grid = (int)std::min<unsigned>(totals[1], 256u * 16u);
+    hipLaunchKernelGGL(k_ov_tiles, dim3(grid), dim3(256), tile_lds_bytes(nF), st, ov->d_sorted, nF, ov->W, ov->H,
+                       ov->tilesX, ov->tilesY, ov->d_offset, ov->d_entries, ov->d_active, ov->d_totals, d_images,
+                       row_stride, frame_stride);
+  }
+  OV_TRY(hipEventRecord(ov->ev[4], st));
+  OV_TRY(hipGetLastError());
+  ov->timed = true;
+  return BODYFIT_OK;
+}
+
+int bodyfit_overlay_render(bodyfit_overlay* ov, const void* cloud, int cloud_is_f64, size_t cloud_frame_stride_elems,
+                           int n_frames, uint8_t* images, size_t row_stride, size_t frame_stride, double fx, double fy,
+                           double cx, double cy, int fill, int backface_cull, int wireframe) {
+  if (!ov || !cloud || !images) return bodyfit_internal_fail(BODYFIT_ERR_INVALID, "bodyfit_overlay_render: null argument");
+  if (n_frames < 1 || n_frames > ov->maxFrames)
+    return bodyfit_internal_fail(BODYFIT_ERR_INVALID, "bodyfit_overlay_render: n_frames exceeds max_frames");
+  if (row_stride < (size_t)ov->W * 3 || (n_frames > 1 && frame_stride < row_stride * (size_t)ov->H))
+    return bodyfit_internal_fail(BODYFIT_ERR_INVALID, "bodyfit_overlay_render: strides smaller than the data");
+  OV_TRY(hipSetDevice(ov->device));
+  const size_t esz = cloud_is_f64 ? 8 : 4;
+  const size_t cbytes = ((size_t)(n_frames - 1) * cloud_frame_stride_elems + (size_t)ov->nV * 3) * esz;
+  const size_t ibytes = (size_t)(n_frames - 1) * frame_stride + row_stride * (size_t)ov->H;
+  if (cbytes > ov->cloudCap) {
+    if (ov->d_cloud) OV_TRY(hipFree(ov->d_cloud));
+    ov->d_cloud = nullptr; ov->cloudCap = 0;
+    OV_TRY(hipMalloc(&ov->d_cloud, cbytes));
+    ov->cloudCap = cbytes;
+  }
+  if (ibytes > ov->imagesCap) {
+    if (ov->d_images) OV_TRY(hipFree(ov->d_images));
+    ov->d_images = nullptr; ov->imagesCap = 0;
+    void* q = nullptr;
+    OV_TRY(hipMalloc(&q, ibytes));
+    ov->d_images = static_cast<unsigned char*>(q);
+    ov->imagesCap = ibytes;
+  }
+  OV_TRY(hipMemcpy(ov->d_cloud, cloud, cbytes, hipMemcpyHostToDevice));
+  OV_TRY(hipMemcpy(ov->d_images, images, ibytes, hipMemcpyHostToDevice));
+  const int rc = bodyfit_overlay_render_device(ov, ov->d_cloud, cloud_is_f64, cloud_frame_stride_elems, n_frames,
+                                               ov->d_images, row_stride, frame_stride, fx, fy, cx, cy, fill,
+                                               backface_cull, wireframe, nullptr);
+  if (rc) return rc;
+  OV_TRY(hipDeviceSynchronize());
+  OV_TRY(hipMemcpy(images, ov->d_images, ibytes, hipMemcpyDeviceToHost));
+  return BODYFIT_OK;
+}
+
+int bodyfit_overlay_drawlist(bodyfit_overlay* ov, int frame, int* n_items, int32_t* face, int32_t* corners,
+                             int32_t* gray) {
+  if (!ov || !n_items) return bodyfit_internal_fail(BODYFIT_ERR_INVALID, "bodyfit_overlay_drawlist: null argument");
+  if (frame < 0 || frame >= ov->lastFrames)
+    return bodyfit_internal_fail(BODYFIT_ERR_INVALID, "bodyfit_overlay_drawlist: frame was not part of the latest render");
+  OV_TRY(hipSetDevice(ov->device));
+  OV_TRY(hipDeviceSynchronize());
+  int n = 0;
+  OV_TRY(hipMemcpy(&n, ov->d_alive + frame, sizeof(int), hipMemcpyDeviceToHost));
+  std::vector<OvFace> h((size_t)std::max(n, 1));
+  if (n) OV_TRY(hipMemcpy(h.data(), ov->d_sorted + (size_t)frame * ov->nF, sizeof(OvFace) * n, hipMemcpyDeviceToHost));
+  for (int k = 0; k < n; ++k) {
+    if (face) face[k] = h[k].face;
+    if (gray) gray[k] = h[k].gray;
+    if (corners)
+      for (int c = 0; c < 3; ++c) { corners[6 * k + 2 * c] = h[k].px[c]; corners[6 * k + 2 * c + 1] = h[k].py[c]; }
+  }
+  *n_items = n;
+  return BODYFIT_OK;
+}
+
+int bodyfit_overlay_last_timing(bodyfit_overlay* ov, float ms[4]) {
+  if (!ov || !ms) return bodyfit_internal_fail(BODYFIT_ERR_INVALID, "bodyfit_overlay_last_timing: null argument");
+  if (!ov->timed) return bodyfit_internal_fail(BODYFIT_ERR_INVALID, "bodyfit_overlay_last_timing: nothing rendered yet");
+  OV_TRY(hipSetDevice(ov->device));
+  OV_TRY(hipEventSynchronize(ov->ev[4]));
+  for (int i = 0; i < 4; ++i) OV_TRY(hipEventElapsedTime(&ms[i], ov->ev[i], ov->ev[i + 1]));
+  return BODYFIT_OK;
+}
+
+}  // extern "C"

@@ -115,6 +115,8 @@ def load_smpl_npz(path: str, landmark_vid=()) -> synth.SynthModel:
     m = synth.SynthModel(np.asarray(z["v_template"], float), np.asarray(z["shapedirs"], float)[:, :, :10],
                          np.asarray(z["posedirs"], float), jr, np.asarray(z["weights"], float),
                          parent.astype(np.int32), np.asarray(landmark_vid, np.int32))
+    if "f" in z.files:
+        m.faces = np.ascontiguousarray(z["f"], dtype=np.int32)   # AvatarModel::mesh (src/main_single_frame.cpp:185-188)
     return m.finalize()
 
 

@@ -94,6 +94,7 @@ class SynthModel:
     # derived (f64): initialJointPos, jointShapeReg  (avatar: jointShapeRegBase / jointShapeReg)
     J0: np.ndarray = field(default=None)
     S: np.ndarray = field(default=None)
+    faces: np.ndarray = field(default=None)  # [nF,3] int32 triangles (AvatarModel::mesh); optional
 
     @property
     def n_verts(self):
@@ -111,6 +112,26 @@ class SynthModel:
         self.J0 = self.j_regressor @ self.v_template
         self.S = np.einsum("jv,vak->jak", self.j_regressor, self.shapedirs).reshape(3 * self.n_joints, -1)
         return self
+
+
+N_FACES = 13776  # SMPL: 2 V - 4
+
+
+def make_faces(model: "SynthModel", n_faces: int = N_FACES, seed: int = 0) -> np.ndarray:
+    """Synthetic connectivity for the overlay (the capsule point cloud has none): two triangles per vertex with its
+    nearest neighbours, so the triangles have the size of the local vertex spacing and a random orientation (about half
+    of them face the camera, as on a closed surface)."""
+    from scipy.spatial import cKDTree
+
+    v = model.v_template
+    k = 2 * ((n_faces + len(v) - 1) // len(v)) + 1
+    _, nn = cKDTree(v).query(v, k=min(k, len(v)))
+    tris = []
+    for c in range(1, nn.shape[1] - 1, 2):
+        tris.append(np.stack([nn[:, 0], nn[:, c], nn[:, c + 1]], 1))
+    f = np.concatenate(tris, 0)
+    f = f[np.random.default_rng(seed).permutation(len(f))[:n_faces]]
+    return np.ascontiguousarray(f, dtype=np.int32)
 
 
 def _seg_dist(p, a, b):

@@ -38,6 +38,8 @@
  */
 #ifndef BODYFIT_H_
 #define BODYFIT_H_
+#include <stddef.h>
+#include <stdint.h>
 
 #ifdef __cplusplus
 extern "C" {
@@ -234,6 +236,47 @@ int bodyfit_solve(bodyfit_problem* p, double* frame_params, double* beta, const 
  * Needs <= 32 keypoints per frame.                                                                        */
 int bodyfit_frame_normals(bodyfit_problem* p, const double* frame_params, const double* beta, double* residuals,
                           int* gmm_comp, double* normals);
+
+/* ---- mesh overlay ------------------------------------------------------------------------
+ * smpl::render::renderSMPLMesh(cloud, faces, img, fx, fy, cx, cy, fill, backface_cull, wireframe) of
+ * include/RenderSMPLMesh.h:16-110, batched over frames with the posed vertices and the 8-bit BGR images
+ * resident on the device: project (:36-46), per-face cull / flat shade / painter depth / integer corners
+ * (:50-88), far-to-near order (:91-92; ties by face index, the reference's std::sort leaves them unspecified)
+ * and cv::fillConvexPoly(..., LINE_AA) per triangle in that order (:95-104).  The result is, pixel for pixel,
+ * what drawing the triangles one after the other gives.  wireframe != 0 (:106-109, never enabled by the
+ * reference's callers: src/main_single_frame.cpp:274, src/main_multi_frame.cpp:210,223) is rejected with
+ * BODYFIT_ERR_INVALID; fill == 0 then draws nothing, as there.
+ *   faces [n_faces][3] vertex ids (ark::AvatarModel::mesh columns, src/main_single_frame.cpp:185-188)
+ *   cloud: x, y, z per vertex (the memory order of the reference's 3xN column-major `cloud`), camera
+ *   coordinates; cloud_is_f64 0: float (bodyfit_device_views.cloud of a write-back), 1: double
+ *   images: n_frames images of height x width x 3 bytes, row_stride / frame_stride in bytes, modified in place
+ *   (the reference draws into a clone of the video frame)                                                    */
+typedef struct bodyfit_overlay bodyfit_overlay;
+typedef struct bodyfit_overlay_desc {
+  int device;
+  int n_vertices, n_faces;
+  const int32_t* faces;
+  int width, height;
+  int max_frames;
+} bodyfit_overlay_desc;
+int bodyfit_overlay_create(const bodyfit_overlay_desc* desc, bodyfit_overlay** out);
+void bodyfit_overlay_destroy(bodyfit_overlay* ov);
+/* device pointers; asynchronous on `stream` except for one 8-byte read-back that sizes the tile lists */
+int bodyfit_overlay_render_device(bodyfit_overlay* ov, const void* d_cloud, int cloud_is_f64,
+                                  size_t cloud_frame_stride_elems, int n_frames, uint8_t* d_images,
+                                  size_t row_stride, size_t frame_stride, double fx, double fy, double cx,
+                                  double cy, int fill, int backface_cull, int wireframe, void* stream);
+/* host pointers (upload, render, download): the one-call form of the reference function */
+int bodyfit_overlay_render(bodyfit_overlay* ov, const void* cloud, int cloud_is_f64, size_t cloud_frame_stride_elems,
+                           int n_frames, uint8_t* images, size_t row_stride, size_t frame_stride, double fx,
+                           double fy, double cx, double cy, int fill, int backface_cull, int wireframe);
+/* draw list of `frame` from the latest render (far to near): face ids [n], corners [n][6] = x0 y0 x1 y1 x2 y2,
+ * gray levels [n]; each array may be NULL; returns the count in *n_items                                   */
+int bodyfit_overlay_drawlist(bodyfit_overlay* ov, int frame, int* n_items, int32_t* face, int32_t* corners,
+                             int32_t* gray);
+/* average launch durations (ms) of the overlay kernels of the latest render_device call, by HIP events:
+ * [0] faces, [1] sort + rank, [2] binning (count, scan, fill), [3] tiles                                  */
+int bodyfit_overlay_last_timing(bodyfit_overlay* ov, float ms[4]);
 
 const char* bodyfit_last_error(void);
 int bodyfit_device_count(void);
