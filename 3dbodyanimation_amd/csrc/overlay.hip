@@ -61,12 +61,13 @@ struct OvFace {      // 32 bytes
   int face;
 };
 
-struct OvLine {      // one anti-aliased edge after clipping, closed form along its major axis
-  long long m0, step;
+struct OvLine {      // one anti-aliased edge after clipping, closed form along its major axis (48 bytes)
+  long long m0;      // minor coordinate at step 0, 16.16
+  int step;          // minor increment per step, |step| <= 1 << 16
   int c0, E;         // first major coordinate, last step index (steps 0..E)
   int flags;         // bit 0 drawn, bit 1 x-major
   unsigned short ep[9];
-  unsigned short pad;
+  unsigned short pad[3];
 };
 
 struct OvFill {      // the two edge walkers of FillConvexPoly, at most two linear pieces each
@@ -75,7 +76,14 @@ struct OvFill {      // the two edge walkers of FillConvexPoly, at most two line
   int y0, y1;        // rows drawn: y0..y1 (empty when y1 < y0)
   int gray;
   int bx0, by0, bx1, by1;   // bounding box + fringe (quick reject)
+  int pad;
 };
+
+struct OvTri {       // everything the per-pixel fold needs of one triangle: 256 bytes, made once by k_ov_setup
+  OvLine l[3];
+  OvFill f;
+};
+static_assert(sizeof(OvLine) == 48 && sizeof(OvFill) == 112 && sizeof(OvTri) == 256, "OvTri layout");
 
 __device__ __forceinline__ int round_to_int(float f) {
   const float r = roundf(f);
@@ -385,7 +393,7 @@ __device__ void setup_line(OvLine& L, int xa, int ya, int xb, int yb, int W, int
     L.c0 = (int)(pt1.y >> XY_SHIFT);
     L.m0 = pt1.x;
   }
-  L.step = step;
+  L.step = (int)step;   // |dy| <= ax (resp. |dx| <= ay): at most one minor pixel per step
   L.E = ecount;
   slope = (slope & 0x20) ? 0x100 : cSlopeCorr[slope];
   const int t0 = slope << 7;
@@ -403,63 +411,87 @@ __device__ void setup_line(OvLine& L, int xa, int ya, int xb, int yb, int W, int
 
 // drawing.cpp FillConvexPoly (LINE_AA, shift 0, three points): the row loop only changes state at vertex rows, so
 // the same state machine is run from event row to event row and every walker piece is kept as (first row, x, dx)
+__device__ __forceinline__ int sel3(int a, int b, int c, int i) { return i == 0 ? a : (i == 1 ? b : c); }
+
 __device__ void setup_fill(OvFill& Fl, const OvFace& o, int W, int H) {
-  const int vx[3] = {o.px[0], o.px[1], o.px[2]}, vy[3] = {o.py[0], o.py[1], o.py[2]};
+  const int vx0 = o.px[0], vx1 = o.px[1], vx2 = o.px[2], vy0 = o.py[0], vy1 = o.py[1], vy2 = o.py[2];
   int imin = 0;
-  long long xmin = vx[0], xmax = vx[0], ymin = vy[0], ymax = vy[0];
-  for (int i = 0; i < 3; ++i) {
-    if (vy[i] < ymin) { ymin = vy[i]; imin = i; }
-    if (vy[i] > ymax) ymax = vy[i];
-    if (vx[i] > xmax) xmax = vx[i];
-    if (vx[i] < xmin) xmin = vx[i];
-  }
+  long long ymin = vy0;
+  if (vy1 < ymin) { ymin = vy1; imin = 1; }
+  if (vy2 < ymin) { ymin = vy2; imin = 2; }
+  long long ymax = max(vy0, max(vy1, vy2));
+  const long long xmin = min(vx0, min(vx1, vx2)), xmax = max(vx0, max(vx1, vx2));
   Fl.gray = o.gray;
+  Fl.pad = 0;
   Fl.bx0 = (int)max(xmin - kFringe, (long long)INT32_MIN); Fl.bx1 = (int)min(xmax + kFringe, (long long)INT32_MAX);
   Fl.by0 = (int)max(ymin - kFringe, (long long)INT32_MIN); Fl.by1 = (int)min(ymax + kFringe, (long long)INT32_MAX);
   Fl.y0 = 0; Fl.y1 = -1;
-  for (int w = 0; w < 2; ++w) {
-    Fl.ys[w][0] = (int)ymin; Fl.xs[w][0] = -XY_ONE; Fl.dx[w][0] = 0;
-    Fl.ys[w][1] = INT32_MAX; Fl.xs[w][1] = 0; Fl.dx[w][1] = 0;
-  }
-  if (xmax < 0 || ymax < 0 || xmin >= W || ymin >= H) return;
+  long long xs[2][2] = {{-XY_ONE, 0}, {-XY_ONE, 0}}, dxs[2][2] = {{0, 0}, {0, 0}};
+  int ys[2][2] = {{(int)ymin, INT32_MAX}, {(int)ymin, INT32_MAX}};
+  auto store = [&]() {
+    for (int w = 0; w < 2; ++w)
+      for (int q = 0; q < 2; ++q) { Fl.xs[w][q] = xs[w][q]; Fl.dx[w][q] = dxs[w][q]; Fl.ys[w][q] = ys[w][q]; }
+  };
+  if (xmax < 0 || ymax < 0 || xmin >= W || ymin >= H) { store(); return; }
   if (ymax > H - 1) ymax = H - 1;
   int edges = 3;
-  int idxs[2] = {imin, imin}, di[2] = {1, 2}, ye[2] = {(int)ymin, (int)ymin}, npiece[2] = {0, 0};
+  int idx_a = imin, idx_b = imin, ye_a = (int)ymin, ye_b = (int)ymin, np_a = 0, np_b = 0;
   int y = (int)ymin;
   int y_end = (int)ymax;
   for (;;) {
     // an event row: (y < ymax || y == ymin) holds here by construction
+#pragma unroll
     for (int i = 0; i < 2; ++i) {
-      if (y >= ye[i]) {
-        int idx0 = idxs[i];
-        int idx = idx0 + di[i];
+      const int ye = i ? ye_b : ye_a;
+      if (y >= ye) {
+        int idx0 = i ? idx_b : idx_a;
+        const int di = i ? 2 : 1;
+        int idx = idx0 + di;
         if (idx >= 3) idx -= 3;
         for (; edges-- > 0;) {
-          const int ty = vy[idx];
+          const int ty = sel3(vy0, vy1, vy2, idx);
           if (ty > y) {
-            const long long xs = (long long)vx[idx0] * XY_ONE, xe = (long long)vx[idx] * XY_ONE;
-            ye[i] = ty;
-            const int p = min(npiece[i], 1);
-            Fl.ys[i][p] = y;
-            Fl.xs[i][p] = xs;
-            Fl.dx[i][p] = ((xe - xs) * 2 + (ty - y)) / (2 * (long long)(ty - y));
-            npiece[i] = p + 1;
-            idxs[i] = idx;
+            const long long x0 = (long long)sel3(vx0, vx1, vx2, idx0) * XY_ONE;
+            const long long x1 = (long long)sel3(vx0, vx1, vx2, idx) * XY_ONE;
+            const long long d = ((x1 - x0) * 2 + (ty - y)) / (2 * (long long)(ty - y));
+            const int q = min(i ? np_b : np_a, 1);
+            if (i) { ye_b = ty; idx_b = idx; np_b = q + 1; } else { ye_a = ty; idx_a = idx; np_a = q + 1; }
+#pragma unroll
+            for (int qq = 0; qq < 2; ++qq)
+              if (qq == q) { ys[i][qq] = y; xs[i][qq] = x0; dxs[i][qq] = d; }
             break;
           }
           idx0 = idx;
-          idx += di[i];
+          idx += di;
           if (idx >= 3) idx -= 3;
         }
       }
     }
     if (edges < 0) { y_end = y - 1; break; }
-    const int next = min(ye[0], ye[1]);       // > y: every walker that was due has moved on (or edges < 0 above)
+    const int next = min(ye_a, ye_b);         // > y: every walker that was due has moved on (or edges < 0 above)
     if (next <= y || next >= (int)ymax) break;   // no further update row before the last one
     y = next;
   }
+  store();
   Fl.y0 = max((int)ymin, 0);
   Fl.y1 = y_end;
+}
+
+// one thread per (frame, rank): the triangle's three AA edges and its fill walkers, once, for every tile it touches
+__global__ __launch_bounds__(256) void k_ov_setup(const OvFace* __restrict__ sorted, int nF, int W, int H,
+                                                  OvTri* __restrict__ tris) {
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  const int frame = blockIdx.y;
+  if (r >= nF) return;
+  const OvFace o = sorted[(size_t)frame * nF + r];
+  if (o.gray < 0) return;
+  OvTri t = {};
+  // FillConvexPoly draws p0 = v[2] -> v[0], v[0] -> v[1], v[1] -> v[2]
+  setup_line(t.l[0], o.px[2], o.py[2], o.px[0], o.py[0], W, H);
+  setup_line(t.l[1], o.px[0], o.py[0], o.px[1], o.py[1], W, H);
+  setup_line(t.l[2], o.px[1], o.py[1], o.px[2], o.py[2], W, H);
+  setup_fill(t.f, o, W, H);
+  tris[(size_t)frame * nF + r] = t;
 }
 
 // ---- tiles --------------------------------------------------------------------------------------------------
@@ -468,7 +500,7 @@ __device__ __forceinline__ void blend2(int& v, int col, int a) {   // ICV_PUT_PO
   v += ((col - v) * a + 127) >> 8;
 }
 
-__global__ __launch_bounds__(256) void k_ov_tiles(const OvFace* __restrict__ sorted, int nF, int W, int H, int tilesX,
+__global__ __launch_bounds__(256) void k_ov_tiles(const OvTri* __restrict__ tris, int nF, int W, int H, int tilesX,
                                                   int tilesY, const unsigned* __restrict__ offset,
                                                   const unsigned* __restrict__ entries,
                                                   const unsigned* __restrict__ active,
@@ -476,13 +508,13 @@ __global__ __launch_bounds__(256) void k_ov_tiles(const OvFace* __restrict__ sor
                                                   size_t row_stride, size_t frame_stride) {
   extern __shared__ unsigned char smem[];
   const int nWords = (nF + 31) >> 5;
-  unsigned* bitmap = reinterpret_cast<unsigned*>(smem);                 // [nWords]
-  unsigned* wordPos = bitmap + nWords;                                  // [nWords] ordinal of the word's first bit
-  unsigned* list = wordPos + nWords;                                    // [kListCap]
-  OvLine* lines = reinterpret_cast<OvLine*>(list + kListCap);           // [kGroup][3]
-  OvFill* fills = reinterpret_cast<OvFill*>(lines + kGroup * 3);        // [kGroup]
-  unsigned* scan = reinterpret_cast<unsigned*>(fills + kGroup);         // [256]
-  unsigned char* filt = reinterpret_cast<unsigned char*>(scan + 256);   // [64]
+  OvTri* tri = reinterpret_cast<OvTri*>(smem);                          // [kGroup]
+  unsigned* list = reinterpret_cast<unsigned*>(tri + kGroup);           // [kListCap] ranks in draw order
+  unsigned* raw = list + kListCap;                                      // [256] short lists before ordering
+  unsigned* scan = raw + 256;                                           // [256]
+  unsigned* bitmap = scan + 256;                                        // [nWords]  long lists only
+  unsigned* wordPos = bitmap + nWords;                                  // [nWords]
+  unsigned char* filt = reinterpret_cast<unsigned char*>(wordPos + nWords);   // [64]
   const int tid = threadIdx.x;
   if (tid < 64) filt[tid] = cFilter[tid];
   const unsigned nActive = totals[1];
@@ -498,7 +530,8 @@ __global__ __launch_bounds__(256) void k_ov_tiles(const OvFace* __restrict__ sor
     const int tt = (int)(t - (unsigned)frame * tilesPerFrame);
     const int tx = tt % tilesX, ty = tt / tilesX;
     const unsigned e0 = offset[t], e1 = offset[t + 1];
-    const OvFace* fs = sorted + (size_t)frame * nF;
+    const unsigned nList = e1 - e0;
+    const OvTri* ft = tris + (size_t)frame * nF;
     const int px = tx * kTile + lx, py = ty * kTile + ly;
     const bool inside = px < W && py < H;
     unsigned char* pix = images + (size_t)frame * frame_stride + (size_t)py * row_stride + (size_t)px * 3;
@@ -506,15 +539,28 @@ __global__ __launch_bounds__(256) void k_ov_tiles(const OvFace* __restrict__ sor
     if (inside) { c0 = pix[0]; c1 = pix[1]; c2 = pix[2]; }
     const int wx0 = tx * kTile + (wave & 1) * 8, wy0 = ty * kTile + (wave >> 1) * 8;
 
-    __syncthreads();   // previous tile's LDS is no longer read
-    for (int w = tid; w < nWords; w += 256) bitmap[w] = 0;
-    __syncthreads();
-    for (unsigned e = e0 + tid; e < e1; e += 256) {
-      const unsigned r = entries[e];
-      atomicOr(&bitmap[r >> 5], 1u << (r & 31));
-    }
-    __syncthreads();
-    {   // ordinal of every word's first set bit: block scan over `per` words per thread
+    __syncthreads();   // the previous tile's LDS is no longer read
+    const bool shortList = nList <= 256;
+    if (shortList) {
+      // order by counting: every entry's position is the number of smaller ranks (they are distinct)
+      unsigned mine = 0;
+      if ((unsigned)tid < nList) { mine = entries[e0 + tid]; raw[tid] = mine; }
+      __syncthreads();
+      if ((unsigned)tid < nList) {
+        unsigned pos = 0;
+        for (unsigned j = 0; j < nList; ++j) pos += raw[j] < mine ? 1u : 0u;
+        list[pos] = mine;
+      }
+      __syncthreads();
+    } else {
+      for (int w = tid; w < nWords; w += 256) bitmap[w] = 0;
+      __syncthreads();
+      for (unsigned e = e0 + tid; e < e1; e += 256) {
+        const unsigned r = entries[e];
+        atomicOr(&bitmap[r >> 5], 1u << (r & 31));
+      }
+      __syncthreads();
+      // ordinal of every word's first set bit: block scan over `per` words per thread
       unsigned s = 0;
       for (int k = 0; k < per; ++k) { const int w = tid * per + k; if (w < nWords) s += __popc(bitmap[w]); }
       scan[tid] = s;
@@ -530,46 +576,39 @@ __global__ __launch_bounds__(256) void k_ov_tiles(const OvFace* __restrict__ sor
         const int w = tid * per + k;
         if (w < nWords) { wordPos[w] = run; run += __popc(bitmap[w]); }
       }
-    }
-    __syncthreads();
-    const unsigned nList = e1 - e0;
-    for (unsigned pass0 = 0; pass0 < nList; pass0 += kListCap) {
-      // ranks with ordinal in [pass0, pass0 + kListCap), ascending
-      for (int w = tid; w < nWords; w += 256) {
-        unsigned bits = bitmap[w], pos = wordPos[w];
-        while (bits) {
-          const int b = __ffs(bits) - 1;
-          bits &= bits - 1;
-          if (pos >= pass0 && pos < pass0 + kListCap) list[pos - pass0] = (unsigned)(w * 32 + b);
-          ++pos;
-        }
-      }
       __syncthreads();
+    }
+    for (unsigned pass0 = 0; pass0 < nList; pass0 += kListCap) {
+      if (!shortList) {
+        // ranks with ordinal in [pass0, pass0 + kListCap), ascending
+        for (int w = tid; w < nWords; w += 256) {
+          unsigned bits = bitmap[w], pos = wordPos[w];
+          while (bits) {
+            const int b = __ffs(bits) - 1;
+            bits &= bits - 1;
+            if (pos >= pass0 && pos < pass0 + kListCap) list[pos - pass0] = (unsigned)(w * 32 + b);
+            ++pos;
+          }
+        }
+        __syncthreads();
+      }
       const unsigned nPass = min((unsigned)kListCap, nList - pass0);
       for (unsigned g0 = 0; g0 < nPass; g0 += kGroup) {
         const int ng = (int)min((unsigned)kGroup, nPass - g0);
-        // set-up: threads 0..95 one edge each, threads 128..159 one fill each
-        if (tid < kGroup * 3) {
-          const int fi = tid / 3, li = tid - fi * 3;
-          if (fi < ng) {
-            const OvFace o = fs[list[g0 + fi]];
-            // FillConvexPoly draws p0 = v[2] -> v[0], v[0] -> v[1], v[1] -> v[2]
-            const int ia = li == 0 ? 2 : li - 1, ib = li;
-            setup_line(lines[fi * 3 + li], o.px[ia], o.py[ia], o.px[ib], o.py[ib], W, H);
-          }
-        } else if (tid >= 128 && tid < 128 + kGroup) {
-          const int fi = tid - 128;
-          if (fi < ng) setup_fill(fills[fi], fs[list[g0 + fi]], W, H);
+        // the group's set-up records: 256 B each, 16 B per thread and step
+        for (int q = tid; q < ng * 16; q += 256) {
+          const uint4* src = reinterpret_cast<const uint4*>(ft + list[g0 + (q >> 4)]) + (q & 15);
+          reinterpret_cast<uint4*>(tri)[q] = *src;
         }
         __syncthreads();
         for (int fi = 0; fi < ng; ++fi) {
-          const OvFill& Fl = fills[fi];
+          const OvFill& Fl = tri[fi].f;
           // wave-uniform reject: the wave's 8x8 pixels against the triangle's box + fringe
           if (Fl.bx1 < wx0 || Fl.bx0 > wx0 + 7 || Fl.by1 < wy0 || Fl.by0 > wy0 + 7) continue;
           const int g = Fl.gray;
 #pragma unroll
           for (int li = 0; li < 3; ++li) {
-            const OvLine& L = lines[fi * 3 + li];
+            const OvLine& L = tri[fi].l[li];
             if (!(L.flags & 1)) continue;
             const bool xm = (L.flags & 2) != 0;
             const int major = xm ? px : py, minor = xm ? py : px;
@@ -604,7 +643,7 @@ __global__ __launch_bounds__(256) void k_ov_tiles(const OvFace* __restrict__ sor
 
 size_t tile_lds_bytes(int nF) {
   const int nWords = (nF + 31) >> 5;
-  return (size_t)nWords * 8 + kListCap * 4 + sizeof(OvLine) * kGroup * 3 + sizeof(OvFill) * kGroup + 256 * 4 + 64;
+  return sizeof(OvTri) * kGroup + kListCap * 4 + 256 * 4 * 2 + (size_t)nWords * 8 + 64;
 }
 
 #define OV_TRY(expr)                                                                                          \
@@ -621,6 +660,7 @@ struct bodyfit_overlay {
   int tilesX = 0, tilesY = 0, nChunks = 0;
   int* d_faces = nullptr;
   OvFace *d_tmp = nullptr, *d_sorted = nullptr;
+  OvTri* d_tris = nullptr;
   unsigned long long *d_key = nullptr, *d_skey = nullptr;
   unsigned *d_sidx = nullptr, *d_count = nullptr, *d_offset = nullptr, *d_blockSum = nullptr, *d_active = nullptr,
            *d_totals = nullptr, *d_entries = nullptr;
@@ -676,6 +716,7 @@ int bodyfit_overlay_create(const bodyfit_overlay_desc* desc, bodyfit_overlay** o
   chk(ov->alloc(&ov->d_faces, (size_t)ov->nF * 3));
   chk(ov->alloc(&ov->d_tmp, F * ov->nF));
   chk(ov->alloc(&ov->d_sorted, F * ov->nF));
+  chk(ov->alloc(&ov->d_tris, F * ov->nF));
   chk(ov->alloc(&ov->d_key, F * ov->nF));
   chk(ov->alloc(&ov->d_skey, F * ov->nChunks * kChunk));
   chk(ov->alloc(&ov->d_sidx, F * ov->nChunks * kChunk));
@@ -712,7 +753,7 @@ int bodyfit_overlay_render_device(bodyfit_overlay* ov, const void* d_cloud, int 
   if (wireframe) return bodyfit_internal_fail(BODYFIT_ERR_INVALID, "bodyfit_overlay_render: wireframe is not supported");
   if (n_frames < 1 || n_frames > ov->maxFrames)
     return bodyfit_internal_fail(BODYFIT_ERR_INVALID, "bodyfit_overlay_render: n_frames exceeds max_frames");
-  if (cloud_frame_stride_elems < (size_t)ov->nV * 3 || row_stride < (size_t)ov->W * 3 ||
+  if ((n_frames > 1 && cloud_frame_stride_elems < (size_t)ov->nV * 3) || row_stride < (size_t)ov->W * 3 ||
       (n_frames > 1 && frame_stride < row_stride * (size_t)ov->H))
     return bodyfit_internal_fail(BODYFIT_ERR_INVALID, "bodyfit_overlay_render: strides smaller than the data");
   OV_TRY(hipSetDevice(ov->device));
@@ -769,13 +810,14 @@ int bodyfit_overlay_render_device(bodyfit_overlay* ov, const void* d_cloud, int 
     ov->d_entries = static_cast<unsigned*>(q);
   }
   if (totals[0]) {
+    hipLaunchKernelGGL(k_ov_setup, dim3((nF + 255) / 256, F), dim3(256), 0, st, ov->d_sorted, nF, ov->W, ov->H, ov->d_tris);
     hipLaunchKernelGGL(k_ov_bin<true>, dim3((nF + 255) / 256, F), dim3(256), 0, st, ov->d_sorted, nF, ov->W, ov->H,
                        ov->tilesX, ov->tilesY, ov->d_count, ov->d_offset, ov->d_entries);
   }
   OV_TRY(hipEventRecord(ov->ev[3], st));
   if (totals[1]) {
     const int grid = (int)std::min<unsigned>(totals[1], 256u * 16u);
-    hipLaunchKernelGGL(k_ov_tiles, dim3(grid), dim3(256), tile_lds_bytes(nF), st, ov->d_sorted, nF, ov->W, ov->H,
+    hipLaunchKernelGGL(k_ov_tiles, dim3(grid), dim3(256), tile_lds_bytes(nF), st, ov->d_tris, nF, ov->W, ov->H,
                        ov->tilesX, ov->tilesY, ov->d_offset, ov->d_entries, ov->d_active, ov->d_totals, d_images,
                        row_stride, frame_stride);
   }

@@ -136,6 +136,38 @@ def _updated(gpu_model, kps, intr, r0, t, joint_aa, beta):
     return wb["joints"], wb["mean_px"]
 
 
+def render_overlays(gpu_model, faces, kps, intr, r0, t, joint_aa, beta, size, frames_bgr=None, out_dir=None, names=None):
+    """smpl::render::renderSMPLMesh on every frame's updated avatar (src/main_single_frame.cpp:273-277,
+    src/main_multi_frame.cpp:205-229), batched: Avatar::update() on the device with the vertices left resident
+    (bodyfit_writeback_batch), then bodyfit_overlay_render_device into device images.  `size` = (W, H); frames_bgr
+    [F][H][W][3] uint8 are the video frames to draw on (black when None).  Returns the overlays; with out_dir they are
+    also written as binary PPM (PNG encoding is outside the path)."""
+    import torch
+
+    F = r0.shape[0]
+    W, H = int(size[0]), int(size[1])
+    off, kid, uv = kps
+    x = np.zeros((F, 76)); x[:, 0] = 1.0; x[:, 4:7] = t; x[:, 7:] = joint_aa
+    p = api.Problem(gpu_model, off, kid, uv, intr, r0.reshape(F, 9), n_cols=86, use_shape=True,
+                    beta_per_frame=(np.ndim(beta) == 2), want_mesh=True)
+    p.writeback(x, beta, want_cloud=True)
+    v = p.views()
+    imgs = (torch.zeros((F, H, W, 3), dtype=torch.uint8, device="cuda") if frames_bgr is None
+            else torch.from_numpy(np.ascontiguousarray(frames_bgr, dtype=np.uint8)).cuda())
+    ov = api.Overlay(faces, gpu_model.n_verts, W, H, max_frames=F)
+    ov.render_device(v.cloud, False, v.cloud_frame_stride, F, imgs.data_ptr(), intr)
+    torch.cuda.synchronize()
+    out = imgs.cpu().numpy()
+    ov.close(); p.close()
+    if out_dir is not None:
+        os.makedirs(out_dir, exist_ok=True)
+        for k in range(F):
+            with open(os.path.join(out_dir, (names[k] if names else f"frame_{k}_render") + ".ppm"), "wb") as f:
+                f.write(b"P6\n%d %d\n255\n" % (W, H))
+                f.write(out[k, :, :, ::-1].tobytes())
+    return out
+
+
 def _subsequence(seq, ids):
     offs, kid, uv = [0], [], []
     for f in ids:
@@ -146,7 +178,7 @@ def _subsequence(seq, ids):
 
 
 def run_single(gpu_model, seq: KeypointSequence, intr, max_iters=100, beta_pose=20.0, beta_shape=30.0, opt_shape=False,
-               gmm: api.Gmm | None = None, out_dir: str | None = None):
+               gmm: api.Gmm | None = None, out_dir: str | None = None, faces=None, image_size=None, frames_bgr=None):
     """3dba_single: all frames in one batched solve, each with its own LM state (the frames never interact).
     Frames without keypoints are skipped as in src/main_single_frame.cpp:200-203.  In the pose-only mode the
     reference's shape block only carries its own prior and stays at zero (include/Sim3BA.h:630-637), so it is
@@ -175,11 +207,18 @@ def run_single(gpu_model, seq: KeypointSequence, intr, max_iters=100, beta_pose=
     r0_new = wb["R0"]
     rows = [(f, float(wb["mean_px"][k]), ms) for k, f in enumerate(keep)]
     _write_log(out_dir, rows)
-    return dict(frames=keep, params=x, beta=beta, r0=r0_new, log=rows, summaries=summ)
+    overlays = None
+    if faces is not None and image_size is not None:               # frame_<i>_render (src/main_single_frame.cpp:273-277)
+        bsh = beta if beta is not None else np.zeros(10)
+        overlays = render_overlays(gpu_model, faces, (off, kid, uv), intr, r0_new, x[:, 4:7], x[:, 7:], bsh, image_size,
+                                   None if frames_bgr is None else np.asarray(frames_bgr)[keep], out_dir,
+                                   [f"frame_{f}_render" for f in keep])
+    return dict(frames=keep, params=x, beta=beta, r0=r0_new, log=rows, summaries=summ, overlays=overlays)
 
 
 def run_multi(gpu_model, seq: KeypointSequence, intr, max_iters_s1=1000, skip=10, wsize=20, overlap=5, beta_pose=5.0,
-              beta_shape=25.0, lambda_t=3.0, out_dir: str | None = None, stage2_iters=60):
+              beta_shape=25.0, lambda_t=3.0, out_dir: str | None = None, stage2_iters=60, faces=None, image_size=None,
+              frames_bgr=None):
     """3dba_multi: stage 1 on the anchors (shared beta), stage 2 on sliding windows with the beta 'lock'."""
     F = seq.n_frames
     r0 = np.tile(synth.R0_DEFAULT.reshape(1, 3, 3), (F, 1, 1))      # avatars[i]->r[0]
@@ -225,7 +264,13 @@ def run_multi(gpu_model, seq: KeypointSequence, intr, max_iters_s1=1000, skip=10
         for k, f in enumerate(ids):
             rows.append((f, float(px[k]), ms_win / (e - s)))
     _write_log(out_dir, rows)
-    return dict(poses=poses, r0=r0, t=t, joint_aa=jaa, w=w, log=rows, stage1=s1[0])
+    overlays = None
+    if faces is not None and image_size is not None:
+        # the reference renders a frame once no later window touches it (src/main_multi_frame.cpp:205-229): that is its
+        # final state, so all frames are drawn here in one batch
+        overlays = render_overlays(gpu_model, faces, _subsequence(seq, list(range(F))), intr, r0, t, jaa, w, image_size,
+                                   frames_bgr, out_dir, [f"frame_{f}_multi" for f in range(F)])
+    return dict(poses=poses, r0=r0, t=t, joint_aa=jaa, w=w, log=rows, stage1=s1[0], overlays=overlays)
 
 
 def _write_log(out_dir, rows):

@@ -330,4 +330,52 @@ inline double mean_pixel_error(const std::vector<PixelKP>& kps, const Avatar& av
   return bodyfit_mean_pixel_error((int)ids.size(), ids.data(), uv.data(), avatar.jointPos.data(), fx, fy, cx, cy);
 }
 
+// ---- mesh overlay: include/RenderSMPLMesh.h ------------------------------------------------------------------
+// cv::Mat stand-in for an 8-bit 3-channel image the caller owns (data, rows, cols, step in bytes).
+struct ImageView {
+  unsigned char* data;
+  int rows, cols;
+  size_t step;
+};
+
+// A reusable overlay context for one face list and image size (the device buffers live here).
+class MeshOverlay {
+ public:
+  MeshOverlay(const std::vector<std::array<int, 3>>& faces, int n_vertices, int width, int height, int max_frames = 1,
+              int device = 0) {
+    bodyfit_overlay_desc d{};
+    d.device = device; d.n_vertices = n_vertices; d.n_faces = (int)faces.size();
+    d.faces = faces.empty() ? nullptr : faces[0].data();
+    d.width = width; d.height = height; d.max_frames = max_frames;
+    check(bodyfit_overlay_create(&d, &h_));
+  }
+  ~MeshOverlay() { bodyfit_overlay_destroy(h_); }
+  MeshOverlay(const MeshOverlay&) = delete;
+  MeshOverlay& operator=(const MeshOverlay&) = delete;
+  bodyfit_overlay* handle() const { return h_; }
+  // one frame, host buffers; cloud: x, y, z per vertex (Avatar::cloud, or the data() of the reference's 3xN matrix)
+  template <typename T>
+  void render(const T* cloud, ImageView img, double fx, double fy, double cx, double cy, bool fill = true,
+              bool backface_cull = true, bool wireframe = false) {
+    static_assert(sizeof(T) == 4 || sizeof(T) == 8, "float or double vertices");
+    check(bodyfit_overlay_render(h_, cloud, sizeof(T) == 8, 0, 1, img.data, img.step, img.step * (size_t)img.rows, fx, fy,
+                                 cx, cy, fill, backface_cull, wireframe));
+  }
+ private:
+  bodyfit_overlay* h_ = nullptr;
+};
+
 }  // namespace bodyfit
+
+namespace smpl {
+namespace render {
+// include/RenderSMPLMesh.h:16-24, same argument order; `cloud` is the avatar's vertex buffer (3 values per vertex).
+template <typename T>
+inline void renderSMPLMesh(const std::vector<T>& cloud, const std::vector<std::array<int, 3>>& faces,
+                           bodyfit::ImageView img, double fx, double fy, double cx, double cy, bool fill = true,
+                           bool backface_cull = true, bool wireframe = false) {
+  bodyfit::MeshOverlay ov(faces, (int)(cloud.size() / 3), img.cols, img.rows);
+  ov.render(cloud.data(), img, fx, fy, cx, cy, fill, backface_cull, wireframe);
+}
+}  // namespace render
+}  // namespace smpl

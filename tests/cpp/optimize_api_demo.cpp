@@ -2,6 +2,7 @@
 // reference API: avatars at (0,0,3) with r[0] = Ry(pi) diag(1,-1,1), zero poses, then OptimizeMultiFrame
 // and OptimizePoseShapeReprojection.  Inputs come from a binary blob written by tests/test_gpu_cpp_api.py;
 // results go back as raw doubles.
+#include <array>
 #include <cstdint>
 #include <cstdio>
 #include <fstream>
@@ -78,6 +79,23 @@ int main(int argc, char** argv) {
     std::cout << "single: " << (ok2 ? "OK " : "FAIL ") << rep2 << "\n";
     o.write(reinterpret_cast<const char*>(s3.data), 7 * sizeof(double));
     o.write(reinterpret_cast<const char*>(single.w.data()), nS * sizeof(double));
+    if (argc >= 5) {
+      // the overlay of the fitted avatar, as src/main_single_frame.cpp:273-275 draws it (here on a 640x360 image)
+      std::ifstream ff(argv[3], std::ios::binary);
+      auto nf = rd<int32_t>(ff, 1);
+      auto fraw = rd<int32_t>(ff, (size_t)nf[0] * 3);
+      std::vector<std::array<int, 3>> faces(nf[0]);
+      for (int i = 0; i < nf[0]; ++i) faces[i] = {fraw[3 * i], fraw[3 * i + 1], fraw[3 * i + 2]};
+      single.update();
+      const int W = 640, H = 360;
+      std::vector<unsigned char> img((size_t)W * H * 3, 17);
+      smpl::render::renderSMPLMesh(single.cloud, faces, bodyfit::ImageView{img.data(), H, W, (size_t)W * 3}, intr[0] / 3,
+                                   intr[1] / 3, intr[2] / 3, intr[3] / 3, /*fill=*/true, /*backface_cull=*/true,
+                                   /*wireframe=*/false);
+      std::ofstream oi(argv[4], std::ios::binary);
+      oi.write(reinterpret_cast<const char*>(single.cloud.data()), single.cloud.size() * sizeof(float));
+      oi.write(reinterpret_cast<const char*>(img.data()), img.size());
+    }
     return (ok && ok2) ? 0 : 1;
   } catch (const std::exception& e) {
     std::cerr << e.what() << "\n";

@@ -152,3 +152,34 @@ def test_run_multi_on_reference_keypoints(gpu_model, tmp_path):
     assert np.abs(w[1]).max() > 1e-3 and np.array_equal(w[1], w[2])   # the rest keep the stage-1 shape
     lines = (tmp_path / "log.csv").read_text().splitlines()
     assert len(lines) == 1 + len(frames)
+
+
+@pytest.mark.gpu
+def test_drivers_render_overlays(gpu_model, model, tmp_path):
+    """frame_<i>_render / frame_<i>_multi: the overlay of every fitted frame (src/main_single_frame.cpp:273-277,
+    src/main_multi_frame.cpp:205-229), against the CPU restatements of update() and renderSMPLMesh."""
+    from oracle import oracle, overlay
+    seq, intr = _fixture_sequence(6)
+    faces = synth.make_faces(model)
+    W, H = 480, 270
+    out = drivers.run_single(gpu_model, seq, intr, faces=faces, image_size=(W, H), out_dir=str(tmp_path))
+    keep = out["frames"]
+    assert out["overlays"].shape == (len(keep), H, W, 3) and out["overlays"].any()
+    om = oracle.OracleModel(model)
+    for k in (0, len(keep) - 1):
+        x = np.zeros(76); x[0] = 1.0; x[4:7] = out["params"][k, 4:7]; x[7:] = out["params"][k, 7:]
+        _, cloud = om.forward(x, np.zeros(10), out["r0"][k].reshape(9))
+        want = np.zeros((H, W, 3), np.uint8)
+        overlay.render(cloud.astype(np.float32), faces, want, *intr)
+        diff = np.abs(out["overlays"][k].astype(int) - want.astype(int))
+        # the device vertices are f32 products of an MFMA blend: a few pixels may round to the neighbouring column
+        assert (diff > 0).mean() < 2e-3
+    ppm = (tmp_path / f"frame_{keep[0]}_render.ppm").read_bytes()
+    assert ppm.startswith(b"P6\n480 270\n255\n") and len(ppm) == 15 + W * H * 3
+    frames_bgr = np.random.default_rng(0).integers(0, 256, (seq.n_frames, H, W, 3), dtype=np.uint8)
+    out2 = drivers.run_multi(gpu_model, seq, intr, max_iters_s1=30, stage2_iters=10, faces=faces, image_size=(W, H),
+                             frames_bgr=frames_bgr)
+    ov = out2["overlays"]
+    assert ov.shape == frames_bgr.shape
+    changed = (ov != frames_bgr).any(axis=-1).mean(axis=(1, 2))
+    assert np.all(changed > 0.005) and np.all(changed < 0.9)       # a body drawn over each video frame, the rest intact

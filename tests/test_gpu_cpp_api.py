@@ -29,7 +29,12 @@ def test_cpp_optimize_api_matches_python_path(tmp_path, api, synth, model, gpu_m
                            os.path.join(ROOT, "tests", "cpp", "optimize_api_demo.cpp"), "-o", str(exe),
                            "-L", libdir, "-lbodyfit", f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib"])
     out = tmp_path / "out.bin"
-    res = subprocess.run([str(exe), str(blob), str(out)], capture_output=True, text=True, timeout=600)
+    faces = synth.make_faces(model)
+    with open(tmp_path / "faces.bin", "wb") as f:
+        f.write(struct.pack("i", len(faces)))
+        f.write(faces.tobytes())
+    res = subprocess.run([str(exe), str(blob), str(out), str(tmp_path / "faces.bin"), str(tmp_path / "overlay.bin")],
+                         capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stdout + res.stderr
     assert "multi: OK" in res.stdout and "single: OK" in res.stdout
     raw = np.fromfile(out, np.float64)
@@ -55,3 +60,11 @@ def test_cpp_optimize_api_matches_python_path(tmp_path, api, synth, model, gpu_m
     # mean_pixel_error indexes jointPos by jid: only meaningful for FK joints (the reference loader emits only those)
     assert px > 0 and np.isfinite(px)
     assert 0.3 <= s3[0] <= 3.0 and np.isfinite(w_single).all()
+    # smpl::render::renderSMPLMesh through the C++ mirror == the CPU restatement on the same vertices
+    from oracle import overlay
+    rawo = np.fromfile(tmp_path / "overlay.bin", np.uint8)
+    cloud = rawo[:model.n_verts * 12].view(np.float32).reshape(-1, 3)
+    img = rawo[model.n_verts * 12:].reshape(360, 640, 3)
+    want = np.full((360, 640, 3), 17, np.uint8)
+    overlay.render(cloud, faces, want, *(np.asarray(seq.intr) / 3))
+    assert (img != 17).any() and np.array_equal(img, want)
