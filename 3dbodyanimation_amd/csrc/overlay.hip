@@ -22,6 +22,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstddef>
 #include <cstdint>
 #include <cstring>
 #include <string>
@@ -38,8 +39,6 @@ constexpr int kTile = 16;               // pixels per tile side; one thread per 
 constexpr int kChunk = 8192;            // faces per LDS sort
 constexpr int kSortThreads = 1024;
 constexpr int kMaxFaces = 65536;        // LDS bitmap of the tile kernel
-constexpr int kGroup = 32;              // triangles set up per round of the tile kernel
-constexpr int kListCap = 2048;          // ordered ranks held in LDS per pass
 constexpr int kFringe = 2;              // pixels around a triangle's bounding box the AA lines can touch
 constexpr int XY_SHIFT = 16;
 constexpr int XY_ONE = 1 << XY_SHIFT;
@@ -66,8 +65,8 @@ struct OvLine {      // one anti-aliased edge after clipping, closed form along 
   int step;          // minor increment per step, |step| <= 1 << 16
   int c0, E;         // first major coordinate, last step index (steps 0..E)
   int flags;         // bit 0 drawn, bit 1 x-major
-  unsigned short ep[9];
-  unsigned short pad[3];
+  unsigned epk[3];   // end-point correction table, row min(step, 2): three 9-bit entries, column min(E - step, 2)
+  unsigned pad[3];
 };
 
 struct OvFill {      // the two edge walkers of FillConvexPoly, at most two linear pieces each
@@ -84,6 +83,10 @@ struct OvTri {       // everything the per-pixel fold needs of one triangle: 256
   OvFill f;
 };
 static_assert(sizeof(OvLine) == 48 && sizeof(OvFill) == 112 && sizeof(OvTri) == 256, "OvTri layout");
+static_assert(offsetof(OvLine, step) == 8 && offsetof(OvLine, flags) == 20 && offsetof(OvLine, epk) == 24 &&
+                  offsetof(OvTri, f) == 144 && offsetof(OvFill, dx) == 32 && offsetof(OvFill, ys) == 64 &&
+                  offsetof(OvFill, y0) == 80 && offsetof(OvFill, gray) == 88 && offsetof(OvFill, bx0) == 92,
+              "k_ov_tiles reads the record by dword index");
 
 __device__ __forceinline__ int round_to_int(float f) {
   const float r = roundf(f);
@@ -289,24 +292,31 @@ __global__ __launch_bounds__(1024) void k_ov_scan2(unsigned* __restrict__ blockS
 __global__ __launch_bounds__(256) void k_ov_scan3(const unsigned* __restrict__ count, size_t n,
                                                   const unsigned* __restrict__ blockBase, unsigned* __restrict__ offset,
                                                   unsigned* __restrict__ active, unsigned* __restrict__ totals) {
-  __shared__ unsigned part[256];
+  __shared__ unsigned part[256], nz[256];
+  __shared__ unsigned slotBase;
   const size_t i0 = (size_t)blockIdx.x * kScanBlock + threadIdx.x * 4;
-  unsigned c[4], s = 0;
-  for (int k = 0; k < 4; ++k) { c[k] = i0 + k < n ? count[i0 + k] : 0; s += c[k]; }
+  unsigned c[4], s = 0, z = 0;
+  for (int k = 0; k < 4; ++k) { c[k] = i0 + k < n ? count[i0 + k] : 0; s += c[k]; z += c[k] ? 1u : 0u; }
   part[threadIdx.x] = s;
+  nz[threadIdx.x] = z;
   __syncthreads();
   for (int o = 1; o < 256; o <<= 1) {
-    const unsigned v = threadIdx.x >= o ? part[threadIdx.x - o] : 0;
+    const unsigned v = threadIdx.x >= o ? part[threadIdx.x - o] : 0, w = threadIdx.x >= o ? nz[threadIdx.x - o] : 0;
     __syncthreads();
     part[threadIdx.x] += v;
+    nz[threadIdx.x] += w;
     __syncthreads();
   }
+  // one atomic per block reserves the block's slots in the list of non-empty tiles (its order is immaterial)
+  if (threadIdx.x == 255) slotBase = nz[255] ? atomicAdd(&totals[1], nz[255]) : 0u;
+  __syncthreads();
   unsigned run = blockBase[blockIdx.x] + part[threadIdx.x] - s;
+  unsigned slot = slotBase + nz[threadIdx.x] - z;
   for (int k = 0; k < 4; ++k)
     if (i0 + k < n) {
       offset[i0 + k] = run;
       run += c[k];
-      if (c[k]) active[atomicAdd(&totals[1], 1u)] = (unsigned)(i0 + k);
+      if (c[k]) active[slot++] = (unsigned)(i0 + k);
     }
 }
 
@@ -399,14 +409,16 @@ __device__ void setup_line(OvLine& L, int xa, int ya, int xb, int yb, int W, int
   const int t0 = slope << 7;
   const int t1 = ((0x78 - (int)i) | 4) * slope;
   const int t2 = ((int)j | 4) * slope;
-  L.ep[0] = 0;
-  L.ep[8] = (unsigned short)slope;
-  L.ep[1] = L.ep[3] = (unsigned short)(((((int)(j - i) & 0x78) | 4) * slope >> 8) & 0x1ff);
-  L.ep[2] = (unsigned short)((t1 >> 8) & 0x1ff);
-  L.ep[4] = (unsigned short)((((((int)(j - i) + 0x80) | 4) * slope) >> 8) & 0x1ff);
-  L.ep[5] = (unsigned short)(((t1 + t0) >> 8) & 0x1ff);
-  L.ep[6] = (unsigned short)((t2 >> 8) & 0x1ff);
-  L.ep[7] = (unsigned short)(((t2 + t0) >> 8) & 0x1ff);
+  int ep[9];
+  ep[0] = 0;
+  ep[8] = slope;
+  ep[1] = ep[3] = ((((int)(j - i) & 0x78) | 4) * slope >> 8) & 0x1ff;
+  ep[2] = (t1 >> 8) & 0x1ff;
+  ep[4] = (((((int)(j - i) + 0x80) | 4) * slope) >> 8) & 0x1ff;
+  ep[5] = ((t1 + t0) >> 8) & 0x1ff;
+  ep[6] = (t2 >> 8) & 0x1ff;
+  ep[7] = ((t2 + t0) >> 8) & 0x1ff;
+  for (int r = 0; r < 3; ++r) L.epk[r] = (unsigned)ep[3 * r] | ((unsigned)ep[3 * r + 1] << 9) | ((unsigned)ep[3 * r + 2] << 18);
 }
 
 // drawing.cpp FillConvexPoly (LINE_AA, shift 0, three points): the row loop only changes state at vertex rows, so
@@ -496,154 +508,220 @@ __global__ __launch_bounds__(256) void k_ov_setup(const OvFace* __restrict__ sor
 
 // ---- tiles --------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void blend2(int& v, int col, int a) {   // ICV_PUT_POINT, applied twice
-  v += ((col - v) * a + 127) >> 8;
-  v += ((col - v) * a + 127) >> 8;
+  v += (__mul24(col - v, a) + 127) >> 8;   // |col - v|, a <= 255: the full-rate 24-bit multiply is exact
+  v += (__mul24(col - v, a) + 127) >> 8;
 }
 
-__global__ __launch_bounds__(256) void k_ov_tiles(const OvTri* __restrict__ tris, int nF, int W, int H, int tilesX,
-                                                  int tilesY, const unsigned* __restrict__ offset,
-                                                  const unsigned* __restrict__ entries,
-                                                  const unsigned* __restrict__ active,
-                                                  const unsigned* __restrict__ totals, unsigned char* __restrict__ images,
-                                                  size_t row_stride, size_t frame_stride) {
+// One wave per tile.  The tile's pixels live in LDS as packed 0x00RRGGBB words; the triangles of the tile are taken in
+// draw order, and for each one the LANES SPAN THE TRIANGLE'S OWN WORK: an edge's (step, tap) pairs inside the tile
+// (<= 16 steps x 3 taps), then the fill's (row, column) pairs four rows at a time.  Within one edge no two taps share
+// a pixel and a wave's LDS operations execute in program order, so the fold over triangles, edges and fill is the
+// sequential one.  A set-up record is exactly one dword per lane: it is fetched with one coalesced load several
+// triangles ahead, its fields are read with v_readlane, and the per-triangle bookkeeping (bounding box, step range, row range)
+// runs on the scalar unit.
+constexpr int kTileThreads = 64;
+constexpr int kTileList = 256;    // ordered ranks held in LDS per pass
+constexpr int kAhead = 8;         // set-up records in flight per wave
+
+__device__ __forceinline__ unsigned wave_excl_scan(unsigned v, unsigned& total) {
+  unsigned incl = v;
+  for (int o = 1; o < 64; o <<= 1) {
+    const unsigned u = __shfl_up(incl, o);
+    if ((int)(threadIdx.x & 63) >= o) incl += u;
+  }
+  total = __shfl(incl, 63);
+  return incl - v;
+}
+
+__global__ __launch_bounds__(kTileThreads) void k_ov_tiles(const OvTri* __restrict__ tris, int nF, int W, int H,
+                                                           int tilesX, int tilesY, const unsigned* __restrict__ offset,
+                                                           const unsigned* __restrict__ entries,
+                                                           const unsigned* __restrict__ active,
+                                                           const unsigned* __restrict__ totals,
+                                                           unsigned char* __restrict__ images, size_t row_stride,
+                                                           size_t frame_stride) {
   extern __shared__ unsigned char smem[];
   const int nWords = (nF + 31) >> 5;
-  OvTri* tri = reinterpret_cast<OvTri*>(smem);                          // [kGroup]
-  unsigned* list = reinterpret_cast<unsigned*>(tri + kGroup);           // [kListCap] ranks in draw order
-  unsigned* raw = list + kListCap;                                      // [256] short lists before ordering
-  unsigned* scan = raw + 256;                                           // [256]
-  unsigned* bitmap = scan + 256;                                        // [nWords]  long lists only
+  unsigned* pix = reinterpret_cast<unsigned*>(smem);                    // [256] the tile, row-major
+  unsigned* list = pix + 256;                                           // [kTileList] ranks in draw order
+  unsigned* raw = list + kTileList;                                     // [256] short lists before ordering
+  unsigned* span = raw + 256;                                           // [16] a triangle's span per tile row
+  unsigned* bitmap = span + kTile;                                      // [nWords]  long lists only
   unsigned* wordPos = bitmap + nWords;                                  // [nWords]
   unsigned char* filt = reinterpret_cast<unsigned char*>(wordPos + nWords);   // [64]
-  const int tid = threadIdx.x;
-  if (tid < 64) filt[tid] = cFilter[tid];
+  const int lane = threadIdx.x;
+  filt[lane] = cFilter[lane];
   const unsigned nActive = totals[1];
   const int tilesPerFrame = tilesX * tilesY;
-  // 4 waves = 4 quadrants of 8x8 pixels: a triangle's bounding box is tested per wave
-  const int wave = tid >> 6, lane = tid & 63;
-  const int lx = (wave & 1) * 8 + (lane & 7), ly = (wave >> 1) * 8 + (lane >> 3);
-  const int per = (nWords + 255) / 256;
+  const int per = (nWords + 63) / 64;
+  // edge lanes: 16 steps x 3 taps on lanes 0..47; fill lanes: 4 rows x 16 columns
+  const int eStep = lane / 3, eTap = lane - eStep * 3;
+  const int fRow = lane >> 4, fCol = lane & 15;
 
   for (unsigned a = blockIdx.x; a < nActive; a += gridDim.x) {
     const unsigned t = active[a];
     const int frame = (int)(t / tilesPerFrame);
     const int tt = (int)(t - (unsigned)frame * tilesPerFrame);
-    const int tx = tt % tilesX, ty = tt / tilesX;
+    const int tx0 = (tt % tilesX) * kTile, ty0 = (tt / tilesX) * kTile;
     const unsigned e0 = offset[t], e1 = offset[t + 1];
     const unsigned nList = e1 - e0;
     const OvTri* ft = tris + (size_t)frame * nF;
-    const int px = tx * kTile + lx, py = ty * kTile + ly;
-    const bool inside = px < W && py < H;
-    unsigned char* pix = images + (size_t)frame * frame_stride + (size_t)py * row_stride + (size_t)px * 3;
-    int c0 = 0, c1 = 0, c2 = 0;
-    if (inside) { c0 = pix[0]; c1 = pix[1]; c2 = pix[2]; }
-    const int wx0 = tx * kTile + (wave & 1) * 8, wy0 = ty * kTile + (wave >> 1) * 8;
-
-    __syncthreads();   // the previous tile's LDS is no longer read
+    unsigned char* img = images + (size_t)frame * frame_stride;
+    __syncthreads();   // the previous tile's LDS is no longer in use
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int y = ty0 + fRow + 4 * i, x = tx0 + fCol;
+      unsigned v = 0;
+      if (x < W && y < H) {
+        const unsigned char* q = img + (size_t)y * row_stride + (size_t)x * 3;
+        v = (unsigned)q[0] | ((unsigned)q[1] << 8) | ((unsigned)q[2] << 16);
+      }
+      pix[(fRow + 4 * i) * kTile + fCol] = v;
+    }
     const bool shortList = nList <= 256;
     if (shortList) {
-      // order by counting: every entry's position is the number of smaller ranks (they are distinct)
-      unsigned mine = 0;
-      if ((unsigned)tid < nList) { mine = entries[e0 + tid]; raw[tid] = mine; }
-      __syncthreads();
-      if ((unsigned)tid < nList) {
-        unsigned pos = 0;
-        for (unsigned j = 0; j < nList; ++j) pos += raw[j] < mine ? 1u : 0u;
-        list[pos] = mine;
+      // order by counting: an entry's position is the number of smaller ranks (they are distinct)
+      unsigned mine[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const unsigned j = lane + 64 * i;
+        mine[i] = j < nList ? entries[e0 + j] : 0xFFFFFFFFu;
+        if (j < nList) raw[j] = mine[i];
       }
       __syncthreads();
+      unsigned pos[4] = {0, 0, 0, 0};
+      for (unsigned j = 0; j < nList; ++j) {
+        const unsigned r = raw[j];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pos[i] += r < mine[i] ? 1u : 0u;
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (lane + 64 * i < (int)nList) list[pos[i]] = mine[i];
     } else {
-      for (int w = tid; w < nWords; w += 256) bitmap[w] = 0;
+      for (int w = lane; w < nWords; w += 64) bitmap[w] = 0;
       __syncthreads();
-      for (unsigned e = e0 + tid; e < e1; e += 256) {
+      for (unsigned e = e0 + lane; e < e1; e += 64) {
         const unsigned r = entries[e];
         atomicOr(&bitmap[r >> 5], 1u << (r & 31));
       }
       __syncthreads();
-      // ordinal of every word's first set bit: block scan over `per` words per thread
-      unsigned s = 0;
-      for (int k = 0; k < per; ++k) { const int w = tid * per + k; if (w < nWords) s += __popc(bitmap[w]); }
-      scan[tid] = s;
-      __syncthreads();
-      for (int o = 1; o < 256; o <<= 1) {
-        const unsigned v = tid >= o ? scan[tid - o] : 0;
-        __syncthreads();
-        scan[tid] += v;
-        __syncthreads();
-      }
-      unsigned run = scan[tid] - s;
+      unsigned sum = 0;
+      for (int k = 0; k < per; ++k) { const int w = lane * per + k; if (w < nWords) sum += __popc(bitmap[w]); }
+      unsigned total;
+      unsigned run = wave_excl_scan(sum, total);
       for (int k = 0; k < per; ++k) {
-        const int w = tid * per + k;
+        const int w = lane * per + k;
         if (w < nWords) { wordPos[w] = run; run += __popc(bitmap[w]); }
       }
-      __syncthreads();
     }
-    for (unsigned pass0 = 0; pass0 < nList; pass0 += kListCap) {
+    __syncthreads();
+    for (unsigned pass0 = 0; pass0 < nList; pass0 += kTileList) {
       if (!shortList) {
-        // ranks with ordinal in [pass0, pass0 + kListCap), ascending
-        for (int w = tid; w < nWords; w += 256) {
+        __syncthreads();
+        for (int w = lane; w < nWords; w += 64) {   // ranks with ordinal in [pass0, pass0 + kTileList), ascending
           unsigned bits = bitmap[w], pos = wordPos[w];
           while (bits) {
             const int b = __ffs(bits) - 1;
             bits &= bits - 1;
-            if (pos >= pass0 && pos < pass0 + kListCap) list[pos - pass0] = (unsigned)(w * 32 + b);
+            if (pos >= pass0 && pos < pass0 + kTileList) list[pos - pass0] = (unsigned)(w * 32 + b);
             ++pos;
           }
         }
         __syncthreads();
       }
-      const unsigned nPass = min((unsigned)kListCap, nList - pass0);
-      for (unsigned g0 = 0; g0 < nPass; g0 += kGroup) {
-        const int ng = (int)min((unsigned)kGroup, nPass - g0);
-        // the group's set-up records: 256 B each, 16 B per thread and step
-        for (int q = tid; q < ng * 16; q += 256) {
-          const uint4* src = reinterpret_cast<const uint4*>(ft + list[g0 + (q >> 4)]) + (q & 15);
-          reinterpret_cast<uint4*>(tri)[q] = *src;
-        }
-        __syncthreads();
-        for (int fi = 0; fi < ng; ++fi) {
-          const OvFill& Fl = tri[fi].f;
-          // wave-uniform reject: the wave's 8x8 pixels against the triangle's box + fringe
-          if (Fl.bx1 < wx0 || Fl.bx0 > wx0 + 7 || Fl.by1 < wy0 || Fl.by0 > wy0 + 7) continue;
-          const int g = Fl.gray;
+      const unsigned nPass = min((unsigned)kTileList, nList - pass0);
+      // a set-up record is 64 dwords: one dword per lane, one load per triangle, two triangles ahead of the fold;
+      // its fields are then picked out with v_readlane (dword offsets of OvTri: edges at 0 / 12 / 24, fill at 36)
+      auto fetch = [&](unsigned i) -> unsigned {
+        return i < nPass ? reinterpret_cast<const unsigned*>(ft + list[i])[lane] : 0u;
+      };
+      unsigned ring[kAhead];
 #pragma unroll
-          for (int li = 0; li < 3; ++li) {
-            const OvLine& L = tri[fi].l[li];
-            if (!(L.flags & 1)) continue;
-            const bool xm = (L.flags & 2) != 0;
-            const int major = xm ? px : py, minor = xm ? py : px;
-            const int k = major - L.c0;
-            if ((unsigned)k <= (unsigned)L.E && L.E >= 0) {
-              const long long m = L.m0 + (long long)k * L.step;
-              const int d = minor - ((int)(m >> XY_SHIFT) - 1);
-              if ((unsigned)d < 3u) {
-                const int dist = (int)((m >> (XY_SHIFT - 5)) & 31);
-                const int f = d == 0 ? filt[dist + 32] : (d == 1 ? filt[dist] : filt[63 - dist]);
-                const int ep = L.ep[min(k, 2) * 3 + min(L.E - k, 2)];
-                const int al = (ep * f >> 8) & 0xff;
-                blend2(c0, g, al); blend2(c1, g, al); blend2(c2, g, al);
-              }
-            }
-          }
-          if (py >= Fl.y0 && py <= Fl.y1) {
-            const int p0 = py >= Fl.ys[0][1] ? 1 : 0, p1 = py >= Fl.ys[1][1] ? 1 : 0;
-            long long xa = Fl.xs[0][p0] + Fl.dx[0][p0] * (long long)(py - Fl.ys[0][p0]);
-            long long xb = Fl.xs[1][p1] + Fl.dx[1][p1] * (long long)(py - Fl.ys[1][p1]);
-            if (xa > xb) { const long long tmp = xa; xa = xb; xb = tmp; }
-            const int xx1 = (int)((xa + (XY_ONE - 1)) >> XY_SHIFT), xx2 = (int)(xb >> XY_SHIFT);
-            if (px >= xx1 && px <= xx2) { c0 = g; c1 = g; c2 = g; }
+      for (int j = 0; j < kAhead; ++j) ring[j] = fetch(j);
+      for (unsigned it = 0; it < nPass; ++it) {
+        const unsigned rec = ring[0];
+#pragma unroll
+        for (int j = 0; j + 1 < kAhead; ++j) ring[j] = ring[j + 1];
+        ring[kAhead - 1] = fetch(it + kAhead);
+#define RL(i) ((int)__builtin_amdgcn_readlane(rec, (i)))
+#define RL64(i) ((long long)(((unsigned long long)(unsigned)RL((i) + 1) << 32) | (unsigned)RL(i)))
+        if (RL(61) < tx0 || RL(59) > tx0 + kTile - 1 || RL(62) < ty0 || RL(60) > ty0 + kTile - 1) continue;
+        const int g = RL(58);
+        // ---- the three anti-aliased edges, in the order FillConvexPoly draws them ----
+#pragma unroll
+        for (int li = 0; li < 3; ++li) {
+          const int o = 12 * li;
+          const int flags = RL(o + 5);
+          if (!(flags & 1)) continue;
+          const bool xm = (flags & 2) != 0;
+          const int major0 = xm ? tx0 : ty0, minor0 = xm ? ty0 : tx0;
+          const int c0 = RL(o + 3), E = RL(o + 4);
+          const int kA = max(0, major0 - c0), kB = min(E, major0 + kTile - 1 - c0);
+          if (kA > kB) continue;
+          const int k = kA + eStep;
+          const int m = RL(o) + __mul24(k, RL(o + 2));   // k < 2^15, |step| <= 2^16; the true value fits 32 bits
+          const int mi = (m >> XY_SHIFT) - 1 + eTap - minor0;
+          const int ma = c0 + k - major0;
+          const unsigned ep0 = (unsigned)RL(o + 6), ep1 = (unsigned)RL(o + 7), ep2 = (unsigned)RL(o + 8);
+          if (lane < 48 && k <= kB && (unsigned)mi < (unsigned)kTile) {
+            const int dist = (m >> (XY_SHIFT - 5)) & 31;
+            const int f = filt[eTap == 0 ? dist + 32 : (eTap == 1 ? dist : 63 - dist)];
+            const int row = min(k, 2), col = min(E - k, 2);
+            const unsigned er = row == 0 ? ep0 : (row == 1 ? ep1 : ep2);
+            const int ep = (int)((er >> (9 * col)) & 0x1ffu);
+            const int al = (__mul24(ep, f) >> 8) & 0xff;
+            const int idx = xm ? mi * kTile + ma : ma * kTile + mi;
+            const unsigned v = pix[idx];
+            int c0v = (int)(v & 0xff), c1v = (int)((v >> 8) & 0xff), c2v = (int)((v >> 16) & 0xff);
+            blend2(c0v, g, al); blend2(c1v, g, al); blend2(c2v, g, al);
+            pix[idx] = (unsigned)c0v | ((unsigned)c1v << 8) | ((unsigned)c2v << 16);
           }
         }
-        __syncthreads();
+        // ---- the opaque span of every row: the two walkers once per tile row (lanes 0..15), then 4 rows per pass ----
+        const int ya = max(RL(56), ty0), yb = min(RL(57), ty0 + kTile - 1);
+        if (ya <= yb) {
+          if (lane < kTile) {
+            const int y = ty0 + lane;
+            const int ys0b = RL(53), ys1b = RL(55);
+            const bool pb0 = y >= ys0b, pb1 = y >= ys1b;
+            const long long xs0 = pb0 ? RL64(38) : RL64(36), dx0 = pb0 ? RL64(46) : RL64(44);
+            const long long xs1 = pb1 ? RL64(42) : RL64(40), dx1 = pb1 ? RL64(50) : RL64(48);
+            const int yy0 = pb0 ? ys0b : RL(52), yy1 = pb1 ? ys1b : RL(54);
+            long long xa = xs0 + dx0 * (long long)(y - yy0);
+            long long xb = xs1 + dx1 * (long long)(y - yy1);
+            if (xa > xb) { const long long tmp = xa; xa = xb; xb = tmp; }
+            long long xx1 = ((xa + (XY_ONE - 1)) >> XY_SHIFT) - tx0, xx2 = (xb >> XY_SHIFT) - tx0;   // tile-relative
+            const bool on = y >= ya && y <= yb && xx2 >= 0 && xx1 <= kTile - 1 && xx1 <= xx2;
+            const int lo = (int)max(xx1, 0ll), hi = (int)min(xx2, (long long)kTile - 1);
+            span[lane] = on ? (unsigned)lo | ((unsigned)hi << 8) : 0x00ffu;   // empty: lo = 255 > hi = 0
+          }
+          const unsigned gg = (unsigned)g * 0x010101u;
+          for (int r0 = (ya - ty0) & ~3; r0 <= yb - ty0; r0 += 4) {
+            const unsigned sp = span[r0 + fRow];
+            if (fCol >= (int)(sp & 0xff) && fCol <= (int)(sp >> 8)) pix[(r0 + fRow) * kTile + fCol] = gg;
+          }
+        }
+#undef RL
+#undef RL64
       }
     }
-    if (inside) { pix[0] = (unsigned char)c0; pix[1] = (unsigned char)c1; pix[2] = (unsigned char)c2; }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int y = ty0 + fRow + 4 * i, x = tx0 + fCol;
+      if (x < W && y < H) {
+        unsigned char* q = img + (size_t)y * row_stride + (size_t)x * 3;
+        const unsigned v = pix[(fRow + 4 * i) * kTile + fCol];
+        q[0] = (unsigned char)v; q[1] = (unsigned char)(v >> 8); q[2] = (unsigned char)(v >> 16);
+      }
+    }
   }
 }
 
 size_t tile_lds_bytes(int nF) {
   const int nWords = (nF + 31) >> 5;
-  return sizeof(OvTri) * kGroup + kListCap * 4 + 256 * 4 * 2 + (size_t)nWords * 8 + 64;
+  return 256 * 4 + kTileList * 4 + 256 * 4 + kTile * 4 + (size_t)nWords * 8 + 64;
 }
 
 #define OV_TRY(expr)                                                                                          \
@@ -695,8 +773,8 @@ extern "C" {
 int bodyfit_overlay_create(const bodyfit_overlay_desc* desc, bodyfit_overlay** out) {
   if (!desc || !out || !desc->faces) return bodyfit_internal_fail(BODYFIT_ERR_INVALID, "bodyfit_overlay_create: null argument");
   if (desc->n_faces < 1 || desc->n_faces > kMaxFaces || desc->n_vertices < 1 || desc->width < 1 || desc->height < 1 ||
-      desc->max_frames < 1 || desc->width > 32768 || desc->height > 32768)
-    return bodyfit_internal_fail(BODYFIT_ERR_INVALID, "bodyfit_overlay_create: sizes out of range (n_faces <= 65536)");
+      desc->max_frames < 1 || desc->width > 16384 || desc->height > 16384)
+    return bodyfit_internal_fail(BODYFIT_ERR_INVALID, "bodyfit_overlay_create: sizes out of range (n_faces <= 65536, images <= 16384 x 16384)");
   for (int i = 0; i < desc->n_faces * 3; ++i)
     if (desc->faces[i] < 0 || desc->faces[i] >= desc->n_vertices)
       return bodyfit_internal_fail(BODYFIT_ERR_INVALID, "bodyfit_overlay_create: face refers to a vertex out of range");
@@ -816,8 +894,8 @@ int bodyfit_overlay_render_device(bodyfit_overlay* ov, const void* d_cloud, int 
   }
   OV_TRY(hipEventRecord(ov->ev[3], st));
   if (totals[1]) {
-    const int grid = (int)std::min<unsigned>(totals[1], 256u * 16u);
-    hipLaunchKernelGGL(k_ov_tiles, dim3(grid), dim3(256), tile_lds_bytes(nF), st, ov->d_tris, nF, ov->W, ov->H,
+    const int grid = (int)std::min<unsigned>(totals[1], 256u * 64u);
+    hipLaunchKernelGGL(k_ov_tiles, dim3(grid), dim3(kTileThreads), tile_lds_bytes(nF), st, ov->d_tris, nF, ov->W, ov->H,
                        ov->tilesX, ov->tilesY, ov->d_offset, ov->d_entries, ov->d_active, ov->d_totals, d_images,
                        row_stride, frame_stride);
   }
