@@ -64,7 +64,21 @@ def cpu_baseline(synth, model, seq, F_sample, gmm_np):
         t_fw += time.perf_counter() - t0
         passes += 1
     n = F_sample * passes
-    return {"value": n / (t_ad + t_fw), "unit": "evals/s", "cores": nthr, "kind": "port",
+    # the thread counts the reference itself uses (options.num_threads = 4 / 8: include/Sim3BA.h:476,
+    # include/MultiFrameBA.h:148) and one core, one pass of a smaller sample each (~1-2 s per entry)
+    ladder = {}
+    Fl = min(F_sample, 32)
+    sl = S()
+    sl.kp_offset = seq.kp_offset[:Fl + 1]; sl.kp_id = seq.kp_id; sl.kp_uv = seq.kp_uv
+    sl.intr = seq.intr; sl.R0 = seq.R0[:Fl]
+    for nt in (1, 4, 8):
+        if nt > nthr:
+            continue
+        t0 = time.perf_counter()
+        om.evaluate_batch(sl, x[:Fl], beta[:Fl], 86, True, True, mode=1, nthreads=nt)
+        om.forward_batch(x[:Fl], beta[:Fl], sl.R0, nthreads=nt)
+        ladder[str(nt)] = Fl / (time.perf_counter() - t0)
+    return {"value": n / (t_ad + t_fw), "unit": "evals/s", "cores": nthr, "kind": "port", "evals_per_s_by_threads": ladder,
             "sample": f"{passes} x {F_sample} frames of the bench workload: autodiff-style (stride-4 dual numbers) "
                       f"residual+Jacobian {t_ad:.2f}s + f64 SMPL forward {t_fw:.2f}s, OpenMP over blocks/frames",
             "evals_per_s_analytic_jacobian": n / (t_an + t_fw)}
