@@ -241,7 +241,7 @@ def main():
             for _ in range(20):
                 prob.evaluate(params_h, beta_h, True)
             out["pcie_inclusive_evals_per_s"] = F * 20 / (time.perf_counter() - t1)
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # the CPU leg is timed at N = 1 only
             n_cpu = args.cpu_sample_frames or min(F, 256)
             cseq = seq if args.workload == "c3" else synth.make_sequence(model, n_cpu, seed=0)
             out["cpu_baseline"] = cpu_baseline(synth, model, cseq, n_cpu, None)
