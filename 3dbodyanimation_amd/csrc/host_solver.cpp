@@ -15,6 +15,8 @@
 // here is the linear algebra of the normal equations.  DENSE_QR is replaced by a block-tridiagonal
 // Cholesky (76x76 frame blocks coupled by the temporal term) with a Schur complement on the shared
 // shape block: same minimiser, O(F 76^3) instead of O(m n^2).
+#include <immintrin.h>
+
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -34,16 +36,21 @@ namespace {
 constexpr int NP = BODYFIT_FRAME_PARAMS;
 
 // ---- small dense helpers (row-major) ------------------------------------------------------------
-// contiguous dot product, four independent partial sums (fixed association: results do not depend on the
-// compiler's vectoriser)
+// contiguous dot product on AVX2 (every MI355X host has it): two 4-lane accumulators, fixed association
 inline double dot4(const double* a, const double* b, int n) {
-  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  __m256d s0 = _mm256_setzero_pd(), s1 = _mm256_setzero_pd();
   int k = 0;
-  for (; k + 4 <= n; k += 4) {
-    s0 += a[k] * b[k]; s1 += a[k + 1] * b[k + 1]; s2 += a[k + 2] * b[k + 2]; s3 += a[k + 3] * b[k + 3];
+  for (; k + 8 <= n; k += 8) {
+    s0 = _mm256_fmadd_pd(_mm256_loadu_pd(a + k), _mm256_loadu_pd(b + k), s0);
+    s1 = _mm256_fmadd_pd(_mm256_loadu_pd(a + k + 4), _mm256_loadu_pd(b + k + 4), s1);
   }
-  for (; k < n; ++k) s0 += a[k] * b[k];
-  return (s0 + s1) + (s2 + s3);
+  if (k + 4 <= n) { s0 = _mm256_fmadd_pd(_mm256_loadu_pd(a + k), _mm256_loadu_pd(b + k), s0); k += 4; }
+  s0 = _mm256_add_pd(s0, s1);
+  const __m128d lo = _mm256_castpd256_pd128(s0), hi = _mm256_extractf128_pd(s0, 1);
+  const __m128d q = _mm_add_pd(lo, hi);
+  double s = _mm_cvtsd_f64(q) + _mm_cvtsd_f64(_mm_unpackhi_pd(q, q));
+  for (; k < n; ++k) s += a[k] * b[k];
+  return s;
 }
 bool chol_inplace(double* A, int n) {  // lower Cholesky in the lower triangle
   for (int j = 0; j < n; ++j) {
@@ -291,6 +298,120 @@ void build_normal(const Ctx& c, const Group& g, const double* r, const double* J
     for (int j = 0; j < i; ++j) N.C[j * nb + i] = N.C[i * nb + j];
 }
 
+// c[0..len) -= a0 b0 + a1 b1 + a2 b2 + a3 b3 (rank-4 row update)
+inline void axpy4(double* c, int len, const double* a, const double* b0, const double* b1, const double* b2,
+                  const double* b3) {
+  const __m256d a0 = _mm256_set1_pd(a[0]), a1 = _mm256_set1_pd(a[1]), a2 = _mm256_set1_pd(a[2]), a3 = _mm256_set1_pd(a[3]);
+  int j = 0;
+  for (; j + 4 <= len; j += 4) {
+    __m256d v = _mm256_loadu_pd(c + j);
+    v = _mm256_fnmadd_pd(a0, _mm256_loadu_pd(b0 + j), v);
+    v = _mm256_fnmadd_pd(a1, _mm256_loadu_pd(b1 + j), v);
+    v = _mm256_fnmadd_pd(a2, _mm256_loadu_pd(b2 + j), v);
+    v = _mm256_fnmadd_pd(a3, _mm256_loadu_pd(b3 + j), v);
+    _mm256_storeu_pd(c + j, v);
+  }
+  for (; j < len; ++j) c[j] -= a[0] * b0[j] + a[1] * b1[j] + a[2] * b2[j] + a[3] * b3[j];
+}
+
+// two rows at once against the same four b rows (the b loads are shared): c0 over len0, c1 over len1 >= len0
+inline void axpy4x2(double* c0, int len0, const double* a, double* c1, int len1, const double* e, const double* b0,
+                    const double* b1, const double* b2, const double* b3) {
+  const __m256d a0 = _mm256_set1_pd(a[0]), a1 = _mm256_set1_pd(a[1]), a2 = _mm256_set1_pd(a[2]), a3 = _mm256_set1_pd(a[3]);
+  const __m256d e0 = _mm256_set1_pd(e[0]), e1 = _mm256_set1_pd(e[1]), e2 = _mm256_set1_pd(e[2]), e3 = _mm256_set1_pd(e[3]);
+  int j = 0;
+  for (; j + 4 <= len0; j += 4) {
+    const __m256d v0 = _mm256_loadu_pd(b0 + j), v1 = _mm256_loadu_pd(b1 + j), v2 = _mm256_loadu_pd(b2 + j),
+                  v3 = _mm256_loadu_pd(b3 + j);
+    __m256d x = _mm256_loadu_pd(c0 + j), y = _mm256_loadu_pd(c1 + j);
+    x = _mm256_fnmadd_pd(a0, v0, x); y = _mm256_fnmadd_pd(e0, v0, y);
+    x = _mm256_fnmadd_pd(a1, v1, x); y = _mm256_fnmadd_pd(e1, v1, y);
+    x = _mm256_fnmadd_pd(a2, v2, x); y = _mm256_fnmadd_pd(e2, v2, y);
+    x = _mm256_fnmadd_pd(a3, v3, x); y = _mm256_fnmadd_pd(e3, v3, y);
+    _mm256_storeu_pd(c0 + j, x);
+    _mm256_storeu_pd(c1 + j, y);
+  }
+  for (int q = j; q < len0; ++q) c0[q] -= a[0] * b0[q] + a[1] * b1[q] + a[2] * b2[q] + a[3] * b3[q];
+  for (int q = j; q < len1; ++q) c1[q] -= e[0] * b0[q] + e[1] * b1[q] + e[2] * b2[q] + e[3] * b3[q];
+}
+
+// B = A^T for 76 x 76 row-major matrices, 4 x 4 blocks in registers
+inline void transpose76(const double* A, double* B) {
+  for (int i = 0; i < NP; i += 4)
+    for (int j = 0; j < NP; j += 4) {
+      const __m256d r0 = _mm256_loadu_pd(A + (size_t)i * NP + j), r1 = _mm256_loadu_pd(A + (size_t)(i + 1) * NP + j);
+      const __m256d r2 = _mm256_loadu_pd(A + (size_t)(i + 2) * NP + j), r3 = _mm256_loadu_pd(A + (size_t)(i + 3) * NP + j);
+      const __m256d t0 = _mm256_unpacklo_pd(r0, r1), t1 = _mm256_unpackhi_pd(r0, r1);
+      const __m256d t2 = _mm256_unpacklo_pd(r2, r3), t3 = _mm256_unpackhi_pd(r2, r3);
+      _mm256_storeu_pd(B + (size_t)j * NP + i, _mm256_permute2f128_pd(t0, t2, 0x20));
+      _mm256_storeu_pd(B + (size_t)(j + 1) * NP + i, _mm256_permute2f128_pd(t1, t3, 0x20));
+      _mm256_storeu_pd(B + (size_t)(j + 2) * NP + i, _mm256_permute2f128_pd(t0, t2, 0x31));
+      _mm256_storeu_pd(B + (size_t)(j + 3) * NP + i, _mm256_permute2f128_pd(t1, t3, 0x31));
+    }
+}
+
+// Right-looking Cholesky of the 76 x 76 matrix M (lower triangle, row-major, leading dimension 76), four columns at a
+// time, with two borders that receive L^{-T} from the right as the factorisation proceeds: Eb (76 rows, row r starts
+// as E_r e_r^T and ends as row r of diag(E) L^{-T}, which is zero left of column r; may be null) and Yb (m rows).
+bool bordered_chol(double* M, double* Eb, double* Yb, int m) {
+  static_assert(NP % 4 == 0, "column blocks of 4");
+  double Lt[4][NP];   // the current panel transposed: Lt[k][j] = M[j][jb + k]
+  for (int jb = 0; jb < NP; jb += 4) {
+    // diagonal 4 x 4 block
+    for (int j = jb; j < jb + 4; ++j) {
+      double d = M[(size_t)j * NP + j];
+      for (int k = jb; k < j; ++k) d -= M[(size_t)j * NP + k] * M[(size_t)j * NP + k];
+      if (!(d > 0.0) || !std::isfinite(d)) return false;
+      d = std::sqrt(d);
+      M[(size_t)j * NP + j] = d;
+      const double inv = 1.0 / d;
+      for (int i = j + 1; i < jb + 4; ++i) {
+        double v = M[(size_t)i * NP + j];
+        for (int k = jb; k < j; ++k) v -= M[(size_t)i * NP + k] * M[(size_t)j * NP + k];
+        M[(size_t)i * NP + j] = v * inv;
+      }
+    }
+    const double* D = M + (size_t)jb * NP + jb;   // the factored diagonal block (lower, leading dimension 76)
+    // panel: rows below solve x L11^T = a
+    const double i0 = 1.0 / D[0], i1 = 1.0 / D[NP + 1], i2 = 1.0 / D[2 * NP + 2], i3 = 1.0 / D[3 * NP + 3];
+    const double d10 = D[NP], d20 = D[2 * NP], d21 = D[2 * NP + 1], d30 = D[3 * NP], d31 = D[3 * NP + 1], d32 = D[3 * NP + 2];
+    auto panel_row = [&](double* row) {
+      const double x0 = row[jb] * i0;
+      const double x1 = (row[jb + 1] - x0 * d10) * i1;
+      const double x2 = (row[jb + 2] - x0 * d20 - x1 * d21) * i2;
+      const double x3 = (row[jb + 3] - x0 * d30 - x1 * d31 - x2 * d32) * i3;
+      row[jb] = x0; row[jb + 1] = x1; row[jb + 2] = x2; row[jb + 3] = x3;
+    };
+    const int j1 = jb + 4, rest = NP - j1;
+    for (int i = j1; i < NP; ++i) {
+      panel_row(M + (size_t)i * NP);
+      for (int k = 0; k < 4; ++k) Lt[k][i] = M[(size_t)i * NP + jb + k];
+    }
+    const int er = Eb ? std::min(NP, jb + 4) : 0;   // border rows r < jb + 4 have entered their non-zero part
+    for (int r = 0; r < er; ++r) panel_row(Eb + (size_t)r * NP);
+    for (int c = 0; c < m; ++c) panel_row(Yb + (size_t)c * NP);
+    if (rest == 0) break;
+    // trailing update with the transposed panel
+    const double *t0 = Lt[0] + j1, *t1 = Lt[1] + j1, *t2 = Lt[2] + j1, *t3 = Lt[3] + j1;
+    int i = j1;
+    for (; i + 1 < NP; i += 2)
+      axpy4x2(M + (size_t)i * NP + j1, i - j1 + 1, M + (size_t)i * NP + jb, M + (size_t)(i + 1) * NP + j1, i - j1 + 2,
+              M + (size_t)(i + 1) * NP + jb, t0, t1, t2, t3);
+    if (i < NP) axpy4(M + (size_t)i * NP + j1, i - j1 + 1, M + (size_t)i * NP + jb, t0, t1, t2, t3);
+    int r = 0;
+    for (; r + 1 < er; r += 2)
+      axpy4x2(Eb + (size_t)r * NP + j1, rest, Eb + (size_t)r * NP + jb, Eb + (size_t)(r + 1) * NP + j1, rest,
+              Eb + (size_t)(r + 1) * NP + jb, t0, t1, t2, t3);
+    if (r < er) axpy4(Eb + (size_t)r * NP + j1, rest, Eb + (size_t)r * NP + jb, t0, t1, t2, t3);
+    int c = 0;
+    for (; c + 1 < m; c += 2)
+      axpy4x2(Yb + (size_t)c * NP + j1, rest, Yb + (size_t)c * NP + jb, Yb + (size_t)(c + 1) * NP + j1, rest,
+              Yb + (size_t)(c + 1) * NP + jb, t0, t1, t2, t3);
+    if (c < m) axpy4(Yb + (size_t)c * NP + j1, rest, Yb + (size_t)c * NP + jb, t0, t1, t2, t3);
+  }
+  return true;
+}
+
 // Solve (S H S + diag(clamp(diag(S H S)))/radius) ds = -S g for the scaled step, return d = S ds and the
 // model cost change  -d^T (g + 1/2 H d).  `free_mask` zeroes constant parameters.
 bool solve_step(const Normal& N, const std::vector<double>& scale, const unsigned char* constant, double radius,
@@ -331,43 +452,48 @@ bool solve_step(const Normal& N, const std::vector<double>& scale, const unsigne
   for (int i = 0; i < nb; ++i) C[i * nb + i] += std::min(std::max(C[i * nb + i], 1e-6), 1e32) / radius;
   (void)is_const;
 
-  // block-tridiagonal Cholesky T = L L^T:  Ld_f = chol(A_f - Ls_{f-1} Ls_{f-1}^T),  Ls_f = diag(E_f) Ld_f^{-T}
-  // then forward substitution of the nb + 1 right-hand sides [B | rhs].
+  // block-tridiagonal Cholesky T = L L^T:  Ld_f = chol(A_f - Ls_{f-1} Ls_{f-1}^T),  Ls_f = diag(E_f) Ld_f^{-T}, and the
+  // forward substitution of the nb + 1 right-hand sides [B | rhs], all three as ONE bordered factorisation per frame:
+  // the rows of diag(E_f) and of [B | rhs]^T are appended below A_f and receive L^{-T} from the right while the top
+  // 76 x 76 block is factorised (right-looking, 4 columns at a time, rank-4 row updates on AVX2).
   const int m = nb + 1;
-  std::vector<double> Ls((size_t)std::max(0, nf - 1) * NP * NP, 0.0);  // Ls_f: block (f+1, f)
-  std::vector<double> Y((size_t)nf * NP * m);                          // L^{-1} [B | rhs]
+  static thread_local std::vector<double> wsLs, wsYt, wsLsT;
+  wsLs.resize((size_t)std::max(1, nf - 1) * NP * NP);   // Ls_f: block (f+1, f), row i is zero left of column i
+  wsYt.resize((size_t)nf * m * NP);                     // (L^{-1} [B | rhs])^T: [frame][column][76]
+  wsLsT.resize((size_t)NP * NP);
+  double* const Ls = wsLs.data();
+  double* const Yt = wsYt.data();
+  double* const LsT = wsLsT.data();                     // transpose of the latest Ls
   for (int lf = 0; lf < nf; ++lf) {
-    double* Af = &A[(size_t)lf * NP * NP];
-    double* Yf = &Y[(size_t)lf * NP * m];
-    for (int i = 0; i < NP; ++i) {
-      for (int j = 0; j < nb; ++j) Yf[i * m + j] = B[((size_t)lf * NP + i) * nb + j];
-      Yf[i * m + nb] = rhs[lf * NP + i];
-    }
+    double* Af = &A[(size_t)lf * NP * NP];              // factorised in place (lower triangle)
+    const bool has_next = lf + 1 < nf;
+    double* Eb = has_next ? Ls + (size_t)lf * NP * NP : nullptr;   // rows of diag(E) -> Ls
+    double* Yb = Yt + (size_t)lf * m * NP;                         // rows of [B | rhs]^T -> Yt
+    for (int c = 0; c < nb; ++c)
+      for (int i = 0; i < NP; ++i) Yb[(size_t)c * NP + i] = B[((size_t)lf * NP + i) * nb + c];
+    for (int i = 0; i < NP; ++i) Yb[(size_t)nb * NP + i] = rhs[lf * NP + i];
     if (lf > 0) {
-      // Ls (block (lf, lf-1)) = diag(E) Ld^{-T} is upper triangular: row i is zero left of column i
-      const double* Lp = &Ls[(size_t)(lf - 1) * NP * NP];
-      const double* Yp = &Y[(size_t)(lf - 1) * NP * m];
+      // A_f -= Ls Ls^T and [B | rhs]^T -= (Ls Yp)^T as rank-4 row updates against Ls^T (LsT[k][j] = Ls[j][k], zero for
+      // j > k; Ls[i][k] is zero for k < i, so the k groups may start at a multiple of 4 below i)
+      const double* Lp = Ls + (size_t)(lf - 1) * NP * NP;
+      const double* Yp = Yt + (size_t)(lf - 1) * m * NP;
       for (int i = 0; i < NP; ++i) {
-        const double* Li = Lp + (size_t)i * NP;
-        for (int j = 0; j <= i; ++j) Af[i * NP + j] -= dot4(Li + i, Lp + (size_t)j * NP + i, NP - i);
-        for (int k = i; k < NP; ++k) {
-          const double l = Li[k];
-          if (l == 0.0) continue;
-          for (int j = 0; j < m; ++j) Yf[i * m + j] -= l * Yp[k * m + j];
-        }
+        double* Mi = Af + (size_t)i * NP;
+        for (int k = i & ~3; k < NP; k += 4)
+          axpy4(Mi, i + 1, Lp + (size_t)i * NP + k, LsT + (size_t)k * NP, LsT + (size_t)(k + 1) * NP,
+                LsT + (size_t)(k + 2) * NP, LsT + (size_t)(k + 3) * NP);
       }
+      for (int c = 0; c < m; ++c)
+        for (int k = 0; k < NP; k += 4)
+          axpy4(Yb + (size_t)c * NP, k + 4, Yp + (size_t)c * NP + k, LsT + (size_t)k * NP, LsT + (size_t)(k + 1) * NP,
+                LsT + (size_t)(k + 2) * NP, LsT + (size_t)(k + 3) * NP);
     }
-    if (!chol_inplace(Af, NP)) return false;
-    fwd_solve(Af, NP, Yf, m);
-    if (lf + 1 < nf) {
-      // Ls = diag(E) Ld^{-T}:  solve Ld X^T = diag(E)  ->  X = Ls
-      double* Lsf = &Ls[(size_t)lf * NP * NP];
-      std::vector<double> X((size_t)NP * NP, 0.0);
-      for (int i = 0; i < NP; ++i) X[i * NP + i] = E[(size_t)lf * NP + i];
-      fwd_solve(Af, NP, X.data(), NP, /*lower_rhs=*/true);   // X = Ld^{-1} diag(E), lower triangular
-      for (int i = 0; i < NP; ++i)
-        for (int j = i; j < NP; ++j) Lsf[i * NP + j] = X[j * NP + i];   // transpose (upper triangle; the rest stays 0)
+    if (has_next) {
+      std::memset(Eb, 0, sizeof(double) * NP * NP);
+      for (int i = 0; i < NP; ++i) Eb[(size_t)i * NP + i] = E[(size_t)lf * NP + i];
     }
+    if (!bordered_chol(Af, Eb, Yb, m)) return false;
+    if (has_next) transpose76(Eb, LsT);
   }
   // Schur complement on beta: S = C - Yb^T Yb, rb = rhs_b - Yb^T y
   std::vector<double> db(nb, 0.0);
@@ -375,14 +501,11 @@ bool solve_step(const Normal& N, const std::vector<double>& scale, const unsigne
     std::vector<double> S(C), rb(nb);
     for (int i = 0; i < nb; ++i) rb[i] = rhs[nf * NP + i];
     for (int lf = 0; lf < nf; ++lf) {
-      const double* Yf = &Y[(size_t)lf * NP * m];
-      for (int k = 0; k < NP; ++k)
-        for (int i = 0; i < nb; ++i) {
-          const double yi = Yf[k * m + i];
-          if (yi == 0.0) continue;
-          rb[i] -= yi * Yf[k * m + nb];
-          for (int j = 0; j <= i; ++j) S[i * nb + j] -= yi * Yf[k * m + j];
-        }
+      const double* Yf = Yt + (size_t)lf * m * NP;
+      for (int i = 0; i < nb; ++i) {
+        rb[i] -= dot4(Yf + (size_t)i * NP, Yf + (size_t)nb * NP, NP);
+        for (int j = 0; j <= i; ++j) S[i * nb + j] -= dot4(Yf + (size_t)i * NP, Yf + (size_t)j * NP, NP);
+      }
     }
     if (!chol_inplace(S.data(), nb)) return false;
     fwd_solve(S.data(), nb, rb.data(), 1);
@@ -392,19 +515,23 @@ bool solve_step(const Normal& N, const std::vector<double>& scale, const unsigne
   // back substitution:  z = y - Yb db ;  x = L^{-T} z  (block bidiagonal)
   std::vector<double> ds(n, 0.0);
   std::vector<double> z((size_t)nf * NP);
-  for (int lf = 0; lf < nf; ++lf)
+  for (int lf = 0; lf < nf; ++lf) {
+    const double* Yf = Yt + (size_t)lf * m * NP;
     for (int i = 0; i < NP; ++i) {
-      double v = Y[((size_t)lf * NP + i) * m + nb];
-      for (int j = 0; j < nb; ++j) v -= Y[((size_t)lf * NP + i) * m + j] * db[j];
+      double v = Yf[(size_t)nb * NP + i];
+      for (int j = 0; j < nb; ++j) v -= Yf[(size_t)j * NP + i] * db[j];
       z[lf * NP + i] = v;
     }
+  }
   for (int lf = nf - 1; lf >= 0; --lf) {
     double* zf = &z[(size_t)lf * NP];
     if (lf + 1 < nf) {
-      const double* Lsf = &Ls[(size_t)lf * NP * NP];   // block (lf+1, lf): contributes Ls^T x_{lf+1}
+      const double* Lsf = Ls + (size_t)lf * NP * NP;   // block (lf+1, lf): contributes Ls^T x_{lf+1}
       const double* xn = &ds[(size_t)(lf + 1) * NP];
-      for (int i = 0; i < NP; ++i)
-        for (int k = 0; k < NP; ++k) zf[k] -= Lsf[i * NP + k] * xn[i];
+      for (int i = 0; i < NP; ++i) {
+        const double xi = xn[i];
+        for (int k = i; k < NP; ++k) zf[k] -= Lsf[i * NP + k] * xi;
+      }
     }
     bwd_solve(&A[(size_t)lf * NP * NP], NP, zf, 1);
     for (int i = 0; i < NP; ++i) ds[lf * NP + i] = zf[i];
@@ -419,8 +546,7 @@ bool solve_step(const Normal& N, const std::vector<double>& scale, const unsigne
     const double* Af = &N.A[(size_t)lf * NP * NP];
     const double* x = &d[(size_t)lf * NP];
     for (int i = 0; i < NP; ++i) {
-      double s = 0.0;
-      for (int j = 0; j < NP; ++j) s += Af[i * NP + j] * x[j];
+      double s = dot4(Af + (size_t)i * NP, x, NP);
       for (int j = 0; j < nb; ++j) s += 2.0 * N.B[((size_t)lf * NP + i) * nb + j] * d[nf * NP + j];
       if (lf + 1 < nf) s += 2.0 * N.E[(size_t)lf * NP + i] * d[(size_t)(lf + 1) * NP + i];
       dHd += x[i] * s;
