@@ -28,3 +28,26 @@ for rep in range(30):
     xs, bs, s = prob.solve(seq.init_params, np.zeros((64, 10)), independent=True, max_iters=60)
     assert all(q.usable for q in s) and np.isfinite(xs).all()
 print("solves ok", round(time.time() - t0, 1), "s")
+# repeated solves on ONE problem (the LM state pool and stream are reused), then overlay create / render / destroy cycles
+seq = synth.make_sequence(model, 64, seed=7)
+prob = api.Problem.from_sequence(gm, seq, n_cols=86, use_shape=True, beta_per_frame=True, beta_pose=20.0, gmm=gmm, beta_shape=30.0,
+                                 want_mesh=True)
+ref = None
+for rep in range(40):
+    xs, bs, s = prob.solve(seq.init_params, np.zeros((64, 10)), independent=True, max_iters=40)
+    if ref is None: ref = xs.copy()
+    assert np.array_equal(ref, xs)
+faces = synth.make_faces(model)
+free0 = torch.cuda.mem_get_info()[0]
+wb = prob.writeback(xs, bs, want_cloud=True)
+img0 = None
+for rep in range(30):
+    ov = api.Overlay(faces, model.n_verts, 640, 360, max_frames=64)
+    img = np.zeros((64, 360, 640, 3), np.uint8)
+    ov.render(wb["cloud"], img, synth.camera_intrinsics(640, 360))
+    if img0 is None: img0 = img.copy()
+    assert np.array_equal(img0, img)
+    ov.close()
+free1 = torch.cuda.mem_get_info()[0]
+assert abs(free0 - free1) < 64 << 20, (free0, free1)
+print("pooled solves + overlay cycles ok", round(time.time() - t0, 1), "s")
