@@ -539,7 +539,7 @@ __global__ __launch_bounds__(kTileThreads) void k_ov_tiles(const OvTri* __restri
                                                            const unsigned* __restrict__ active,
                                                            const unsigned* __restrict__ totals,
                                                            unsigned char* __restrict__ images, size_t row_stride,
-                                                           size_t frame_stride) {
+                                                           size_t frame_stride, int mode /* 1 fill, 2 wireframe */) {
   extern __shared__ unsigned char smem[];
   const int nWords = (nF + 31) >> 5;
   unsigned* pix = reinterpret_cast<unsigned*>(smem);                    // [256] the tile, row-major
@@ -648,17 +648,15 @@ __global__ __launch_bounds__(kTileThreads) void k_ov_tiles(const OvTri* __restri
 #define RL64(i) ((long long)(((unsigned long long)(unsigned)RL((i) + 1) << 32) | (unsigned)RL(i)))
         if (RL(61) < tx0 || RL(59) > tx0 + kTile - 1 || RL(62) < ty0 || RL(60) > ty0 + kTile - 1) continue;
         const int g = RL(58);
-        // ---- the three anti-aliased edges, in the order FillConvexPoly draws them ----
-#pragma unroll
-        for (int li = 0; li < 3; ++li) {
-          const int o = 12 * li;
+        // one anti-aliased segment (record dwords o .. o + 8) in colour `col`
+        auto draw_edge = [&](int o, int col) {
           const int flags = RL(o + 5);
-          if (!(flags & 1)) continue;
+          if (!(flags & 1)) return;
           const bool xm = (flags & 2) != 0;
           const int major0 = xm ? tx0 : ty0, minor0 = xm ? ty0 : tx0;
           const int c0 = RL(o + 3), E = RL(o + 4);
           const int kA = max(0, major0 - c0), kB = min(E, major0 + kTile - 1 - c0);
-          if (kA > kB) continue;
+          if (kA > kB) return;
           const int k = kA + eStep;
           const int m = RL(o) + __mul24(k, RL(o + 2));   // k < 2^15, |step| <= 2^16; the true value fits 32 bits
           const int mi = (m >> XY_SHIFT) - 1 + eTap - minor0;
@@ -667,17 +665,22 @@ __global__ __launch_bounds__(kTileThreads) void k_ov_tiles(const OvTri* __restri
           if (lane < 48 && k <= kB && (unsigned)mi < (unsigned)kTile) {
             const int dist = (m >> (XY_SHIFT - 5)) & 31;
             const int f = filt[eTap == 0 ? dist + 32 : (eTap == 1 ? dist : 63 - dist)];
-            const int row = min(k, 2), col = min(E - k, 2);
+            const int row = min(k, 2), cl = min(E - k, 2);
             const unsigned er = row == 0 ? ep0 : (row == 1 ? ep1 : ep2);
-            const int ep = (int)((er >> (9 * col)) & 0x1ffu);
+            const int ep = (int)((er >> (9 * cl)) & 0x1ffu);
             const int al = (__mul24(ep, f) >> 8) & 0xff;
             const int idx = xm ? mi * kTile + ma : ma * kTile + mi;
             const unsigned v = pix[idx];
             int c0v = (int)(v & 0xff), c1v = (int)((v >> 8) & 0xff), c2v = (int)((v >> 16) & 0xff);
-            blend2(c0v, g, al); blend2(c1v, g, al); blend2(c2v, g, al);
+            blend2(c0v, col, al); blend2(c1v, col, al); blend2(c2v, col, al);
             pix[idx] = (unsigned)c0v | ((unsigned)c1v << 8) | ((unsigned)c2v << 16);
           }
-        }
+        };
+        if (mode & 1) {
+        // ---- cv::fillConvexPoly: the three anti-aliased edges v2-v0, v0-v1, v1-v2, then the spans ----
+        draw_edge(0, g);
+        draw_edge(12, g);
+        draw_edge(24, g);
         // ---- the opaque span of every row: the two walkers once per tile row (lanes 0..15), then 4 rows per pass ----
         const int ya = max(RL(56), ty0), yb = min(RL(57), ty0 + kTile - 1);
         if (ya <= yb) {
@@ -701,6 +704,13 @@ __global__ __launch_bounds__(kTileThreads) void k_ov_tiles(const OvTri* __restri
             const unsigned sp = span[r0 + fRow];
             if (fCol >= (int)(sp & 0xff) && fCol <= (int)(sp >> 8)) pix[(r0 + fRow) * kTile + fCol] = gg;
           }
+        }
+        }
+        if (mode & 2) {
+          // ---- cv::polylines({v0, v1, v2, v0}, open, gray 40, LINE_AA): the same three segments, after the fill ----
+          draw_edge(12, 40);
+          draw_edge(24, 40);
+          draw_edge(0, 40);
         }
 #undef RL
 #undef RL64
@@ -828,7 +838,6 @@ int bodyfit_overlay_render_device(bodyfit_overlay* ov, const void* d_cloud, int 
                                   size_t frame_stride, double fx, double fy, double cx, double cy, int fill,
                                   int backface_cull, int wireframe, void* stream) {
   if (!ov || !d_cloud || !d_images) return bodyfit_internal_fail(BODYFIT_ERR_INVALID, "bodyfit_overlay_render: null argument");
-  if (wireframe) return bodyfit_internal_fail(BODYFIT_ERR_INVALID, "bodyfit_overlay_render: wireframe is not supported");
   if (n_frames < 1 || n_frames > ov->maxFrames)
     return bodyfit_internal_fail(BODYFIT_ERR_INVALID, "bodyfit_overlay_render: n_frames exceeds max_frames");
   if ((n_frames > 1 && cloud_frame_stride_elems < (size_t)ov->nV * 3) || row_stride < (size_t)ov->W * 3 ||
@@ -861,7 +870,7 @@ int bodyfit_overlay_render_device(bodyfit_overlay* ov, const void* d_cloud, int 
   hipLaunchKernelGGL(k_ov_rank, dim3((ov->nChunks * kChunk + 255) / 256, F), dim3(256), 0, st, ov->d_skey, ov->d_sidx, nF,
                      ov->nChunks, ov->d_tmp, ov->d_sorted, ov->d_alive);
   OV_TRY(hipEventRecord(ov->ev[2], st));
-  if (!fill) {   // wireframe is off too: the reference draws nothing (RenderSMPLMesh.h:97,106)
+  if (!fill && !wireframe) {   // the reference draws nothing (RenderSMPLMesh.h:97,106)
     OV_TRY(hipEventRecord(ov->ev[3], st));
     OV_TRY(hipEventRecord(ov->ev[4], st));
     OV_TRY(hipGetLastError());
@@ -897,7 +906,7 @@ int bodyfit_overlay_render_device(bodyfit_overlay* ov, const void* d_cloud, int 
     const int grid = (int)std::min<unsigned>(totals[1], 256u * 64u);
     hipLaunchKernelGGL(k_ov_tiles, dim3(grid), dim3(kTileThreads), tile_lds_bytes(nF), st, ov->d_tris, nF, ov->W, ov->H,
                        ov->tilesX, ov->tilesY, ov->d_offset, ov->d_entries, ov->d_active, ov->d_totals, d_images,
-                       row_stride, frame_stride);
+                       row_stride, frame_stride, (fill ? 1 : 0) | (wireframe ? 2 : 0));
   }
   OV_TRY(hipEventRecord(ov->ev[4], st));
   OV_TRY(hipGetLastError());

@@ -243,9 +243,9 @@ int bodyfit_frame_normals(bodyfit_problem* p, const double* frame_params, const 
  * resident on the device: project (:36-46), per-face cull / flat shade / painter depth / integer corners
  * (:50-88), far-to-near order (:91-92; ties by face index, the reference's std::sort leaves them unspecified)
  * and cv::fillConvexPoly(..., LINE_AA) per triangle in that order (:95-104).  The result is, pixel for pixel,
- * what drawing the triangles one after the other gives.  wireframe != 0 (:106-109, never enabled by the
- * reference's callers: src/main_single_frame.cpp:274, src/main_multi_frame.cpp:210,223) is rejected with
- * BODYFIT_ERR_INVALID; fill == 0 then draws nothing, as there.
+ * what drawing the triangles one after the other gives.  wireframe != 0 adds cv::polylines in gray 40 after each
+ * triangle's fill (:106-109; the reference's callers never enable it: src/main_single_frame.cpp:274,
+ * src/main_multi_frame.cpp:210,223); fill == 0 and wireframe == 0 draws nothing, as there.
  *   faces [n_faces][3] vertex ids (ark::AvatarModel::mesh columns, src/main_single_frame.cpp:185-188)
  *   cloud: x, y, z per vertex (the memory order of the reference's 3xN column-major `cloud`), camera
  *   coordinates; cloud_is_f64 0: float (bodyfit_device_views.cloud of a write-back), 1: double

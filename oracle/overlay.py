@@ -60,15 +60,16 @@ def fill_triangle(img, pts, gray):
     return img
 
 
-def render(cloud, faces, img, fx, fy, cx, cy, fill=True, backface_cull=True):
-    """renderSMPLMesh(cloud, faces, img, fx, fy, cx, cy, fill, backface_cull, wireframe=false), in place."""
+def render(cloud, faces, img, fx, fy, cx, cy, fill=True, backface_cull=True, wireframe=False):
+    """renderSMPLMesh(cloud, faces, img, fx, fy, cx, cy, fill, backface_cull, wireframe), in place."""
     assert img.dtype == np.uint8 and img.ndim == 3 and img.shape[2] == 3 and img.strides[2] == 1 and img.strides[1] == 3
     cloud = np.ascontiguousarray(cloud, dtype=np.float64).reshape(-1, 3)
     faces = np.ascontiguousarray(faces, dtype=np.int32).reshape(-1, 3)
     lib().overlay_oracle_render(_p(cloud, C.c_double), C.c_int(cloud.shape[0]), _p(faces, C.c_int32),
                                 C.c_int(faces.shape[0]), _p(img, C.c_uint8), C.c_int(img.shape[1]),
                                 C.c_int(img.shape[0]), C.c_size_t(img.strides[0]), C.c_double(fx), C.c_double(fy),
-                                C.c_double(cx), C.c_double(cy), C.c_int(int(fill)), C.c_int(int(backface_cull)))
+                                C.c_double(cx), C.c_double(cy), C.c_int(int(fill)), C.c_int(int(backface_cull)),
+                                C.c_int(int(wireframe)))
     return img
 
 

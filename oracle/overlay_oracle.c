@@ -13,7 +13,9 @@
  *            pixel corners via std::round
  *   :91-92   sort far to near (std::sort there, whose tie order is unspecified: a stable sort by face index here)
  *   :95-104  fill each triangle with gray round(220*shade), cv::LINE_AA
- * The wireframe branch (:106-109, never enabled by the reference's callers) is not restated.
+ *   :106-109 wireframe: cv::polylines(img, {p0, p1, p2, p0}, false, Scalar(40,40,40), 1, LINE_AA) after the fill, i.e.
+ *            (imgproc drawing.cpp: PolyLine -> ThickLine with thickness 1 and LINE_AA -> LineAA) three more
+ *            anti-aliased segments p0-p1, p1-p2, p2-p0 [recalled]
  *
  * Plain sequential C on purpose: one triangle after the other, one scanline after the other, exactly as the
  * reference draws.  Compile with -ffp-contract=off (the shade is a chain of products and sums).
@@ -346,6 +348,16 @@ int overlay_oracle_drawlist(const double* cloud, int n_vertices, const int32_t* 
   return n;
 }
 
+/* cv::polylines(img, {p0, p1, p2, p0}, false, Scalar(40, 40, 40), 1, cv::LINE_AA) */
+static void wire_triangle(image3* im, const pt2l v[3]) {
+  const int col[3] = {40, 40, 40};
+  for (int i = 0; i < 3; ++i) {
+    pt2l a = v[i], b = v[(i + 1) % 3];
+    a.x *= XY_ONE; a.y *= XY_ONE; b.x *= XY_ONE; b.y *= XY_ONE;
+    line_aa(im, a, b, col);
+  }
+}
+
 /* cv::fillConvexPoly(img, pts, 3, Scalar(g,g,g), cv::LINE_AA) for one triangle (unit-test entry) */
 void overlay_oracle_fill_triangle(uint8_t* img, int width, int height, size_t step, const int32_t pts[6], int gray) {
   image3 im = {img, width, height, step};
@@ -356,16 +368,22 @@ void overlay_oracle_fill_triangle(uint8_t* img, int width, int height, size_t st
   fill_convex_tri_aa(&im, v, col);
 }
 
-/* renderSMPLMesh(cloud, faces, img, fx, fy, cx, cy, fill, backface_cull, wireframe = false) on one 8UC3 image */
+/* renderSMPLMesh(cloud, faces, img, fx, fy, cx, cy, fill, backface_cull, wireframe) on one 8UC3 image */
 int overlay_oracle_render(const double* cloud, int n_vertices, const int32_t* faces, int n_faces, uint8_t* img, int width,
                           int height, size_t step, double fx, double fy, double cx, double cy, int fill,
-                          int backface_cull) {
+                          int backface_cull, int wireframe) {
   int32_t* pts = (int32_t*)malloc(sizeof(int32_t) * 6 * (size_t)(n_faces > 0 ? n_faces : 1));
   int32_t* gray = (int32_t*)malloc(sizeof(int32_t) * (size_t)(n_faces > 0 ? n_faces : 1));
   const int n = overlay_oracle_drawlist(cloud, n_vertices, faces, n_faces, fx, fy, cx, cy, backface_cull, NULL, NULL,
                                         pts, gray);
-  if (fill)
-    for (int k = 0; k < n; ++k) overlay_oracle_fill_triangle(img, width, height, step, pts + 6 * k, gray[k]);
+  for (int k = 0; k < n; ++k) {
+    if (fill) overlay_oracle_fill_triangle(img, width, height, step, pts + 6 * k, gray[k]);
+    if (wireframe) {
+      image3 im = {img, width, height, step};
+      const pt2l v[3] = {{pts[6 * k], pts[6 * k + 1]}, {pts[6 * k + 2], pts[6 * k + 3]}, {pts[6 * k + 4], pts[6 * k + 5]}};
+      wire_triangle(&im, v);
+    }
+  }
   free(pts); free(gray);
   return n;
 }

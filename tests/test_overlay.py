@@ -36,10 +36,10 @@ def posed_clouds(synth, model, F, seed, depth=3.0, shift=(0.0, 0.0)):
     return np.stack([synth.forward_numpy(model, x[f], rng.normal(size=10) * 0.5, R0)[1] for f in range(F)])
 
 
-def oracle_images(ovo, clouds, faces, bg, intr, fill=True, cull=True):
+def oracle_images(ovo, clouds, faces, bg, intr, fill=True, cull=True, wire=False):
     out = bg.copy()
     for f in range(clouds.shape[0]):
-        ovo.render(clouds[f], faces, out[f], *intr, fill=fill, backface_cull=cull)
+        ovo.render(clouds[f], faces, out[f], *intr, fill=fill, backface_cull=cull, wireframe=wire)
     return out
 
 
@@ -92,6 +92,20 @@ def test_painter_order_and_cull(ovo):
     # a vertex at or behind the camera drops the face (RenderSMPLMesh.h:42,52)
     cloud2 = cloud.copy(); cloud2[0, 2] = 1e-7
     assert list(ovo.drawlist(cloud2, faces, *intr)[0]) == [1]
+
+
+def test_wireframe_outline(ovo):
+    cloud = np.array([[-1, -1, 4.0], [1, -1, 4.0], [0, 1, 4.0]])
+    faces = np.array([[0, 2, 1]], np.int32)
+    intr = (40.0, 40.0, 12.0, 12.0)
+    img = np.zeros((24, 24, 3), np.uint8)
+    ovo.render(cloud, faces, img, *intr, fill=False, wireframe=True)
+    assert 0 < img.max() <= 40 and img[8, 12, 0] == 0          # outline only, never brighter than its colour
+    both = np.zeros((24, 24, 3), np.uint8)
+    ovo.render(cloud, faces, both, *intr, fill=True, wireframe=True)
+    filled = np.zeros((24, 24, 3), np.uint8)
+    ovo.render(cloud, faces, filled, *intr)
+    assert both[8, 12, 0] == filled[8, 12, 0] and (both != filled).any()   # interior untouched, rim darkened
 
 
 def test_drawlist_order_is_stable(ovo):
@@ -180,8 +194,11 @@ def test_gpu_flags_and_errors(api, ovo, synth, model, faces):
     ov, got = gpu_render(api, faces, clouds, bg, intr, fill=False)
     assert np.array_equal(got, bg)                                  # nothing is drawn without fill (wireframe is off)
     assert len(ov.drawlist(0)[0]) == len(ovo.drawlist(clouds[0], faces, *intr)[0])
-    with pytest.raises(api.BodyfitError):
-        ov.render(clouds, bg.copy(), intr, wireframe=True)
+    # the wireframe branch (RenderSMPLMesh.h:106-109): gray-40 outlines after each fill, and outlines alone
+    _, got = gpu_render(api, faces, clouds, bg, intr, wireframe=True)
+    assert_same(got, oracle_images(ovo, clouds, faces, bg, intr, wire=True))
+    _, got = gpu_render(api, faces, clouds, bg, intr, fill=False, wireframe=True, backface_cull=False)
+    assert_same(got, oracle_images(ovo, clouds, faces, bg, intr, fill=False, cull=False, wire=True))
     with pytest.raises(api.BodyfitError):
         ov.render(np.concatenate([clouds, clouds]), np.zeros((2, H, W, 3), np.uint8), intr)   # > max_frames
     with pytest.raises(api.BodyfitError):
@@ -206,11 +223,12 @@ def test_gpu_random_triangle_soup(api, ovo, n_faces, n_verts, W, H, seed):
     fc[::7, 1] = fc[::7, 0]                                          # degenerate: repeated vertex
     intr = (0.9 * W, 0.9 * W, W / 2, H / 2)
     bg = rng.integers(0, 256, (1, H, W, 3), dtype=np.uint8)
-    ov, got = gpu_render(api, fc, cloud[None], bg, intr, backface_cull=False)
+    wire = bool(seed & 1)
+    ov, got = gpu_render(api, fc, cloud[None], bg, intr, backface_cull=False, wireframe=wire)
     face, pts, gray = ov.drawlist(0)
     oface, _, opts, ogray = ovo.drawlist(cloud, fc, *intr, backface_cull=False)
     assert np.array_equal(face, oface) and np.array_equal(pts, opts) and np.array_equal(gray, ogray)
-    assert_same(got, oracle_images(ovo, cloud[None], fc, bg, intr, cull=False))
+    assert_same(got, oracle_images(ovo, cloud[None], fc, bg, intr, cull=False, wire=wire))
 
 
 @pytest.mark.gpu
