@@ -569,8 +569,16 @@ int bodyfit_problem_create(const bodyfit_model* m, const bodyfit_problem_desc* d
   d.nFTiles = (F + kFTile - 1) / kFTile;
   d.fx = desc->fx; d.fy = desc->fy; d.cx = desc->cx; d.cy = desc->cy;
   HIP_TRY(p->mem.upload(&d.kp_offset, p->kp_offset));
-  HIP_TRY(p->mem.upload(&d.kp_id, p->kp_id));
-  HIP_TRY(p->mem.upload(&d.kp_uv, p->kp_uv));
+  {
+    // the device copies carry one keypoint chunk (32 entries) of zero padding: k_frame_resjac prefetches a frame's first
+    // chunk with unconditional loads
+    std::vector<int> ids(p->kp_id);
+    std::vector<double> uv(p->kp_uv);
+    ids.resize(ids.size() + 32, 0);
+    uv.resize(uv.size() + 64, 0.0);
+    HIP_TRY(p->mem.upload(&d.kp_id, ids));
+    HIP_TRY(p->mem.upload(&d.kp_uv, uv));
+  }
   std::vector<double> R0(desc->R0, desc->R0 + (size_t)F * 9);
   HIP_TRY(p->mem.upload(&d.R0, R0));
 

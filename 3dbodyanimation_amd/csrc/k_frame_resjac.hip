@@ -249,18 +249,26 @@ __global__ __launch_bounds__(kThreads, 4) void k_frame_resjac(DevModel M, DevPro
       if (i < nds) { sDS[i] = t0[u]; sSc[i] = t1[u]; }
     }
   }
-  {
-    const int k_begin0 = Pb.kp_offset[f], nk0 = min(KC, Pb.kp_offset[f + 1] - k_begin0);
-    if (tid < nk0) {
-      sTab[TAB_KPID + tid] = Pb.kp_id[k_begin0 + tid];
-      sKpUv[2 * tid] = Pb.kp_uv[2 * (size_t)(k_begin0 + tid)];
-      sKpUv[2 * tid + 1] = Pb.kp_uv[2 * (size_t)(k_begin0 + tid) + 1];
-    }
-  }
-  if (tid >= 128 && tid - 128 < npose) sx[tid - 128] = params[(size_t)f * npose + tid - 128];
-  if (tid >= 224 && tid - 224 < nS)
-    sx[npose + tid - 224] = (use_shape && beta) ? beta[(size_t)f * Pb.beta_stride + tid - 224] : 0.0;
+  // the first keypoint chunk depends on kp_offset[f] (a second round trip): its loads are issued here but land in LDS
+  // only after the barrier, so phase A waits for one round trip, not two (the staged keypoints are first read in F)
+  const int k_begin0 = Pb.kp_offset[f], nk0 = min(KC, Pb.kp_offset[f + 1] - k_begin0);
+  double x_in = 0.0;
+  const bool x_lane = tid >= 128 && tid - 128 < npose, b_lane = tid >= 224 && tid - 224 < nS;
+  if (x_lane) x_in = params[(size_t)f * npose + tid - 128];
+  if (b_lane) x_in = (use_shape && beta) ? beta[(size_t)f * Pb.beta_stride + tid - 224] : 0.0;
+  // issued last and by every lane (the arrays are padded by one chunk): loads return in order, so everything above is
+  // waited for with these still in flight
+  const int kp_id0 = Pb.kp_id[k_begin0 + (tid & (KC - 1))];
+  const double kp_u0 = Pb.kp_uv[2 * (size_t)(k_begin0 + (tid & (KC - 1)))];
+  const double kp_v0 = Pb.kp_uv[2 * (size_t)(k_begin0 + (tid & (KC - 1))) + 1];
+  if (x_lane) sx[tid - 128] = x_in;
+  if (b_lane) sx[npose + tid - 224] = x_in;
   __syncthreads();
+  if (tid < nk0) {
+    sTab[TAB_KPID + tid] = kp_id0;
+    sKpUv[2 * tid] = kp_u0;
+    sKpUv[2 * tid + 1] = kp_v0;
+  }
   const double* sbeta = sx + npose;
 
   STAMP(1);
