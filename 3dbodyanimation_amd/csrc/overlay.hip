@@ -891,10 +891,12 @@ int bodyfit_overlay_render_device(bodyfit_overlay* ov, const void* d_cloud, int 
   if (totals[0] > ov->entriesCap) {
     if (ov->d_entries) OV_TRY(hipFree(ov->d_entries));
     ov->d_entries = nullptr;
-    ov->entriesCap = (size_t)totals[0] + totals[0] / 4 + 1024;
+    ov->entriesCap = 0;
+    const size_t want = (size_t)totals[0] + totals[0] / 4 + 1024;
     void* q = nullptr;
-    OV_TRY(hipMalloc(&q, ov->entriesCap * sizeof(unsigned)));
+    OV_TRY(hipMalloc(&q, want * sizeof(unsigned)));
     ov->d_entries = static_cast<unsigned*>(q);
+    ov->entriesCap = want;
   }
   if (totals[0]) {
     hipLaunchKernelGGL(k_ov_setup, dim3((nF + 255) / 256, F), dim3(256), 0, st, ov->d_sorted, nF, ov->W, ov->H, ov->d_tris);
