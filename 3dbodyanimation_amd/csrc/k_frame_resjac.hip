@@ -252,6 +252,13 @@ __global__ __launch_bounds__(kThreads, 4) void k_frame_resjac(DevModel M, DevPro
   // the first keypoint chunk depends on kp_offset[f] (a second round trip): its loads are issued here but land in LDS
   // only after the barrier, so phase A waits for one round trip, not two (the staged keypoints are first read in F)
   const int k_begin0 = Pb.kp_offset[f], nk0 = min(KC, Pb.kp_offset[f + 1] - k_begin0);
+  // model constants phase B needs (chain offsets, centred rest joints, landmark template rows): requested here, with
+  // the tables, and consumed from registers after the barrier, so phase B has no round trip of its own
+  const int o_i = tid - 128, v_row = tid - 256;
+  const bool o_lane = tid >= 128 && o_i < nJ * 3, v_lane = tid >= 256 && v_row < nL * 3;
+  double o_pre = 0.0, jc_pre = 0.0, vt_pre = 0.0;
+  if (o_lane) { o_pre = M.offset[o_i]; jc_pre = M.Jc0[o_i]; }
+  if (v_lane) vt_pre = M.lm_vt[v_row];
   double x_in = 0.0;
   const bool x_lane = tid >= 128 && tid - 128 < npose, b_lane = tid >= 224 && tid - 224 < nS;
   if (x_lane) x_in = params[(size_t)f * npose + tid - 128];
@@ -286,30 +293,29 @@ __global__ __launch_bounds__(kThreads, 4) void k_frame_resjac(DevModel M, DevPro
 #pragma unroll
     for (int i = 0; i < 9; ++i) sdR[jj * 27 + k * 9 + i] = dRk[i];
   }
-  if (tid >= 256 && tid - 256 < nL * 3) {
+  if (v_lane) {
     // landmark rest vertex before the pose blend: v_t + shapedirs . beta (10 independent loads)
-    const int row = tid - 256;
+    const int row = v_row;
     double sv[kMaxShape];
 #pragma unroll
     for (int k = 0; k < kMaxShape; ++k) sv[k] = (use_shape && k < nS) ? sLmSd[row * nS + k] : 0.0;
-    double acc = M.lm_vt[row];
+    double acc = vt_pre;
 #pragma unroll
     for (int k = 0; k < kMaxShape; ++k) acc += sv[k] * sbeta[min(k, nS > 0 ? nS - 1 : 0)];
     sPart[row] = acc;
   }
-  if (tid >= 128 && tid < 256) {
-    for (int i = tid - 128; i < nJ * 3; i += 128) {
-      double o = M.offset[i], jc = M.Jc0[i];
-      if (use_shape) {
-        for (int k = 0; k < nS; ++k) {
-          o += sDS[i * nS + k] * sbeta[k];
-          jc += sSc[i * nS + k] * sbeta[k];
-        }
+  if (o_lane) {   // 3 nJ <= 72 < 128: one item per lane
+    const int i = o_i;
+    double o = o_pre, jc = jc_pre;
+    if (use_shape) {
+      for (int k = 0; k < nS; ++k) {
+        o += sDS[i * nS + k] * sbeta[k];
+        jc += sSc[i * nS + k] * sbeta[k];
       }
-      sO[i] = (i < 3) ? 0.0 : o;
-      if (i < 3) sPart[100 + i] = o;     // the root keypoint's own q = offset_0 + S_0 beta (include/Sim3BA.h:142-170)
-      sJc[i] = jc;
     }
+    sO[i] = (i < 3) ? 0.0 : o;
+    if (i < 3) sPart[100 + i] = o;     // the root keypoint's own q = offset_0 + S_0 beta (include/Sim3BA.h:142-170)
+    sJc[i] = jc;
   }
   __syncthreads();
 
