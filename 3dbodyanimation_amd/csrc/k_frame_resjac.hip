@@ -508,8 +508,65 @@ __global__ __launch_bounds__(kThreads, 4) void k_frame_resjac(DevModel M, DevPro
   const double* Rr0 = sCam;
   const double* dRr0 = sCam + 9;
 
+  // keypoint stage of a chunk (phase F): camera point, residual, projection derivative per keypoint.  It depends on
+  // nothing phase E produces, so the frame's first chunk runs on wave 6 (which has the least to do there) DURING E
+  const int k_begin = k_begin0, k_end = k_begin0 + (Pb.kp_offset[f + 1] - k_begin0);
+  const bool fold = Pb.beta_partials != nullptr && want_jac && ncols > npose && nS == kMaxShape;
+  auto stage_kp = [&](int tid, int kc0) {   // `tid`: slot of the keypoint in its chunk
+    {
+      const int kg = kc0 + tid;
+      const bool first = kc0 == k_begin;
+      const int id = first ? sKpId[tid] : Pb.kp_id[kg];
+      const double u_obs = first ? sKpUv[2 * tid] : Pb.kp_uv[2 * (size_t)kg];
+      const double v_obs = first ? sKpUv[2 * tid + 1] : Pb.kp_uv[2 * (size_t)kg + 1];
+      sKpId[tid] = id;
+      sKpAnc[tid] = (id < nJ) ? sAnc[id] : 0u;    // the Jacobian sweep reads id and mask in one LDS round trip
+      double q[3];
+      if (id < nJ) {
+        if (id == 0 || sParent[id] < 0) {
+          // include/Sim3BA.h:142-170 without a chain: q = offset + S_id beta (no parent term), staged in phase B
+#pragma unroll
+          for (int a = 0; a < 3; ++a) q[a] = sPart[100 + a];
+        } else {
+#pragma unroll
+          for (int a = 0; a < 3; ++a) q[a] = sP[id * 3 + a];
+        }
+      } else {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) q[a] = sLm[(id - nJ) * LM_STRIDE + LM_Q + a];
+      }
+      double z[3];
+      mv3(Rr0, q[0], q[1], q[2], z);                     // include/Sim3BA.h:210-216
+      const double X0 = s * z[0] + sx[4], X1 = s * z[1] + sx[5], X2 = s * z[2] + sx[6];  // :217-219
+      const double iz = 1.0 / X2;                        // :222-223, Z unguarded as in the reference
+      const double res0 = Pb.fx * X0 * iz + Pb.cx - u_obs, res1 = Pb.fy * X1 * iz + Pb.cy - v_obs;
+      r_out[2 * (size_t)kg] = res0;
+      r_out[2 * (size_t)kg + 1] = res1;
+      if (fold) {   // kept for the folded beta reduction (the observation in sKpUv was consumed above; sFeat is dead)
+        const double sq = res0 * res0 + res1 * res1, d2 = Pb.huber * Pb.huber;
+        const bool outl = Pb.huber > 0.0 && sq > d2;
+        const double rt = sqrt(sq);
+        sKpUv[2 * tid] = res0;
+        sKpUv[2 * tid + 1] = res1;
+        sFeat[tid] = outl ? sqrt(Pb.huber / rt) : 1.0;                // sqrt(rho')
+        sFeat[KC + tid] = 0.5 * (outl ? 2.0 * Pb.huber * rt - d2 : sq);   // 1/2 rho
+      }
+      double* kp = sKp + tid * 18;
+      const double dpi[6] = {Pb.fx * iz, 0.0, -Pb.fx * X0 * iz * iz, 0.0, Pb.fy * iz, -Pb.fy * X1 * iz * iz};
+#pragma unroll
+      for (int a = 0; a < 3; ++a) { kp[a] = q[a]; kp[3 + a] = z[a]; }
+#pragma unroll
+      for (int i = 0; i < 6; ++i) kp[6 + i] = dpi[i];
+#pragma unroll
+      for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+          kp[12 + rr * 3 + c] = s * (dpi[rr * 3] * Rr0[c] + dpi[rr * 3 + 1] * Rr0[3 + c] + dpi[rr * 3 + 2] * Rr0[6 + c]);
+    }
+  };
   STAMP(5);
-  // ---- E. independent items: mesh operands + posed joints, landmark Jacobian terms ---------------------------
+  // ---- E. independent items: mesh operands + posed joints, landmark Jacobian terms, first keypoint chunk ----------
+  if (wave == 6 && lane < min(KC, k_end - k_begin)) stage_kp(lane, k_begin);
   if (wave == 7 && lane < nJ) {   // (waves 6 and 7 carry no landmark items below unless the model has more than 12)
     const int jj = lane;
     double RA[9], t[3], q[3];
@@ -589,8 +646,6 @@ __global__ __launch_bounds__(kThreads, 4) void k_frame_resjac(DevModel M, DevPro
   STAMP(6);
   // ---- F. keypoints of this frame, KC at a time: stage per-keypoint data, then the flat (keypoint, column)
   //         sweep over all 512 threads (consecutive threads on consecutive columns of the row-major panel) ------
-  const int k_begin = Pb.kp_offset[f], k_end = Pb.kp_offset[f + 1];
-  const bool fold = Pb.beta_partials != nullptr && want_jac && ncols > npose && nS == kMaxShape;
   double* sJb = sdR;            // [2 KC][10] d r / d beta of the chunk; dR is dead after phase D
   double fold_acc = 0.0;
   typedef __attribute__((ext_vector_type(4))) double fold_d4;
@@ -598,57 +653,10 @@ __global__ __launch_bounds__(kThreads, 4) void k_frame_resjac(DevModel M, DevPro
   for (int kc0 = k_begin; kc0 < k_end; kc0 += KC) {
     const int nk = min(KC, k_end - kc0);
     __syncthreads();   // phase E results visible / previous chunk's staging consumed
-    if (tid < nk) {
-      const int kg = kc0 + tid;
-      const bool first = kc0 == k_begin;
-      const int id = first ? sKpId[tid] : Pb.kp_id[kg];
-      const double u_obs = first ? sKpUv[2 * tid] : Pb.kp_uv[2 * (size_t)kg];
-      const double v_obs = first ? sKpUv[2 * tid + 1] : Pb.kp_uv[2 * (size_t)kg + 1];
-      sKpId[tid] = id;
-      sKpAnc[tid] = (id < nJ) ? sAnc[id] : 0u;    // the Jacobian sweep reads id and mask in one LDS round trip
-      double q[3];
-      if (id < nJ) {
-        if (id == 0 || sParent[id] < 0) {
-          // include/Sim3BA.h:142-170 without a chain: q = offset + S_id beta (no parent term), staged in phase B
-#pragma unroll
-          for (int a = 0; a < 3; ++a) q[a] = sPart[100 + a];
-        } else {
-#pragma unroll
-          for (int a = 0; a < 3; ++a) q[a] = sP[id * 3 + a];
-        }
-      } else {
-#pragma unroll
-        for (int a = 0; a < 3; ++a) q[a] = sLm[(id - nJ) * LM_STRIDE + LM_Q + a];
-      }
-      double z[3];
-      mv3(Rr0, q[0], q[1], q[2], z);                     // include/Sim3BA.h:210-216
-      const double X0 = s * z[0] + sx[4], X1 = s * z[1] + sx[5], X2 = s * z[2] + sx[6];  // :217-219
-      const double iz = 1.0 / X2;                        // :222-223, Z unguarded as in the reference
-      const double res0 = Pb.fx * X0 * iz + Pb.cx - u_obs, res1 = Pb.fy * X1 * iz + Pb.cy - v_obs;
-      r_out[2 * (size_t)kg] = res0;
-      r_out[2 * (size_t)kg + 1] = res1;
-      if (fold) {   // kept for the folded beta reduction (the observation in sKpUv was consumed above; sFeat is dead)
-        const double sq = res0 * res0 + res1 * res1, d2 = Pb.huber * Pb.huber;
-        const bool outl = Pb.huber > 0.0 && sq > d2;
-        const double rt = sqrt(sq);
-        sKpUv[2 * tid] = res0;
-        sKpUv[2 * tid + 1] = res1;
-        sFeat[tid] = outl ? sqrt(Pb.huber / rt) : 1.0;                // sqrt(rho')
-        sFeat[KC + tid] = 0.5 * (outl ? 2.0 * Pb.huber * rt - d2 : sq);   // 1/2 rho
-      }
-      double* kp = sKp + tid * 18;
-      const double dpi[6] = {Pb.fx * iz, 0.0, -Pb.fx * X0 * iz * iz, 0.0, Pb.fy * iz, -Pb.fy * X1 * iz * iz};
-#pragma unroll
-      for (int a = 0; a < 3; ++a) { kp[a] = q[a]; kp[3 + a] = z[a]; }
-#pragma unroll
-      for (int i = 0; i < 6; ++i) kp[6 + i] = dpi[i];
-#pragma unroll
-      for (int rr = 0; rr < 2; ++rr)
-#pragma unroll
-        for (int c = 0; c < 3; ++c)
-          kp[12 + rr * 3 + c] = s * (dpi[rr * 3] * Rr0[c] + dpi[rr * 3 + 1] * Rr0[3 + c] + dpi[rr * 3 + 2] * Rr0[6 + c]);
+    if (kc0 != k_begin) {   // (the first chunk was staged by wave 6 during phase E: the barrier above published it)
+      if (tid < nk) stage_kp(tid, kc0);
+      __syncthreads();
     }
-    __syncthreads();
     STAMP(7);
     if (want_jac) {
       // (1) joint columns: thread = (column kc, keypoint group g).  W_{k,c} and P_k stay in registers for
