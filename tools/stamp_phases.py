@@ -15,7 +15,7 @@ F = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 model = synth.make_model(0)
 seq = synth.make_sequence(model, F, seed=0)
 gm = api.Model(model)
-prob = api.Problem.from_sequence(gm, seq, n_cols=86, use_shape=True, beta_per_frame=True, want_mesh=True)
+prob = api.Problem.from_sequence(gm, seq, n_cols=86, use_shape=True, beta_per_frame=True, want_mesh=os.environ.get("STAMP_NO_MESH") is None)
 lib = api.load_library()
 buf = torch.zeros((1 << 20) + 216 * 8 * 16, dtype=torch.int64, device="cuda")   # the mesh kernel stamps behind 1 << 20
 lib.bodyfit_debug_set_stamp_buffer.argtypes = [C.c_void_p, C.c_void_p]
