@@ -32,3 +32,10 @@ def test_product_does_not_reference_the_oracle():
             if fn.endswith((".py", ".hip", ".cpp", ".h", ".hpp", "Makefile")):
                 txt = open(os.path.join(dp, fn), errors="ignore").read()
                 assert "liboracle" not in txt and "from oracle" not in txt and "import oracle" not in txt, fn
+
+
+def test_cpp_mirror_header_compiles():
+    """include/bodyfit.hpp (the C++17 mirror of the reference's entry points) and its demo driver parse on their own."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-I", os.path.join(root, "include"),
+                           os.path.join(root, "tests", "cpp", "optimize_api_demo.cpp")])
