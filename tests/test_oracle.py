@@ -26,6 +26,17 @@ def test_rodrigues_matches_finite_differences(oracle_mod):
             assert np.abs(fd - dR[c]).max() < 1e-8
 
 
+def test_rodrigues_matches_scipy(oracle_mod):
+    """An implementation that shares nothing with the restatement: scipy's rotation vectors (general branch)."""
+    from scipy.spatial.transform import Rotation
+    rng = np.random.default_rng(5)
+    for scale in [3.0, 1.0, 1e-2, 1e-4]:
+        for _ in range(20):
+            a = rng.normal(size=3) * scale
+            R, _ = oracle_mod.rodrigues(a)
+            assert np.abs(R - Rotation.from_rotvec(a).as_matrix()).max() < 5e-15
+
+
 def test_rodrigues_first_order_branch(oracle_mod):
     # theta^2 <= DBL_EPSILON: R = I + [a]x and dR_c = [e_c]x (Ceres' Taylor branch)
     a = np.array([1e-9, -2e-9, 0.5e-9])
@@ -241,3 +252,41 @@ def test_reference_pose_prior_fixture(oracle_mod):
     # at x = 0 (the reference's initial pose) the residual is finite and reproducible
     r0, k0 = gm.residual(np.zeros(69))
     assert k0 == int(g["comp_at_zero"]) and np.abs(r0 - g["resid_at_zero"]).max() < 1e-9
+
+
+def test_dense_lm_answer_is_a_minimum_for_an_independent_solver(oracle_mod, omodel, model, synth):
+    """The Ceres-style dense LM (oracle/lm_dense.py) against scipy.optimize.least_squares on the same objective
+    (1/2 sum rho_Huber(|r_k|^2) + 1/2 |prior|^2, single frame, pose + Sim3, L2 prior).  scipy shares no code with the
+    restatement (trust-region reflective, finite-difference Jacobian): started at the LM's answer it must not find a lower
+    cost, and started nearby it must come back to it.  This pins the restated objective, its analytic Jacobian and the
+    LM's convergence against a third party; Ceres itself is not available to compare with."""
+    from scipy.optimize import least_squares
+    from oracle import lm_dense
+    seq = synth.make_sequence(model, 1, seed=12, noise_px=1.0)
+    seq.kp_uv[3] += 40.0                                   # one outlier: the Huber branch is active at the optimum
+    beta_pose = 20.0
+
+    def rows(xv):
+        x = xv.reshape(1, 76)
+        r, _ = omodel.evaluate_batch(seq, x, np.zeros(10), 76, False, True, mode=0, want_jac=False)
+        r2 = r.reshape(-1, 2)
+        s = (r2 ** 2).sum(1)
+        rho = np.array([oracle_mod.huber(3.0, v)[0] for v in s])
+        pr, _, _ = oracle_mod.pose_prior(None, beta_pose, x[0, 7:], want_jac=False)
+        return np.concatenate([(np.sqrt(rho / np.maximum(s, 1e-300))[:, None] * r2).ravel(), pr])   # |row_k|^2 = rho(s_k)
+
+    xd, _, info = lm_dense.solve(omodel, seq, seq.init_params, None, n_cols=76, use_shape=False, beta_pose=beta_pose,
+                                 max_iters=300)
+    cost_dense = 0.5 * (rows(xd.ravel()) ** 2).sum()
+    assert abs(cost_dense - info["final_cost"]) < 1e-9 * max(1.0, cost_dense)   # same objective on both sides
+    assert info["final_cost"] < info["initial_cost"] * 0.1 and (rows(xd.ravel())[6:8] ** 2).sum() > 9.0   # outlier stays out
+    lo = np.full(76, -np.inf); hi = np.full(76, np.inf); lo[0], hi[0] = 0.3, 3.0
+    sp = least_squares(rows, xd.ravel(), bounds=(lo, hi), xtol=1e-12, ftol=1e-12, gtol=1e-12, max_nfev=30)
+    assert sp.cost >= cost_dense * (1.0 - 2e-5)            # nothing lower next to the LM's answer
+    start = xd.ravel() + np.random.default_rng(0).normal(scale=2e-3, size=76)
+    start[0] = np.clip(start[0], 0.31, 2.9)
+    sp2 = least_squares(rows, start, bounds=(lo, hi), xtol=1e-12, ftol=1e-12, gtol=1e-12, max_nfev=60)
+    assert abs(sp2.cost - cost_dense) <= 1e-4 * cost_dense
+    # gauge-free comparison (the Sim3 scale is a null direction of the reprojection): rotations, joint angles, t / s
+    assert np.abs(sp2.x[1:4] - xd[0, 1:4]).max() < 2e-3 and np.abs(sp2.x[7:] - xd[0, 7:]).max() < 2e-3
+    assert np.abs(sp2.x[4:7] / sp2.x[0] - xd[0, 4:7] / xd[0, 0]).max() < 2e-3
