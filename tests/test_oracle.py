@@ -196,6 +196,24 @@ def test_pose_prior_l2_and_gmm(oracle_mod, synth):
     assert np.allclose(J[:69], 2.0 * L[kbest].T) and np.all(J[69] == 0)  # include/Sim3BA.h:298-299, last row zero
 
 
+def test_gmm_component_is_the_most_likely_one_by_scipy(oracle_mod, synth):
+    """The max-mixture prior picks argmax_k w_k N(x; mu_k, Sigma_k) and its squared residual is that component's negative
+    log-likelihood up to a constant shared by all components (checked with scipy.stats, which shares nothing with the
+    restatement)."""
+    from scipy.stats import multivariate_normal
+    w, mu, cov = synth.make_gmm(0)
+    g = oracle_mod.OracleGmm(w, mu, cov)
+    rng = np.random.default_rng(11)
+    offs = []
+    for t in range(12):
+        x = mu[t % 8] + rng.normal(scale=0.2, size=69)
+        ll = np.array([np.log(w[k]) + multivariate_normal.logpdf(x, mu[k], cov[k]) for k in range(8)])
+        rr, kk = g.residual(x)
+        assert kk == int(np.argmax(ll))
+        offs.append(rr @ rr + ll[kk])              # |r|^2 = -log(w_k N_k) + const
+    assert np.ptp(offs) < 1e-7 * max(1.0, abs(np.mean(offs)))
+
+
 def test_huber(oracle_mod):
     assert np.allclose(oracle_mod.huber(3.0, 4.0), [4.0, 1.0, 0.0])
     rho = oracle_mod.huber(3.0, 25.0)
