@@ -347,6 +347,15 @@ int bodyfit_model_create(const bodyfit_model_desc* desc, int device, bodyfit_mod
         if (v >= V) continue;
         for (int c = 0; c < 3; ++c) {
           vtB[((size_t)vt_i * 3 + c) * 32 + col] = (float)(desc->v_template[(size_t)v * 3 + c] - J0[c]);
+          {
+            // the template rides in the contraction on two of its padding slots (coefficient 1 in k_frame_resjac's
+            // fragments): slot 217 carries its first 16 bits (bf16 hi + lo), slot 218 what those left over
+            const float t0 = vtB[((size_t)vt_i * 3 + c) * 32 + col];
+            const uint16_t h0 = f32_to_bf16(t0);
+            const uint16_t l0 = f32_to_bf16(t0 - bf16_to_f32(h0));
+            put(vt_i, c, col, kPoseFeat + kMaxShape, t0);
+            put(vt_i, c, col, kPoseFeat + kMaxShape + 1, t0 - (bf16_to_f32(h0) + bf16_to_f32(l0)));
+          }
           for (int k = 0; k < nS && k < kMaxShape; ++k)
             put(vt_i, c, col, kPoseFeat + k, (float)(desc->shapedirs[((size_t)v * 3 + c) * nS + k] - S[(size_t)c * nS + k]));
           for (int k = 0; k < P && k < kPoseFeat; ++k) put(vt_i, c, col, k, (float)desc->posedirs[((size_t)v * 3 + c) * P + k]);

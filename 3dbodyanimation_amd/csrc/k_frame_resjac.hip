@@ -454,6 +454,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_frame_resjac(DevModel M, DevPro
           float x = 0.0f;
           if (k < kPoseFeat) x = Pb.pose_blend ? (float)sFeat[k] : 0.0f;
           else if (k - kPoseFeat < nS) x = (float)sbeta[k - kPoseFeat];
+          else if (k == kPoseFeat + kMaxShape || k == kPoseFeat + kMaxShape + 1) x = 1.0f;   // the template's two slots
           const uint16_t hi = f32_to_bf16(x);
           b[u] = hl == 0 ? hi : f32_to_bf16(x - bf16_to_f32(hi));
         }

@@ -6,7 +6,8 @@
 //   blend     D[frame][vertex] per coordinate = [pose feature | beta] . [posedirs | shapedirs - S_root],
 //             K = 207 + 10 -> 14 k-steps of v_mfma_f32_32x32x16_bf16, both operands split hi + lo in
 //             bf16, three products hi.hi + hi.lo + lo.hi (relative product error <= 2^-16 on
-//             displacements of centimetres), f32 accumulation; the template is added in f32 afterwards
+//             displacements of centimetres), f32 accumulation; the template rides in the same contraction on two
+//             of K's seven padding slots (coefficient 1.0; one slot for its first 16 bits, one for the remainder)
 //   skinning  per frame row: gather the vertex's <= 4 joint transforms (3x4 f32) from LDS, blend and apply
 //             in packed f32 (v_pk_fma_f32), one 12-byte store per lane (lane = vertex -> 384 contiguous
 //             bytes per half-wave); the blended vertices never touch HBM
@@ -64,7 +65,6 @@ __device__ inline void lds_dma_16(const void* g, void* l) {
 }
 
 struct Lane {                    // per-lane constants of the skinning rows
-  float vt[3];                   // template (centred on the rest root joint)
   f32x2 w2[4];                   // skinning weights, broadcast pairs
   const unsigned char* tj[4];    // LDS address of joint i's transform in frame row 4h of the wave's slice
   unsigned out_off;              // byte offset of (frame 4h, vertex v) in the cloud
@@ -111,8 +111,8 @@ __device__ __forceinline__ void row_apply(const Lane& L, const float4 (&t)[12], 
       b[2 * k] += L.w2[i] * f32x2{t[3 * i + k].x, t[3 * i + k].y};
       b[2 * k + 1] += L.w2[i] * f32x2{t[3 * i + k].z, t[3 * i + k].w};
     }
-  const f32x2 pxy = {acc[0][R] + L.vt[0], acc[1][R] + L.vt[1]};
-  const f32x2 pz1 = {acc[2][R] + L.vt[2], 1.0f};
+  const f32x2 pxy = {acc[0][R], acc[1][R]};       // the accumulators hold the rest vertex: the template rides in the
+  const f32x2 pz1 = {acc[2][R], 1.0f};            // contraction (two padding K slots with coefficient 1)
   float o[3];
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
@@ -231,8 +231,6 @@ __global__ __launch_bounds__(64 * kWaves) void k_mesh_blend_lbs(DevModel M, DevP
     }
   }
   Lane L;
-#pragma unroll
-  for (int c = 0; c < 3; ++c) L.vt[c] = M.vtB[((size_t)vtile * 3 + c) * 32 + col];
   {
     const uint32_t widx = M.wIdx[(size_t)vtile * 32 + col];
     const float4 wv = reinterpret_cast<const float4*>(M.wVal)[(size_t)vtile * 32 + col];
