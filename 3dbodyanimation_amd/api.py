@@ -310,10 +310,11 @@ class Problem:
         _check(load_library().bodyfit_reduce_shared_device(self.h, d_out_ptr, stream))
 
     def profile_sweep(self, d_params_ptr, d_beta_ptr, want_jacobian=True, with_reduce=False, iters=50, stream=None):
-        ms = np.zeros(4)
+        ms = np.zeros(5)
         _check(load_library().bodyfit_profile_sweep(self.h, d_params_ptr, d_beta_ptr, int(want_jacobian),
                                                     int(with_reduce), int(iters), stream, _d(ms)))
-        return dict(frame_resjac=ms[0], mesh_blend_lbs=ms[2], reduce_shared=ms[3])   # priors ride on one of the two launches
+        # (the prior workgroups ride on one of the launches; sweep_fused != 0: the sweep was ONE launch)
+        return dict(frame_resjac=ms[0], mesh_blend_lbs=ms[2], reduce_shared=ms[3], sweep_fused=ms[4])
 
     def views(self) -> DeviceViews:
         v = DeviceViews()

@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <mutex>
@@ -62,6 +63,7 @@ struct Allocs {
 
 struct bodyfit_model {
   int device = 0;
+  int n_cus = 0;
   int V = 0, nJ = 0, nS = 0, P = 0, nL = 0;
   bool mesh_ok = true;
   DevModel d{};
@@ -101,6 +103,11 @@ struct bodyfit_problem {
   unsigned char* lm_pool = nullptr;    // device LM state of bodyfit_solve, one allocation kept across solves
   hipStream_t lm_stream = nullptr;
   double* d_writeback = nullptr;
+  // fused sweep (k_sweep_fused): in-launch synchronisation words [done shards | error | pad | claim[F]], launch counter
+  unsigned char* d_fused = nullptr;
+  unsigned fused_epoch = 0;
+  int fused_test_skip = 0;
+  bool fused_enabled = true, fused_unchecked = false;
   double* d_frame_partials = nullptr; // [F][258] per-frame beta partials written by k_frame_resjac (shared-beta problems)
   int partials_tiles = 0;             // prior tiles that added their plain-cost rows behind the frame rows
   bool partials_fresh = false;        // the last sweep produced them (want_jac)      // [F][76] update parameters + [F][9] R0' + [F] mean pixel error, on first use   // [F][87][88] per-frame normal-equation panels (window solver), on first use
@@ -134,7 +141,24 @@ bool chol_lower(std::vector<double>& A, int n) {
   return true;
 }
 
-// One evaluation sweep: two launches on the caller's stream.  The prior residuals are produced by extra
+// The bounded waits of the fused sweep set an error word instead of hanging; the synchronous entry points read it after
+// their stream synchronisation.
+int fused_check(bodyfit_problem* p) {
+  if (!p->fused_unchecked || !p->d_fused) return BODYFIT_OK;
+  p->fused_unchecked = false;
+  unsigned err = 0;
+  if (hipMemcpy(&err, p->d_fused + kFusedSyncHeader - 16, sizeof(err), hipMemcpyDeviceToHost) != hipSuccess) return BODYFIT_OK;
+  if (err) {
+    (void)hipMemset(p->d_fused + kFusedSyncHeader - 16, 0, 4);
+    p->fused_enabled = false;   // fall back to the two-launch sweep for the rest of this problem's life
+    return fail(BODYFIT_ERR_HIP, "fused sweep: an in-launch wait timed out (results of that sweep are incomplete); "
+                                 "the problem now uses the two-launch sweep");
+  }
+  return BODYFIT_OK;
+}
+
+// One evaluation sweep on the caller's stream: ONE launch (k_sweep_fused) when the mesh is on and the frames fit one
+// workgroup per CU, otherwise two launches.  The prior residuals are produced by extra
 // workgroups (priors_inl.h) of the mesh launch when the mesh is on (its vertex tiles leave 40 CUs idle), otherwise
 // of the k_frame_resjac launch.  ev (optional, 4 events): the dispatches' own begin / end timestamps,
 // [0],[1] k_frame_resjac, [2],[3] k_mesh_blend_lbs.
@@ -172,9 +196,26 @@ int sweep(bodyfit_problem* p, const double* d_params, const double* d_beta, int 
   p->partials_tiles = dp.beta_partials ? pa.n_tiles : 0;
   PriorArgs none = pa;
   none.n_tiles = 0;
-  launch_frame_resjac(m->d, dp, d_params, d_beta, d_r, want_jac ? p->d_J : nullptr, p->d_joints, mc, want_jac,
-                      mesh ? none : pa, st, ev ? ev[0] : nullptr, ev ? ev[1] : nullptr);
-  if (mesh) launch_mesh(m->d, p->d, p->mc, p->d_cloud, pa, d_params, st, ev ? ev[2] : nullptr, ev ? ev[3] : nullptr);
+  if (mesh && !frame_flags && p->fused_enabled && p->d_fused && fused_sweep_fits(m->d, dp, pa.n_tiles, m->n_cus)) {
+    // ONE launch: frame part + mesh part per workgroup, operands handed over inside the launch (k_sweep.hip)
+    FusedSync sy{};
+    sy.done = reinterpret_cast<unsigned long long*>(p->d_fused);
+    sy.error = reinterpret_cast<unsigned*>(p->d_fused + kFusedSyncHeader - 16);
+    sy.claim = reinterpret_cast<unsigned*>(p->d_fused + kFusedSyncHeader);
+    if (p->fused_epoch == 0xffffffffu) {   // the 32-bit launch counter is about to wrap: start over (stream-ordered)
+      (void)hipMemsetAsync(p->d_fused, 0, kFusedSyncHeader + (size_t)p->d.F * 4, st);
+      p->fused_epoch = 0;
+    }
+    sy.epoch = ++p->fused_epoch;
+    sy.test_skip = p->fused_test_skip;
+    p->fused_unchecked = true;
+    launch_sweep_fused(m->d, dp, d_params, d_beta, d_r, want_jac ? p->d_J : nullptr, p->d_joints, mc, want_jac, pa,
+                       p->d_cloud, sy, st, ev ? ev[4] : nullptr, ev ? ev[5] : nullptr);
+  } else {
+    launch_frame_resjac(m->d, dp, d_params, d_beta, d_r, want_jac ? p->d_J : nullptr, p->d_joints, mc, want_jac,
+                        mesh ? none : pa, st, ev ? ev[0] : nullptr, ev ? ev[1] : nullptr);
+    if (mesh) launch_mesh(m->d, p->d, p->mc, p->d_cloud, pa, d_params, st, ev ? ev[2] : nullptr, ev ? ev[3] : nullptr);
+  }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(BODYFIT_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
   return BODYFIT_OK;
@@ -218,6 +259,7 @@ int bodyfit_model_create(const bodyfit_model_desc* desc, int device, bodyfit_mod
   bodyfit_model* m = new bodyfit_model();
   std::unique_ptr<bodyfit_model> guard(m);
   m->device = device;
+  HIP_TRY(hipDeviceGetAttribute(&m->n_cus, hipDeviceAttributeMultiprocessorCount, device));
   m->V = V; m->nJ = nJ; m->nS = nS; m->P = P; m->nL = nL;
   m->parent.assign(desc->parent, desc->parent + nJ);
 
@@ -617,6 +659,13 @@ int bodyfit_problem_create(const bodyfit_model* m, const bodyfit_problem_desc* d
     // unconditionally, whole 128-byte lines per half-wave
     HIP_TRY(p->mem.alloc(&p->d_cloud, (size_t)d.nFTiles * kFTile * m->d.nVTiles * kVTile * 3));
     HIP_TRY(hipMemset(p->mc.featA, 0, nfa * sizeof(uint16_t)));
+    const size_t nfu = kFusedSyncHeader + (size_t)F * 4;
+    HIP_TRY(p->mem.alloc(&p->d_fused, nfu));
+    HIP_TRY(hipMemset(p->d_fused, 0, nfu));
+    const char* fe = std::getenv("BODYFIT_FUSED");             // "0": always two launches (A/B measurements)
+    p->fused_enabled = !(fe && fe[0] == '0');
+    const char* ts = std::getenv("BODYFIT_FUSED_TEST_SKIP");   // tests: every n-th workgroup leaves its frame to be adopted
+    p->fused_test_skip = ts ? std::atoi(ts) : 0;
   }
   *out = p.release();
   return BODYFIT_OK;
@@ -683,6 +732,7 @@ int bodyfit_evaluate_batch(bodyfit_problem* p, const double* frame_params, const
     HIP_TRY(hipMemcpyAsync(p->c_J.data(), p->d_J, p->c_J.size() * sizeof(double), hipMemcpyDeviceToHost, nullptr));
   }
   HIP_TRY(hipStreamSynchronize(nullptr));
+  if (int fc = fused_check(p)) return fc;
   p->cache_valid = true;
   p->cache_has_jac = wj != 0;
   if (residuals) std::memcpy(residuals, p->c_r.data(), p->c_r.size() * sizeof(double));
@@ -747,41 +797,49 @@ int bodyfit_reduce_shared_device(bodyfit_problem* p, double* d_out66, void* stre
   return BODYFIT_OK;
 }
 
-// Per-kernel timing with HIP events on `stream`: `iters` sweeps, avg_ms[0..3] = {frame_resjac, priors,
-// mesh_blend_lbs, reduce_shared} average launch durations in milliseconds.
+// Per-kernel timing with HIP events on `stream`: `iters` sweeps, avg_ms[0..4] = {frame_resjac, priors,
+// mesh_blend_lbs, reduce_shared, sweep_fused} average launch durations in milliseconds.
 int bodyfit_profile_sweep(bodyfit_problem* p, const double* d_frame_params, const double* d_beta,
                           int want_jacobian, int with_reduce, int iters, void* stream, double* avg_ms) {
   if (!p || !d_frame_params || !avg_ms || iters <= 0) return fail(BODYFIT_ERR_INVALID, "bad argument");
   HIP_TRY(hipSetDevice(p->m->device));
   hipStream_t st = static_cast<hipStream_t>(stream);
-  // per sweep: [0],[1] begin / end of the k_frame_resjac dispatch, [2],[3] of the mesh dispatch (both taken from the
-  // dispatch's own timestamps, so they match rocprofv3's kernel durations), [4],[5] around the reduction launches
+  // per sweep: [0],[1] begin / end of the k_frame_resjac dispatch, [2],[3] of the mesh dispatch, [4],[5] of the fused
+  // dispatch (all taken from the dispatch's own timestamps, so they match rocprofv3's kernel durations; a sweep is
+  // either the first two pairs or the third), [6],[7] around the reduction launches
   const bool mesh = p->desc.want_mesh != 0;
-  std::vector<hipEvent_t> ev((size_t)iters * 6);
+  std::vector<hipEvent_t> ev((size_t)iters * 8);
   for (auto& e : ev) HIP_TRY(hipEventCreate(&e));
   int rc = BODYFIT_OK;
+  const unsigned epoch0 = p->fused_epoch;
   for (int it = 0; it < iters && rc == BODYFIT_OK; ++it) {
-    hipEvent_t* e = ev.data() + (size_t)it * 6;
+    hipEvent_t* e = ev.data() + (size_t)it * 8;
     rc = sweep(p, d_frame_params, d_beta, want_jacobian, mesh, st, e);
     if (rc == BODYFIT_OK && with_reduce) {
-      (void)hipEventRecord(e[4], st);
+      (void)hipEventRecord(e[6], st);
       rc = bodyfit_reduce_shared_device(p, nullptr, stream);
-      (void)hipEventRecord(e[5], st);
+      (void)hipEventRecord(e[7], st);
     }
   }
+  const bool fused = p->fused_epoch != epoch0;
   hipError_t se = hipStreamSynchronize(st);
-  for (int k = 0; k < 4; ++k) avg_ms[k] = 0.0;
+  for (int k = 0; k < 5; ++k) avg_ms[k] = 0.0;
   if (rc == BODYFIT_OK && se == hipSuccess) {
     for (int it = 0; it < iters; ++it) {
-      hipEvent_t* e = ev.data() + (size_t)it * 6;
+      hipEvent_t* e = ev.data() + (size_t)it * 8;
       float ms = 0.f;
-      (void)hipEventElapsedTime(&ms, e[0], e[1]); avg_ms[0] += ms / iters;
-      if (mesh) { (void)hipEventElapsedTime(&ms, e[2], e[3]); avg_ms[2] += ms / iters; }
-      if (with_reduce) { (void)hipEventElapsedTime(&ms, e[4], e[5]); avg_ms[3] += ms / iters; }
+      if (fused) {
+        (void)hipEventElapsedTime(&ms, e[4], e[5]); avg_ms[4] += ms / iters;
+      } else {
+        (void)hipEventElapsedTime(&ms, e[0], e[1]); avg_ms[0] += ms / iters;
+        if (mesh) { (void)hipEventElapsedTime(&ms, e[2], e[3]); avg_ms[2] += ms / iters; }
+      }
+      if (with_reduce) { (void)hipEventElapsedTime(&ms, e[6], e[7]); avg_ms[3] += ms / iters; }
     }
   }
   for (auto& e : ev) (void)hipEventDestroy(e);
   if (se != hipSuccess) return fail(BODYFIT_ERR_HIP, std::string("profile sync: ") + hipGetErrorString(se));
+  if (rc == BODYFIT_OK) rc = fused_check(p);
   return rc;
 }
 
@@ -949,7 +1007,7 @@ int bodyfit_writeback_batch(bodyfit_problem* p, const double* frame_params, cons
   }
   HIP_TRY(hipStreamSynchronize(nullptr));
   HIP_TRY(hipGetLastError());
-  return BODYFIT_OK;
+  return fused_check(p);
 }
 
 int bodyfit_forward(bodyfit_problem* p, const double* frame_params, const double* beta, double* joints,
@@ -975,7 +1033,7 @@ int bodyfit_forward(bodyfit_problem* p, const double* frame_params, const double
     HIP_TRY(hipMemcpy2D(cloud, row, p->d_cloud, pitch, row, (size_t)p->d.F, hipMemcpyDeviceToHost));
   }
   HIP_TRY(hipDeviceSynchronize());
-  return BODYFIT_OK;
+  return fused_check(p);
 }
 
 double bodyfit_mean_pixel_error(int n_kp, const int* jid, const double* uv, const double* joints, double fx,

@@ -90,6 +90,18 @@ struct PriorArgs {
   double* plain_cost;   // optional [n_tiles][258]: entry 257 of row `tile` receives the tile's 1/2 sum r^2 (folded reduction)
 };
 
+// in-launch synchronisation words of the fused sweep (k_sweep.hip), one set per problem, zeroed at creation only
+constexpr int kFusedShards = 16;        // the hand-off counter is sharded (frame f adds to shard f % 16): 256 arrivals on ONE
+constexpr int kFusedShardStride = 16;   // word serialise at ~12 ns each; shards sit on cache lines of their own (16 x 8 B)
+constexpr size_t kFusedSyncHeader = (size_t)kFusedShards * kFusedShardStride * 8 + 16;   // shards, error word, pad
+struct FusedSync {
+  unsigned long long* done;    // [16 shards x 16] frames handed over so far per shard, monotonic over launches
+  unsigned* claim;             // [F] epoch of the launch that last claimed frame f
+  unsigned* error;             // set when a workgroup's bounded wait ran out
+  unsigned epoch;              // launch number, >= 1: shard s is complete at epoch * (number of frames f with f % 16 == s)
+  int test_skip;               // diagnostic (tests): workgroups b % test_skip == 1 leave their frame to be adopted
+};
+
 // ---- device-resident LM for batches of independent frames (k_lm_batched.hip) ------------------------
 constexpr int kLmActive = 1;        // flags: frame still iterating
 constexpr int kLmHasCand = 2;       //        a candidate point awaits its residual sweep
@@ -143,6 +155,10 @@ void launch_frame_resjac(const DevModel& M, const DevProblem& P, const double* d
                          const PriorArgs& priors, hipStream_t s, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 void launch_mesh(const DevModel& M, const DevProblem& P, const MeshCoef& mc, float* d_cloud, const PriorArgs& pa,
                  const double* d_params, hipStream_t s, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
+bool fused_sweep_fits(const DevModel& M, const DevProblem& P, int n_prior_tiles, int n_cus);
+void launch_sweep_fused(const DevModel& M, const DevProblem& P, const double* d_params, const double* d_beta, double* d_r,
+                        double* d_J, double* d_joints, const MeshCoef& mc, int want_jac, const PriorArgs& pa, float* d_cloud,
+                        const FusedSync& sy, hipStream_t s, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 // (ev_start / ev_stop: optional events that take the dispatch's own begin / end timestamps, hipExtLaunchKernelGGL)
 void launch_reduce_shared_ex(int K, int ncols, int npose, int nS, int total_rows, const double* d_r,
                              const double* d_J, double huber_delta, int shape_row0, int shape_rows,

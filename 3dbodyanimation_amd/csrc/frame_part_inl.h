@@ -1,4 +1,6 @@
-// k_frame_resjac.hip — per-frame keypoint residuals + analytic Jacobian, f64, one 8-wave workgroup per frame.
+// frame_part_inl.h — per-frame keypoint residuals + analytic Jacobian, f64, one 8-wave workgroup per frame: the body
+// shared by k_frame_resjac (its own launch) and k_sweep_fused (one launch for the whole sweep: frame part, then the
+// workgroup's mesh tile), both in k_sweep.hip.
 //
 // Replaces, for every reprojection block of a frame at once, what the reference evaluates through
 // ceres::DynamicAutoDiffCostFunction<ReprojCost[Shape]> (include/Sim3BA.h:34-88,126-227,420,581;
@@ -27,6 +29,7 @@
 //   F  per chunk of 32 keypoints: keypoint stage (projection, residuals, d pi), then the Jacobian sweep with
 //      thread = column (W_{k,c} and P_k in registers), consecutive threads on consecutive columns of the dense
 //      row-major [2K][ncols] panel, written through L2; then (shared beta only) the frame's Gram partial on wave 0
+#pragma once
 #include <hip/hip_ext.h>
 
 #include "bodyfit_device.h"
@@ -112,7 +115,7 @@ __device__ inline double wave_sum(double v) {
     if (Pb.dbg && (threadIdx.x & 63) == 0) {                                                  \
       unsigned long long t_;                                                                  \
       asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");              \
-      Pb.dbg[((size_t)(blockIdx.x - pa.n_tiles) * 8 + (threadIdx.x >> 6)) * 16 + (i)] = t_;                  \
+      Pb.dbg[((size_t)f * 8 + (threadIdx.x >> 6)) * 16 + (i)] = t_;                  \
     }                                                                                         \
   } while (0)
 #define STAMP_REAL(i)                                                                         \
@@ -120,7 +123,7 @@ __device__ inline double wave_sum(double v) {
     if (Pb.dbg && (threadIdx.x & 63) == 0) {                                                  \
       unsigned long long t_;                                                                  \
       asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");          \
-      Pb.dbg[((size_t)(blockIdx.x - pa.n_tiles) * 8 + (threadIdx.x >> 6)) * 16 + (i)] = t_;                  \
+      Pb.dbg[((size_t)f * 8 + (threadIdx.x >> 6)) * 16 + (i)] = t_;                  \
     }                                                                                         \
   } while (0)
 #else
@@ -166,28 +169,43 @@ constexpr int TAB_PARENT = 0;                  // 24
 constexpr int TAB_ANC = 24;                    // 24
 constexpr int TAB_KPID = 96;                   // KC
 
-__global__ __launch_bounds__(kThreads, 4) void k_frame_resjac(DevModel M, DevProblem Pb, const double* __restrict__ params,
-                                                      const double* __restrict__ beta, double* __restrict__ r_out,
-                                                      double* __restrict__ J_out, double* __restrict__ joints_out,
-                                                      MeshCoef mc, int want_jac, PriorArgs pa) {
-  extern __shared__ __attribute__((aligned(16))) double sm[];
-  if ((int)blockIdx.x < pa.n_tiles) {   // first workgroups of the launch: prior residuals of one 16-frame tile
-#ifdef BODYFIT_STAMPS
-    unsigned long long tp0 = 0;
-    if (Pb.dbg && threadIdx.x == 0) asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tp0)::"memory");
-#endif
-    prior_block(pa, (int)blockIdx.x, params, sm);   // (dispatched first so they never form the tail of the launch)
-#ifdef BODYFIT_STAMPS
-    if (Pb.dbg && threadIdx.x == 0) {
-      unsigned long long tp1;
-      asm volatile("s_waitcnt vmcnt(0)\n\ts_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tp1)::"memory");
-      Pb.dbg[((size_t)Pb.F * 8 + blockIdx.x) * 16 + 0] = tp0;
-      Pb.dbg[((size_t)Pb.F * 8 + blockIdx.x) * 16 + 1] = tp1;
-    }
-#endif
-    return;
+// What the fused sweep adds to the frame part (k_sweep_fused): the workgroup's mesh operands are staged while it runs, and
+// the frame's mesh operands are handed to the other workgroups inside the launch.
+struct FusedFrame {
+  unsigned char* ldsB;            // LDS image of the workgroup's vertex tile operands (null: no tile)
+  const unsigned char* dirsB;     // the tile's operand block in HBM
+  unsigned long long* done;       // sharded counter of published frames, monotonic over launches (agent-scope adds)
+  unsigned claim_old;             // thread 0: what the claim of this frame returned (== epoch: another workgroup owns it)
+  unsigned epoch;                 // this launch's claim value
+};
+
+// Barrier between two phases.  The phases only exchange LDS data, so the fused kernel waits for the LDS counter alone:
+// its tile operands are in flight (LDS-DMA, counted on vmcnt) and the Jacobian stores are outstanding, and a
+// __syncthreads() would drain both at every phase (hipcc emits s_waitcnt vmcnt(0) in front of the barrier whenever an
+// LDS-DMA may be pending).
+template <bool kFused>
+__device__ __forceinline__ void frame_sync() {
+  if constexpr (kFused) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  else __syncthreads();
+}
+
+// 16-byte store of a mesh operand.  Fused: write-through (sc1), the payload form of the in-launch hand-off.
+template <bool kFused>
+__device__ __forceinline__ void store_operand16(void* p, uint4 v) {
+  if constexpr (kFused) {
+    typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_;
+    const u32x4_ x = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(x) : "memory");
+  } else {
+    *reinterpret_cast<uint4*>(p) = v;
   }
-  const int f = (int)blockIdx.x - pa.n_tiles;
+}
+
+template <bool kFused>
+__device__ __forceinline__ void frame_part(const DevModel& M, const DevProblem& Pb, const double* __restrict__ params,
+                                           const double* __restrict__ beta, double* __restrict__ r_out,
+                                           double* __restrict__ J_out, double* __restrict__ joints_out, const MeshCoef& mc,
+                                           int want_jac, double* sm, int f, const FusedFrame& fu) {
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int nJ = M.nJ, nS = M.nS, P = M.P, nL = M.nL;
@@ -270,7 +288,18 @@ __global__ __launch_bounds__(kThreads, 4) void k_frame_resjac(DevModel M, DevPro
   const double kp_v0 = Pb.kp_uv[2 * (size_t)(k_begin0 + (tid & (KC - 1))) + 1];
   if (x_lane) sx[tid - 128] = x_in;
   if (b_lane) sx[npose + tid - 224] = x_in;
-  __syncthreads();
+  frame_sync<kFused>();
+  if constexpr (kFused) {
+    // The workgroup's vertex tile operands (84 x 1 KiB, HBM -> LDS by LDS-DMA), issued by waves 6-7 now that phase A's
+    // own round trip is over: these two waves make no global load before phase E, so nothing of the frame part waits
+    // behind the transfer (vmcnt retires in order), and the tile has landed long before the mesh part reads it.
+    if (fu.ldsB && wave >= 6) {
+#pragma unroll 1
+      for (int pc = wave - 6; pc < 84; pc += 2)
+        __builtin_amdgcn_global_load_lds(fu.dirsB + (size_t)pc * 1024 + lane * 16,
+                                         (__attribute__((address_space(3))) void*)(fu.ldsB + (size_t)pc * 1024), 16, 0, 0);
+    }
+  }
   if (tid < nk0) {
     sTab[TAB_KPID + tid] = kp_id0;
     sKpUv[2 * tid] = kp_u0;
@@ -317,7 +346,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_frame_resjac(DevModel M, DevPro
     if (i < 3) sPart[100 + i] = o;     // the root keypoint's own q = offset_0 + S_0 beta (include/Sim3BA.h:142-170)
     sJc[i] = jc;
   }
-  __syncthreads();
+  frame_sync<kFused>();
 
   STAMP(2);
   // ---- C. everything that only needs R_j and o_j, with no ordering between items:
@@ -430,7 +459,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_frame_resjac(DevModel M, DevPro
     lm_terms(lm_l + 16, pdv1);
   }
   STAMP(3);
-  __syncthreads();
+  frame_sync<kFused>();
 
   STAMP(4);
   // ---- D. wave 0-1: W_{k,c} = A_p (dR_{k,c} R_k^T) A_p^T ; wave 2: landmark LBS ; wave 3: camera matrices ;
@@ -461,7 +490,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_frame_resjac(DevModel M, DevPro
         pk[jj] = (uint32_t)b[0] | ((uint32_t)b[1] << 16);
       }
       uint4* dst = reinterpret_cast<uint4*>(mc.featA + ((((size_t)ftile * kBlendKSteps + kstep) * 2 + hl) * 64 + (h * 32 + row)) * 8);
-      *dst = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+      store_operand16<kFused>(dst, make_uint4(pk[0], pk[1], pk[2], pk[3]));
     }
   }
   if (want_jac && tid < 3 * (nJ - 1)) {
@@ -504,7 +533,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_frame_resjac(DevModel M, DevPro
     const double* L = (mtx == 0) ? sR : (sdR + (mtx - 1) * 9);
     sCam[lane] = L[r * 3] * R0[c] + L[r * 3 + 1] * R0[3 + c] + L[r * 3 + 2] * R0[6 + c];
   }
-  __syncthreads();
+  frame_sync<kFused>();
   const double s = sx[0];
   const double* Rr0 = sCam;
   const double* dRr0 = sCam + 9;
@@ -578,8 +607,9 @@ __global__ __launch_bounds__(kThreads, 4) void k_frame_resjac(DevModel M, DevPro
       float4* T = reinterpret_cast<float4*>(mc.skinT + ((size_t)f * nJ + jj) * 12);
 #pragma unroll
       for (int r = 0; r < 3; ++r)
-        T[r] = make_float4((float)(s * RA[r * 3 + 0]), (float)(s * RA[r * 3 + 1]), (float)(s * RA[r * 3 + 2]),
-                           (float)(s * t[r] + sx[4 + r]));
+        store_operand16<kFused>(T + r, make_uint4(__float_as_uint((float)(s * RA[r * 3 + 0])), __float_as_uint((float)(s * RA[r * 3 + 1])),
+                                                  __float_as_uint((float)(s * RA[r * 3 + 2])),
+                                                  __float_as_uint((float)(s * t[r] + sx[4 + r]))));
     }
     if (joints_out) {
       mv3(Rr0, sP[jj * 3], sP[jj * 3 + 1], sP[jj * 3 + 2], t);
@@ -645,6 +675,17 @@ __global__ __launch_bounds__(kThreads, 4) void k_frame_resjac(DevModel M, DevPro
   }
 
   STAMP(6);
+  if constexpr (kFused) {
+    // Hand-off of this frame's mesh operands (blend coefficients: phase D, transforms: phase E) to every workgroup's mesh
+    // part: write-through stores, every wave drains its own, workgroup barrier, ONE lane adds to the launch's counter
+    // (cdna guide, Guideline 16 R1 in its counter form).  Only the workgroup whose claim won counts the frame.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    frame_sync<true>();
+    if (tid == 0 && fu.claim_old != fu.epoch)
+      __hip_atomic_fetch_add(fu.done + (size_t)(f % kFusedShards) * kFusedShardStride, 1ull, __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT);
+    STAMP_REAL(12);
+  }
   // ---- F. keypoints of this frame, KC at a time: stage per-keypoint data, then the flat (keypoint, column)
   //         sweep over all 512 threads (consecutive threads on consecutive columns of the row-major panel) ------
   double* sJb = sdR;            // [2 KC][10] d r / d beta of the chunk; dR is dead after phase D
@@ -653,10 +694,10 @@ __global__ __launch_bounds__(kThreads, 4) void k_frame_resjac(DevModel M, DevPro
   fold_d4 fold_gram = {0.0, 0.0, 0.0, 0.0};
   for (int kc0 = k_begin; kc0 < k_end; kc0 += KC) {
     const int nk = min(KC, k_end - kc0);
-    __syncthreads();   // phase E results visible / previous chunk's staging consumed
+    frame_sync<kFused>();   // phase E results visible / previous chunk's staging consumed
     if (kc0 != k_begin) {   // (the first chunk was staged by wave 6 during phase E: the barrier above published it)
       if (tid < nk) stage_kp(tid, kc0);
-      __syncthreads();
+      frame_sync<kFused>();
     }
     STAMP(7);
     if (want_jac) {
@@ -745,7 +786,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_frame_resjac(DevModel M, DevPro
       // shared-beta reduction of this frame (k_reduce.hip's definition): the Gram matrix of the robustified rows
       // [sqrt(rho') J_beta | sqrt(rho') r] holds H_bb (upper 10 x 10) and g_beta (column 10); 4 rows per
       // v_mfma_f64_16x16x4_f64 with the same register as A and B operand, wave 0 only; the cost by one lane of wave 1
-      __syncthreads();
+      frame_sync<kFused>();
       if (wave == 0) {
         const int col = lane & 15, kq = lane >> 4;
         for (int s0 = 0; s0 < (2 * nk + 3) / 4; s0 += 4) {   // four steps per pass: their LDS reads are in flight together
@@ -779,21 +820,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_frame_resjac(DevModel M, DevPro
   STAMP_REAL(11);
 }
 
+constexpr size_t frame_lds_bytes(int nL) { return (size_t)(OFF_LM + nL * (LM_STRIDE + 3 * kMaxShape)) * sizeof(double); }
+
 }  // namespace
-
-void launch_frame_resjac(const DevModel& M, const DevProblem& P, const double* d_params, const double* d_beta,
-                         double* d_r, double* d_J, double* d_joints, const MeshCoef& mc, int want_jac,
-                         const PriorArgs& priors, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop) {
-  if (P.F <= 0) return;
-  const size_t lds = (size_t)(OFF_LM + M.nL * (LM_STRIDE + 3 * kMaxShape)) * sizeof(double);
-  static size_t lds_granted = 48 * 1024;
-  if (lds > lds_granted) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_frame_resjac), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)lds);
-    lds_granted = lds;
-  }
-  hipExtLaunchKernelGGL(k_frame_resjac, dim3(P.F + priors.n_tiles), dim3(kThreads), lds, s, ev_start, ev_stop, 0, M, P,
-                        d_params, d_beta, d_r, d_J, d_joints, mc, want_jac, priors);
-}
-
 }  // namespace bodyfit

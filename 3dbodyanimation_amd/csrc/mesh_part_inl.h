@@ -1,4 +1,5 @@
-// k_mesh_blend_lbs.hip — batched SMPL forward of all 6890 vertices: blendshapes (MFMA) fused with
+// mesh_part_inl.h — batched SMPL forward of all 6890 vertices, the body shared by k_mesh_blend_lbs (its own launch) and
+// k_sweep_fused (the mesh part of the one-launch sweep), both in k_sweep.hip: blendshapes (MFMA) fused with
 // 24-joint linear-blend skinning, f32 out.  Replaces ark::Avatar::update()'s cloud
 // (call sites include/Sim3BA.h:371,538; include/MultiFrameBA.h:53,173; src/main_single_frame.cpp:254).
 //
@@ -21,6 +22,7 @@
 // Data movement: the vertex tile's B operands (84 KiB, fragment order, contiguous per tile) go
 // HBM -> LDS by LDS-DMA once per workgroup and serve every frame.
 // LDS: 84 KiB (B) + 8 waves x 9 KiB (transforms) = 156 KiB of the CU's 160 KiB.
+#pragma once
 #include <hip/hip_ext.h>
 
 #include "bodyfit_device.h"
@@ -73,10 +75,41 @@ struct Lane {                    // per-lane constants of the skinning rows
 // one quarter of a unit: 8 frames x 24 transforms, contiguous in HBM.  skinT is allocated (and zeroed) for whole
 // frame tiles, so the loads need no predicate (a predicated load is a branch, and a branch ends the slot's
 // scheduling region).
-__device__ __forceinline__ void skin_load(const unsigned char* skinT, int ftile, int q, int lane, u32x4 (&reg)[kSkinVec]) {
-  const unsigned char* g = skinT + ((size_t)ftile * kFTile + q * 8) * kRowBytes + lane * 16;
+// Fused sweep: the operands were handed over inside the launch by write-through stores, so EVERY load of them is an
+// sc1 load (served by L2, never by this CU's L1, which may hold the previous launch's lines).
+struct OperandSrc {
+  const unsigned char* skinT;
+  const uint4* feat;                       // featA + lane
+  __amdgpu_buffer_rsrc_t skinT_rsrc;       // fused only
+  __amdgpu_buffer_rsrc_t feat_rsrc;        // fused only
+};
+template <bool kFused>
+__device__ __forceinline__ void skin_load(const OperandSrc& src, int ftile, int q, int lane, u32x4 (&reg)[kSkinVec]) {
+  if constexpr (kFused) {
+    const unsigned soff = (unsigned)((ftile * kFTile + q * 8) * kRowBytes);
 #pragma unroll
-  for (int i = 0; i < kSkinVec; ++i) reg[i] = *reinterpret_cast<const u32x4*>(g + i * 1024);
+    for (int i = 0; i < kSkinVec; ++i)
+      reg[i] = __builtin_amdgcn_raw_buffer_load_b128(src.skinT_rsrc, (unsigned)(lane * 16 + i * 1024), soff, 16);
+  } else {
+    const unsigned char* g = src.skinT + ((size_t)ftile * kFTile + q * 8) * kRowBytes + lane * 16;
+#pragma unroll
+    for (int i = 0; i < kSkinVec; ++i) reg[i] = *reinterpret_cast<const u32x4*>(g + i * 1024);
+  }
+}
+// A fragments of k-step ks of frame tile ftile (hi, lo)
+template <bool kFused>
+__device__ __forceinline__ void feat_load(const OperandSrc& src, int ftile, int ks, int lane, uint4& hi, uint4& lo) {
+  if constexpr (kFused) {
+    const unsigned soff = (unsigned)((ftile * kBlendKSteps + ks) * 2 * 1024);
+    const u32x4 h = __builtin_amdgcn_raw_buffer_load_b128(src.feat_rsrc, (unsigned)(lane * 16), soff, 16);
+    const u32x4 l = __builtin_amdgcn_raw_buffer_load_b128(src.feat_rsrc, (unsigned)(lane * 16 + 1024), soff, 16);
+    hi = make_uint4(h.x, h.y, h.z, h.w);
+    lo = make_uint4(l.x, l.y, l.z, l.w);
+  } else {
+    const uint4* fa = src.feat + (size_t)ftile * kBlendKSteps * 2 * 64;
+    hi = fa[(size_t)ks * 128];
+    lo = fa[(size_t)ks * 128 + 64];
+  }
 }
 __device__ __forceinline__ void skin_store(unsigned char* l, int lane, const u32x4 (&reg)[kSkinVec]) {
 #pragma unroll
@@ -130,13 +163,10 @@ __device__ __forceinline__ void row_apply(const Lane& L, const float4 (&t)[12], 
 }
 
 // ---- blend phase: k-step S of the unit whose A fragments start at fa --------------------------------------------
-template <int S>
-__device__ __forceinline__ void blend_step(const unsigned char* sB, int lane, const uint4* fa, f32x16 (&acc)[3],
+template <int S, bool kFused>
+__device__ __forceinline__ void blend_step(const unsigned char* sB, int lane, const OperandSrc& src, int ftile, f32x16 (&acc)[3],
                                            uint4 (&a)[kBlendKSteps][2], uint4 (&bq)[2][3][2]) {
-  if constexpr (S + kAhead < kBlendKSteps) {
-    a[S + kAhead][0] = fa[(size_t)(S + kAhead) * 128];
-    a[S + kAhead][1] = fa[(size_t)(S + kAhead) * 128 + 64];
-  }
+  if constexpr (S + kAhead < kBlendKSteps) feat_load<kFused>(src, ftile, S + kAhead, lane, a[S + kAhead][0], a[S + kAhead][1]);
   if constexpr (S + 1 < kBlendKSteps) {
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
@@ -175,8 +205,8 @@ __device__ __forceinline__ void blend_step(const unsigned char* sB, int lane, co
 }
 
 // ---- skinning phase: row S of the unit at frame tile ftile ----------------------------------------------------------
-template <int S>
-__device__ __forceinline__ void skin_step(const Lane& L, unsigned char* sSkin, int lane, unsigned stride, const unsigned char* skinT,
+template <int S, bool kFused>
+__device__ __forceinline__ void skin_step(const Lane& L, unsigned char* sSkin, int lane, unsigned stride, const OperandSrc& src,
                                           __amdgpu_buffer_rsrc_t cloud, int ftile, const f32x16 (&acc)[3], float4 (&tq)[2][12],
                                           u32x4 (&treg)[kSkinVec]) {
   constexpr int q = S >> 2;
@@ -184,7 +214,7 @@ __device__ __forceinline__ void skin_step(const Lane& L, unsigned char* sSkin, i
     // quarter boundary: every read of the previous quarter has been issued (LDS serves a wave in order), so the slice
     // is overwritten with this quarter (in registers since the previous boundary) and the next one goes in flight
     skin_store(sSkin, lane, treg);
-    if constexpr (q < 3) skin_load(skinT, ftile, q + 1, lane, treg);
+    if constexpr (q < 3) skin_load<kFused>(src, ftile, q + 1, lane, treg);
     row_fetch<S>(L, tq[S & 1]);
   }
   if constexpr ((S & 3) != 3) row_fetch<S + 1>(L, tq[(S + 1) & 1]);
@@ -200,29 +230,22 @@ __device__ __forceinline__ void skin_step(const Lane& L, unsigned char* sSkin, i
   __builtin_amdgcn_sched_barrier(0);
 }
 
-__global__ __launch_bounds__(64 * kWaves) void k_mesh_blend_lbs(DevModel M, DevProblem Pb, MeshCoef mc,
-                                                                   float* __restrict__ cloud_f, PriorArgs pa,
-                                                                   const double* __restrict__ params) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-  if ((int)blockIdx.x >= M.nVTiles) {
-    // The vertex tiles occupy 216 of the 256 CUs; the sweep's prior residuals (one 16-frame tile per workgroup,
-    // priors_inl.h) ride on the idle ones instead of doubling up with k_frame_resjac's frame workgroups.
-    prior_block(pa, (int)blockIdx.x - M.nVTiles, params, reinterpret_cast<double*>(lds));
-    return;
-  }
-  const int vtile = blockIdx.x;
+// One vertex tile x all frames.  sB: the tile's operand image in LDS (84 KiB); sSkinBase: 8 x 9 KiB of transform slices.
+// kFused (k_sweep_fused): the operand image was staged during the frame part and the per-frame operands were handed over
+// inside the launch; the caller has waited for both (counter poll, workgroup barrier) before this is entered.
+template <bool kFused>
+__device__ __forceinline__ void mesh_part(const DevModel& M, const DevProblem& Pb, const MeshCoef& mc, float* __restrict__ cloud_f,
+                                          int vtile, unsigned char* sB, unsigned char* sSkinBase) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int col = lane & 31, h = lane >> 5;
   const int v = vtile * kVTile + col;
   const int nFT = Pb.nFTiles;
-  const unsigned char* skinT = reinterpret_cast<const unsigned char*>(mc.skinT);
 
   MSTAMP(0);
-  unsigned char* sB = lds;                                             // [ks][c][hi/lo][64][16 B]
-  unsigned char* sSkin = lds + kBBytes + wave * kQuarterBytes;         // this wave's transform slice
+  unsigned char* sSkin = sSkinBase + wave * kQuarterBytes;             // this wave's transform slice
 
   // ---- stage this vertex tile's B operands: HBM -> LDS, 1 KiB per wave-instruction -------------------
-  {
+  if constexpr (!kFused) {
     const unsigned char* gp = reinterpret_cast<const unsigned char*>(M.dirsB) + (size_t)vtile * kBBytes;
 #pragma unroll
     for (int i = 0; i < (kPieces + kWaves - 1) / kWaves; ++i) {
@@ -248,18 +271,25 @@ __global__ __launch_bounds__(64 * kWaves) void k_mesh_blend_lbs(DevModel M, DevP
       __builtin_amdgcn_make_buffer_rsrc(cloud_f, 0, (int)((unsigned)nFT * kFTile * stride), 0x00020000);
 
   // this wave's units: frame tiles wave, wave + 8, ...
-  const uint4* feat = reinterpret_cast<const uint4*>(mc.featA) + lane;
+  OperandSrc src;
+  src.skinT = reinterpret_cast<const unsigned char*>(mc.skinT);
+  src.feat = reinterpret_cast<const uint4*>(mc.featA) + lane;
+  if constexpr (kFused) {
+    src.skinT_rsrc = __builtin_amdgcn_make_buffer_rsrc(mc.skinT, 0, nFT * kFTile * kRowBytes, 0x00020000);
+    src.feat_rsrc = __builtin_amdgcn_make_buffer_rsrc(mc.featA, 0, nFT * kBlendKSteps * 2 * 1024, 0x00020000);
+  }
   f32x16 acc[3];
   uint4 a[kBlendKSteps][2], bq[2][3][2];
   u32x4 treg[kSkinVec];
   float4 tq[2][12];
   if (wave < nFT) {
-    const uint4* fa = feat + (size_t)wave * kBlendKSteps * 2 * 64;
 #pragma unroll
-    for (int ks = 0; ks < kAhead; ++ks) { a[ks][0] = fa[(size_t)ks * 128]; a[ks][1] = fa[(size_t)ks * 128 + 64]; }
+    for (int ks = 0; ks < kAhead; ++ks) feat_load<kFused>(src, wave, ks, lane, a[ks][0], a[ks][1]);
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
+  if constexpr (!kFused) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
   MSTAMP(1);
   // Waves w and w + 4 share a SIMD.  Left alone they run their phases in lock-step (both blending at half the matrix
   // rate, then both skinning against each other for LDS bandwidth); with the second wave at a higher issue priority
@@ -267,46 +297,30 @@ __global__ __launch_bounds__(64 * kWaves) void k_mesh_blend_lbs(DevModel M, DevP
   if (wave >= 4) __builtin_amdgcn_s_setprio(2);
 
   for (int ftile = wave; ftile < nFT; ftile += kWaves) {
-    const uint4* fa = feat + (size_t)ftile * kBlendKSteps * 2 * 64;
-    skin_load(skinT, ftile, 0, lane, treg);                            // quarter 0: in flight across the blend phase
+    skin_load<kFused>(src, ftile, 0, lane, treg);                      // quarter 0: in flight across the blend phase
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       const uint4* bp = reinterpret_cast<const uint4*>(sB + (size_t)(c * 2) * 1024) + lane;
       bq[0][c][0] = bp[0]; bq[0][c][1] = bp[64];
     }
-#define BSTEP(S) blend_step<S>(sB, lane, fa, acc, a, bq)
+#define BSTEP(S) blend_step<S, kFused>(sB, lane, src, ftile, acc, a, bq)
     BSTEP(0); BSTEP(1); BSTEP(2); BSTEP(3); BSTEP(4); BSTEP(5); BSTEP(6);
     BSTEP(7); BSTEP(8); BSTEP(9); BSTEP(10); BSTEP(11); BSTEP(12); BSTEP(13);
 #undef BSTEP
     MSTAMP(2);
-#define SSTEP(S) skin_step<S>(L, sSkin, lane, stride, skinT, cloud, ftile, acc, tq, treg)
+#define SSTEP(S) skin_step<S, kFused>(L, sSkin, lane, stride, src, cloud, ftile, acc, tq, treg)
     SSTEP(0); SSTEP(1); SSTEP(2); SSTEP(3); SSTEP(4); SSTEP(5); SSTEP(6); SSTEP(7);
     SSTEP(8); SSTEP(9); SSTEP(10); SSTEP(11); SSTEP(12);
     if (ftile + kWaves < nFT) {      // next unit's first A fragments (the transform staging registers are free now)
-      const uint4* fn = feat + (size_t)(ftile + kWaves) * kBlendKSteps * 2 * 64;
 #pragma unroll
-      for (int ks = 0; ks < kAhead; ++ks) { a[ks][0] = fn[(size_t)ks * 128]; a[ks][1] = fn[(size_t)ks * 128 + 64]; }
+      for (int ks = 0; ks < kAhead; ++ks) feat_load<kFused>(src, ftile + kWaves, ks, lane, a[ks][0], a[ks][1]);
     }
     SSTEP(13); SSTEP(14); SSTEP(15);
 #undef SSTEP
     MSTAMP(3);
   }
+  if (wave >= 4) __builtin_amdgcn_s_setprio(0);
 }
 
 }  // namespace
-
-void launch_mesh(const DevModel& M, const DevProblem& P, const MeshCoef& mc, float* d_cloud, const PriorArgs& pa,
-                 const double* d_params, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop) {
-  if (P.F <= 0) return;
-  if ((size_t)P.nFTiles * kFTile * M.nVTiles * kVTile * 12 >= ((size_t)1 << 32)) return;   // refused at problem creation
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_mesh_blend_lbs),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
-    attr_set = true;
-  }
-  hipExtLaunchKernelGGL(k_mesh_blend_lbs, dim3(M.nVTiles + pa.n_tiles), dim3(64 * kWaves), kLdsBytes, s, ev_start, ev_stop,
-                        0, M, P, mc, d_cloud, pa, d_params);
-}
-
 }  // namespace bodyfit

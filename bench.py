@@ -1,10 +1,12 @@
 #!/usr/bin/env python3
 """bench.py — SMPL residual+Jacobian evaluations per second on MI355X (BASELINE.json metric).
 
-One "step" = one pass of the hot path over one batch of synthetic frames, inputs resident in HBM, two launches:
-  k_frame_resjac   f64 residuals + analytic Jacobian (FK joints + vertex landmarks) and the mesh operands
-  k_mesh_blend_lbs 6890-vertex forward (blendshapes on MFMA + LBS); the prior residuals (pose prior incl. the
+One "step" = one pass of the hot path over one batch of synthetic frames, inputs resident in HBM:
+  frame part       f64 residuals + analytic Jacobian (FK joints + vertex landmarks) and the mesh operands
+  mesh part        6890-vertex forward (blendshapes on MFMA + LBS); the prior residuals (pose prior incl. the
                    GMM sweep, shape prior, temporal) ride on the 40 CUs its 216 vertex tiles leave idle
+  Up to 256 frames per GPU the two parts are ONE launch (k_sweep_fused, operands handed over inside the launch);
+  beyond that two (k_frame_resjac, k_mesh_blend_lbs)
   [-> reduce_shared + RCCL all-reduce of 66 doubles for the shared-shape workload].
 One "eval" = all of that for one frame.
 
@@ -37,12 +39,14 @@ B_FRAME_MESH = 82_680 + 24 * 12 * 4 + 217 * 4                # cloud out + skin 
 B_FRAME_ALL = 118_588                                        # params 608 + kps 500 + r 400 + J 34,400 + cloud 82,680
 
 
-def cpu_baseline(synth, model, seq, F_sample, gmm_np):
+def cpu_baseline(synth, model, seq, F_sample, gmm_np, beta_pose=20.0, beta_shape=30.0):
     """The oracle (CPU restatement, kind 'port') on the host cores over a bounded sample of the same
-    workload: reference-like residual+Jacobian (stride-4 dual-number passes, threads over blocks) plus the
-    SMPL forward (threads over frames)."""
+    workload, the same residual blocks the GPU step evaluates: reference-like reprojection residual+Jacobian
+    (stride-4 dual-number passes, threads over blocks), the pose prior blocks (GMM max-mixture when the workload
+    has one) and the per-frame shape prior blocks (threads over blocks), plus the SMPL forward (threads over frames)."""
     from oracle import oracle
     om = oracle.OracleModel(model)
+    og = oracle.OracleGmm(*gmm_np) if gmm_np is not None else None
     nthr = oracle.max_threads()
     class S: pass
     s = S()
@@ -51,15 +55,18 @@ def cpu_baseline(synth, model, seq, F_sample, gmm_np):
     x = seq.gt_params[:F_sample]; beta = np.tile(seq.gt_beta, (F_sample, 1))
     om.evaluate_batch(s, x[:8] if F_sample >= 8 else x, beta, 86, True, True, mode=1, nthreads=nthr)  # warm the pool
     # repeat the sample until ~10 s of CPU work have been timed (bounded: at most 40 passes)
-    t_ad = t_an = t_fw = 0.0
+    t_ad = t_an = t_fw = t_pr = 0.0
     passes = 0
-    while passes < 40 and (t_ad + t_fw) < 10.0:
+    while passes < 40 and (t_ad + t_fw + t_pr) < 10.0:
         t0 = time.perf_counter()
         om.evaluate_batch(s, x, beta, 86, True, True, mode=1, nthreads=nthr)
         t_ad += time.perf_counter() - t0
         t0 = time.perf_counter()
         om.evaluate_batch(s, x, beta, 86, True, True, mode=0, nthreads=nthr)
         t_an += time.perf_counter() - t0
+        t0 = time.perf_counter()
+        oracle.priors_batch(og, beta_pose, x, beta_shape, beta, want_jac=True, nthreads=nthr)
+        t_pr += time.perf_counter() - t0
         t0 = time.perf_counter()
         om.forward_batch(x, beta, s.R0, nthreads=nthr)
         t_fw += time.perf_counter() - t0
@@ -77,12 +84,15 @@ def cpu_baseline(synth, model, seq, F_sample, gmm_np):
             continue
         t0 = time.perf_counter()
         om.evaluate_batch(sl, x[:Fl], beta[:Fl], 86, True, True, mode=1, nthreads=nt)
+        oracle.priors_batch(og, beta_pose, x[:Fl], beta_shape, beta[:Fl], want_jac=True, nthreads=nt)
         om.forward_batch(x[:Fl], beta[:Fl], sl.R0, nthreads=nt)
         ladder[str(nt)] = Fl / (time.perf_counter() - t0)
-    return {"value": n / (t_ad + t_fw), "unit": "evals/s", "cores": nthr, "kind": "port", "evals_per_s_by_threads": ladder,
-            "sample": f"{passes} x {F_sample} frames of the bench workload: autodiff-style (stride-4 dual numbers) "
-                      f"residual+Jacobian {t_ad:.2f}s + f64 SMPL forward {t_fw:.2f}s, OpenMP over blocks/frames",
-            "evals_per_s_analytic_jacobian": n / (t_an + t_fw)}
+    prior_kind = "GMM max-mixture pose prior" if og is not None else "L2 pose prior"
+    return {"value": n / (t_ad + t_pr + t_fw), "unit": "evals/s", "cores": nthr, "kind": "port", "evals_per_s_by_threads": ladder,
+            "sample": f"{passes} x {F_sample} frames of the bench workload, the blocks the GPU step evaluates: autodiff-style "
+                      f"(stride-4 dual numbers) reprojection residual+Jacobian {t_ad:.2f}s + {prior_kind} and shape prior "
+                      f"blocks {t_pr:.2f}s + f64 SMPL forward {t_fw:.2f}s, OpenMP over blocks/frames",
+            "evals_per_s_analytic_jacobian": n / (t_an + t_pr + t_fw)}
 
 
 def main():
@@ -96,6 +106,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pcie", action="store_true", help="also time the host-pointer form (H2D + sweep + D2H)")
     ap.add_argument("--cpu-sample-frames", type=int, default=0)
+    ap.add_argument("--no-fit", action="store_true", help="skip the frames/sec-to-convergence record")
     args = ap.parse_args()
 
     import torch
@@ -197,11 +208,19 @@ def main():
         # algorithmic bytes per launch: what each kernel must read and write once
         alg = {"mesh_blend_lbs": B_MODEL_MESH + F * B_FRAME_MESH,
                "frame_resjac": F * (608 + 80 + 500 + 400 + 34_400 + 24 * 12 * 4 + 217 * 4)}
-        pmc_name = {"mesh_blend_lbs": "k_mesh_blend_lbs", "frame_resjac": "k_frame_resjac"}
-        pm = None   # HBM bytes per launch from the committed PMC passes (same workload and size only)
+        pmc_name = {"mesh_blend_lbs": "k_mesh_blend_lbs", "frame_resjac": "k_frame_resjac", "sweep_fused": "k_sweep_fused"}
+        fused = prof.get("sweep_fused", 0.0) > 0.0
+        if fused:   # the sweep was ONE launch (frame part + mesh part per workgroup): its bytes are the two kernels' bytes
+            alg = {"sweep_fused": alg["mesh_blend_lbs"] + alg["frame_resjac"]}
+        # HBM bytes per launch: rocprofv3 cannot run inside this process, so `traffic` is what the committed --pmc passes
+        # of THIS command measured (tools/profile_round.sh writes profiles/rN_xx_pmc_traffic.json: FETCH_SIZE doubled per the
+        # gfx950 note + WRITE_SIZE); `traffic_source` names that file.  Null when no committed pass matches the workload
+        # and size, or its kernel names are not the ones this build launches.
+        pm = pm_src = None
         try:
             import glob
-            pm = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))[-1]))
+            pm_src = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))[-1]
+            pm = json.load(open(pm_src))
             if not (args.workload == pm["workload"] and F == pm["frames_per_gpu"]):
                 pm = None
         except Exception:
@@ -210,15 +229,16 @@ def main():
         for k in alg:
             a = alg[k] / (prof[k] * 1e-3) / 1e9
             kernels[k] = {"achieved": a, "frac": a / HBM_PEAK_GBS, "frac_of_measured_copy_rate": a / HBM_COPY_GBS,
-                          "algorithmic_bytes_per_launch": alg[k],
-                          "avg_launch_ms": prof[k], "traffic": pm["kernels"][pmc_name[k]]["hbm_bytes"] if pm else None}
+                          "algorithmic_bytes_per_launch": alg[k], "avg_launch_ms": prof[k],
+                          "traffic": pm["kernels"].get(pmc_name[k], {}).get("hbm_bytes") if pm else None}
         # matrix-pipe view of the mesh kernel: the blend contraction is 2 x 20670 x 217 flop per frame; it is
         # executed as three bf16 products per k-step on v_mfma_f32_32x32x16_bf16 (216 tiles x 14 k-steps x 9 MFMAs per 32 frames)
         alg_flop = 2.0 * 20670 * 217 * F
         exe_flop = 216 * ((F + 31) // 32) * 14 * 9 * 2.0 * 32 * 32 * 16
-        kernels["mesh_blend_lbs"]["mfma"] = {
-            "algorithmic_TFLOPs": alg_flop / (prof["mesh_blend_lbs"] * 1e-3) / 1e12, "f32_mfma_peak_TFLOPs": 157.3,
-            "executed_bf16_TFLOPs": exe_flop / (prof["mesh_blend_lbs"] * 1e-3) / 1e12, "bf16_dense_peak_TFLOPs": 2500.0}
+        mk = "sweep_fused" if fused else "mesh_blend_lbs"
+        kernels[mk]["mfma"] = {
+            "algorithmic_TFLOPs": alg_flop / (prof[mk] * 1e-3) / 1e12, "f32_mfma_peak_TFLOPs": 157.3,
+            "executed_bf16_TFLOPs": exe_flop / (prof[mk] * 1e-3) / 1e12, "bf16_dense_peak_TFLOPs": 2500.0}
         dom = max(alg, key=lambda k: prof[k])
         bytes_launch, ach, traffic = alg[dom], kernels[dom]["achieved"], kernels[dom]["traffic"]
         whole = (B_MODEL_ALL + F * B_FRAME_ALL) / (ms_step * 1e-3) / 1e9
@@ -230,6 +250,8 @@ def main():
             "config": {"workload": wl_name, "frames_per_gpu": F, "keypoints_per_frame": 25, "n_cols": 86},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS, "frac_of_measured_copy_rate": ach / HBM_COPY_GBS, "traffic": traffic,
+                         "traffic_source": (os.path.relpath(pm_src, ROOT) + " (rocprofv3 --pmc passes of this command, "
+                                            "committed; not measured in this run)") if pm else None,
                          "algorithmic_bytes_per_launch": bytes_launch, "avg_launch_ms": prof[dom],
                          "kernels": kernels},
             "kernel_ms": prof,
@@ -246,7 +268,20 @@ def main():
         if not args.no_cpu_baseline and world == 1:   # the CPU leg is timed at N = 1 only
             n_cpu = args.cpu_sample_frames or min(F, 256)
             cseq = seq if args.workload == "c3" else synth.make_sequence(model, n_cpu, seed=0)
-            out["cpu_baseline"] = cpu_baseline(synth, model, cseq, n_cpu, None)
+            out["cpu_baseline"] = cpu_baseline(synth, model, cseq, n_cpu, (w, mu, cov) if args.workload == "c3" else None,
+                                               beta_pose=20.0 if args.workload == "c3" else 5.0,
+                                               beta_shape=30.0 if args.workload == "c3" else 0.0)
+        if not args.no_fit and world == 1 and args.workload == "c3":
+            # the second half of BASELINE.json's metric: frames/sec to convergence of the product's LM on c2 / c3 / c4
+            # (tools/fit_bench.py; reference hooks src/main_single_frame.cpp:234-249,265-269), and the checker's own fits
+            # (oracle evaluator under the dense numpy LM) on a bounded sample beside them
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import fit_bench
+            fit = {"unit": "frames/s", "c2": fit_bench.fit_c2(api, synth, model, gm),
+                   "c3": fit_bench.fit_c3(api, synth, model, gm), "c4": fit_bench.fit_c4(api, synth, model, gm)}
+            if not args.no_cpu_baseline:
+                fit["cpu_baseline"] = fit_bench.cpu_fit_baseline(synth, model)
+            out["fit"] = fit
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -166,8 +166,10 @@ int bodyfit_problem_views(bodyfit_problem* p, bodyfit_device_views* out);
 int bodyfit_reduce_shared_device(bodyfit_problem* p, double* d_out66, void* stream);
 
 /* Measurement aid: `iters` sweeps with HIP events around every kernel on `stream`;
- * avg_ms[4] = average launch duration (ms) of {frame_resjac, 0 (the prior workgroups ride on the mesh launch,
- * or on frame_resjac when the mesh is off), mesh_blend_lbs, reduce_shared}. */
+ * avg_ms[5] = average launch duration (ms) of {frame_resjac, 0 (the prior workgroups ride on the mesh launch,
+ * or on frame_resjac when the mesh is off), mesh_blend_lbs, reduce_shared, sweep_fused}.  A sweep with the mesh on and at
+ * most 256 frames is ONE launch (sweep_fused: frame part + mesh part per workgroup); then entries 0 and 2 are 0, and
+ * otherwise entry 4 is 0. */
 int bodyfit_profile_sweep(bodyfit_problem* p, const double* d_frame_params, const double* d_beta,
                           int want_jacobian, int with_reduce, int iters, void* stream, double* avg_ms);
 

@@ -935,6 +935,30 @@ int oracle_pose_prior(void* gmm, double beta_pose, int D, const double* x, doubl
   return comp;
 }
 
+// The prior blocks of F frames, threads over blocks as Ceres evaluates them: PosePriorAAAnalytic per frame
+// (include/Sim3BA.h:263-315; r_pose [F][nRes], J_pose [F][nRes][D] or NULL, comp [F] or NULL) and
+// ShapePriorL2Analytic per frame (:331-343; r_shape [F][nS], beta [F][nS]; skipped when beta_shape <= 0).
+// The CPU baseline of bench.py times this beside oracle_evaluate_batch so that both sides evaluate the same blocks.
+void oracle_priors_batch(void* gmm, double beta_pose, int D, int F, const double* params /*[F][7 + D]*/,
+                         double beta_shape, int nS, const double* beta /*[F][nS]*/, int want_jac, int nthreads,
+                         double* r_pose, double* J_pose, int* comp, double* r_shape) {
+  Gmm* g = static_cast<Gmm*>(gmm);
+  const int nRes = (g && g->K > 0) ? D + 1 : D;
+#ifdef _OPENMP
+  if (nthreads > 0) omp_set_num_threads(nthreads);
+#endif
+#pragma omp parallel for schedule(dynamic, 1)
+  for (int f = 0; f < F; ++f) {
+    if (beta_pose > 0.0) {
+      const int k = oracle_pose_prior(gmm, beta_pose, D, params + (size_t)f * (7 + D) + 7, r_pose + (size_t)f * nRes,
+                                      (want_jac && J_pose) ? J_pose + (size_t)f * nRes * D : nullptr);
+      if (comp) comp[f] = k;
+    }
+    if (beta_shape > 0.0 && r_shape)
+      for (int i = 0; i < nS; ++i) r_shape[(size_t)f * nS + i] = beta_shape * beta[(size_t)f * nS + i];   // :336
+  }
+}
+
 // ceres::HuberLoss(delta) on s = |r|^2: rho = [rho, rho', rho'']
 void oracle_huber(double delta, double s, double* rho) {
   const double b = delta * delta;

@@ -16,13 +16,13 @@ from . import oracle as O
 NP_ = 76
 
 
-def _rows(om, seq, x, beta, n_cols, use_shape, pose_blend, beta_pose, ogmm, beta_shape, lam, huber, want_jac):
+def _rows(om, seq, x, beta, n_cols, use_shape, pose_blend, beta_pose, ogmm, beta_shape, lam, huber, want_jac, jac_mode=0):
     """All residual rows (robustified) and the dense Jacobian of one problem with a shared beta."""
     F = x.shape[0]
     nb = n_cols - NP_
     n = F * NP_ + nb
-    r, J = om.evaluate_batch(seq, x, beta if nb else np.zeros(10), n_cols, use_shape, pose_blend, mode=0,
-                             want_jac=want_jac)
+    r, J = om.evaluate_batch(seq, x, beta if nb else np.zeros(10), n_cols, use_shape, pose_blend,
+                             mode=jac_mode if want_jac else 0, want_jac=want_jac)
     K = len(r) // 2
     s = r.reshape(K, 2)
     sq = (s ** 2).sum(1)
@@ -67,8 +67,9 @@ def _rows(om, seq, x, beta, n_cols, use_shape, pose_blend, beta_pose, ogmm, beta
 
 
 def solve(om, seq, x0, beta0, n_cols=86, use_shape=True, pose_blend=True, beta_pose=0.0, ogmm=None, beta_shape=0.0,
-          lam=0.0, huber=3.0, max_iters=100, constant=None, scale_bounds=(0.3, 3.0), verbose=False):
-    """One problem over all frames of `seq` with a shared beta.  Returns x, beta, info."""
+          lam=0.0, huber=3.0, max_iters=100, constant=None, scale_bounds=(0.3, 3.0), verbose=False, jac_mode=0):
+    """One problem over all frames of `seq` with a shared beta.  Returns x, beta, info.
+    jac_mode 0: analytic Jacobian; 1: the reference's stride-4 dual-number passes (DynamicAutoDiffCostFunction)."""
     F = x0.shape[0]
     nb = n_cols - NP_
     x = x0.copy(); beta = np.array(beta0, float).copy() if nb else np.zeros(0)
@@ -78,7 +79,7 @@ def solve(om, seq, x0, beta0, n_cols=86, use_shape=True, pose_blend=True, beta_p
         for f in range(F):
             free[f * NP_:(f + 1) * NP_] = ~np.asarray(constant, bool)
     args = (n_cols, use_shape, pose_blend, beta_pose, ogmm, beta_shape, lam, huber)
-    cost, r, J = _rows(om, seq, x, beta, *args, True)
+    cost, r, J = _rows(om, seq, x, beta, *args, True, jac_mode)
     info = dict(initial_cost=cost, iterations=0, n_ok=0, n_bad=0, termination=1)
     radius, dec = 1e4, 2.0
     scale = None
@@ -121,7 +122,7 @@ def solve(om, seq, x0, beta0, n_cols=86, use_shape=True, pose_blend=True, beta_p
         if np.isfinite(new_cost) and model > 0 and rho > 1e-3:
             x, beta = xn, bn
             old = cost
-            cost, r, J = _rows(om, seq, x, beta, *args, True)
+            cost, r, J = _rows(om, seq, x, beta, *args, True, jac_mode)
             radius = min(1e16, radius / max(1.0 / 3.0, 1.0 - (2 * rho - 1) ** 3)); dec = 2.0
             info["n_ok"] += 1
             if verbose:

@@ -149,6 +149,22 @@ def pose_prior(gmm, beta_pose, x, want_jac=True):
     return r, J, k
 
 
+def priors_batch(gmm, beta_pose, params, beta_shape=0.0, beta=None, want_jac=True, nthreads=0):
+    """Pose prior (+ per-frame shape prior) blocks of F frames, threads over blocks (oracle_priors_batch)."""
+    params = _c64(params)
+    F, D = params.shape[0], params.shape[1] - 7
+    nres = D + 1 if gmm is not None else D
+    r = np.zeros((F, nres)); J = np.zeros((F, nres, D)) if want_jac else None
+    comp = np.zeros(F, np.int32)
+    b = _c64(beta) if beta is not None else None
+    nS = b.shape[1] if b is not None else 0
+    rs = np.zeros((F, nS)) if b is not None else None
+    lib().oracle_priors_batch(gmm.h if gmm is not None else None, C.c_double(beta_pose), D, F, _d(params),
+                              C.c_double(beta_shape if b is not None else 0.0), nS, _d(b), int(want_jac), int(nthreads),
+                              _d(r), _d(J), _i(comp), _d(rs))
+    return r, J, comp, rs
+
+
 def huber(delta, s):
     rho = np.empty(3)
     lib().oracle_huber(C.c_double(delta), C.c_double(s), _d(rho))

@@ -30,6 +30,14 @@ def test_bench_single_gpu_line():
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
     assert abs(d["value"] - d["config"]["frames_per_gpu"] / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    assert "traffic_source" in r
+    # the second half of the metric: frames/sec to convergence of c2 / c3 / c4, with iteration and sweep counts
+    fit = d["fit"]
+    assert fit["unit"] == "frames/s"
+    for k in ("c2", "c3", "c4"):
+        assert fit[k]["frames_per_s"] > 0 and fit[k]["frames"] >= 1
+    assert fit["c2"]["iterations"] >= 1 and fit["c2"]["sweeps"] >= 1 and fit["c3"]["converged"] >= 250
+    assert fit["c4"]["windows"] == 9 and fit["c4"]["anchors"] == 13
 
 
 @pytest.mark.gpu

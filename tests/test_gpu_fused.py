@@ -1,0 +1,142 @@
+"""The one-launch sweep (k_sweep_fused: frame part + in-launch hand-off + mesh part per workgroup) against the
+two-launch sweep (k_frame_resjac -> k_mesh_blend_lbs) of the same build, and against the oracle.
+
+What can go wrong in the fused form is specific to it: a consumer reading a stale copy of another workgroup's
+operands (previous launch's values), a frame nobody processes (claim / adoption protocol), the LDS regions the two
+parts share.  So the tests run MANY launches back to back with different parameters and compare every word."""
+import importlib
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+api = importlib.import_module("3dbodyanimation_amd.api")
+synth = importlib.import_module("3dbodyanimation_amd.synth")
+
+
+class _Env:
+    def __init__(self, **kw):
+        self.kw = kw
+
+    def __enter__(self):
+        self.old = {k: os.environ.get(k) for k in self.kw}
+        for k, v in self.kw.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = str(v)
+
+    def __exit__(self, *a):
+        for k, v in self.old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+@pytest.fixture(scope="module")
+def model():
+    m = synth.make_model(0)
+    return m, api.Model(m)
+
+
+def _problem(gm, seq, fused, test_skip=None, shared=False, gmm=None):
+    with _Env(BODYFIT_FUSED="1" if fused else "0", BODYFIT_FUSED_TEST_SKIP=test_skip):
+        if shared:
+            return api.Problem.from_sequence(gm, seq, n_cols=86, use_shape=True, beta_pose=5.0, beta_shape=25.0,
+                                             lambda_temporal=3.0, want_mesh=True)
+        return api.Problem.from_sequence(gm, seq, n_cols=86, use_shape=True, beta_per_frame=True, beta_pose=20.0,
+                                         gmm=gmm, beta_shape=30.0, want_mesh=True)
+
+
+def _compare(pf, pt, x, beta):
+    rf, Jf, cf = pf.evaluate(x, beta, True)
+    rt, Jt, ct = pt.evaluate(x, beta, True)
+    jf, clf = pf.forward(x, beta)
+    jt, clt = pt.forward(x, beta)
+    assert np.array_equal(cf, ct)
+    np.testing.assert_allclose(rf, rt, rtol=0, atol=1e-10)
+    np.testing.assert_allclose(Jf, Jt, rtol=0, atol=1e-9)
+    np.testing.assert_allclose(jf, jt, rtol=0, atol=1e-12)
+    np.testing.assert_allclose(clf, clt, rtol=0, atol=2e-6)
+    return rf, Jf, clf
+
+
+@pytest.mark.parametrize("F", [1, 8, 37, 200, 256])
+def test_fused_equals_two_launches(model, F):
+    m, gm = model
+    seq = synth.make_sequence(m, F, seed=F)
+    w, mu, cov = synth.make_gmm(0)
+    gmm = api.Gmm(w, mu, cov)
+    pf, pt = _problem(gm, seq, True, gmm=gmm), _problem(gm, seq, False, gmm=gmm)
+    rng = np.random.default_rng(F)
+    for it in range(6):   # back-to-back launches, new parameters each time (a stale operand would carry the previous values)
+        x = seq.gt_params + 0.05 * rng.standard_normal(seq.gt_params.shape)
+        beta = np.tile(seq.gt_beta, (F, 1)) + 0.3 * rng.standard_normal((F, 10))
+        _compare(pf, pt, x, beta)
+
+
+def test_fused_many_launches_on_device(model):
+    """300 device-resident sweeps with alternating parameter sets, no host synchronisation in between; the last cloud and
+    Jacobian must be those of the LAST parameter set (every operand word re-read fresh in every launch)."""
+    import torch
+    m, gm = model
+    F = 256
+    seq = synth.make_sequence(m, F, seed=11)
+    pf, pt = _problem(gm, seq, True), _problem(gm, seq, False)
+    rng = np.random.default_rng(5)
+    xs = [seq.gt_params + 0.2 * rng.standard_normal(seq.gt_params.shape) for _ in range(3)]
+    bs = [np.tile(seq.gt_beta, (F, 1)) + rng.standard_normal((F, 10)) for _ in range(3)]
+    dev = torch.device("cuda", 0)
+    dx = [torch.from_numpy(x).to(dev) for x in xs]
+    db = [torch.from_numpy(b).to(dev) for b in bs]
+    st = torch.cuda.current_stream().cuda_stream
+    for it in range(300):
+        k = it % 3
+        pf.evaluate_device(dx[k].data_ptr(), db[k].data_ptr(), True, st)
+    torch.cuda.synchronize()
+    last = 299 % 3
+    # the synchronous calls below sweep once more with the same parameters and read the error word of the fused waits
+    _compare(pf, pt, xs[last], bs[last])
+
+
+def test_fused_adopts_unclaimed_frames(model):
+    """Every 4th workgroup leaves its frame alone (as if it had not been dispatched): the waiting workgroups must adopt
+    those frames after the grace period, and the results must be complete."""
+    m, gm = model
+    F = 64
+    seq = synth.make_sequence(m, F, seed=3)
+    pf, pt = _problem(gm, seq, True, test_skip=4, shared=True), _problem(gm, seq, False, shared=True)
+    rng = np.random.default_rng(1)
+    for it in range(3):
+        x = seq.gt_params + 0.05 * rng.standard_normal(seq.gt_params.shape)
+        _compare(pf, pt, x, seq.gt_beta + 0.1 * it)
+
+
+def test_more_frames_than_cus_takes_two_launches(model):
+    m, gm = model
+    F = 300
+    seq = synth.make_sequence(m, F, seed=9)
+    pf, pt = _problem(gm, seq, True), _problem(gm, seq, False)
+    _compare(pf, pt, seq.gt_params + 0.01, np.tile(seq.gt_beta, (F, 1)))
+
+
+def test_fused_against_oracle(model):
+    from oracle import oracle
+    m, gm = model
+    F = 16
+    seq = synth.make_sequence(m, F, seed=21)
+    pf = _problem(gm, seq, True, shared=True)
+    x = seq.gt_params + 0.02
+    r, J, _ = pf.evaluate(x, seq.gt_beta, True)
+    om = oracle.OracleModel(m)
+    ro, Jo = om.evaluate_batch(seq, x, seq.gt_beta, 86, True, True, mode=0)
+    K2 = pf.layout.reproj_rows
+    assert np.abs(r[:K2] - ro).max() < 1e-9
+    assert np.abs(J - Jo).max() <= 1e-9 * max(1.0, np.abs(Jo).max())
+    _, cloud = pf.forward(x, seq.gt_beta)
+    for f in (0, 7, 15):
+        _, co = om.forward(x[f], seq.gt_beta, seq.R0[f])
+        assert np.abs(cloud[f] - co).max() < 5e-6
