@@ -103,7 +103,7 @@ struct bodyfit_problem {
   unsigned char* lm_pool = nullptr;    // device LM state of bodyfit_solve, one allocation kept across solves
   hipStream_t lm_stream = nullptr;
   double* d_writeback = nullptr;
-  // fused sweep (k_sweep_fused): in-launch synchronisation words [done shards | error | pad | claim[F]], launch counter
+  // fused sweep (k_sweep_fused): in-launch synchronisation words [error | pad | flag[256] | claim[256]], launch counter
   unsigned char* d_fused = nullptr;
   unsigned fused_epoch = 0;
   int fused_test_skip = 0;
@@ -147,9 +147,9 @@ int fused_check(bodyfit_problem* p) {
   if (!p->fused_unchecked || !p->d_fused) return BODYFIT_OK;
   p->fused_unchecked = false;
   unsigned err = 0;
-  if (hipMemcpy(&err, p->d_fused + kFusedSyncHeader - 16, sizeof(err), hipMemcpyDeviceToHost) != hipSuccess) return BODYFIT_OK;
+  if (hipMemcpy(&err, p->d_fused, sizeof(err), hipMemcpyDeviceToHost) != hipSuccess) return BODYFIT_OK;
   if (err) {
-    (void)hipMemset(p->d_fused + kFusedSyncHeader - 16, 0, 4);
+    (void)hipMemset(p->d_fused, 0, 4);
     p->fused_enabled = false;   // fall back to the two-launch sweep for the rest of this problem's life
     return fail(BODYFIT_ERR_HIP, "fused sweep: an in-launch wait timed out (results of that sweep are incomplete); "
                                  "the problem now uses the two-launch sweep");
@@ -199,11 +199,11 @@ int sweep(bodyfit_problem* p, const double* d_params, const double* d_beta, int 
   if (mesh && !frame_flags && p->fused_enabled && p->d_fused && fused_sweep_fits(m->d, dp, pa.n_tiles, m->n_cus)) {
     // ONE launch: frame part + mesh part per workgroup, operands handed over inside the launch (k_sweep.hip)
     FusedSync sy{};
-    sy.done = reinterpret_cast<unsigned long long*>(p->d_fused);
-    sy.error = reinterpret_cast<unsigned*>(p->d_fused + kFusedSyncHeader - 16);
-    sy.claim = reinterpret_cast<unsigned*>(p->d_fused + kFusedSyncHeader);
+    sy.error = reinterpret_cast<unsigned*>(p->d_fused);
+    sy.flag = reinterpret_cast<unsigned*>(p->d_fused + kFusedSyncHeader);
+    sy.claim = sy.flag + kFusedMaxFrames;
     if (p->fused_epoch == 0xffffffffu) {   // the 32-bit launch counter is about to wrap: start over (stream-ordered)
-      (void)hipMemsetAsync(p->d_fused, 0, kFusedSyncHeader + (size_t)p->d.F * 4, st);
+      (void)hipMemsetAsync(p->d_fused, 0, kFusedSyncHeader + (size_t)2 * kFusedMaxFrames * 4, st);
       p->fused_epoch = 0;
     }
     sy.epoch = ++p->fused_epoch;
@@ -659,11 +659,14 @@ int bodyfit_problem_create(const bodyfit_model* m, const bodyfit_problem_desc* d
     // unconditionally, whole 128-byte lines per half-wave
     HIP_TRY(p->mem.alloc(&p->d_cloud, (size_t)d.nFTiles * kFTile * m->d.nVTiles * kVTile * 3));
     HIP_TRY(hipMemset(p->mc.featA, 0, nfa * sizeof(uint16_t)));
-    const size_t nfu = kFusedSyncHeader + (size_t)F * 4;
+    const size_t nfu = kFusedSyncHeader + (size_t)2 * kFusedMaxFrames * 4;
     HIP_TRY(p->mem.alloc(&p->d_fused, nfu));
     HIP_TRY(hipMemset(p->d_fused, 0, nfu));
-    const char* fe = std::getenv("BODYFIT_FUSED");             // "0": always two launches (A/B measurements)
-    p->fused_enabled = !(fe && fe[0] == '0');
+    // The one-launch sweep is opt-in (BODYFIT_FUSED=1): measured on MI355X it is correct but not yet faster than the two
+    // launches it replaces (what the in-launch hand-off saves, the frame part loses beside the tile
+    // transfer and behind the call).
+    const char* fe = std::getenv("BODYFIT_FUSED");
+    p->fused_enabled = fe && fe[0] == '1';
     const char* ts = std::getenv("BODYFIT_FUSED_TEST_SKIP");   // tests: every n-th workgroup leaves its frame to be adopted
     p->fused_test_skip = ts ? std::atoi(ts) : 0;
   }

@@ -91,16 +91,17 @@ struct PriorArgs {
 };
 
 // in-launch synchronisation words of the fused sweep (k_sweep.hip), one set per problem, zeroed at creation only
-constexpr int kFusedShards = 16;        // the hand-off counter is sharded (frame f adds to shard f % 16): 256 arrivals on ONE
-constexpr int kFusedShardStride = 16;   // word serialise at ~12 ns each; shards sit on cache lines of their own (16 x 8 B)
-constexpr size_t kFusedSyncHeader = (size_t)kFusedShards * kFusedShardStride * 8 + 16;   // shards, error word, pad
+// Per frame f: flag[f] == epoch once the frame's mesh operands have been handed over in launch `epoch` (an idempotent
+// store: no counter, no read-modify-write on the normal path); claim[f] == epoch once a workgroup has started on the frame.
+constexpr size_t kFusedSyncHeader = 16;   // error word, pad
 struct FusedSync {
-  unsigned long long* done;    // [16 shards x 16] frames handed over so far per shard, monotonic over launches
-  unsigned* claim;             // [F] epoch of the launch that last claimed frame f
+  unsigned* flag;              // [256]
+  unsigned* claim;             // [256]
   unsigned* error;             // set when a workgroup's bounded wait ran out
-  unsigned epoch;              // launch number, >= 1: shard s is complete at epoch * (number of frames f with f % 16 == s)
+  unsigned epoch;              // launch number, >= 1
   int test_skip;               // diagnostic (tests): workgroups b % test_skip == 1 leave their frame to be adopted
 };
+constexpr int kFusedMaxFrames = 256;
 
 // ---- device-resident LM for batches of independent frames (k_lm_batched.hip) ------------------------
 constexpr int kLmActive = 1;        // flags: frame still iterating

@@ -174,9 +174,8 @@ constexpr int TAB_KPID = 96;                   // KC
 struct FusedFrame {
   unsigned char* ldsB;            // LDS image of the workgroup's vertex tile operands (null: no tile)
   const unsigned char* dirsB;     // the tile's operand block in HBM
-  unsigned long long* done;       // sharded counter of published frames, monotonic over launches (agent-scope adds)
-  unsigned claim_old;             // thread 0: what the claim of this frame returned (== epoch: another workgroup owns it)
-  unsigned epoch;                 // this launch's claim value
+  unsigned* flag;                 // flag[f] = epoch: this frame's mesh operands are published
+  unsigned epoch;                 // this launch's number
 };
 
 // Barrier between two phases.  The phases only exchange LDS data, so the fused kernel waits for the LDS counter alone:
@@ -200,6 +199,15 @@ __device__ __forceinline__ void store_operand16(void* p, uint4 v) {
     *reinterpret_cast<uint4*>(p) = v;
   }
 }
+
+// pieces [p0, p1) of the workgroup's 84 KiB tile operand block, HBM -> LDS by LDS-DMA (1 KiB per wave-instruction)
+__device__ __forceinline__ void tile_dma(const FusedFrame& fu, int lane, int p0, int p1) {
+#pragma unroll 1
+  for (int pc = p0; pc < p1; ++pc)
+    __builtin_amdgcn_global_load_lds(fu.dirsB + (size_t)pc * 1024 + lane * 16,
+                                     (__attribute__((address_space(3))) void*)(fu.ldsB + (size_t)pc * 1024), 16, 0, 0);
+}
+constexpr int kTileDmaB = 15, kTileDmaD = 17, kTileDmaE = 84 - 2 * kTileDmaB - 2 * kTileDmaD;   // pieces per issuing wave
 
 template <bool kFused>
 __device__ __forceinline__ void frame_part(const DevModel& M, const DevProblem& Pb, const double* __restrict__ params,
@@ -240,9 +248,11 @@ __device__ __forceinline__ void frame_part(const DevModel& M, const DevProblem& 
   STAMP_REAL(10);
   STAMP(0);
   if (Pb.frame_flags && !(Pb.frame_flags[f] & Pb.frame_mask)) return;   // frame already converged (device LM)
+  constexpr int kLoaders = kThreads;
+  constexpr bool loader = true;
   // ---- A. small model tables, landmark weights and the frame's parameters into LDS --------------------
   if (tid < nJ) { sParent[tid] = M.parent[tid]; sAnc[tid] = M.anc_mask[tid]; }
-  for (int it = tid; it < nL * kMaxLmNnz; it += kThreads) {
+  for (int it = tid; loader && it < nL * kMaxLmNnz; it += kThreads) {
     // landmark skinning weights, fixed stride (padded with weight 0) -> one round trip
     const int l = it / kMaxLmNnz, i = it % kMaxLmNnz;
     double* L = sLm + l * LM_STRIDE;
@@ -250,21 +260,22 @@ __device__ __forceinline__ void frame_part(const DevModel& M, const DevProblem& 
     reinterpret_cast<int*>(L + LM_J)[i] = M.lm_wj[it];
     if (i == 0) L[LM_NW] = (double)M.lm_woff[l];   // weight count
   }
-  for (int it = tid; it < nL * 3 * nS; it += kThreads) sLmSd[it] = M.lm_sd[it];
+  for (int it = tid; loader && it < nL * 3 * nS; it += kThreads) sLmSd[it] = M.lm_sd[it];
   {
-    // 720 = 24 x 3 x 10 doubles each: fixed 3 predicated passes so all six loads are in flight together
-    double t0[3], t1[3];
+    // 720 = 24 x 3 x 10 doubles each: fixed predicated passes so all the loads are in flight together
+    constexpr int kPasses = (720 + kLoaders - 1) / kLoaders;
+    double t0[kPasses], t1[kPasses];
     const int nds = nJ * 3 * nS;
 #pragma unroll
-    for (int u = 0; u < 3; ++u) {
-      const int i = tid + u * kThreads;
-      t0[u] = (i < nds) ? M.dS[i] : 0.0;
-      t1[u] = (i < nds) ? M.Sc[i] : 0.0;
+    for (int u = 0; u < kPasses; ++u) {
+      const int i = tid + u * kLoaders;
+      t0[u] = (loader && i < nds) ? M.dS[i] : 0.0;
+      t1[u] = (loader && i < nds) ? M.Sc[i] : 0.0;
     }
 #pragma unroll
-    for (int u = 0; u < 3; ++u) {
-      const int i = tid + u * kThreads;
-      if (i < nds) { sDS[i] = t0[u]; sSc[i] = t1[u]; }
+    for (int u = 0; u < kPasses; ++u) {
+      const int i = tid + u * kLoaders;
+      if (loader && i < nds) { sDS[i] = t0[u]; sSc[i] = t1[u]; }
     }
   }
   // the first keypoint chunk depends on kp_offset[f] (a second round trip): its loads are issued here but land in LDS
@@ -283,23 +294,16 @@ __device__ __forceinline__ void frame_part(const DevModel& M, const DevProblem& 
   if (b_lane) x_in = (use_shape && beta) ? beta[(size_t)f * Pb.beta_stride + tid - 224] : 0.0;
   // issued last and by every lane (the arrays are padded by one chunk): loads return in order, so everything above is
   // waited for with these still in flight
-  const int kp_id0 = Pb.kp_id[k_begin0 + (tid & (KC - 1))];
-  const double kp_u0 = Pb.kp_uv[2 * (size_t)(k_begin0 + (tid & (KC - 1)))];
-  const double kp_v0 = Pb.kp_uv[2 * (size_t)(k_begin0 + (tid & (KC - 1))) + 1];
+  int kp_id0 = 0;
+  double kp_u0 = 0.0, kp_v0 = 0.0;
+  if (loader) {
+    kp_id0 = Pb.kp_id[k_begin0 + (tid & (KC - 1))];
+    kp_u0 = Pb.kp_uv[2 * (size_t)(k_begin0 + (tid & (KC - 1)))];
+    kp_v0 = Pb.kp_uv[2 * (size_t)(k_begin0 + (tid & (KC - 1))) + 1];
+  }
   if (x_lane) sx[tid - 128] = x_in;
   if (b_lane) sx[npose + tid - 224] = x_in;
   frame_sync<kFused>();
-  if constexpr (kFused) {
-    // The workgroup's vertex tile operands (84 x 1 KiB, HBM -> LDS by LDS-DMA), issued by waves 6-7 now that phase A's
-    // own round trip is over: these two waves make no global load before phase E, so nothing of the frame part waits
-    // behind the transfer (vmcnt retires in order), and the tile has landed long before the mesh part reads it.
-    if (fu.ldsB && wave >= 6) {
-#pragma unroll 1
-      for (int pc = wave - 6; pc < 84; pc += 2)
-        __builtin_amdgcn_global_load_lds(fu.dirsB + (size_t)pc * 1024 + lane * 16,
-                                         (__attribute__((address_space(3))) void*)(fu.ldsB + (size_t)pc * 1024), 16, 0, 0);
-    }
-  }
   if (tid < nk0) {
     sTab[TAB_KPID + tid] = kp_id0;
     sKpUv[2 * tid] = kp_u0;
@@ -308,6 +312,13 @@ __device__ __forceinline__ void frame_part(const DevModel& M, const DevProblem& 
   const double* sbeta = sx + npose;
 
   STAMP(1);
+  if constexpr (kFused) {
+    // Fused sweep: the workgroup's vertex tile operands (84 x 1 KiB, HBM -> LDS by LDS-DMA) are requested in the idle issue
+    // slots of the frame part, ~150 cycles of a wave per piece: here by waves 6-7 (idle in this phase; LDS work only until
+    // the hand-off, so nothing of theirs waits behind the transfer: vmcnt retires in order), in phase D by waves 0-1 (least
+    // to do there), in phase E by wave 7 behind its operand stores.
+    if (fu.ldsB && wave >= 6) tile_dma(fu, lane, (wave - 6) * kTileDmaB, (wave - 5) * kTileDmaB);
+  }
   // ---- B. wave 0: Rodrigues + gradient per joint (joint 0 = root angle-axis);
   //         waves 1-3: chain offsets o_j(beta) (include/Sim3BA.h:142-170,179-205), centred rest joints ------
   if (tid < 3 * nJ) {     // (joint, k): wave 0 and a few lanes of wave 1
@@ -363,9 +374,12 @@ __device__ __forceinline__ void frame_part(const DevModel& M, const DevProblem& 
   const int lm_k = lane & 31, lm_l = 2 * wave + (lane >> 5);
   const bool lm_blend = Pb.pose_blend && P > 0;
   auto lm_load = [&](int l, double (&pdv)[27]) {
-    const bool on = lm_blend && l < nL && lm_k < nJ - 1;
+    // UNCONDITIONAL loads from a clamped (always valid) row, masked by a factor: written as `on ? load : 0` hipcc branches
+    // around every pair of loads and waits vmcnt(0) inside each branch, i.e. 14 dependent L2 round trips (seen in the .s)
+    const double onf = (lm_blend && l < nL && lm_k < nJ - 1) ? 1.0 : 0.0;
+    const double* row = M.lm_pd + (size_t)min(l, max(nL, 1) - 1) * 27 * 32 + lm_k;
 #pragma unroll
-    for (int ae = 0; ae < 27; ++ae) pdv[ae] = on ? M.lm_pd[((size_t)l * 27 + ae) * 32 + lm_k] : 0.0;
+    for (int ae = 0; ae < 27; ++ae) pdv[ae] = row[ae * 32] * onf;
   };
   auto lm_terms = [&](int l, const double (&pdv)[27]) {
     const int k = min(lm_k + 1, nJ - 1);
@@ -462,6 +476,9 @@ __device__ __forceinline__ void frame_part(const DevModel& M, const DevProblem& 
   frame_sync<kFused>();
 
   STAMP(4);
+  if constexpr (kFused) {
+    if (fu.ldsB && wave < 2) tile_dma(fu, lane, 2 * kTileDmaB + wave * kTileDmaD, 2 * kTileDmaB + (wave + 1) * kTileDmaD);
+  }
   // ---- D. wave 0-1: W_{k,c} = A_p (dR_{k,c} R_k^T) A_p^T ; wave 2: landmark LBS ; wave 3: camera matrices ;
   //         waves 4-7: B_j columns (d P_j / d beta) ----
   if (use_shape && want_jac) {
@@ -617,6 +634,9 @@ __device__ __forceinline__ void frame_part(const DevModel& M, const DevProblem& 
       for (int r = 0; r < 3; ++r) joints_out[((size_t)f * nJ + jj) * 3 + r] = s * t[r] + sx[4 + r];
     }
   }
+  if constexpr (kFused) {
+    if (fu.ldsB && wave == 7) tile_dma(fu, lane, 84 - kTileDmaE, 84);   // behind the stores above: see the counted wait below
+  }
   if (nL > 0 && want_jac) {
     // d q_l / d theta_{k,c} for landmark l, complete, left in LM_PD[l][3 (k - 1) + c] for the Jacobian sweep:
     //   Ablend . (pd[:, 9(k-1):9k] . vec(dR_{k,c}))   the inner products were parked here by phase C (same lane mapping:
@@ -677,13 +697,19 @@ __device__ __forceinline__ void frame_part(const DevModel& M, const DevProblem& 
   STAMP(6);
   if constexpr (kFused) {
     // Hand-off of this frame's mesh operands (blend coefficients: phase D, transforms: phase E) to every workgroup's mesh
-    // part: write-through stores, every wave drains its own, workgroup barrier, ONE lane adds to the launch's counter
-    // (cdna guide, Guideline 16 R1 in its counter form).  Only the workgroup whose claim won counts the frame.
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // part: write-through stores, every wave drains its own, workgroup barrier, ONE lane stores the frame's flag
+    // (cdna guide, Guideline 16 R1).  The flag store is idempotent, so a frame processed twice (adopted, then run by its
+    // late owner) is still published exactly as once.
+    // the waves that stored operands drain them: wave 3 everything, wave 7 all but the kTileDmaE DMA pieces it issued behind
+    // its stores (vmcnt retires in order)
+    static_assert(kTileDmaE == 20, "the counted wait below");
+    if (wave == 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (wave == 7) {
+      if (fu.ldsB) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     frame_sync<true>();
-    if (tid == 0 && fu.claim_old != fu.epoch)
-      __hip_atomic_fetch_add(fu.done + (size_t)(f % kFusedShards) * kFusedShardStride, 1ull, __ATOMIC_RELAXED,
-                             __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == kThreads - 1) __hip_atomic_store(fu.flag + f, fu.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     STAMP_REAL(12);
   }
   // ---- F. keypoints of this frame, KC at a time: stage per-keypoint data, then the flat (keypoint, column)

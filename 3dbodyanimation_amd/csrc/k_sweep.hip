@@ -10,17 +10,19 @@
 //                     dependent kernel boundary between them and hides the mesh part's start-up and its 84 KiB operand
 //                     staging (HBM -> LDS) under the frame part.
 //
-// In-launch hand-off (cdna guide, Guideline 16, R1 with a counter): producers store the operands write-through (sc1), every
-// storing wave drains (s_waitcnt vmcnt(0)), workgroup barrier, one lane adds to an agent-scope counter; consumers poll the
-// counter with sc1 loads from one lane, workgroup barrier, then read the operands with sc1 loads only.  No flag or counter is
-// reset between launches: the counter is monotonic (launch e completes at e * F) and claims carry the launch's epoch.
+// In-launch hand-off (cdna guide, Guideline 16, R1): producers store the operands write-through (sc1), every storing wave
+// drains (s_waitcnt vmcnt(0)), workgroup barrier, one lane stores the frame's flag = the launch's epoch (sc1); consumers
+// poll the F flags with sc1 loads from one wave (one 16-byte load per lane covers 256 flags), workgroup barrier, then read
+// the operands with sc1 loads only.  Nothing is reset between launches (flags and claims carry the launch's epoch) and the
+// normal path has no read-modify-write at all: 256 workgroups arriving on one counter serialise at ~12 ns each.
 //
-// Progress does not depend on dispatch order or on every workgroup being resident: a frame belongs to whoever CLAIMS it
-// (atomic exchange of the epoch into claim[f]).  A workgroup claims and processes frame blockIdx.x first; while it waits for
-// the counter it adopts unclaimed frames after a grace period, so the frames of workgroups that have not been dispatched yet
-// (another process holding CUs, fewer CUs than workgroups) are processed by the resident ones, and the wait ends.  A late
-// workgroup whose frame was adopted recomputes it (identical bytes) without counting it.  Every spin is bounded: after
-// kFusedTimeoutTicks the workgroup sets the problem's error word and leaves.
+// Progress does not depend on dispatch order or on every workgroup being resident.  A workgroup marks frame blockIdx.x as
+// started (claim[f] = epoch, a plain write-through store) and processes it; while it waits for the flags it ADOPTS, after
+// a grace period, frames nobody has started (atomic exchange on claim[f] arbitrates between adopters), so the frames of
+// workgroups that have not been dispatched yet (another process holding CUs, fewer CUs than workgroups) are processed by
+// the resident ones, and the wait ends.  A frame processed twice (adopted, then run by its late owner) is written twice
+// with identical bytes and its flag store is idempotent.  Every spin is bounded: after kFusedTimeoutTicks the workgroup sets
+// the problem's error word and leaves.
 #include <hip/hip_ext.h>
 
 #include "bodyfit_device.h"
@@ -31,7 +33,9 @@
 namespace bodyfit {
 namespace {
 
-constexpr int kFusedFrameLds = 77824;                        // LDS behind the tile operands: frame part, then transform slices
+// LDS of the fused sweep: [0, 86,016) the tile operands (as in k_mesh_blend_lbs), [86,016, 163,840) the frame part's state,
+// later the mesh part's transform slices.
+constexpr int kFusedFrameLds = 77824;
 constexpr int kFusedLdsBytes = kBBytes + kFusedFrameLds;     // 163,840 = the CU's 160 KiB
 constexpr int kFusedCtrlOff = kFusedLdsBytes - 16;           // control words of the wait loop
 constexpr unsigned long long kFusedStealTicks = 3000;        // 30 us of s_memrealtime (100 MHz) before adopting frames
@@ -100,6 +104,25 @@ __device__ __forceinline__ FusedArgP reload_args(FusedArgP p) {
   return p;
 }
 
+// The frame part of the fused sweep as a CALL, not inlined: as part of the kernel's body it is scheduled and register-
+// allocated together with the mesh part (248 VGPRs, ~110 argument SGPRs live), and hipcc then serialises the LDS reads of
+// its latency chains (the chain walk: four LDS round trips per level instead of one) and spills; as a function of its own
+// it is compiled like k_frame_resjac.  Arguments come from the kernel-argument segment, not through the call.
+__device__ __attribute__((noinline)) void fused_frame_call(FusedArgP A, double* smF, int f, unsigned char* ldsB,
+                                                           const unsigned char* dirs, unsigned epoch) {
+#if defined(__HIP_DEVICE_COMPILE__)   // (the host pass cannot copy structs out of address space 4)
+  const DevModel M = A->M;
+  const DevProblem Pb = A->Pb;
+  const MeshCoef mc = A->mc;
+  FusedFrame fu;
+  fu.ldsB = ldsB;
+  fu.dirsB = dirs;
+  fu.flag = A->sy.flag;
+  fu.epoch = epoch;
+  frame_part<true>(M, Pb, A->params, A->beta, A->r_out, A->J_out, A->joints_out, mc, A->want_jac, smF, f, fu);
+#endif
+}
+
 #ifdef BODYFIT_STAMPS
 // diagnostic build: workgroup-level s_memrealtime stamps of the fused sweep (tools/stamp_fused.py)
 #define FSTAMP(i)                                                                                      \
@@ -114,7 +137,7 @@ __device__ __forceinline__ FusedArgP reload_args(FusedArgP p) {
 #define FSTAMP(i)
 #endif
 
-__global__ __launch_bounds__(kThreads) void k_sweep_fused(FusedArgs by_value) {
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_sweep_fused(FusedArgs by_value) {
   (void)by_value;
 #if defined(__HIP_DEVICE_COMPILE__)   // (the host pass only needs the stub; it cannot copy structs out of address space 4)
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -129,14 +152,24 @@ __global__ __launch_bounds__(kThreads) void k_sweep_fused(FusedArgs by_value) {
   const unsigned char* dirs = reinterpret_cast<const unsigned char*>(A->M.dirsB) + (size_t)(has_tile ? b : 0) * kBBytes;
   const unsigned epoch = A->sy.epoch;
   const int test_skip = A->sy.test_skip;
+  {
+    // touch the whole argument block now (scalar cache), so the frame part's argument loads a call later are hits
+    typedef __attribute__((ext_vector_type(16))) unsigned int u32x16_;
+    constexpr int kChunks = (int)((sizeof(FusedArgs) + 63) / 64);
+#pragma unroll
+    for (int i = 0; i < kChunks - 1; ++i) {   // (the last, partial chunk is reached by the field loads above)
+      u32x16_ t = *reinterpret_cast<const __attribute__((address_space(4))) u32x16_*>(
+          reinterpret_cast<const __attribute__((address_space(4))) char*>(A) + i * 64);
+      asm volatile("" ::"s"(t));
+    }
+  }
   FSTAMP(0);
 
   // ---- frames: this workgroup's own first, then (only while the counter is short after a grace period) adopted ones ---
   // One call site of the frame part: `f` is the frame to process in this round, or -1.
   const bool own = b < F && !(test_skip > 0 && b % test_skip == 1);
   int f = own ? b : -1;
-  unsigned claim_old = 0;
-  if (own && tid == 0) claim_old = __hip_atomic_exchange(A->sy.claim + b, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (own && tid == kThreads - 1) __hip_atomic_store(A->sy.claim + b, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   bool staged = false;
   if (has_tile && !own) {   // no frame of its own: stage the tile operands now (all waves)
 #pragma unroll 1
@@ -149,68 +182,56 @@ __global__ __launch_bounds__(kThreads) void k_sweep_fused(FusedArgs by_value) {
   unsigned long long t_enter = 0;
   for (;;) {
     if (f >= 0) {
-      const FusedArgP A1 = reload_args(A);
-      const DevModel M = A1->M;
-      const DevProblem Pb = A1->Pb;
-      const MeshCoef mc = A1->mc;
-      FusedFrame fu;
-      fu.ldsB = (has_tile && !staged) ? ldsB : nullptr;   // a workgroup with a frame of its own stages its tile under it
-      fu.dirsB = dirs;
-      fu.done = A1->sy.done;
-      fu.epoch = epoch;
-      fu.claim_old = claim_old;
-      frame_part<true>(M, Pb, A1->params, A1->beta, A1->r_out, A1->J_out, A1->joints_out, mc, A1->want_jac, smF, f, fu);
-      staged = true;   // (its hand-off drained vmcnt in every wave: the tile DMA has landed)
+      // (a workgroup with a frame of its own stages its tile under it)
+      fused_frame_call(A, smF, f, (has_tile && !staged) ? ldsB : nullptr, dirs, epoch);
+      staged = true;   // (requested in the frame part's phase D; waited for in front of the mesh part)
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // frame part's LDS is free
       FSTAMP(1);
     }
     if (!has_tile) break;   // no mesh part: nothing to wait for (the prior tiles below ride on these workgroups)
-    // wait until every frame's mesh operands have been handed over; adopt an unclaimed frame after a grace period.
-    // (vmcnt is NOT drained here: the Jacobian stores of the frame part's last phase are write-through and complete
-    //  under the mesh part)
+    // wait until every frame's mesh operands have been handed over; adopt an unclaimed frame after a grace period
     if (wave == 0) {
-      // lanes 0..15 poll one shard each (one load instruction per poll); lane 0 runs the adoption scan
+      // every lane polls four flags with one 16-byte sc1 load (256 flags per wave-instruction); lane 0 runs the adoption scan
       const FusedArgP A2 = reload_args(A);
-      unsigned long long* const done = A2->sy.done;
       unsigned* const claim = A2->sy.claim;
-      const int shard = lane & (kFusedShards - 1);
-      const unsigned long long target =
-          (unsigned long long)epoch * (unsigned long long)((F - shard + kFusedShards - 1) / kFusedShards);
-      unsigned action = 0, fs = 0, old = 0;
+      const __amdgpu_buffer_rsrc_t flags = __builtin_amdgcn_make_buffer_rsrc(A2->sy.flag, 0, kFusedMaxFrames * 4, 0x00020000);
+      unsigned action = 0, fs = 0;
       if (t_enter == 0) t_enter = __builtin_amdgcn_s_memrealtime();
       unsigned long long t_grace = __builtin_amdgcn_s_memrealtime();
       const unsigned scan = (unsigned)b * 37u;
       for (;;) {
-        const bool ok = lane >= kFusedShards ||
-                        __hip_atomic_load(done + (size_t)shard * kFusedShardStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target;
+        typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_;
+        const u32x4_ fl = __builtin_amdgcn_raw_buffer_load_b128(flags, (unsigned)lane * 16u, 0, 16);
+        const int f4 = lane * 4;
+        const bool ok = (f4 >= F || fl.x == epoch) && (f4 + 1 >= F || fl.y == epoch) && (f4 + 2 >= F || fl.z == epoch) &&
+                        (f4 + 3 >= F || fl.w == epoch);
         if (__all(ok)) break;
         __builtin_amdgcn_s_sleep(2);
         const unsigned long long now = __builtin_amdgcn_s_memrealtime();
         if (now - t_enter > kFusedTimeoutTicks) { action = 2; break; }
         if (now - t_grace > kFusedStealTicks) {
-          // adopt one frame nobody has claimed in this launch (its workgroup is not resident yet)
+          // adopt one frame nobody has started in this launch (its workgroup is not resident yet)
           unsigned got = 0;
           if (lane == 0) {
             for (int i = 0; i < F && !got; ++i) {
               const unsigned fcand = (scan + (unsigned)i) % (unsigned)F;
-              if (__hip_atomic_load(claim + fcand, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
-                old = __hip_atomic_exchange(claim + fcand, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (old != epoch) { got = 1; fs = fcand; }
+              if (__hip_atomic_load(claim + fcand, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch &&
+                  __hip_atomic_exchange(claim + fcand, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
+                got = 1; fs = fcand;
               }
             }
           }
           got = __builtin_amdgcn_readfirstlane(got);
           if (got) { action = 1; break; }
-          t_grace = now;   // every frame is claimed: its owner is running, keep polling
+          t_grace = now;   // every frame has been started: its workgroup is running, keep polling
         }
       }
-      if (lane == 0) { ctrl[0] = action; ctrl[1] = fs; ctrl[2] = old; }
+      if (lane == 0) { ctrl[0] = action; ctrl[1] = fs; }
     }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     const unsigned action = ctrl[0], fs = ctrl[1];
-    claim_old = ctrl[2];
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // control words read before they are rewritten
-    if (action == 0) { FSTAMP(2); break; }
+    if (action == 0) break;
     if (action == 2) {
       if (tid == 0) __hip_atomic_store(A->sy.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       return;
@@ -225,7 +246,11 @@ __global__ __launch_bounds__(kThreads) void k_sweep_fused(FusedArgs by_value) {
     if (pt < pa.n_tiles) prior_block(pa, pt, A3->params, smF);
     return;
   }
-  // (the barrier above separates the polling lane's last counter read from EVERY load of the handed-off operands, and the
+  // the tile operands have landed (requested at least a phase F earlier; this also retires the frame part's last Jacobian
+  // stores, which the mesh part's first loads would wait for anyway: vmcnt retires in order)
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  FSTAMP(2);
+  // (the barriers above separate the polling lane's last flag read from EVERY load of the handed-off operands, and the
   //  frame part's last LDS use from the transform slices that alias it)
   {
     const FusedArgP A4 = reload_args(A);
@@ -273,7 +298,7 @@ void launch_mesh(const DevModel& M, const DevProblem& P, const MeshCoef& mc, flo
 // grid is one workgroup per frame / vertex tile / prior tile.
 bool fused_sweep_fits(const DevModel& M, const DevProblem& P, int n_prior_tiles, int n_cus) {
   const int grid = P.F > M.nVTiles + n_prior_tiles ? P.F : M.nVTiles + n_prior_tiles;
-  return P.F > 0 && grid <= n_cus && frame_lds_bytes(M.nL) <= (size_t)(kFusedCtrlOff - kBBytes) &&
+  return P.F > 0 && P.F <= kFusedMaxFrames && grid <= n_cus && frame_lds_bytes(M.nL) <= (size_t)(kFusedCtrlOff - kBBytes) &&
          (size_t)P.nFTiles * kFTile * M.nVTiles * kVTile * 12 < ((size_t)1 << 32);
 }
 

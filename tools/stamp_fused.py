@@ -54,7 +54,7 @@ print("mesh: skinning done waves 0-3 ", q(us(ms[:, :4, 3])), "  waves 4-7", q(us
 print("workgroup end                 ", q(us(fs[:tiles, 3])))
 cyc = np.diff(fr[:, :, :9], axis=2)
 names = ["A tables", "B rodrigues/offsets", "C chain walks / landmark items", "C barrier", "D", "E", "hand-off + F1", "F2 sweep"]
-print("frame part phases, shader cycles (median over frames of the slowest wave):")
+print("frame part phases, shader cycles (median over frames of the slowest wave | per wave 0..7):")
 for i, n in enumerate(names):
-    print(f"  {n:32s} {int(np.median(cyc[:, :, i].max(1)))}")
+    print(f"  {n:32s} {int(np.median(cyc[:, :, i].max(1))):6d} |", np.median(cyc[:, :, i], axis=0).astype(int))
 print("frame part total cycles (median):", int(np.median(fr[:, :, 8].max(1) - fr[:, :, 0].min(1))))
