@@ -101,6 +101,7 @@ struct bodyfit_problem {
   float* d_cloud = nullptr;
   double* d_frame_normal = nullptr;
   unsigned char* lm_pool = nullptr;    // device LM state of bodyfit_solve, one allocation kept across solves
+  unsigned char* win_pool = nullptr;   // device window LM (k_window_lm.hip): state + cyclic-reduction buffers
   hipStream_t lm_stream = nullptr;
   double* d_writeback = nullptr;
   // fused sweep (k_sweep_fused): in-launch synchronisation words [error | pad | flag[256] | claim[256]], launch counter
@@ -947,6 +948,153 @@ int bodyfit_internal_solve_batched_device(bodyfit_problem* p, double* frame_para
       s2.n_sweeps = n_sweeps;
       s2.initial_cost = c0[f]; s2.final_cost = c1[f];
     }
+  }
+  return BODYFIT_OK;
+}
+
+// Device-resident LM for ONE problem over all frames with a shared beta (k_window_lm.hip): the outer loop of
+// OptimizeMultiFrame (include/MultiFrameBA.h:144-151) with every piece of linear algebra on the device.  Per LM iteration
+// the host launches: [Jacobian sweep + k_frame_normal when the point moved] -> assemble -> cyclic reduction up and down ->
+// beta Schur + step + model change -> residual sweep at the candidate -> accept, and reads back one status record.
+int bodyfit_internal_solve_window_device(bodyfit_problem* p, double* frame_params, double* beta,
+                                         const unsigned char* param_constant, const bodyfit_fit_options* opt,
+                                         bodyfit_fit_summary* summary) {
+  const bodyfit_model* m = p->m;
+  const int F = p->d.F, npose = 7 + 3 * (m->nJ - 1), n = p->lay.n_cols, nb = n - npose;
+  if (npose != kFrameParams || nb != kMaxShape || p->desc.beta_per_frame || p->has_gmm || p->desc.temporal_halo)
+    return fail(BODYFIT_ERR_INVALID, "device window solver: needs 24 joints, a shared 10-coefficient beta, the L2 pose prior, no halo");
+  HIP_TRY(hipSetDevice(m->device));
+  std::lock_guard<std::mutex> lock(p->mu);
+  p->cache_valid = false;
+  // ---- one pooled allocation, kept across solves ----
+  WinBuf W{};
+  double *d_x, *d_b, *d_xn, *d_bn, *d_rn;
+  int *d_compn, *d_sched;
+  unsigned char* d_const = nullptr;
+  // cyclic-reduction schedule: per level the eliminated frames (j, left, right) and the remaining ones (a, jl, jr, next)
+  std::vector<int> sched;
+  struct Level { int elim_off, n_elim, surv_off, n_surv; };
+  std::vector<Level> levels;
+  {
+    std::vector<int> active(F);
+    for (int f = 0; f < F; ++f) active[f] = f;
+    while (active.size() > 1) {
+      Level lv{};
+      const int na = (int)active.size();
+      lv.elim_off = (int)sched.size();
+      for (int pos = 1; pos < na; pos += 2) {
+        sched.push_back(active[pos]); sched.push_back(active[pos - 1]); sched.push_back(pos + 1 < na ? active[pos + 1] : -1);
+        ++lv.n_elim;
+      }
+      lv.surv_off = (int)sched.size();
+      std::vector<int> next;
+      for (int pos = 0; pos < na; pos += 2) {
+        sched.push_back(active[pos]); sched.push_back(pos > 0 ? active[pos - 1] : -1);
+        sched.push_back(pos + 1 < na ? active[pos + 1] : -1); sched.push_back(pos + 2 < na ? active[pos + 2] : -1);
+        ++lv.n_surv;
+        next.push_back(active[pos]);
+      }
+      levels.push_back(lv);
+      active.swap(next);
+    }
+    Level root{};
+    root.elim_off = (int)sched.size(); root.n_elim = 1;
+    sched.push_back(active[0]); sched.push_back(-1); sched.push_back(-1);
+    levels.push_back(root);
+  }
+  {
+    const size_t blk = (size_t)kWinBlock * kWinBlock, rhs = (size_t)kWinRhs * kWinBlock;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+    const size_t o_D = take(F * blk * 8), o_U = take(F * blk * 8), o_L = take(F * blk * 8), o_P = take(F * blk * 8),
+                 o_Q = take(F * blk * 8), o_R = take(F * rhs * 8), o_R0 = take(F * rhs * 8), o_Y = take(F * rhs * 8),
+                 o_X = take(F * rhs * 8), o_A = take((size_t)F * npose * npose * 8), o_B = take((size_t)F * npose * nb * 8),
+                 o_g = take((size_t)F * npose * 8), o_E = take((size_t)F * npose * 8), o_sc = take(((size_t)F * npose + nb) * 8),
+                 o_Cs = take(100 * 8), o_rb = take(16 * 8), o_Cr = take(100 * 8), o_gb = take(16 * 8), o_dsb = take(16 * 8),
+                 o_part = take((size_t)F * kWinPart * 8), o_gm = take((size_t)(F + 1) * 8), o_d = take(((size_t)F * npose + nb) * 8),
+                 o_st = take(kWsCount * 8), o_fail = take(8), o_x = take((size_t)F * npose * 8), o_b = take(nb * 8),
+                 o_xn = take((size_t)F * npose * 8), o_bn = take(nb * 8), o_rn = take((size_t)std::max(1, p->lay.total_rows) * 8),
+                 o_cn = take((size_t)F * 4), o_sched = take(sched.size() * 4), o_const = take((size_t)npose);
+    if (!p->win_pool) {
+      HIP_TRY(p->mem.alloc(&p->win_pool, off));
+      HIP_TRY(hipMemset(p->win_pool, 0, off));
+    }
+    unsigned char* Bp = p->win_pool;
+    auto dp = [&](size_t o) { return reinterpret_cast<double*>(Bp + o); };
+    W.D = dp(o_D); W.U = dp(o_U); W.L = dp(o_L); W.Pt = dp(o_P); W.Qt = dp(o_Q); W.Rt = dp(o_R); W.Rt0 = dp(o_R0);
+    W.Yt = dp(o_Y); W.Xt = dp(o_X); W.Araw = dp(o_A); W.Braw = dp(o_B); W.graw = dp(o_g); W.Eraw = dp(o_E);
+    W.scale = dp(o_sc); W.Cs = dp(o_Cs); W.rhsb = dp(o_rb); W.Craw = dp(o_Cr); W.gbraw = dp(o_gb); W.dsb = dp(o_dsb);
+    W.part = dp(o_part); W.gmaxp = dp(o_gm); W.d = dp(o_d); W.status = dp(o_st);
+    W.fail = reinterpret_cast<int*>(Bp + o_fail);
+    d_x = dp(o_x); d_b = dp(o_b); d_xn = dp(o_xn); d_bn = dp(o_bn); d_rn = dp(o_rn);
+    d_compn = reinterpret_cast<int*>(Bp + o_cn);
+    d_sched = reinterpret_cast<int*>(Bp + o_sched);
+    if (param_constant) d_const = Bp + o_const;
+  }
+  if (!p->d_frame_normal) HIP_TRY(p->mem.alloc(&p->d_frame_normal, (size_t)F * kNormalRows * kNormalLd));
+  if (!p->lm_stream) HIP_TRY(hipStreamCreateWithFlags(&p->lm_stream, hipStreamNonBlocking));
+  hipStream_t st = p->lm_stream;
+  WinProblem P{};
+  P.F = F; P.K = p->lay.n_keypoints; P.total_rows = p->lay.total_rows; P.nb = nb;
+  P.prior_rows = p->lay.prior_rows_per_frame; P.row_prior = p->row_prior;
+  P.shape_rows = p->lay.shape_rows; P.row_shape = p->row_shape; P.row_temporal = p->row_temporal;
+  P.huber = p->desc.huber_delta; P.beta_pose = p->desc.beta_pose; P.beta_shape = p->desc.beta_shape;
+  P.lambda_t = p->desc.lambda_temporal; P.scale_lo = opt->scale_lo; P.scale_hi = opt->scale_hi;
+  HIP_TRY(hipMemcpyAsync(d_x, frame_params, (size_t)F * npose * sizeof(double), hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(d_b, beta, (size_t)nb * sizeof(double), hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(d_sched, sched.data(), sched.size() * sizeof(int), hipMemcpyHostToDevice, st));
+  if (param_constant) HIP_TRY(hipMemcpyAsync(d_const, param_constant, (size_t)npose, hipMemcpyHostToDevice, st));
+  auto jac_sweep = [&]() -> int {
+    int rc = sweep(p, d_x, d_b, 1, false, st);
+    if (rc) return rc;
+    launch_frame_normal(F, n, p->d.kp_offset, p->desc.huber_delta, p->d_r, p->d_J, p->d_frame_normal, st);
+    return BODYFIT_OK;
+  };
+  int rc = jac_sweep();
+  if (rc) return rc;
+  launch_win_init(P, W, p->d_r, st);
+  int n_sweeps = 1;
+  double status[kWsCount] = {0};
+  bool need_jac = false, first = true;
+  for (int it = 0; it < opt->max_iters; ++it) {
+    if (need_jac) {
+      rc = jac_sweep();
+      if (rc) return rc;
+      ++n_sweeps;
+    }
+    launch_win_assemble(P, W, p->d_frame_normal, p->d_r, d_x, d_const, first ? 1 : 0, st);
+    for (size_t l = 0; l < levels.size(); ++l) {
+      const Level& lv = levels[l];
+      launch_cr_factor(W, d_sched + lv.elim_off, lv.n_elim, st);
+      launch_cr_update(W, d_sched + lv.surv_off, lv.n_surv, st);
+    }
+    for (size_t l = levels.size(); l-- > 0;) launch_cr_back(W, d_sched + levels[l].elim_off, levels[l].n_elim, st);
+    launch_win_step(P, W, d_x, d_b, d_xn, d_bn, st);
+    rc = sweep(p, d_xn, d_bn, 0, false, st, nullptr, d_rn, d_compn);
+    if (rc) return rc;
+    ++n_sweeps;
+    launch_win_accept(P, W, d_rn, d_x, d_b, d_xn, d_bn, st);
+    HIP_TRY(hipMemcpyAsync(status, W.status, sizeof(status), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    first = false;
+    need_jac = status[kWsAccepted] != 0.0;
+    if (opt->verbose)
+      std::printf("[bodyfit-dev] it %3d cost %.6e radius %.3e accepted %d gmax %.2e\n", (int)status[kWsIters], status[kWsCost],
+                  status[kWsRadius], (int)status[kWsAccepted], status[kWsGmax]);
+    if (status[kWsActive] == 0.0) break;
+  }
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(status, W.status, sizeof(status), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(frame_params, d_x, (size_t)F * npose * sizeof(double), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(beta, d_b, (size_t)nb * sizeof(double), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  if (summary) {
+    summary->iterations = (int)status[kWsIters];
+    summary->termination = status[kWsActive] != 0.0 ? 1 : (int)status[kWsTermination];
+    summary->usable = summary->termination != 2;
+    summary->n_successful = (int)status[kWsOk]; summary->n_unsuccessful = (int)status[kWsBad];
+    summary->n_sweeps = n_sweeps;
+    summary->initial_cost = status[kWsInitialCost]; summary->final_cost = status[kWsCost];
   }
   return BODYFIT_OK;
 }

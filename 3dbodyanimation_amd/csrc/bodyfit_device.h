@@ -138,6 +138,43 @@ constexpr int kNormalRows = 87, kNormalLd = 88;   // per-frame normal-equation p
 void launch_frame_normal(int F, int n, const int* d_kp_offset, double huber, const double* d_r, const double* d_J,
                          double* d_out, hipStream_t s);
 
+// ---- device-resident LM for one shared-beta window (k_window_lm.hip): block cyclic reduction over the frames ----------
+constexpr int kWinBlock = 80;     // 76 frame parameters padded to whole 16-column panels (identity on the padding)
+constexpr int kWinRhs = 16;       // [B (10 columns) | rhs] transposed, padded to one 16-row tile
+constexpr int kWinPart = 128;     // per-frame partials: Schur S_f (100) + rb_f (10) + pad + model / |d|^2 / |x|^2 at 112..114
+enum {   // status record of the window LM (doubles), read back by the host once per iteration
+  kWsCost = 0, kWsRadius, kWsDec, kWsModel, kWsHasCand, kWsIters, kWsOk, kWsBad, kWsTermination, kWsActive,
+  kWsInitialCost, kWsAccepted, kWsGmax, kWsNewCost, kWsCount = 16
+};
+struct WinProblem {
+  int F, K, total_rows, nb;
+  int prior_rows, row_prior, shape_rows, row_shape, row_temporal;
+  double huber, beta_pose, beta_shape, lambda_t, scale_lo, scale_hi;
+};
+struct WinBuf {
+  double *D, *U, *L, *Pt, *Qt;      // [F][80][80]: diagonal blocks, couplings, factors, solved couplings (transposed)
+  double *Rt, *Rt0, *Yt, *Xt;       // [F][16][80]: right-hand sides (working copy, as assembled), L^-1 R, solution
+  double *Araw, *Braw, *graw, *Eraw;   // undamped, unscaled blocks for the model cost change: [F][76][76], [F][76][10], [F][76] x 2
+  double *scale;                    // [F * 76 + 10] Jacobi scaling, fixed at the first iterate
+  double *Cs, *rhsb, *Craw, *gbraw, *dsb;   // beta block: scaled damped C, scaled rhs, raw C, raw gradient, scaled step
+  double *part;                     // [F][kWinPart]
+  double *gmaxp;                    // [F + 1] per-frame max |g| (entry F: beta)
+  double *d;                        // [F * 76 + 10] the step
+  double *status;                   // [kWsCount]
+  int* fail;                        // a factorisation met a non-positive pivot
+};
+size_t win_factor_lds_bytes();
+void launch_win_init(const WinProblem& P, const WinBuf& W, const double* d_r, hipStream_t s);
+void launch_win_assemble(const WinProblem& P, const WinBuf& W, const double* d_Hpan, const double* d_r, const double* d_x,
+                         const unsigned char* d_constant, int first, hipStream_t s);
+void launch_cr_factor(const WinBuf& W, const int* d_elim, int n_elim, hipStream_t s);
+void launch_cr_update(const WinBuf& W, const int* d_surv, int n_surv, hipStream_t s);
+void launch_cr_back(const WinBuf& W, const int* d_elim, int n_elim, hipStream_t s);
+void launch_win_step(const WinProblem& P, const WinBuf& W, const double* d_x, const double* d_beta, double* d_x_new,
+                     double* d_beta_new, hipStream_t s);
+void launch_win_accept(const WinProblem& P, const WinBuf& W, const double* d_r_new, double* d_x, double* d_beta,
+                       const double* d_x_new, const double* d_beta_new, hipStream_t s);
+
 // f32 -> bf16 round-to-nearest-even (finite inputs)
 __host__ __device__ inline uint16_t f32_to_bf16(float x) {
   union { float f; uint32_t u; } c;

@@ -597,6 +597,15 @@ extern "C" int bodyfit_solve(bodyfit_problem* p, double* frame_params, double* b
   if (device_ok && opt.solver != 1)
     return bodyfit_internal_solve_batched_device(p, frame_params, beta, param_constant, &opt, summaries, n_summaries);
 
+  // one problem over all frames with a shared beta: the device-resident window LM (block cyclic reduction over the
+  // frames, k_window_lm.hip) when the problem has the shape it is built for; solver 1 keeps the host loop
+  const bool window_ok = !independent_frames && c.nb == view.n_shape && view.n_shape == 10 && !c.beta_per_frame &&
+                         !view.has_gmm && view.max_kp_per_frame <= 32;
+  if (opt.solver == 3 && !window_ok)
+    return bodyfit_internal_fail(BODYFIT_ERR_INVALID, "bodyfit_solve: the device window loop needs a shared 10-coefficient beta, the L2 pose prior and <= 32 keypoints per frame");
+  if (window_ok && opt.solver == 3)
+    return bodyfit_internal_solve_window_device(p, frame_params, beta, param_constant, &opt, summaries);
+
   const int F = c.F, nb = c.nb;
   std::vector<Group> groups;
   if (independent_frames) {

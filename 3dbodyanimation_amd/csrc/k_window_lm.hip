@@ -1,0 +1,778 @@
+// k_window_lm.hip — device-resident Levenberg-Marquardt for ONE problem over all frames of a window with a shared shape
+// block: what OptimizeMultiFrame hands to ceres::Solve with DENSE_QR (include/MultiFrameBA.h:144-151).
+//
+// The normal equations of such a window are block tridiagonal in the frames (76 x 76 blocks, coupled by the temporal
+// term: diagonal off-diagonal blocks) with a 10-wide border (beta).  host_solver.cpp factors the chain frame after frame
+// on the host; here it is solved on the device, parallel in the frames, by BLOCK CYCLIC REDUCTION with the border carried
+// as 11 right-hand sides [B | rhs]:
+//   level l: every second remaining frame j (neighbours a < j < b) is eliminated:
+//       D_j = L L^T,  P = L^-1 U_a^T,  Q = L^-1 U_j,  Y = L^-1 R_j                         (k_cr_factor, two workgroups per j)
+//       D_a -= P^T P,  D_b -= Q^T Q,  U_a := -P^T Q,  R_a -= P^T Y,  R_b -= Q^T Y          (k_cr_update, f64 MFMA)
+//   after ceil(log2 F) levels one frame is left: x = D^-1 R; then down again: x_j = L^-T (Y - P x_a - Q x_b)  (k_cr_back)
+//   beta:  S = C - B^T X_B,  d_beta = S^-1 (rhs_b - B^T x),  d_f = x_f - X_B,f d_beta     (k_win_schur*, k_win_beta_solve)
+// (U_j: coupling block (j, next remaining frame); at level 0 it is the diagonal temporal block, afterwards dense.)
+// Around it, all of Ceres' trust-region logic as restated in host_solver.cpp (Jacobi scaling fixed at the first iterate,
+// LM damping, projected scale bounds, step quality, radius update, the three termination tests) runs in small kernels on
+// the device: per LM iteration the host launches a fixed sequence and reads back one 16-double status record.
+// Blocks are padded to 80 x 80 (identity on the padding), right-hand sides to 16 rows, all stored row-major; "t" buffers
+// hold transposes (Pt[i][k] = P[k][i]) so that every product is  C[i][i'] = sum_k X[i][k] Y[i'][k]  with k contiguous.
+#include "bodyfit_device.h"
+
+namespace bodyfit {
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) double d4;
+constexpr int NP = kFrameParams;     // 76
+constexpr int NBETA = kMaxShape;     // 10
+constexpr int WB = kWinBlock;        // 80
+constexpr int WR = kWinRhs;          // 16
+constexpr int LD = WB + 1;           // LDS leading dimension
+constexpr int kHLd = kNormalLd, kHRows = kNormalRows;   // k_frame_normal panels: 87 x 88, n = 86
+
+__device__ inline double huber_rho_w(double delta, double s) {
+  const double b = delta * delta;
+  if (delta > 0.0 && s > b) return 2.0 * delta * sqrt(s) - b;
+  return s;
+}
+__device__ inline double readlane_f64w(double v, int src) {
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), src);
+  const int hi = __builtin_amdgcn_readlane((int)(b >> 32), src);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ inline double block_sum_n(double v, double* red, int tid, int nwaves) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  __syncthreads();
+  if ((tid & 63) == 0) red[tid >> 6] = v;
+  __syncthreads();
+  double s = 0.0;
+  for (int w = 0; w < nwaves; ++w) s += red[w];
+  return s;
+}
+__device__ inline double block_max_n(double v, double* red, int tid, int nwaves) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
+  __syncthreads();
+  if ((tid & 63) == 0) red[tid >> 6] = v;
+  __syncthreads();
+  double s = 0.0;
+  for (int w = 0; w < nwaves; ++w) s = fmax(s, red[w]);
+  return s;
+}
+// temporal row i (0..74) constrains parameter src(i): rootT, rootAA, then the joints (include/MultiFrameBA.h:121-142)
+__device__ inline int temporal_src(int i) { return (i < 3) ? (4 + i) : (i < 6 ? (1 + (i - 3)) : (7 + (i - 6))); }
+__device__ inline int temporal_row_of(int s) { return (s >= 7) ? (s - 7 + 6) : (s >= 4 ? (s - 4) : (s - 1 + 3)); }   // s >= 1
+
+// ---- cost of a residual vector: 1/2 sum rho(|r_kp|^2) over the keypoints + 1/2 |other rows|^2 -----------------------
+__device__ double window_cost(const WinProblem& P, const double* __restrict__ r, double* red, int tid, int nthreads) {
+  double acc = 0.0;
+  for (int k = tid; k < P.K; k += nthreads) {
+    const double r0 = r[2 * (size_t)k], r1 = r[2 * (size_t)k + 1];
+    acc += 0.5 * huber_rho_w(P.huber, r0 * r0 + r1 * r1);
+  }
+  for (int i = 2 * P.K + tid; i < P.total_rows; i += nthreads) acc += 0.5 * r[i] * r[i];
+  return block_sum_n(acc, red, tid, nthreads / 64);
+}
+
+__global__ __launch_bounds__(1024) void k_win_init(WinProblem P, WinBuf W, const double* __restrict__ r) {
+  __shared__ double red[16];
+  const double c = window_cost(P, r, red, threadIdx.x, 1024);
+  if (threadIdx.x == 0) {
+    double* st = W.status;
+    st[kWsCost] = c; st[kWsInitialCost] = c; st[kWsRadius] = 1e4; st[kWsDec] = 2.0; st[kWsModel] = 0.0;
+    st[kWsHasCand] = 0.0; st[kWsIters] = 0.0; st[kWsOk] = 0.0; st[kWsBad] = 0.0;
+    const bool finite = (c == c) && c < 1e300;
+    st[kWsActive] = finite ? 1.0 : 0.0;
+    st[kWsTermination] = finite ? 1.0 : 2.0;
+    st[kWsAccepted] = 1.0; st[kWsGmax] = 0.0; st[kWsNewCost] = c;
+    *W.fail = 0;
+  }
+}
+
+// ---- beta block: C = sum_f C_f (+ shape prior), g_beta; scaling; damped scaled copy ------------------------------------
+__global__ __launch_bounds__(256) void k_win_beta(WinProblem P, WinBuf W, const double* __restrict__ Hpan,
+                                                  const double* __restrict__ r, int first) {
+  __shared__ double sC[NBETA * NBETA], sg[NBETA], ssc[NBETA];
+  const int tid = threadIdx.x, F = P.F;
+  if (tid == 0) *W.fail = 0;
+  if (P.nb == 0) return;
+  if (tid < NBETA * NBETA + NBETA) {
+    size_t off;
+    if (tid < NBETA * NBETA) {
+      const int a = tid / NBETA, b = tid % NBETA, lo = a > b ? a : b, hi = a > b ? b : a;
+      off = (size_t)(NP + lo) * kHLd + NP + hi;
+    } else {
+      off = (size_t)(NP + NBETA) * kHLd + NP + (tid - NBETA * NBETA);
+    }
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    int f = 0;
+    for (; f + 4 <= F; f += 4) {
+      a0 += Hpan[(size_t)f * kHRows * kHLd + off];
+      a1 += Hpan[(size_t)(f + 1) * kHRows * kHLd + off];
+      a2 += Hpan[(size_t)(f + 2) * kHRows * kHLd + off];
+      a3 += Hpan[(size_t)(f + 3) * kHRows * kHLd + off];
+    }
+    for (; f < F; ++f) a0 += Hpan[(size_t)f * kHRows * kHLd + off];
+    const double v = (a0 + a1) + (a2 + a3);
+    if (tid < NBETA * NBETA) sC[tid] = v; else sg[tid - NBETA * NBETA] = v;
+  }
+  __syncthreads();
+  if (tid < NBETA && P.shape_rows > 0) {   // ShapePriorL2Analytic: r = beta_s w, J = beta_s I (include/Sim3BA.h:336-340)
+    sC[tid * NBETA + tid] += P.beta_shape * P.beta_shape;
+    sg[tid] += P.beta_shape * r[P.row_shape + tid];
+  }
+  __syncthreads();
+  if (tid < NBETA) {
+    const double s = first ? 1.0 / (1.0 + sqrt(sC[tid * NBETA + tid])) : W.scale[(size_t)F * NP + tid];
+    if (first) W.scale[(size_t)F * NP + tid] = s;
+    ssc[tid] = s;
+    W.gbraw[tid] = sg[tid];
+    W.rhsb[tid] = -sg[tid] * s;
+    W.gmaxp[F] = 0.0;
+  }
+  __syncthreads();
+  if (tid < NBETA * NBETA) {
+    const int a = tid / NBETA, b = tid % NBETA;
+    W.Craw[tid] = sC[tid];
+    double v = sC[tid] * ssc[a] * ssc[b];
+    if (a == b) v += fmin(fmax(v, 1e-6), 1e32) / W.status[kWsRadius];
+    W.Cs[tid] = v;
+  }
+  if (tid == 0) {
+    double gm = 0.0;
+    for (int b = 0; b < NBETA; ++b) gm = fmax(gm, fabs(sg[b]));
+    W.gmaxp[F] = gm;
+  }
+}
+
+// ---- per frame: complete the normal-equation block (priors, temporal), scale, damp, write the CR operands ---------------
+__global__ __launch_bounds__(256) void k_win_assemble(WinProblem P, WinBuf W, const double* __restrict__ Hpan,
+                                                      const double* __restrict__ r, const double* __restrict__ x,
+                                                      const unsigned char* __restrict__ constant, int first) {
+  __shared__ double sA[NP * (NP + 1)];
+  __shared__ double sg[NP], ss[NP], ssn[NP], red[4];
+  const int f = blockIdx.x, tid = threadIdx.x, F = P.F;
+  const double* H = Hpan + (size_t)f * kHRows * kHLd;
+  const double lam2 = P.lambda_t * P.lambda_t, bp2 = P.beta_pose * P.beta_pose;
+  const int npairs = (P.lambda_t > 0.0) ? ((f + 1 < F) + (f > 0)) : 0;
+  for (int e = tid; e < NP * NP; e += 256) {
+    const int i = e / NP, j = e % NP, lo = i > j ? i : j, hi = i > j ? j : i;
+    double v = H[(size_t)lo * kHLd + hi];
+    if (i == j) {
+      if (i >= 7 && P.prior_rows > 0) v += bp2;       // PosePriorAAAnalytic, L2 branch (include/Sim3BA.h:304-310)
+      if (i >= 1) v += lam2 * npairs;                 // Vec3DiffCost on rootT, rootAA, joints (include/MultiFrameBA.h:121-142)
+    }
+    sA[i * (NP + 1) + j] = v;
+  }
+  if (tid < NP) {
+    double g = H[(size_t)(NP + NBETA) * kHLd + tid];
+    if (tid >= 7 && P.prior_rows > 0) g += P.beta_pose * r[P.row_prior + (size_t)f * P.prior_rows + tid - 7];
+    if (tid >= 1 && P.lambda_t > 0.0) {
+      const int ti = temporal_row_of(tid);
+      if (f + 1 < F) g += P.lambda_t * r[P.row_temporal + (size_t)f * 75 + ti];
+      if (f > 0) g -= P.lambda_t * r[P.row_temporal + (size_t)(f - 1) * 75 + ti];
+    }
+    sg[tid] = g;
+  }
+  __syncthreads();
+  if (tid < NP) {
+    double s, sn = 0.0;
+    if (first) {
+      s = 1.0 / (1.0 + sqrt(sA[tid * (NP + 1) + tid]));
+      W.scale[(size_t)f * NP + tid] = s;
+      if (f + 1 < F) {   // the next frame's scale, from its diagonal entry alone (its workgroup may not have run yet)
+        double dn = Hpan[(size_t)(f + 1) * kHRows * kHLd + (size_t)tid * kHLd + tid];
+        if (tid >= 7 && P.prior_rows > 0) dn += bp2;
+        if (tid >= 1 && P.lambda_t > 0.0) dn += lam2 * (1 + (f + 2 < F));
+        sn = 1.0 / (1.0 + sqrt(dn));
+      }
+    } else {
+      s = W.scale[(size_t)f * NP + tid];
+      if (f + 1 < F) sn = W.scale[(size_t)(f + 1) * NP + tid];
+    }
+    ss[tid] = s; ssn[tid] = sn;
+    W.graw[(size_t)f * NP + tid] = sg[tid];
+    W.Eraw[(size_t)f * NP + tid] = (tid >= 1 && f + 1 < F && P.lambda_t > 0.0) ? -lam2 : 0.0;
+  }
+  __syncthreads();
+  const double inv_radius = 1.0 / W.status[kWsRadius];
+  double* D = W.D + (size_t)f * WB * WB;
+  double* U = W.U + (size_t)f * WB * WB;
+  for (int e = tid; e < WB * WB; e += 256) {
+    const int i = e / WB, j = e % WB;
+    double v = (i == j) ? 1.0 : 0.0, u = 0.0;
+    if (i < NP && j < NP) {
+      const bool ci = constant && constant[i], cj = constant && constant[j];
+      if (!ci && !cj) {
+        v = sA[i * (NP + 1) + j] * ss[i] * ss[j];
+        if (i == j) {
+          v += fmin(fmax(v, 1e-6), 1e32) * inv_radius;
+          if (i >= 1 && f + 1 < F && P.lambda_t > 0.0) u = -lam2 * ss[i] * ssn[i];
+        }
+      }
+    }
+    D[e] = v;
+    U[e] = u;
+  }
+  for (int e = tid; e < NP * NP; e += 256) W.Araw[(size_t)f * NP * NP + e] = sA[(e / NP) * (NP + 1) + e % NP];
+  double* Rt = W.Rt + (size_t)f * WR * WB;
+  double* Rt0 = W.Rt0 + (size_t)f * WR * WB;
+  for (int e = tid; e < WR * WB; e += 256) {
+    const int c = e / WB, i = e % WB;
+    double v = 0.0;
+    if (i < NP && !(constant && constant[i])) {
+      if (c < P.nb) {
+        const double b = H[(size_t)(NP + c) * kHLd + i];
+        v = b * ss[i] * W.scale[(size_t)F * NP + c];
+      } else if (c == NBETA) {
+        v = -sg[i] * ss[i];
+      }
+    }
+    Rt[e] = v;
+    Rt0[e] = v;
+  }
+  for (int e = tid; e < NP * NBETA; e += 256) {
+    const int i = e / NBETA, c = e % NBETA;
+    W.Braw[(size_t)f * NP * NBETA + e] = (c < P.nb) ? H[(size_t)(NP + c) * kHLd + i] : 0.0;
+  }
+  // gradient tolerance test: max |g_i| over the free parameters, the bounded scale projected (Ceres gradient_tolerance)
+  double gm = 0.0;
+  if (tid < NP && !(constant && constant[tid])) {
+    double gi = sg[tid];
+    if (tid == 0) {
+      const double s0 = x[(size_t)f * NP];
+      gi = s0 - fmin(fmax(s0 - gi, P.scale_lo), P.scale_hi);
+    }
+    gm = fabs(gi);
+  }
+  gm = block_max_n(gm, red, tid, 4);
+  if (tid == 0) W.gmaxp[f] = gm;
+}
+
+// ---- cyclic reduction: factor one eliminated block, solve its appended rows -------------------------------------------
+// Two workgroups per eliminated frame j (side = blockIdx.x & 1): both factor D_j = L L^T (right-looking, 16-column
+// panels, the k_lm_step scheme: diagonal block in the registers of wave 0, panel solve one row per thread, trailing update
+// on the f64 matrix cores) with rows appended below that receive L^-T from the right:
+//   side 0:  rows of U_a (-> Pt_j)  and the 16 rows of Rt_j (-> Yt_j);  writes L_j
+//   side 1:  rows of U_j^T (-> Qt_j)
+constexpr int kCrThreads = 512, kCrWaves = 8;
+constexpr int kCrRowsMax = WB + WB + WR;   // 176
+__global__ __launch_bounds__(kCrThreads) void k_cr_factor(WinBuf W, const int* __restrict__ elim, int n_elim) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  double* M = sm;                          // [kCrRowsMax][LD]
+  double* invd = sm + kCrRowsMax * LD;     // [WB]
+  double* stat = invd + WB;                // [1]
+  const int e = blockIdx.x >> 1, side = blockIdx.x & 1;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int j = elim[3 * e], a = elim[3 * e + 1], b = elim[3 * e + 2];
+  if (side == 1 && b < 0) return;
+  const int nU = (side == 0) ? (a >= 0 ? WB : 0) : WB;       // appended coupling rows
+  const int nApp = nU + (side == 0 ? WR : 0);
+  const int nRows = WB + nApp;
+  const double* D = W.D + (size_t)j * WB * WB;
+  for (int idx = tid; idx < WB * WB; idx += kCrThreads) {
+    const int i = idx / WB, k = idx % WB;
+    M[i * LD + k] = (k <= i) ? D[idx] : 0.0;
+  }
+  if (nU) {
+    if (side == 0) {
+      const double* Ua = W.U + (size_t)a * WB * WB;          // row i of U_a
+      for (int idx = tid; idx < WB * WB; idx += kCrThreads) M[(WB + idx / WB) * LD + idx % WB] = Ua[idx];
+    } else {
+      const double* Uj = W.U + (size_t)j * WB * WB;          // row i of U_j^T = column i of U_j
+      for (int idx = tid; idx < WB * WB; idx += kCrThreads) M[(WB + idx % WB) * LD + idx / WB] = Uj[idx];
+    }
+  }
+  if (side == 0) {
+    const double* Rt = W.Rt + (size_t)j * WR * WB;
+    for (int idx = tid; idx < WR * WB; idx += kCrThreads) M[(WB + nU + idx / WB) * LD + idx % WB] = Rt[idx];
+  }
+  if (tid == 0) stat[0] = 1.0;
+  __syncthreads();
+  constexpr int NPAN = WB / 16;   // 5
+  for (int p = 0; p < NPAN; ++p) {
+    const int c0 = 16 * p;
+    if (wave == 0) {   // (a) diagonal block: lane r holds row r, columns travel by v_readlane
+      const int rr = lane & 15;
+      double av[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) av[k] = M[(c0 + rr) * LD + c0 + k];
+      bool okp = true;
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        const double piv = readlane_f64w(av[c], c);
+        if (!(piv > 0.0) || !(piv < 1e300)) okp = false;
+        double inv = __builtin_amdgcn_rsq(piv);
+        inv = inv * (1.5 - 0.5 * piv * inv * inv);
+        inv = inv * (1.5 - 0.5 * piv * inv * inv);
+        const double rt = piv * inv;
+        if (lane == 0) invd[c0 + c] = inv;
+        const double l = (rr == c) ? rt : av[c] * inv;
+        av[c] = l;
+#pragma unroll
+        for (int k = c + 1; k < 16; ++k) {
+          const double lk = readlane_f64w(l, k);
+          if (rr >= k) av[k] -= l * lk;
+        }
+      }
+      if (lane < 16) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
+          if (k <= rr) M[(c0 + rr) * LD + c0 + k] = av[k];
+      }
+      if (lane == 0 && !okp) stat[0] = 0.0;
+    }
+    __syncthreads();
+    // (b) panel solve: every row below the diagonal block (matrix rows and appended rows) x <- x L_pp^-T
+    {
+      const int nbelow = nRows - (c0 + 16);
+      if (tid < nbelow) {
+        const int i = c0 + 16 + tid;
+        double xv[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) xv[k] = M[i * LD + c0 + k];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+          double v = xv[c];
+#pragma unroll
+          for (int k = 0; k < c; ++k) v -= xv[k] * M[(c0 + c) * LD + c0 + k];
+          xv[c] = v * invd[c0 + c];
+        }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) M[i * LD + c0 + k] = xv[k];
+      }
+    }
+    __syncthreads();
+    // (c) trailing update on the matrix cores: rows of tile I, columns of panel Kc > p:  M[I][Kc] -= X_I X_Kc^T
+    if (p + 1 < NPAN) {
+      const int m = lane & 15, kk = lane >> 4;
+      const int nRowTiles = nRows / 16;
+      int t = 0;
+      for (int I = p + 1; I < nRowTiles; ++I) {
+        const int kcmax = (I < NPAN) ? I : NPAN - 1;
+        for (int Kc = p + 1; Kc <= kcmax; ++Kc, ++t) {
+          if (t % kCrWaves != wave) continue;
+          d4 acc;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) acc[q] = M[(16 * I + kk + 4 * q) * LD + 16 * Kc + m];
+#pragma unroll
+          for (int s4 = 0; s4 < 4; ++s4) {
+            const double av = -M[(16 * I + m) * LD + c0 + 4 * s4 + kk];
+            const double bv = M[(16 * Kc + m) * LD + c0 + 4 * s4 + kk];
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+          }
+#pragma unroll
+          for (int q = 0; q < 4; ++q) M[(16 * I + kk + 4 * q) * LD + 16 * Kc + m] = acc[q];
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (tid == 0 && stat[0] == 0.0) *W.fail = 1;
+  if (side == 0) {
+    double* L = W.L + (size_t)j * WB * WB;
+    for (int idx = tid; idx < WB * WB; idx += kCrThreads) {
+      const int i = idx / WB, k = idx % WB;
+      L[idx] = (k <= i) ? M[i * LD + k] : 0.0;
+    }
+    if (nU) {
+      double* Pt = W.Pt + (size_t)j * WB * WB;
+      for (int idx = tid; idx < WB * WB; idx += kCrThreads) Pt[idx] = M[(WB + idx / WB) * LD + idx % WB];
+    }
+    double* Yt = W.Yt + (size_t)j * WR * WB;
+    for (int idx = tid; idx < WR * WB; idx += kCrThreads) Yt[idx] = M[(WB + nU + idx / WB) * LD + idx % WB];
+  } else {
+    double* Qt = W.Qt + (size_t)j * WB * WB;
+    for (int idx = tid; idx < WB * WB; idx += kCrThreads) Qt[idx] = M[(WB + idx / WB) * LD + idx % WB];
+  }
+}
+
+// C[ti][tj] (16 x 16 tile, accumulator layout: row = (lane >> 4) + 4 q, column = lane & 15) += sign * sum_k X[i][k] Y[i'][k]
+// with X, Y staged in LDS (leading dimension LD), K = WB
+__device__ __forceinline__ d4 tile_xyT(const double* X, const double* Y, int ti, int tj, int lane, d4 acc, double sign) {
+  const int m = lane & 15, kk = lane >> 4;
+#pragma unroll 4
+  for (int s = 0; s < WB / 4; ++s) {
+    const double av = sign * X[(16 * ti + m) * LD + 4 * s + kk];
+    const double bv = Y[(16 * tj + m) * LD + 4 * s + kk];
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+  }
+  return acc;
+}
+__device__ inline void stage_block(double* dst, const double* __restrict__ src, int rows, int tid, int nthreads) {
+  for (int idx = tid; idx < rows * WB; idx += nthreads) dst[(idx / WB) * LD + idx % WB] = src[idx];
+}
+
+// ---- cyclic reduction: Schur updates of one remaining frame a (left eliminated neighbour jl, right one jr, next
+//      remaining frame b).  Three workgroups per frame (part = blockIdx.x % 3): diagonal block, coupling block, rhs. -----
+__global__ __launch_bounds__(kCrThreads) void k_cr_update(WinBuf W, const int* __restrict__ surv, int n_surv) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  double* X0 = sm;                 // [WB][LD]
+  double* X1 = sm + WB * LD;       // [WB][LD]
+  double* Ys = X1 + WB * LD;       // [WR][LD]
+  const int sidx = blockIdx.x / 3, part = blockIdx.x % 3;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int a = surv[4 * sidx], jl = surv[4 * sidx + 1], jr = surv[4 * sidx + 2], b = surv[4 * sidx + 3];
+  const int m = lane & 15, kk = lane >> 4;
+  if (part == 0) {
+    // D_a -= Qt_jl Qt_jl^T + Pt_jr Pt_jr^T  (lower tiles)
+    double* D = W.D + (size_t)a * WB * WB;
+    for (int src = 0; src < 2; ++src) {
+      const int j = src == 0 ? jl : jr;
+      if (j < 0) continue;
+      __syncthreads();
+      stage_block(X0, (src == 0 ? W.Qt : W.Pt) + (size_t)j * WB * WB, WB, tid, kCrThreads);
+      __syncthreads();
+      int t = 0;
+      for (int ti = 0; ti < 5; ++ti)
+        for (int tj = 0; tj <= ti; ++tj, ++t) {
+          if (t % kCrWaves != wave) continue;
+          d4 acc;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) acc[q] = D[(size_t)(16 * ti + kk + 4 * q) * WB + 16 * tj + m];
+          acc = tile_xyT(X0, X0, ti, tj, lane, acc, -1.0);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) D[(size_t)(16 * ti + kk + 4 * q) * WB + 16 * tj + m] = acc[q];
+        }
+    }
+  } else if (part == 1) {
+    // U_a := -Pt_jr Qt_jr^T  (coupling of a with the next remaining frame b)
+    if (jr < 0 || b < 0) return;
+    stage_block(X0, W.Pt + (size_t)jr * WB * WB, WB, tid, kCrThreads);
+    stage_block(X1, W.Qt + (size_t)jr * WB * WB, WB, tid, kCrThreads);
+    __syncthreads();
+    double* U = W.U + (size_t)a * WB * WB;
+    for (int t = wave; t < 25; t += kCrWaves) {
+      const int ti = t / 5, tj = t % 5;
+      d4 acc = {0.0, 0.0, 0.0, 0.0};
+      acc = tile_xyT(X0, X1, ti, tj, lane, acc, -1.0);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) U[(size_t)(16 * ti + kk + 4 * q) * WB + 16 * tj + m] = acc[q];
+    }
+  } else {
+    // Rt_a -= Yt_jl Qt_jl^T + Yt_jr Pt_jr^T   ([16 x 80])
+    double* Rt = W.Rt + (size_t)a * WR * WB;
+    for (int src = 0; src < 2; ++src) {
+      const int j = src == 0 ? jl : jr;
+      if (j < 0) continue;
+      __syncthreads();
+      stage_block(X0, (src == 0 ? W.Qt : W.Pt) + (size_t)j * WB * WB, WB, tid, kCrThreads);
+      stage_block(Ys, W.Yt + (size_t)j * WR * WB, WR, tid, kCrThreads);
+      __syncthreads();
+      if (wave < 5) {
+        const int tj = wave;
+        d4 acc;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[q] = Rt[(size_t)(kk + 4 * q) * WB + 16 * tj + m];
+        acc = tile_xyT(Ys, X0, 0, tj, lane, acc, -1.0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) Rt[(size_t)(kk + 4 * q) * WB + 16 * tj + m] = acc[q];
+      }
+    }
+  }
+}
+
+// ---- cyclic reduction, way down: x_j = L_j^-T (Y_j - P_j x_a - Q_j x_b), 11 right-hand sides ---------------------------
+__global__ __launch_bounds__(kCrThreads) void k_cr_back(WinBuf W, const int* __restrict__ elim, int n_elim) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  double* Ls = sm;                 // [WB][LD]
+  double* Zt = sm + WB * LD;       // [WR][LD]
+  double* Xa = Zt + WR * LD;       // [WR][LD]
+  double* Xb = Xa + WR * LD;       // [WR][LD]
+  const int e = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int j = elim[3 * e], a = elim[3 * e + 1], b = elim[3 * e + 2];
+  stage_block(Ls, W.L + (size_t)j * WB * WB, WB, tid, kCrThreads);
+  if (a >= 0) stage_block(Xa, W.Xt + (size_t)a * WR * WB, WR, tid, kCrThreads);
+  if (b >= 0) stage_block(Xb, W.Xt + (size_t)b * WR * WB, WR, tid, kCrThreads);
+  __syncthreads();
+  const double* Yt = W.Yt + (size_t)j * WR * WB;
+  const double* Pt = W.Pt + (size_t)j * WB * WB;
+  const double* Qt = W.Qt + (size_t)j * WB * WB;
+  for (int idx = tid; idx < (NBETA + 1) * WB; idx += kCrThreads) {
+    const int c = idx / WB, k = idx % WB;
+    double z = Yt[(size_t)c * WB + k];
+    if (a >= 0)
+      for (int i = 0; i < NP; ++i) z -= Xa[c * LD + i] * Pt[(size_t)i * WB + k];
+    if (b >= 0)
+      for (int i = 0; i < NP; ++i) z -= Xb[c * LD + i] * Qt[(size_t)i * WB + k];
+    Zt[c * LD + k] = z;
+  }
+  __syncthreads();
+  double* Xt = W.Xt + (size_t)j * WR * WB;
+  for (int c = wave; c < NBETA + 1; c += kCrWaves) {   // one right-hand side per wave: unknowns lane and lane + 64
+    double z0 = Zt[c * LD + lane];
+    double z1 = (lane + 64 < WB) ? Zt[c * LD + lane + 64] : 0.0;
+    const double i0 = 1.0 / Ls[lane * LD + lane];
+    const double i1 = (lane + 64 < WB) ? 1.0 / Ls[(lane + 64) * LD + lane + 64] : 1.0;
+    for (int k = WB - 1; k >= 0; --k) {
+      const double zk = (k < 64) ? readlane_f64w(z0, k) : readlane_f64w(z1, k - 64);
+      const double ik = (k < 64) ? readlane_f64w(i0, k) : readlane_f64w(i1, k - 64);
+      const double xk = zk * ik;
+      const double l0 = Ls[k * LD + lane];                                   // L[k][i], i = lane
+      const double l1 = (lane + 64 < WB) ? Ls[k * LD + lane + 64] : 0.0;
+      if (lane < k) z0 -= l0 * xk;
+      if (lane == k) z0 = xk;
+      if (lane + 64 < k) z1 -= l1 * xk;
+      if (lane + 64 == k) z1 = xk;
+    }
+    Xt[(size_t)c * WB + lane] = z0;
+    if (lane + 64 < WB) Xt[(size_t)c * WB + lane + 64] = z1;
+  }
+  for (int idx = tid; idx < (WR - NBETA - 1) * WB; idx += kCrThreads) Xt[(size_t)(NBETA + 1) * WB + idx] = 0.0;
+}
+
+// ---- beta Schur complement: per-frame partials, then the 10 x 10 solve ---------------------------------------------------
+__global__ __launch_bounds__(128) void k_win_schur_part(WinProblem P, WinBuf W) {
+  const int f = blockIdx.x, tid = threadIdx.x;
+  const double* B = W.Rt0 + (size_t)f * WR * WB;     // scaled [B | rhs]^T as assembled
+  const double* X = W.Xt + (size_t)f * WR * WB;
+  if (tid < NBETA * NBETA + NBETA) {
+    const int a = (tid < NBETA * NBETA) ? tid / NBETA : tid - NBETA * NBETA;
+    const int c = (tid < NBETA * NBETA) ? tid % NBETA : NBETA;
+    double s = 0.0;
+    for (int i = 0; i < NP; ++i) s += B[a * WB + i] * X[c * WB + i];
+    W.part[(size_t)f * kWinPart + tid] = s;
+  }
+}
+
+__global__ __launch_bounds__(128) void k_win_beta_solve(WinProblem P, WinBuf W, const double* __restrict__ beta,
+                                                        double* __restrict__ beta_new) {
+  __shared__ double S[NBETA * NBETA], rb[NBETA];
+  const int tid = threadIdx.x, F = P.F;
+  if (P.nb == 0) return;
+  if (tid < NBETA * NBETA + NBETA) {
+    double s = 0.0;
+    for (int f = 0; f < F; ++f) s += W.part[(size_t)f * kWinPart + tid];
+    if (tid < NBETA * NBETA) S[tid] = W.Cs[tid] - s; else rb[tid - NBETA * NBETA] = W.rhsb[tid - NBETA * NBETA] - s;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    bool ok = true;
+    for (int j = 0; j < NBETA && ok; ++j) {
+      double d = S[j * NBETA + j];
+      for (int k = 0; k < j; ++k) d -= S[j * NBETA + k] * S[j * NBETA + k];
+      if (!(d > 0.0) || !(d < 1e300)) { ok = false; break; }
+      d = sqrt(d);
+      S[j * NBETA + j] = d;
+      for (int i = j + 1; i < NBETA; ++i) {
+        double v = S[i * NBETA + j];
+        for (int k = 0; k < j; ++k) v -= S[i * NBETA + k] * S[j * NBETA + k];
+        S[i * NBETA + j] = v / d;
+      }
+    }
+    if (!ok) {
+      *W.fail = 1;
+      for (int i = 0; i < NBETA; ++i) W.dsb[i] = 0.0;
+    } else {
+      double y[NBETA];
+      for (int i = 0; i < NBETA; ++i) {
+        double v = rb[i];
+        for (int k = 0; k < i; ++k) v -= S[i * NBETA + k] * y[k];
+        y[i] = v / S[i * NBETA + i];
+      }
+      for (int i = NBETA - 1; i >= 0; --i) {
+        double v = y[i];
+        for (int k = i + 1; k < NBETA; ++k) v -= S[k * NBETA + i] * y[k];
+        y[i] = v / S[i * NBETA + i];
+      }
+      for (int i = 0; i < NBETA; ++i) W.dsb[i] = y[i];
+    }
+    for (int i = 0; i < NBETA; ++i) {
+      const double di = W.dsb[i] * W.scale[(size_t)F * NP + i];
+      W.d[(size_t)F * NP + i] = di;
+      beta_new[i] = beta[i] + di;
+    }
+  }
+}
+
+// ---- step of one frame: d_f = S_f (x_f - X_B,f d_beta), candidate projected on the scale bounds --------------------------
+__global__ __launch_bounds__(128) void k_win_step(WinProblem P, WinBuf W, const double* __restrict__ x,
+                                                  double* __restrict__ x_new) {
+  const int f = blockIdx.x, tid = threadIdx.x;
+  if (tid >= NP) return;
+  const double* X = W.Xt + (size_t)f * WR * WB;
+  double ds = X[NBETA * WB + tid];
+  for (int c = 0; c < P.nb; ++c) ds -= X[c * WB + tid] * W.dsb[c];
+  double di = ds * W.scale[(size_t)f * NP + tid];
+  const double xi = x[(size_t)f * NP + tid];
+  if (tid == 0) {
+    const double s_new = fmin(fmax(xi + di, P.scale_lo), P.scale_hi);
+    di = s_new - xi;
+  }
+  W.d[(size_t)f * NP + tid] = di;
+  x_new[(size_t)f * NP + tid] = xi + di;
+}
+
+// ---- model cost change  -d^T g - 1/2 d^T H d  with the undamped, unscaled system: per-frame partials --------------------
+__global__ __launch_bounds__(128) void k_win_model(WinProblem P, WinBuf W, const double* __restrict__ x) {
+  __shared__ double sd[NP], sdn[NP], sdb[NBETA], red[2];
+  const int f = blockIdx.x, tid = threadIdx.x, F = P.F;
+  if (tid < NP) {
+    sd[tid] = W.d[(size_t)f * NP + tid];
+    sdn[tid] = (f + 1 < F) ? W.d[(size_t)(f + 1) * NP + tid] : 0.0;
+  }
+  if (tid < NBETA) sdb[tid] = (tid < P.nb) ? W.d[(size_t)F * NP + tid] : 0.0;
+  __syncthreads();
+  double pm = 0.0, dn = 0.0, xn = 0.0;
+  if (tid < NP) {
+    const double* Ar = W.Araw + ((size_t)f * NP + tid) * NP;
+    double hd = 0.0;
+    for (int jj = 0; jj < NP; ++jj) hd += Ar[jj] * sd[jj];
+    for (int c = 0; c < NBETA; ++c) hd += 2.0 * W.Braw[((size_t)f * NP + tid) * NBETA + c] * sdb[c];
+    hd += 2.0 * W.Eraw[(size_t)f * NP + tid] * sdn[tid];
+    pm = -sd[tid] * W.graw[(size_t)f * NP + tid] - 0.5 * sd[tid] * hd;
+    dn = sd[tid] * sd[tid];
+    const double xv = x[(size_t)f * NP + tid];
+    xn = xv * xv;
+  }
+  pm = block_sum_n(pm, red, tid, 2);
+  dn = block_sum_n(dn, red, tid, 2);
+  xn = block_sum_n(xn, red, tid, 2);
+  if (tid == 0) {
+    double* o = W.part + (size_t)f * kWinPart + 112;
+    o[0] = pm; o[1] = dn; o[2] = xn;
+  }
+}
+
+// ---- decide: gradient tolerance, failed factorisation, parameter tolerance, or a candidate --------------------------------
+__global__ __launch_bounds__(256) void k_win_finish(WinProblem P, WinBuf W, const double* __restrict__ x,
+                                                    const double* __restrict__ beta, double* __restrict__ x_new,
+                                                    double* __restrict__ beta_new) {
+  __shared__ double red[4];
+  const int tid = threadIdx.x, F = P.F;
+  double pm = 0.0, dn = 0.0, xn = 0.0, gm = 0.0;
+  for (int f = tid; f < F; f += 256) {
+    const double* o = W.part + (size_t)f * kWinPart + 112;
+    pm += o[0]; dn += o[1]; xn += o[2];
+    gm = fmax(gm, W.gmaxp[f]);
+  }
+  if (tid == 0) gm = fmax(gm, W.gmaxp[F]);
+  pm = block_sum_n(pm, red, tid, 4);
+  dn = block_sum_n(dn, red, tid, 4);
+  xn = block_sum_n(xn, red, tid, 4);
+  gm = block_max_n(gm, red, tid, 4);
+  __shared__ int no_cand;
+  if (tid == 0) {
+    double* st = W.status;
+    for (int a = 0; a < P.nb; ++a) {
+      const double da = W.d[(size_t)F * NP + a];
+      pm -= da * W.gbraw[a];
+      double h = 0.0;
+      for (int c = 0; c < P.nb; ++c) h += W.Craw[a * NBETA + c] * W.d[(size_t)F * NP + c];
+      pm -= 0.5 * da * h;
+      dn += da * da;
+      xn += beta[a] * beta[a];
+    }
+    st[kWsGmax] = gm;
+    st[kWsHasCand] = 0.0;
+    no_cand = 1;
+    if (st[kWsActive] != 0.0) {
+      if (gm <= 1e-10) {                                   // Ceres gradient_tolerance
+        st[kWsActive] = 0.0; st[kWsTermination] = 0.0;
+      } else if (*W.fail) {                                // the damped system was not positive definite
+        const double rad = st[kWsRadius] / st[kWsDec];
+        st[kWsRadius] = rad; st[kWsDec] *= 2.0; st[kWsBad] += 1.0; st[kWsIters] += 1.0;
+        st[kWsAccepted] = 0.0;
+        if (rad < 1e-32) { st[kWsActive] = 0.0; st[kWsTermination] = 2.0; }
+      } else if (sqrt(dn) <= 1e-8 * (sqrt(xn) + 1e-8)) {   // Ceres parameter_tolerance
+        st[kWsActive] = 0.0; st[kWsTermination] = 0.0;
+      } else {
+        st[kWsModel] = pm; st[kWsHasCand] = 1.0;
+        no_cand = 0;
+      }
+    }
+  }
+  __syncthreads();
+  if (no_cand) {   // the residual sweep that follows still reads a well-defined point
+    for (int i = tid; i < F * NP; i += 256) x_new[i] = x[i];
+    if (tid < P.nb) beta_new[tid] = beta[tid];
+  }
+}
+
+// ---- accept / reject the candidate (Ceres' step quality and radius rules, host_solver.cpp) ------------------------------
+__global__ __launch_bounds__(1024) void k_win_accept(WinProblem P, WinBuf W, const double* __restrict__ r_new,
+                                                     double* __restrict__ x, double* __restrict__ beta,
+                                                     const double* __restrict__ x_new, const double* __restrict__ beta_new) {
+  __shared__ double red[16];
+  __shared__ int acc_flag;
+  const int tid = threadIdx.x;
+  double* st = W.status;
+  if (st[kWsHasCand] == 0.0) return;
+  const double new_cost = window_cost(P, r_new, red, tid, 1024);
+  if (tid == 0) {
+    const double cost = st[kWsCost], model = st[kWsModel];
+    const double change = cost - new_cost, rho = change / model;
+    const bool accept = (new_cost == new_cost) && new_cost < 1e300 && model > 0.0 && rho > 1e-3;
+    st[kWsIters] += 1.0;
+    st[kWsNewCost] = new_cost;
+    if (accept) {
+      st[kWsCost] = new_cost;
+      const double t = 2.0 * rho - 1.0;
+      st[kWsRadius] = fmin(1e16, st[kWsRadius] / fmax(1.0 / 3.0, 1.0 - t * t * t));
+      st[kWsDec] = 2.0;
+      st[kWsOk] += 1.0;
+      if (fabs(change) < 1e-6 * cost) { st[kWsActive] = 0.0; st[kWsTermination] = 0.0; }   // function_tolerance
+    } else {
+      const double rad = st[kWsRadius] / st[kWsDec];
+      st[kWsRadius] = rad; st[kWsDec] *= 2.0; st[kWsBad] += 1.0;
+      if (rad < 1e-32) { st[kWsActive] = 0.0; st[kWsTermination] = 2.0; }
+    }
+    st[kWsAccepted] = accept ? 1.0 : 0.0;
+    st[kWsHasCand] = 0.0;
+    acc_flag = accept ? 1 : 0;
+  }
+  __syncthreads();
+  if (acc_flag) {
+    for (int i = tid; i < P.F * NP; i += 1024) x[i] = x_new[i];
+    if (tid < P.nb) beta[tid] = beta_new[tid];
+  }
+}
+
+}  // namespace
+
+size_t win_factor_lds_bytes() { return (size_t)(kCrRowsMax * LD + WB + 8) * sizeof(double); }
+size_t win_update_lds_bytes() { return (size_t)(2 * WB * LD + WR * LD) * sizeof(double); }
+size_t win_back_lds_bytes() { return (size_t)(WB * LD + 3 * WR * LD) * sizeof(double); }
+
+void launch_win_init(const WinProblem& P, const WinBuf& W, const double* d_r, hipStream_t s) {
+  hipLaunchKernelGGL(k_win_init, dim3(1), dim3(1024), 0, s, P, W, d_r);
+}
+void launch_win_assemble(const WinProblem& P, const WinBuf& W, const double* d_Hpan, const double* d_r, const double* d_x,
+                         const unsigned char* d_constant, int first, hipStream_t s) {
+  hipLaunchKernelGGL(k_win_beta, dim3(1), dim3(256), 0, s, P, W, d_Hpan, d_r, first);
+  hipLaunchKernelGGL(k_win_assemble, dim3(P.F), dim3(256), 0, s, P, W, d_Hpan, d_r, d_x, d_constant, first);
+}
+void launch_cr_factor(const WinBuf& W, const int* d_elim, int n_elim, hipStream_t s) {
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_cr_factor), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)win_factor_lds_bytes());
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_cr_update), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)win_update_lds_bytes());
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_cr_back), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)win_back_lds_bytes());
+    attr = true;
+  }
+  if (n_elim > 0) hipLaunchKernelGGL(k_cr_factor, dim3(2 * n_elim), dim3(kCrThreads), win_factor_lds_bytes(), s, W, d_elim, n_elim);
+}
+void launch_cr_update(const WinBuf& W, const int* d_surv, int n_surv, hipStream_t s) {
+  if (n_surv > 0) hipLaunchKernelGGL(k_cr_update, dim3(3 * n_surv), dim3(kCrThreads), win_update_lds_bytes(), s, W, d_surv, n_surv);
+}
+void launch_cr_back(const WinBuf& W, const int* d_elim, int n_elim, hipStream_t s) {
+  if (n_elim > 0) hipLaunchKernelGGL(k_cr_back, dim3(n_elim), dim3(kCrThreads), win_back_lds_bytes(), s, W, d_elim, n_elim);
+}
+void launch_win_step(const WinProblem& P, const WinBuf& W, const double* d_x, const double* d_beta, double* d_x_new,
+                     double* d_beta_new, hipStream_t s) {
+  hipLaunchKernelGGL(k_win_schur_part, dim3(P.F), dim3(128), 0, s, P, W);
+  hipLaunchKernelGGL(k_win_beta_solve, dim3(1), dim3(128), 0, s, P, W, d_beta, d_beta_new);
+  hipLaunchKernelGGL(k_win_step, dim3(P.F), dim3(128), 0, s, P, W, d_x, d_x_new);
+  hipLaunchKernelGGL(k_win_model, dim3(P.F), dim3(128), 0, s, P, W, d_x);
+  hipLaunchKernelGGL(k_win_finish, dim3(1), dim3(256), 0, s, P, W, d_x, d_beta, d_x_new, d_beta_new);
+}
+void launch_win_accept(const WinProblem& P, const WinBuf& W, const double* d_r_new, double* d_x, double* d_beta,
+                       const double* d_x_new, const double* d_beta_new, hipStream_t s) {
+  hipLaunchKernelGGL(k_win_accept, dim3(1), dim3(1024), 0, s, P, W, d_r_new, d_x, d_beta, d_x_new, d_beta_new);
+}
+
+}  // namespace bodyfit
