@@ -603,7 +603,10 @@ extern "C" int bodyfit_solve(bodyfit_problem* p, double* frame_params, double* b
                          !view.has_gmm && view.max_kp_per_frame <= 32;
   if (opt.solver == 3 && !window_ok)
     return bodyfit_internal_fail(BODYFIT_ERR_INVALID, "bodyfit_solve: the device window loop needs a shared 10-coefficient beta, the L2 pose prior and <= 32 keypoints per frame");
-  if (window_ok && opt.solver == 3)
+  // (below a dozen frames the chain is short enough for the host's sequential factorisation to win: measured per LM iteration
+  //  on MI355X, host / device: 20 frames 0.60 / 0.49 ms, 103 frames 2.7 / 0.69 ms, 1024 frames 54 / 1.8 ms)
+  const int window_min = std::getenv("BODYFIT_WINDOW_MIN") ? std::atoi(std::getenv("BODYFIT_WINDOW_MIN")) : 12;
+  if (window_ok && (opt.solver == 3 || (opt.solver == 0 && c.F >= window_min)))
     return bodyfit_internal_solve_window_device(p, frame_params, beta, param_constant, &opt, summaries);
 
   const int F = c.F, nb = c.nb;

@@ -474,52 +474,92 @@ __global__ __launch_bounds__(kCrThreads) void k_cr_update(WinBuf W, const int* _
 }
 
 // ---- cyclic reduction, way down: x_j = L_j^-T (Y_j - P_j x_a - Q_j x_b), 11 right-hand sides ---------------------------
+// In the transposed storage:  Zt = Yt - Xt_a Pt - Xt_b Qt  ([16 x 80] = [16 x 80][80 x 80], f64 MFMA, B operands straight from
+// L2: 16 consecutive doubles per lane group), then  Xt L = Zt  solved panel by panel from the last one: the products with
+// the already known panels on the matrix cores, the 16 x 16 diagonal blocks through their explicit inverses (computed
+// here, one block per wave, while the other waves form Zt).
 __global__ __launch_bounds__(kCrThreads) void k_cr_back(WinBuf W, const int* __restrict__ elim, int n_elim) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
-  double* Ls = sm;                 // [WB][LD]
-  double* Zt = sm + WB * LD;       // [WR][LD]
-  double* Xa = Zt + WR * LD;       // [WR][LD]
-  double* Xb = Xa + WR * LD;       // [WR][LD]
+  double* Ls = sm;                     // [WB][LD]
+  double* Zt = sm + WB * LD;           // [WR][LD]   right-hand sides, overwritten by the solution panel by panel
+  double* Xa = Zt + WR * LD;           // [WR][LD]
+  double* Xb = Xa + WR * LD;           // [WR][LD]
+  double* Li = Xb + WR * LD;           // [5][16][17]  inverses of the diagonal blocks of L
   const int e = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int m = lane & 15, kk = lane >> 4;
   const int j = elim[3 * e], a = elim[3 * e + 1], b = elim[3 * e + 2];
   stage_block(Ls, W.L + (size_t)j * WB * WB, WB, tid, kCrThreads);
   if (a >= 0) stage_block(Xa, W.Xt + (size_t)a * WR * WB, WR, tid, kCrThreads);
   if (b >= 0) stage_block(Xb, W.Xt + (size_t)b * WR * WB, WR, tid, kCrThreads);
   __syncthreads();
-  const double* Yt = W.Yt + (size_t)j * WR * WB;
-  const double* Pt = W.Pt + (size_t)j * WB * WB;
-  const double* Qt = W.Qt + (size_t)j * WB * WB;
-  for (int idx = tid; idx < (NBETA + 1) * WB; idx += kCrThreads) {
-    const int c = idx / WB, k = idx % WB;
-    double z = Yt[(size_t)c * WB + k];
-    if (a >= 0)
-      for (int i = 0; i < NP; ++i) z -= Xa[c * LD + i] * Pt[(size_t)i * WB + k];
-    if (b >= 0)
-      for (int i = 0; i < NP; ++i) z -= Xb[c * LD + i] * Qt[(size_t)i * WB + k];
-    Zt[c * LD + k] = z;
+  if (wave < 5) {
+    // Zt tile (all 16 rows, columns 16 wave ..): accumulate -X P and -X Q on top of Yt
+    const int tj = wave;
+    const double* Yt = W.Yt + (size_t)j * WR * WB;
+    d4 acc;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[q] = Yt[(size_t)(kk + 4 * q) * WB + 16 * tj + m];
+    for (int src = 0; src < 2; ++src) {
+      const int nb_ = src == 0 ? a : b;
+      if (nb_ < 0) continue;
+      const double* G = (src == 0 ? W.Pt : W.Qt) + (size_t)j * WB * WB;
+      const double* Xs = src == 0 ? Xa : Xb;
+      double bv[WB / 4];
+#pragma unroll
+      for (int s4 = 0; s4 < WB / 4; ++s4) bv[s4] = G[(size_t)(4 * s4 + kk) * WB + 16 * tj + m];
+#pragma unroll
+      for (int s4 = 0; s4 < WB / 4; ++s4)
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-Xs[m * LD + 4 * s4 + kk], bv[s4], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) Zt[(kk + 4 * q) * LD + 16 * tj + m] = acc[q];
+  } else if (wave == 5 || wave == 6) {
+    // inverses of the five 16 x 16 diagonal blocks of L: lane = (block, column c): forward substitution on e_c
+    for (int it = lane + 64 * (wave - 5); it < 5 * 16; it += 128) {
+      const int blk = it >> 4, c = it & 15, o = 16 * blk;
+      double x[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        double v = (r == c) ? 1.0 : 0.0;
+#pragma unroll
+        for (int k = 0; k < r; ++k) v -= Ls[(o + r) * LD + o + k] * x[k];
+        x[r] = (r >= c) ? v / Ls[(o + r) * LD + o + r] : 0.0;
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) Li[(blk * 16 + r) * 17 + c] = x[r];
+    }
+  }
+  __syncthreads();
+  // Xt[:, p] = (Zt[:, p] - sum_{q > p} Xt[:, q] L[q, p]) Linv_pp, panels from the last to the first; wave 0 only (each step
+  // depends on the previous one; 4 + 4 (5 - p - 1) MFMAs per step)
+  if (wave == 0) {
+    for (int p = 4; p >= 0; --p) {
+      d4 acc;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc[q] = Zt[(kk + 4 * q) * LD + 16 * p + m];
+      for (int qp = p + 1; qp < 5; ++qp) {
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4)
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-Zt[m * LD + 16 * qp + 4 * s4 + kk], Ls[(16 * qp + 4 * s4 + kk) * LD + 16 * p + m],
+                                                     acc, 0, 0, 0);
+      }
+      // through LDS: the accumulator tile becomes the A operand of the product with the inverse
+#pragma unroll
+      for (int q = 0; q < 4; ++q) Zt[(kk + 4 * q) * LD + 16 * p + m] = acc[q];
+      d4 xo = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4)
+        xo = __builtin_amdgcn_mfma_f64_16x16x4f64(Zt[m * LD + 16 * p + 4 * s4 + kk], Li[(p * 16 + 4 * s4 + kk) * 17 + m], xo, 0, 0, 0);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) Zt[(kk + 4 * q) * LD + 16 * p + m] = xo[q];
+    }
   }
   __syncthreads();
   double* Xt = W.Xt + (size_t)j * WR * WB;
-  for (int c = wave; c < NBETA + 1; c += kCrWaves) {   // one right-hand side per wave: unknowns lane and lane + 64
-    double z0 = Zt[c * LD + lane];
-    double z1 = (lane + 64 < WB) ? Zt[c * LD + lane + 64] : 0.0;
-    const double i0 = 1.0 / Ls[lane * LD + lane];
-    const double i1 = (lane + 64 < WB) ? 1.0 / Ls[(lane + 64) * LD + lane + 64] : 1.0;
-    for (int k = WB - 1; k >= 0; --k) {
-      const double zk = (k < 64) ? readlane_f64w(z0, k) : readlane_f64w(z1, k - 64);
-      const double ik = (k < 64) ? readlane_f64w(i0, k) : readlane_f64w(i1, k - 64);
-      const double xk = zk * ik;
-      const double l0 = Ls[k * LD + lane];                                   // L[k][i], i = lane
-      const double l1 = (lane + 64 < WB) ? Ls[k * LD + lane + 64] : 0.0;
-      if (lane < k) z0 -= l0 * xk;
-      if (lane == k) z0 = xk;
-      if (lane + 64 < k) z1 -= l1 * xk;
-      if (lane + 64 == k) z1 = xk;
-    }
-    Xt[(size_t)c * WB + lane] = z0;
-    if (lane + 64 < WB) Xt[(size_t)c * WB + lane + 64] = z1;
+  for (int idx = tid; idx < WR * WB; idx += kCrThreads) {
+    const int c = idx / WB, k = idx % WB;
+    Xt[idx] = (c <= NBETA) ? Zt[c * LD + k] : 0.0;
   }
-  for (int idx = tid; idx < (WR - NBETA - 1) * WB; idx += kCrThreads) Xt[(size_t)(NBETA + 1) * WB + idx] = 0.0;
 }
 
 // ---- beta Schur complement: per-frame partials, then the 10 x 10 solve ---------------------------------------------------
@@ -733,7 +773,7 @@ __global__ __launch_bounds__(1024) void k_win_accept(WinProblem P, WinBuf W, con
 
 size_t win_factor_lds_bytes() { return (size_t)(kCrRowsMax * LD + WB + 8) * sizeof(double); }
 size_t win_update_lds_bytes() { return (size_t)(2 * WB * LD + WR * LD) * sizeof(double); }
-size_t win_back_lds_bytes() { return (size_t)(WB * LD + 3 * WR * LD) * sizeof(double); }
+size_t win_back_lds_bytes() { return (size_t)(WB * LD + 3 * WR * LD + 5 * 16 * 17) * sizeof(double); }
 
 void launch_win_init(const WinProblem& P, const WinBuf& W, const double* d_r, hipStream_t s) {
   hipLaunchKernelGGL(k_win_init, dim3(1), dim3(1024), 0, s, P, W, d_r);

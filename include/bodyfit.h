@@ -205,7 +205,8 @@ double bodyfit_mean_pixel_error(int n_kp, const int* jid, const double* uv, cons
 /* ---- outer loop (what the reference hands to ceres::Solve) ------------------------------------
  * Ceres-like trust-region Levenberg-Marquardt over one bodyfit_problem (see host_solver.cpp for the
  * restated algorithm).  Every evaluation is one device sweep; the linear solve is a block-tridiagonal
- * Cholesky with a Schur complement on the shared shape block.
+ * Cholesky with a Schur complement on the shared shape block: on the device by block cyclic reduction over the
+ * frames (k_window_lm.hip), for short windows on the host (host_solver.cpp).
  *   frame_params [F][76] in/out, beta [nS] or [F][nS] in/out (NULL when n_cols == 76)
  *   param_constant [76] flags or NULL: 1 = SetParameterBlockConstant (include/Sim3BA.h:608-611)
  *   independent_frames 1: every frame is its own problem with its own LM state (3dba_single: frames
@@ -215,8 +216,10 @@ typedef struct bodyfit_fit_options {
   int max_iters;            /* ceres::Solver::Options::max_num_iterations */
   double scale_lo, scale_hi;/* SetParameterLowerBound / UpperBound on the scale: 0.3, 3.0 */
   int verbose;
-  int solver;               /* 0 auto: independent frames iterate on the device (k_lm_batched), a shared-beta
-                               window on the host; 1 force the host loop; 2 force the device loop */
+  int solver;               /* 0 auto: independent frames iterate on the device (k_lm_batched); a shared-beta window
+                               of >= 12 frames iterates on the device too (k_window_lm: block cyclic reduction over the
+                               frames), shorter ones on the host; 1 force the host loop; 2 force the device loop for
+                               independent frames; 3 force the device loop for a shared-beta window */
 } bodyfit_fit_options;
 typedef struct bodyfit_fit_summary {
   int iterations;           /* LM iterations (successful + unsuccessful) */
