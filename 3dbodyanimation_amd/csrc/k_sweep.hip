@@ -38,8 +38,8 @@ namespace {
 constexpr int kFusedFrameLds = 77824;
 constexpr int kFusedLdsBytes = kBBytes + kFusedFrameLds;     // 163,840 = the CU's 160 KiB
 constexpr int kFusedCtrlOff = kFusedLdsBytes - 16;           // control words of the wait loop
-constexpr unsigned long long kFusedStealTicks = 3000;        // 30 us of s_memrealtime (100 MHz) before adopting frames
-constexpr unsigned long long kFusedTimeoutTicks = 5000000;   // 50 ms: give up, set the error word
+[[maybe_unused]] constexpr unsigned long long kFusedStealTicks = 3000;        // 30 us of s_memrealtime (100 MHz) before adopting frames
+[[maybe_unused]] constexpr unsigned long long kFusedTimeoutTicks = 5000000;   // 50 ms: give up, set the error word
 static_assert(kWaves * kQuarterBytes <= kFusedCtrlOff - kBBytes, "transform slices fit behind the tile operands");
 
 __global__ __launch_bounds__(kThreads, 4) void k_frame_resjac(DevModel M, DevProblem Pb, const double* __restrict__ params,

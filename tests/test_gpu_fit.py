@@ -113,3 +113,61 @@ def test_window_solve_device_normals_match_host_normals(api, synth, model, gpu_m
     assert s1[0].iterations == s2[0].iterations
     assert abs(s1[0].final_cost - s2[0].final_cost) < 1e-9 * s2[0].final_cost
     assert np.abs(x1[:, 1:] - x2[:, 1:]).max() < 1e-6 and np.abs(b1 - b2).max() < 1e-6
+
+
+def test_c3_at_size_256_frames_sampled_against_dense_lm(api, synth, model, gpu_model, oracle_mod, omodel):
+    """BASELINE configs[2] at its real size: 256 independent frames, --opt-shape, GMM prior, ONE batched device solve (pooled
+    LM state, the batch runs as long as its slowest frame).  Eight frames, the slowest-converging one among them, are refitted
+    by the dense numpy LM over the oracle evaluator and compared (include/Sim3BA.h:348-511)."""
+    F = 256
+    seq = synth.make_sequence(model, F, seed=1)
+    w, mu, cov = synth.make_gmm(0)
+    gmm = api.Gmm(w, mu, cov); ogmm = oracle_mod.OracleGmm(w, mu, cov)
+    prob = api.Problem.from_sequence(gpu_model, seq, n_cols=86, use_shape=True, beta_per_frame=True, beta_pose=20.0,
+                                     gmm=gmm, beta_shape=30.0)
+    x, b, summ = prob.solve(seq.init_params, np.zeros((F, 10)), independent=True, max_iters=100)
+    its = np.array([q.iterations for q in summ])
+    assert sum(q.termination == 0 for q in summ) >= 250 and all(q.usable for q in summ)
+    slow = int(np.argmax(its))
+    sample = sorted(set([slow, 0, 37, 64, 101, 150, 203, 255]))
+    lm = _lm(oracle_mod)
+    for f in sample:
+        class S: pass
+        s = S(); k0, k1 = seq.kp_offset[f], seq.kp_offset[f + 1]
+        s.kp_offset = np.array([0, k1 - k0], np.int32); s.kp_id = seq.kp_id[k0:k1]; s.kp_uv = seq.kp_uv[k0:k1]
+        s.intr = seq.intr; s.R0 = seq.R0[f:f + 1]
+        xo, bo, info = lm.solve(omodel, s, seq.init_params[f:f + 1], np.zeros(10), n_cols=86, use_shape=True,
+                                beta_pose=20.0, ogmm=ogmm, beta_shape=30.0, max_iters=100)
+        if summ[f].termination != 0 or info["termination"] != 0:
+            continue   # (a frame that ran into the iteration limit on either side is not a parity case)
+        assert abs(summ[f].final_cost - info["final_cost"]) < 1e-5 * info["final_cost"], f
+        d, ok_s = gauge_free_diff(x[f], xo[0])
+        assert d < TOL and ok_s and np.abs(b[f] - bo).max() < TOL, (f, d)
+    assert summ[slow].termination == 0 or its[slow] == 100
+
+
+def test_c5_stage1_103_anchors_against_oracle_evaluator(api, synth, model, gpu_model, oracle_mod, omodel):
+    """BASELINE configs[4], stage 1 at its real size: 1024 frames, anchor_skip 10 -> 103 anchors, one shared beta
+    (src/main_multi_frame.cpp:109-134).  The fit runs on the device (window LM); at the fitted point the oracle evaluator
+    reproduces the residuals and Jacobian rows of sampled anchors, and the cost has dropped to the noise floor."""
+    seq = synth.make_sequence(model, 1024, seed=3)
+    ids = list(range(0, 1024, 10))
+    class S: pass
+    s = S(); offs = [0]; kid = []; uv = []
+    for f in ids:
+        k0, k1 = seq.kp_offset[f], seq.kp_offset[f + 1]
+        kid.append(seq.kp_id[k0:k1]); uv.append(seq.kp_uv[k0:k1]); offs.append(offs[-1] + k1 - k0)
+    s.kp_offset = np.array(offs, np.int32); s.kp_id = np.concatenate(kid); s.kp_uv = np.concatenate(uv)
+    s.intr = seq.intr; s.R0 = seq.R0[ids]
+    prob = api.Problem.from_sequence(gpu_model, s, n_cols=86, use_shape=True, beta_pose=5.0, beta_shape=25.0, lambda_temporal=3.0)
+    x, b, summ = prob.solve(seq.init_params[ids], np.zeros(10), independent=False, max_iters=200, scale_bounds=(-1e300, 1e300))
+    assert summ[0].usable and summ[0].final_cost < 0.02 * summ[0].initial_cost
+    r, J, _ = prob.evaluate(x, b, True)
+    ro, Jo = omodel.evaluate_batch(s, x, b, 86, True, True, mode=0)
+    K2 = prob.layout.reproj_rows
+    assert np.abs(r[:K2] - ro).max() < 1e-9
+    for a in (0, 17, 51, 102):
+        k0, k1 = 2 * s.kp_offset[a], 2 * s.kp_offset[a + 1]
+        assert np.abs(J[k0:k1] - Jo[k0:k1]).max() <= 1e-9 * max(1.0, np.abs(Jo[k0:k1]).max())
+    K = prob.layout.n_keypoints
+    assert np.sqrt((r[:K2].reshape(K, 2) ** 2).sum(1)).mean() < 2.5
