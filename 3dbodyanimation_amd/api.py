@@ -64,6 +64,15 @@ class _OverlayDesc(C.Structure):
                 ("width", C.c_int), ("height", C.c_int), ("max_frames", C.c_int)]
 
 
+_ALLREDUCE_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, _dp, C.c_int, C.c_int)
+_ALLGATHER_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, _dp, _dp, C.c_int)
+
+
+class Comm(C.Structure):   # bodyfit_comm (include/bodyfit.h)
+    _fields_ = [("rank", C.c_int), ("size", C.c_int), ("ctx", C.c_void_p), ("allreduce", _ALLREDUCE_CB),
+                ("allgather", _ALLGATHER_CB)]
+
+
 class DeviceViews(C.Structure):
     _fields_ = [("residuals", C.c_void_p), ("jacobian", C.c_void_p), ("gmm_comp", C.c_void_p),
                 ("cloud", C.c_void_p), ("joints", C.c_void_p), ("normal_eq", C.c_void_p),
@@ -114,6 +123,8 @@ def load_library():
     lib.bodyfit_profile_sweep.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, _dp]
     lib.bodyfit_solve.argtypes = [C.c_void_p, _dp, _dp, C.POINTER(C.c_ubyte), C.c_int, C.POINTER(FitOptions),
                                   C.POINTER(FitSummary), C.c_int]
+    lib.bodyfit_solve_sharded.argtypes = [C.c_void_p, _dp, _dp, C.POINTER(C.c_ubyte), C.POINTER(Comm), C.POINTER(FitOptions),
+                                          C.POINTER(FitSummary)]
     lib.bodyfit_forward.argtypes = [C.c_void_p, _dp, _dp, _dp, _fp]
     lib.bodyfit_writeback_batch.argtypes = [C.c_void_p, _dp, _dp, _dp, _dp, _fp, _dp]
     lib.bodyfit_evaluate_block.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(_dp), _dp, C.POINTER(_dp)]
@@ -354,6 +365,21 @@ class Problem:
         _check(load_library().bodyfit_solve(self.h, _d(x), _d(b), cst.ctypes.data_as(C.POINTER(C.c_ubyte)) if cst is not None else None,
                                             int(independent), C.byref(opt), sums, n_sum))
         return x, b, list(sums)
+
+    def solve_sharded(self, frame_params, beta, comm: "Comm", constant=None, max_iters=100, scale_bounds=(-1e300, 1e300),
+                      verbose=False):
+        """This rank's shard of one window (bodyfit_solve_sharded).  frame_params: the shard's rows (+ the halo row when the
+        problem has one).  Returns the shard's fitted rows, beta (the same on every rank) and the FitSummary."""
+        x = _c64(frame_params).copy()
+        b = _c64(beta).copy()
+        assert x.size == self.n_param_rows * N_FRAME_PARAMS
+        cst = np.ascontiguousarray(constant, dtype=np.uint8) if constant is not None else None
+        summ = FitSummary()
+        opt = FitOptions(int(max_iters), float(scale_bounds[0]), float(scale_bounds[1]), int(verbose), 3)
+        _check(load_library().bodyfit_solve_sharded(self.h, _d(x), _d(b),
+                                                    cst.ctypes.data_as(C.POINTER(C.c_ubyte)) if cst is not None else None,
+                                                    C.byref(comm), C.byref(opt), C.byref(summ)))
+        return x.reshape(-1)[:self.n_frames * N_FRAME_PARAMS].reshape(self.n_frames, N_FRAME_PARAMS).copy(), b, summ
 
     def evaluate_block(self, kind: int, index: int, blocks: list[np.ndarray], n_res: int, want=None):
         """ceres::CostFunction::Evaluate on one block.  `want[b]` False -> jacobians[b] = NULL."""

@@ -102,6 +102,7 @@ struct bodyfit_problem {
   double* d_frame_normal = nullptr;
   unsigned char* lm_pool = nullptr;    // device LM state of bodyfit_solve, one allocation kept across solves
   unsigned char* win_pool = nullptr;   // device window LM (k_window_lm.hip): state + cyclic-reduction buffers
+  size_t win_pool_bytes = 0;
   hipStream_t lm_stream = nullptr;
   double* d_writeback = nullptr;
   // fused sweep (k_sweep_fused): in-launch synchronisation words [error | pad | flag[256] | claim[256]], launch counter
@@ -952,98 +953,187 @@ int bodyfit_internal_solve_batched_device(bodyfit_problem* p, double* frame_para
   return BODYFIT_OK;
 }
 
-// Device-resident LM for ONE problem over all frames with a shared beta (k_window_lm.hip): the outer loop of
-// OptimizeMultiFrame (include/MultiFrameBA.h:144-151) with every piece of linear algebra on the device.  Per LM iteration
-// the host launches: [Jacobian sweep + k_frame_normal when the point moved] -> assemble -> cyclic reduction up and down ->
-// beta Schur + step + model change -> residual sweep at the candidate -> accept, and reads back one status record.
-int bodyfit_internal_solve_window_device(bodyfit_problem* p, double* frame_params, double* beta,
-                                         const unsigned char* param_constant, const bodyfit_fit_options* opt,
-                                         bodyfit_fit_summary* summary) {
-  const bodyfit_model* m = p->m;
-  const int F = p->d.F, npose = 7 + 3 * (m->nJ - 1), n = p->lay.n_cols, nb = n - npose;
-  if (npose != kFrameParams || nb != kMaxShape || p->desc.beta_per_frame || p->has_gmm || p->desc.temporal_halo)
-    return fail(BODYFIT_ERR_INVALID, "device window solver: needs 24 joints, a shared 10-coefficient beta, the L2 pose prior, no halo");
-  HIP_TRY(hipSetDevice(m->device));
-  std::lock_guard<std::mutex> lock(p->mu);
-  p->cache_valid = false;
-  // ---- one pooled allocation, kept across solves ----
-  WinBuf W{};
-  double *d_x, *d_b, *d_xn, *d_bn, *d_rn;
-  int *d_compn, *d_sched;
-  unsigned char* d_const = nullptr;
-  // cyclic-reduction schedule: per level the eliminated frames (j, left, right) and the remaining ones (a, jl, jr, next)
-  std::vector<int> sched;
-  struct Level { int elim_off, n_elim, surv_off, n_surv; };
-  std::vector<Level> levels;
-  {
-    std::vector<int> active(F);
-    for (int f = 0; f < F; ++f) active[f] = f;
-    while (active.size() > 1) {
-      Level lv{};
-      const int na = (int)active.size();
-      lv.elim_off = (int)sched.size();
-      for (int pos = 1; pos < na; pos += 2) {
+// Cyclic-reduction schedule over `n` chain nodes (ids base .. base + n - 1): per level the eliminated nodes (j, left, right)
+// and the remaining ones that receive an update (a, jl, jr, next).  pinned: the two end nodes are never eliminated (a shard's
+// interface with its neighbours); otherwise the last level is the root (j, -1, -1).
+struct CrLevel { int elim_off, n_elim, surv_off, n_surv; };
+static void build_cr_schedule(int n, bool pinned, std::vector<int>& sched, std::vector<CrLevel>& levels) {
+  std::vector<int> active(n);
+  for (int f = 0; f < n; ++f) active[f] = f;
+  for (;;) {
+    const int na = (int)active.size();
+    std::vector<char> el(na, 0);
+    int ne = 0;
+    for (int pos = 1; pos < na; pos += 2)
+      if (!(pinned && pos == na - 1)) { el[pos] = 1; ++ne; }
+    if (ne == 0) break;
+    CrLevel lv{};
+    lv.elim_off = (int)sched.size();
+    for (int pos = 0; pos < na; ++pos)
+      if (el[pos]) {
         sched.push_back(active[pos]); sched.push_back(active[pos - 1]); sched.push_back(pos + 1 < na ? active[pos + 1] : -1);
         ++lv.n_elim;
       }
-      lv.surv_off = (int)sched.size();
-      std::vector<int> next;
-      for (int pos = 0; pos < na; pos += 2) {
-        sched.push_back(active[pos]); sched.push_back(pos > 0 ? active[pos - 1] : -1);
-        sched.push_back(pos + 1 < na ? active[pos + 1] : -1); sched.push_back(pos + 2 < na ? active[pos + 2] : -1);
-        ++lv.n_surv;
-        next.push_back(active[pos]);
-      }
-      levels.push_back(lv);
-      active.swap(next);
+    lv.surv_off = (int)sched.size();
+    std::vector<int> next;
+    for (int pos = 0; pos < na; ++pos) {
+      if (el[pos]) continue;
+      next.push_back(active[pos]);
+      const int jl = (pos > 0 && el[pos - 1]) ? active[pos - 1] : -1;
+      const int jr = (pos + 1 < na && el[pos + 1]) ? active[pos + 1] : -1;
+      if (jl < 0 && jr < 0) continue;
+      sched.push_back(active[pos]); sched.push_back(jl); sched.push_back(jr);
+      sched.push_back((jr >= 0 && pos + 2 < na) ? active[pos + 2] : -1);
+      ++lv.n_surv;
     }
-    Level root{};
+    levels.push_back(lv);
+    active.swap(next);
+  }
+  if (!pinned) {
+    CrLevel root{};
     root.elim_off = (int)sched.size(); root.n_elim = 1;
     sched.push_back(active[0]); sched.push_back(-1); sched.push_back(-1);
     levels.push_back(root);
   }
+}
+
+// carve the cyclic-reduction buffers of `n` nodes out of a pool
+static size_t carve_cr(unsigned char* base, size_t off, int n, WinBuf& W, bool dry) {
+  const size_t blk = (size_t)kWinBlock * kWinBlock * 8, rhs = (size_t)kWinRhs * kWinBlock * 8;
+  auto take = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+  const size_t o_D = take(n * blk), o_U = take(n * blk), o_L = take(n * blk), o_P = take(n * blk), o_Q = take(n * blk),
+               o_R = take(n * rhs), o_R0 = take(n * rhs), o_Y = take(n * rhs), o_X = take(n * rhs), o_fail = take(8);
+  if (!dry) {
+    auto dp = [&](size_t o) { return reinterpret_cast<double*>(base + o); };
+    W.D = dp(o_D); W.U = dp(o_U); W.L = dp(o_L); W.Pt = dp(o_P); W.Qt = dp(o_Q); W.Rt = dp(o_R); W.Rt0 = dp(o_R0);
+    W.Yt = dp(o_Y); W.Xt = dp(o_X); W.fail = reinterpret_cast<int*>(base + o_fail);
+  }
+  return off;
+}
+
+// Device-resident LM for ONE problem over all frames with a shared beta (k_window_lm.hip): the outer loop of
+// OptimizeMultiFrame (include/MultiFrameBA.h:144-151) with every piece of linear algebra on the device.  Per LM iteration
+// the host launches: [Jacobian sweep + k_frame_normal when the point moved] -> assemble -> cyclic reduction up and down ->
+// beta Schur + step + model change -> residual sweep at the candidate -> accept, and reads back one status record.
+//
+// comm != NULL: this problem is ONE SHARD (contiguous frames) of the window, one process per GPU (bodyfit_solve_sharded).
+// Every rank reduces its own chain down to its two end frames (cyclic reduction with the ends pinned), the 2 N interface
+// blocks are all-gathered and solved redundantly by every rank, then each rank substitutes back through its own levels.
+// What crosses ranks per LM iteration: the beta terms [C, g_beta] (one all-reduce of 110 doubles), the interface blocks
+// (one all-gather of 225 KB per rank), the beta Schur partials (110), three boundary parameter rows, and four scalars.
+int bodyfit_internal_solve_window_device(bodyfit_problem* p, double* frame_params, double* beta,
+                                         const unsigned char* param_constant, const bodyfit_fit_options* opt,
+                                         bodyfit_fit_summary* summary, const bodyfit_comm* comm) {
+  const bodyfit_model* m = p->m;
+  const int F = p->d.F, npose = 7 + 3 * (m->nJ - 1), n = p->lay.n_cols, nb = n - npose;
+  const bool sharded = comm != nullptr && comm->size > 1;
+  const int halo = p->desc.temporal_halo ? 1 : 0;
+  if (npose != kFrameParams || nb != kMaxShape || p->desc.beta_per_frame || p->has_gmm)
+    return fail(BODYFIT_ERR_INVALID, "device window solver: needs 24 joints, a shared 10-coefficient beta and the L2 pose prior");
+  if (halo && !sharded) return fail(BODYFIT_ERR_INVALID, "device window solver: a halo row needs bodyfit_solve_sharded");
+  if (sharded && F < 2) return fail(BODYFIT_ERR_INVALID, "bodyfit_solve_sharded: every shard needs at least two frames");
+  const int R = sharded ? comm->rank : 0, N = sharded ? comm->size : 1;
+  const bool has_left = sharded && R > 0;
+  if (sharded && (halo != 0) != (R + 1 < N))
+    return fail(BODYFIT_ERR_INVALID, "bodyfit_solve_sharded: every shard but the last needs temporal_halo");
+  HIP_TRY(hipSetDevice(m->device));
+  std::lock_guard<std::mutex> lock(p->mu);
+  p->cache_valid = false;
+  // ---- schedules ----
+  std::vector<int> sched;
+  std::vector<CrLevel> levels, ilevels;
+  build_cr_schedule(F, sharded, sched, levels);
+  const int NI = 2 * N;   // interface nodes
+  if (sharded) build_cr_schedule(NI, false, sched, ilevels);
+  // ---- one pooled allocation, kept across solves ----
+  WinBuf W{}, Wi{};
+  double *d_x, *d_b, *d_xn, *d_bn, *d_rn, *d_xl, *d_sh, *d_dh, *d_io;
+  int *d_compn, *d_sched;
+  unsigned char* d_const = nullptr;
+  const size_t io_doubles = (size_t)NI * (3 * kWinBlock * kWinBlock + kWinRhs * kWinBlock);   // gathered interface blocks
   {
-    const size_t blk = (size_t)kWinBlock * kWinBlock, rhs = (size_t)kWinRhs * kWinBlock;
-    size_t off = 0;
+    size_t off = carve_cr(nullptr, 0, F, W, true);
+    if (sharded) off = carve_cr(nullptr, off, NI, Wi, true);
     auto take = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
-    const size_t o_D = take(F * blk * 8), o_U = take(F * blk * 8), o_L = take(F * blk * 8), o_P = take(F * blk * 8),
-                 o_Q = take(F * blk * 8), o_R = take(F * rhs * 8), o_R0 = take(F * rhs * 8), o_Y = take(F * rhs * 8),
-                 o_X = take(F * rhs * 8), o_A = take((size_t)F * npose * npose * 8), o_B = take((size_t)F * npose * nb * 8),
+    const size_t o_A = take((size_t)F * npose * npose * 8), o_B = take((size_t)F * npose * nb * 8),
                  o_g = take((size_t)F * npose * 8), o_E = take((size_t)F * npose * 8), o_sc = take(((size_t)F * npose + nb) * 8),
-                 o_Cs = take(100 * 8), o_rb = take(16 * 8), o_Cr = take(100 * 8), o_gb = take(16 * 8), o_dsb = take(16 * 8),
+                 o_Cs = take(100 * 8), o_rb = take(16 * 8), o_Cr = take(112 * 8), o_dsb = take(16 * 8),
+                 o_sred = take(112 * 8), o_fin = take(8 * 8),
                  o_part = take((size_t)F * kWinPart * 8), o_gm = take((size_t)(F + 1) * 8), o_d = take(((size_t)F * npose + nb) * 8),
-                 o_st = take(kWsCount * 8), o_fail = take(8), o_x = take((size_t)F * npose * 8), o_b = take(nb * 8),
-                 o_xn = take((size_t)F * npose * 8), o_bn = take(nb * 8), o_rn = take((size_t)std::max(1, p->lay.total_rows) * 8),
-                 o_cn = take((size_t)F * 4), o_sched = take(sched.size() * 4), o_const = take((size_t)npose);
-    if (!p->win_pool) {
+                 o_st = take(kWsCount * 8), o_x = take((size_t)(F + 1) * npose * 8), o_b = take(nb * 8),
+                 o_xn = take((size_t)(F + 1) * npose * 8), o_bn = take(nb * 8), o_rn = take((size_t)std::max(1, p->lay.total_rows) * 8),
+                 o_cn = take((size_t)F * 4), o_sched = take(sched.size() * 4), o_const = take((size_t)npose),
+                 o_xl = take(npose * 8), o_sh = take(npose * 8), o_dh = take(npose * 8), o_io = take(sharded ? io_doubles * 8 : 8);
+    if (!p->win_pool || p->win_pool_bytes < off) {
       HIP_TRY(p->mem.alloc(&p->win_pool, off));
       HIP_TRY(hipMemset(p->win_pool, 0, off));
+      p->win_pool_bytes = off;
     }
     unsigned char* Bp = p->win_pool;
+    size_t o2 = carve_cr(Bp, 0, F, W, false);
+    if (sharded) carve_cr(Bp, o2, NI, Wi, false);
     auto dp = [&](size_t o) { return reinterpret_cast<double*>(Bp + o); };
-    W.D = dp(o_D); W.U = dp(o_U); W.L = dp(o_L); W.Pt = dp(o_P); W.Qt = dp(o_Q); W.Rt = dp(o_R); W.Rt0 = dp(o_R0);
-    W.Yt = dp(o_Y); W.Xt = dp(o_X); W.Araw = dp(o_A); W.Braw = dp(o_B); W.graw = dp(o_g); W.Eraw = dp(o_E);
-    W.scale = dp(o_sc); W.Cs = dp(o_Cs); W.rhsb = dp(o_rb); W.Craw = dp(o_Cr); W.gbraw = dp(o_gb); W.dsb = dp(o_dsb);
+    W.Araw = dp(o_A); W.Braw = dp(o_B); W.graw = dp(o_g); W.Eraw = dp(o_E);
+    W.scale = dp(o_sc); W.Cs = dp(o_Cs); W.rhsb = dp(o_rb); W.Craw = dp(o_Cr); W.gbraw = dp(o_Cr) + 100; W.dsb = dp(o_dsb);
+    W.sred = dp(o_sred); W.fin = dp(o_fin);
     W.part = dp(o_part); W.gmaxp = dp(o_gm); W.d = dp(o_d); W.status = dp(o_st);
-    W.fail = reinterpret_cast<int*>(Bp + o_fail);
     d_x = dp(o_x); d_b = dp(o_b); d_xn = dp(o_xn); d_bn = dp(o_bn); d_rn = dp(o_rn);
     d_compn = reinterpret_cast<int*>(Bp + o_cn);
     d_sched = reinterpret_cast<int*>(Bp + o_sched);
     if (param_constant) d_const = Bp + o_const;
+    d_xl = dp(o_xl); d_sh = dp(o_sh); d_dh = dp(o_dh); d_io = dp(o_io);
   }
   if (!p->d_frame_normal) HIP_TRY(p->mem.alloc(&p->d_frame_normal, (size_t)F * kNormalRows * kNormalLd));
   if (!p->lm_stream) HIP_TRY(hipStreamCreateWithFlags(&p->lm_stream, hipStreamNonBlocking));
   hipStream_t st = p->lm_stream;
   WinProblem P{};
-  P.F = F; P.K = p->lay.n_keypoints; P.total_rows = p->lay.total_rows; P.nb = nb;
+  P.F = F; P.K = p->lay.n_keypoints; P.total_rows = p->lay.total_rows; P.nb = nb; P.halo = halo;
   P.prior_rows = p->lay.prior_rows_per_frame; P.row_prior = p->row_prior;
   P.shape_rows = p->lay.shape_rows; P.row_shape = p->row_shape; P.row_temporal = p->row_temporal;
   P.huber = p->desc.huber_delta; P.beta_pose = p->desc.beta_pose; P.beta_shape = p->desc.beta_shape;
   P.lambda_t = p->desc.lambda_temporal; P.scale_lo = opt->scale_lo; P.scale_hi = opt->scale_hi;
-  HIP_TRY(hipMemcpyAsync(d_x, frame_params, (size_t)F * npose * sizeof(double), hipMemcpyHostToDevice, st));
+  const int rows_x = F + halo;
+  HIP_TRY(hipMemcpyAsync(d_x, frame_params, (size_t)rows_x * npose * sizeof(double), hipMemcpyHostToDevice, st));
   HIP_TRY(hipMemcpyAsync(d_b, beta, (size_t)nb * sizeof(double), hipMemcpyHostToDevice, st));
   HIP_TRY(hipMemcpyAsync(d_sched, sched.data(), sched.size() * sizeof(int), hipMemcpyHostToDevice, st));
   if (param_constant) HIP_TRY(hipMemcpyAsync(d_const, param_constant, (size_t)npose, hipMemcpyHostToDevice, st));
+  // ---- collectives of a sharded solve: small host buffers through the caller's communicator ----
+  std::vector<double> hb(std::max<size_t>(256, sharded ? io_doubles / NI * 1 : 0)), hg;
+  auto comm_fail = [&](const char* what) { return fail(BODYFIT_ERR_INVALID, std::string("bodyfit_solve_sharded: ") + what + " failed"); };
+  // all-reduce `cnt` device doubles in place (op 0 sum, 1 max)
+  auto allreduce_dev = [&](double* dptr, int cnt, int op) -> int {
+    HIP_TRY(hipMemcpyAsync(hb.data(), dptr, cnt * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (comm->allreduce(comm->ctx, hb.data(), cnt, op)) return comm_fail("allreduce");
+    HIP_TRY(hipMemcpyAsync(dptr, hb.data(), cnt * sizeof(double), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));   // (hb is reused by the next collective)
+    return BODYFIT_OK;
+  };
+  std::vector<double> bnd(3 * npose), bnd_all, x_left_new(npose, 0.0);
+  // boundary rows of a point: every rank contributes [first row, last row, extra row]; rank r receives its left neighbour's last
+  // row (-> left_out, host) and its right neighbour's first row (-> the halo row of d_pt) and extra row (-> d_extra_halo)
+  auto exchange_boundary = [&](double* d_pt, const double* d_extra_first, double* left_out, double* d_extra_halo) -> int {
+    HIP_TRY(hipMemcpyAsync(bnd.data(), d_pt, npose * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(bnd.data() + npose, d_pt + (size_t)(F - 1) * npose, npose * sizeof(double), hipMemcpyDeviceToHost, st));
+    if (d_extra_first) HIP_TRY(hipMemcpyAsync(bnd.data() + 2 * npose, d_extra_first, npose * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    bnd_all.resize((size_t)N * 3 * npose);
+    if (comm->allgather(comm->ctx, bnd.data(), bnd_all.data(), 3 * npose)) return comm_fail("allgather");
+    if (has_left) std::memcpy(left_out, &bnd_all[((size_t)(R - 1) * 3 + 1) * npose], npose * sizeof(double));
+    if (halo) {
+      HIP_TRY(hipMemcpyAsync(d_pt + (size_t)F * npose, &bnd_all[(size_t)(R + 1) * 3 * npose], npose * sizeof(double), hipMemcpyHostToDevice, st));
+      if (d_extra_halo)
+        HIP_TRY(hipMemcpyAsync(d_extra_halo, &bnd_all[((size_t)(R + 1) * 3 + 2) * npose], npose * sizeof(double), hipMemcpyHostToDevice, st));
+    }
+    HIP_TRY(hipStreamSynchronize(st));
+    return BODYFIT_OK;
+  };
+  std::vector<double> x_left(npose, 0.0);
+  if (sharded) {
+    int rc0 = exchange_boundary(d_x, nullptr, x_left.data(), nullptr);
+    if (rc0) return rc0;
+    if (has_left) HIP_TRY(hipMemcpyAsync(d_xl, x_left.data(), npose * sizeof(double), hipMemcpyHostToDevice, st));
+  }
   auto jac_sweep = [&]() -> int {
     int rc = sweep(p, d_x, d_b, 1, false, st);
     if (rc) return rc;
@@ -1052,40 +1142,140 @@ int bodyfit_internal_solve_window_device(bodyfit_problem* p, double* frame_param
   };
   int rc = jac_sweep();
   if (rc) return rc;
-  launch_win_init(P, W, p->d_r, st);
+  if (!sharded) {
+    launch_win_init(P, W, p->d_r, 0, st);
+  } else {
+    launch_win_init(P, W, p->d_r, 1, st);
+    if ((rc = allreduce_dev(W.fin, 1, 0))) return rc;
+    launch_win_init(P, W, p->d_r, 2, st);
+  }
   int n_sweeps = 1;
   double status[kWsCount] = {0};
   bool need_jac = false, first = true;
+  const size_t blk = (size_t)kWinBlock * kWinBlock, rhs = (size_t)kWinRhs * kWinBlock;
   for (int it = 0; it < opt->max_iters; ++it) {
     if (need_jac) {
-      rc = jac_sweep();
-      if (rc) return rc;
+      if ((rc = jac_sweep())) return rc;
       ++n_sweeps;
     }
-    launch_win_assemble(P, W, p->d_frame_normal, p->d_r, d_x, d_const, first ? 1 : 0, st);
+    // ---- beta block and per-frame blocks ----
+    if (!sharded) {
+      launch_win_beta(P, W, p->d_frame_normal, p->d_r, first ? 1 : 0, 0, st);
+      launch_win_assemble(P, W, p->d_frame_normal, p->d_r, d_x, d_const, first ? 1 : 0, nullptr, nullptr, st);
+    } else {
+      launch_win_beta(P, W, p->d_frame_normal, p->d_r, first ? 1 : 0, 1, st);
+      if ((rc = allreduce_dev(W.Craw, 110, 0))) return rc;       // [C (100) | g_beta (10)]: the beta terms, once per iteration
+      launch_win_beta(P, W, p->d_frame_normal, p->d_r, first ? 1 : 0, 2, st);
+      if (first) {
+        // first pass: this shard's Jacobi scaling; the next shard's first-frame scaling then completes the boundary coupling
+        launch_win_assemble(P, W, p->d_frame_normal, p->d_r, d_x, d_const, 1, has_left ? d_xl : nullptr, nullptr, st);
+        HIP_TRY(hipMemcpyAsync(bnd.data(), W.scale, npose * sizeof(double), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        bnd_all.resize((size_t)N * npose);
+        if (comm->allgather(comm->ctx, bnd.data(), bnd_all.data(), npose)) return comm_fail("allgather");
+        if (halo) HIP_TRY(hipMemcpyAsync(d_sh, &bnd_all[(size_t)(R + 1) * npose], npose * sizeof(double), hipMemcpyHostToDevice, st));
+        HIP_TRY(hipStreamSynchronize(st));
+      }
+      launch_win_assemble(P, W, p->d_frame_normal, p->d_r, d_x, d_const, 0, has_left ? d_xl : nullptr, halo ? d_sh : nullptr, st);
+    }
+    // ---- cyclic reduction over the local chain ----
     for (size_t l = 0; l < levels.size(); ++l) {
-      const Level& lv = levels[l];
+      const CrLevel& lv = levels[l];
       launch_cr_factor(W, d_sched + lv.elim_off, lv.n_elim, st);
       launch_cr_update(W, d_sched + lv.surv_off, lv.n_surv, st);
     }
+    if (sharded) {
+      // ---- interface system of the 2 N end frames: gathered, solved by every rank ----
+      const size_t per = 3 * blk + 2 * rhs;   // doubles per rank: [D_first, D_last, U_first (-> last), U_last diag block.., R_first, R_last]
+      (void)per;
+      std::vector<double>& hs = hg;
+      const size_t per_rank = 4 * blk + 2 * rhs;
+      hs.resize(per_rank);
+      const int fl = F - 1;
+      HIP_TRY(hipMemcpyAsync(&hs[0], W.D, blk * 8, hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipMemcpyAsync(&hs[blk], W.D + (size_t)fl * blk, blk * 8, hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipMemcpyAsync(&hs[2 * blk], W.U, blk * 8, hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipMemcpyAsync(&hs[3 * blk], W.U + (size_t)fl * blk, blk * 8, hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipMemcpyAsync(&hs[4 * blk], W.Rt, rhs * 8, hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipMemcpyAsync(&hs[4 * blk + rhs], W.Rt + (size_t)fl * rhs, rhs * 8, hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipStreamSynchronize(st));
+      static thread_local std::vector<double> all;
+      all.resize(per_rank * N);
+      if (comm->allgather(comm->ctx, hs.data(), all.data(), (int)per_rank)) return comm_fail("allgather");
+      for (int r2 = 0; r2 < N; ++r2) {
+        const double* src = &all[(size_t)r2 * per_rank];
+        HIP_TRY(hipMemcpyAsync(Wi.D + (size_t)(2 * r2) * blk, src, 2 * blk * 8, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(Wi.U + (size_t)(2 * r2) * blk, src + 2 * blk, 2 * blk * 8, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(Wi.Rt + (size_t)(2 * r2) * rhs, src + 4 * blk, 2 * rhs * 8, hipMemcpyHostToDevice, st));
+      }
+      HIP_TRY(hipMemsetAsync(Wi.fail, 0, sizeof(int), st));
+      for (size_t l = 0; l < ilevels.size(); ++l) {
+        const CrLevel& lv = ilevels[l];
+        launch_cr_factor(Wi, d_sched + lv.elim_off, lv.n_elim, st);
+        launch_cr_update(Wi, d_sched + lv.surv_off, lv.n_surv, st);
+      }
+      for (size_t l = ilevels.size(); l-- > 0;) launch_cr_back(Wi, d_sched + ilevels[l].elim_off, ilevels[l].n_elim, st);
+      HIP_TRY(hipMemcpyAsync(W.Xt, Wi.Xt + (size_t)(2 * R) * rhs, rhs * 8, hipMemcpyDeviceToDevice, st));
+      HIP_TRY(hipMemcpyAsync(W.Xt + (size_t)fl * rhs, Wi.Xt + (size_t)(2 * R + 1) * rhs, rhs * 8, hipMemcpyDeviceToDevice, st));
+    }
     for (size_t l = levels.size(); l-- > 0;) launch_cr_back(W, d_sched + levels[l].elim_off, levels[l].n_elim, st);
-    launch_win_step(P, W, d_x, d_b, d_xn, d_bn, st);
+    // ---- beta Schur complement, step, model change, decision ----
+    launch_win_schur_part(P, W, st);
+    if (!sharded) {
+      launch_win_beta_solve(P, W, d_b, d_bn, 0, st);
+      launch_win_step(P, W, d_x, d_xn, st);
+      launch_win_model(P, W, d_x, nullptr, st);
+      launch_win_finish(P, W, d_x, d_b, d_xn, d_bn, 0, st);
+    } else {
+      if (Wi.fail) {   // a failed interface factorisation is everybody's failure
+        int hf = 0;
+        HIP_TRY(hipMemcpyAsync(&hf, Wi.fail, sizeof(int), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        if (opt->verbose) {
+          int lf = 0;
+          HIP_TRY(hipMemcpy(&lf, W.fail, sizeof(int), hipMemcpyDeviceToHost));
+          std::printf("[bodyfit-dev r%d] local fail %d interface fail %d\n", R, lf, hf);
+        }
+        if (hf) { const int one = 1; HIP_TRY(hipMemcpyAsync(W.fail, &one, sizeof(int), hipMemcpyHostToDevice, st)); HIP_TRY(hipStreamSynchronize(st)); }
+      }
+      launch_win_beta_solve(P, W, d_b, d_bn, 1, st);
+      if ((rc = allreduce_dev(W.sred, 110, 0))) return rc;
+      launch_win_beta_solve(P, W, d_b, d_bn, 2, st);
+      launch_win_step(P, W, d_x, d_xn, st);
+      if ((rc = exchange_boundary(d_xn, W.d, x_left_new.data(), d_dh))) return rc;   // candidate's boundary rows + the next shard's first step
+      launch_win_model(P, W, d_x, halo ? d_dh : nullptr, st);
+      launch_win_finish(P, W, d_x, d_b, d_xn, d_bn, 1, st);
+      if ((rc = allreduce_dev(W.fin, 3, 0))) return rc;
+      if ((rc = allreduce_dev(W.fin + 3, 2, 1))) return rc;
+      launch_win_finish(P, W, d_x, d_b, d_xn, d_bn, 2, st);
+    }
     rc = sweep(p, d_xn, d_bn, 0, false, st, nullptr, d_rn, d_compn);
     if (rc) return rc;
     ++n_sweeps;
-    launch_win_accept(P, W, d_rn, d_x, d_b, d_xn, d_bn, st);
+    if (!sharded) {
+      launch_win_accept(P, W, d_rn, d_x, d_b, d_xn, d_bn, 0, st);
+    } else {
+      launch_win_accept(P, W, d_rn, d_x, d_b, d_xn, d_bn, 1, st);
+      if ((rc = allreduce_dev(W.fin, 1, 0))) return rc;
+      launch_win_accept(P, W, d_rn, d_x, d_b, d_xn, d_bn, 2, st);
+    }
     HIP_TRY(hipMemcpyAsync(status, W.status, sizeof(status), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     first = false;
     need_jac = status[kWsAccepted] != 0.0;
-    if (opt->verbose)
+    if (sharded && need_jac) {   // the accepted point's boundary rows become the current ones
+      if (halo) HIP_TRY(hipMemcpyAsync(d_x + (size_t)F * npose, d_xn + (size_t)F * npose, npose * sizeof(double), hipMemcpyDeviceToDevice, st));
+      if (has_left) { x_left = x_left_new; HIP_TRY(hipMemcpyAsync(d_xl, x_left.data(), npose * sizeof(double), hipMemcpyHostToDevice, st)); }
+      HIP_TRY(hipStreamSynchronize(st));
+    }
+    if (opt->verbose && R == 0)
       std::printf("[bodyfit-dev] it %3d cost %.6e radius %.3e accepted %d gmax %.2e\n", (int)status[kWsIters], status[kWsCost],
                   status[kWsRadius], (int)status[kWsAccepted], status[kWsGmax]);
     if (status[kWsActive] == 0.0) break;
   }
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(status, W.status, sizeof(status), hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipMemcpyAsync(frame_params, d_x, (size_t)F * npose * sizeof(double), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(frame_params, d_x, (size_t)rows_x * npose * sizeof(double), hipMemcpyDeviceToHost, st));
   HIP_TRY(hipMemcpyAsync(beta, d_b, (size_t)nb * sizeof(double), hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
   if (summary) {
@@ -1097,6 +1287,21 @@ int bodyfit_internal_solve_window_device(bodyfit_problem* p, double* frame_param
     summary->initial_cost = status[kWsInitialCost]; summary->final_cost = status[kWsCost];
   }
   return BODYFIT_OK;
+}
+
+// One window sharded over several processes (one per GPU): this rank's shard of the frames, collectives through `comm`.
+int bodyfit_solve_sharded(bodyfit_problem* p, double* frame_params, double* beta, const unsigned char* param_constant,
+                          const bodyfit_comm* comm, const bodyfit_fit_options* opt_in, bodyfit_fit_summary* summary) {
+  if (!p || !frame_params || !beta || !comm || !comm->allreduce || !comm->allgather || comm->size < 1 || comm->rank < 0 ||
+      comm->rank >= comm->size)
+    return fail(BODYFIT_ERR_INVALID, "bodyfit_solve_sharded: bad argument");
+  bodyfit_fit_options opt;
+  opt.max_iters = 100; opt.scale_lo = -1e300; opt.scale_hi = 1e300; opt.verbose = 0; opt.solver = 3;
+  if (opt_in) opt = *opt_in;
+  int maxk = 0;
+  for (int f = 0; f < p->d.F; ++f) maxk = std::max(maxk, p->kp_offset[f + 1] - p->kp_offset[f]);
+  if (maxk > 32) return fail(BODYFIT_ERR_INVALID, "bodyfit_solve_sharded: at most 32 keypoints per frame");
+  return bodyfit_internal_solve_window_device(p, frame_params, beta, param_constant, &opt, summary, comm);
 }
 
 int bodyfit_internal_fail(int code, const char* msg) { return fail(code, msg ? msg : ""); }

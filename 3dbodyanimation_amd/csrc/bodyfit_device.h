@@ -148,6 +148,7 @@ enum {   // status record of the window LM (doubles), read back by the host once
 };
 struct WinProblem {
   int F, K, total_rows, nb;
+  int halo;                         // shard of a window: a temporal pair links the last frame to the next shard's first
   int prior_rows, row_prior, shape_rows, row_shape, row_temporal;
   double huber, beta_pose, beta_shape, lambda_t, scale_lo, scale_hi;
 };
@@ -157,6 +158,8 @@ struct WinBuf {
   double *Araw, *Braw, *graw, *Eraw;   // undamped, unscaled blocks for the model cost change: [F][76][76], [F][76][10], [F][76] x 2
   double *scale;                    // [F * 76 + 10] Jacobi scaling, fixed at the first iterate
   double *Cs, *rhsb, *Craw, *gbraw, *dsb;   // beta block: scaled damped C, scaled rhs, raw C, raw gradient, scaled step
+  double *sred;                     // [110] Schur partial sums of this shard (sharded solve: all-reduced by the host)
+  double *fin;                      // [8] scalars a sharded solve reduces over the shards
   double *part;                     // [F][kWinPart]
   double *gmaxp;                    // [F + 1] per-frame max |g| (entry F: beta)
   double *d;                        // [F * 76 + 10] the step
@@ -164,16 +167,24 @@ struct WinBuf {
   int* fail;                        // a factorisation met a non-positive pivot
 };
 size_t win_factor_lds_bytes();
-void launch_win_init(const WinProblem& P, const WinBuf& W, const double* d_r, hipStream_t s);
+// (mode 0: single GPU, everything in the kernel; 1: this shard's partial sums only; 2: finish from the sums the host reduced)
+void launch_win_init(const WinProblem& P, const WinBuf& W, const double* d_r, int mode, hipStream_t s);
+void launch_win_beta(const WinProblem& P, const WinBuf& W, const double* d_Hpan, const double* d_r, int first, int mode,
+                     hipStream_t s);
 void launch_win_assemble(const WinProblem& P, const WinBuf& W, const double* d_Hpan, const double* d_r, const double* d_x,
-                         const unsigned char* d_constant, int first, hipStream_t s);
+                         const unsigned char* d_constant, int first, const double* d_x_left, const double* d_scale_halo,
+                         hipStream_t s);
 void launch_cr_factor(const WinBuf& W, const int* d_elim, int n_elim, hipStream_t s);
 void launch_cr_update(const WinBuf& W, const int* d_surv, int n_surv, hipStream_t s);
 void launch_cr_back(const WinBuf& W, const int* d_elim, int n_elim, hipStream_t s);
-void launch_win_step(const WinProblem& P, const WinBuf& W, const double* d_x, const double* d_beta, double* d_x_new,
-                     double* d_beta_new, hipStream_t s);
+void launch_win_schur_part(const WinProblem& P, const WinBuf& W, hipStream_t s);
+void launch_win_beta_solve(const WinProblem& P, const WinBuf& W, const double* d_beta, double* d_beta_new, int mode, hipStream_t s);
+void launch_win_step(const WinProblem& P, const WinBuf& W, const double* d_x, double* d_x_new, hipStream_t s);
+void launch_win_model(const WinProblem& P, const WinBuf& W, const double* d_x, const double* d_halo_step, hipStream_t s);
+void launch_win_finish(const WinProblem& P, const WinBuf& W, const double* d_x, const double* d_beta, double* d_x_new,
+                       double* d_beta_new, int mode, hipStream_t s);
 void launch_win_accept(const WinProblem& P, const WinBuf& W, const double* d_r_new, double* d_x, double* d_beta,
-                       const double* d_x_new, const double* d_beta_new, hipStream_t s);
+                       const double* d_x_new, const double* d_beta_new, int mode, hipStream_t s);
 
 // f32 -> bf16 round-to-nearest-even (finite inputs)
 __host__ __device__ inline uint16_t f32_to_bf16(float x) {

@@ -580,7 +580,7 @@ extern "C" int bodyfit_solve(bodyfit_problem* p, double* frame_params, double* b
   c.prior_rows = c.lay.prior_rows_per_frame;
   c.prec_cho = view.has_gmm ? view.prec_cho : nullptr;
   c.kp_off.assign(view.kp_offset, view.kp_offset + c.F + 1);
-  if (view.n_joints != 24 || view.temporal_halo)
+  if (view.n_joints != 24 || view.temporal_halo)   // (a shard with a halo row goes through bodyfit_solve_sharded)
     return bodyfit_internal_fail(BODYFIT_ERR_INVALID, "bodyfit_solve: needs a 24-joint model and a whole window (no halo)");
   if (c.nb && !beta) return bodyfit_internal_fail(BODYFIT_ERR_INVALID, "bodyfit_solve: beta required (shape block present)");
   if (independent_frames && c.F > 1 && (c.lambda_t > 0.0 || (c.nb && !c.beta_per_frame)))
@@ -607,7 +607,7 @@ extern "C" int bodyfit_solve(bodyfit_problem* p, double* frame_params, double* b
   //  on MI355X, host / device: 20 frames 0.60 / 0.49 ms, 103 frames 2.7 / 0.69 ms, 1024 frames 54 / 1.8 ms)
   const int window_min = std::getenv("BODYFIT_WINDOW_MIN") ? std::atoi(std::getenv("BODYFIT_WINDOW_MIN")) : 12;
   if (window_ok && (opt.solver == 3 || (opt.solver == 0 && c.F >= window_min)))
-    return bodyfit_internal_solve_window_device(p, frame_params, beta, param_constant, &opt, summaries);
+    return bodyfit_internal_solve_window_device(p, frame_params, beta, param_constant, &opt, summaries, nullptr);
 
   const int F = c.F, nb = c.nb;
   std::vector<Group> groups;

@@ -75,9 +75,13 @@ __device__ double window_cost(const WinProblem& P, const double* __restrict__ r,
   return block_sum_n(acc, red, tid, nthreads / 64);
 }
 
-__global__ __launch_bounds__(1024) void k_win_init(WinProblem P, WinBuf W, const double* __restrict__ r) {
+// mode 0: all; 1: this shard's cost -> W.fin[0] only; 2: initialise the status from W.fin[0] (summed over the shards)
+__global__ __launch_bounds__(1024) void k_win_init(WinProblem P, WinBuf W, const double* __restrict__ r, int mode) {
   __shared__ double red[16];
-  const double c = window_cost(P, r, red, threadIdx.x, 1024);
+  double c = 0.0;
+  if (mode != 2) c = window_cost(P, r, red, threadIdx.x, 1024);
+  if (mode == 1) { if (threadIdx.x == 0) W.fin[0] = c; return; }
+  if (mode == 2) c = W.fin[0];
   if (threadIdx.x == 0) {
     double* st = W.status;
     st[kWsCost] = c; st[kWsInitialCost] = c; st[kWsRadius] = 1e4; st[kWsDec] = 2.0; st[kWsModel] = 0.0;
@@ -91,13 +95,18 @@ __global__ __launch_bounds__(1024) void k_win_init(WinProblem P, WinBuf W, const
 }
 
 // ---- beta block: C = sum_f C_f (+ shape prior), g_beta; scaling; damped scaled copy ------------------------------------
+// mode 0: all; 1: this shard's sums -> W.Craw, W.gbraw only; 2: scaling and the damped copy from W.Craw, W.gbraw (summed
+// over the shards by the caller)
 __global__ __launch_bounds__(256) void k_win_beta(WinProblem P, WinBuf W, const double* __restrict__ Hpan,
-                                                  const double* __restrict__ r, int first) {
+                                                  const double* __restrict__ r, int first, int mode) {
   __shared__ double sC[NBETA * NBETA], sg[NBETA], ssc[NBETA];
   const int tid = threadIdx.x, F = P.F;
-  if (tid == 0) *W.fail = 0;
+  if (tid == 0 && mode != 2) *W.fail = 0;
   if (P.nb == 0) return;
-  if (tid < NBETA * NBETA + NBETA) {
+  if (mode == 2) {
+    if (tid < NBETA * NBETA) sC[tid] = W.Craw[tid];
+    if (tid < NBETA) sg[tid] = W.gbraw[tid];
+  } else if (tid < NBETA * NBETA + NBETA) {
     size_t off;
     if (tid < NBETA * NBETA) {
       const int a = tid / NBETA, b = tid % NBETA, lo = a > b ? a : b, hi = a > b ? b : a;
@@ -118,11 +127,16 @@ __global__ __launch_bounds__(256) void k_win_beta(WinProblem P, WinBuf W, const 
     if (tid < NBETA * NBETA) sC[tid] = v; else sg[tid - NBETA * NBETA] = v;
   }
   __syncthreads();
-  if (tid < NBETA && P.shape_rows > 0) {   // ShapePriorL2Analytic: r = beta_s w, J = beta_s I (include/Sim3BA.h:336-340)
+  if (mode != 2 && tid < NBETA && P.shape_rows > 0) {   // ShapePriorL2Analytic: r = beta_s w, J = beta_s I (include/Sim3BA.h:336-340)
     sC[tid * NBETA + tid] += P.beta_shape * P.beta_shape;
     sg[tid] += P.beta_shape * r[P.row_shape + tid];
   }
   __syncthreads();
+  if (mode == 1) {
+    if (tid < NBETA * NBETA) W.Craw[tid] = sC[tid];
+    if (tid < NBETA) W.gbraw[tid] = sg[tid];
+    return;
+  }
   if (tid < NBETA) {
     const double s = first ? 1.0 / (1.0 + sqrt(sC[tid * NBETA + tid])) : W.scale[(size_t)F * NP + tid];
     if (first) W.scale[(size_t)F * NP + tid] = s;
@@ -147,15 +161,20 @@ __global__ __launch_bounds__(256) void k_win_beta(WinProblem P, WinBuf W, const 
 }
 
 // ---- per frame: complete the normal-equation block (priors, temporal), scale, damp, write the CR operands ---------------
+// Shards of a window (bodyfit_solve_sharded): x_left = parameters of the frame in front of the shard's first one (null: none),
+// P.halo: a temporal pair leaves the shard behind its last frame (its residual rows are this shard's), scale_halo = Jacobi
+// scaling of that next frame (null on the first pass of the first iteration, which only produces this shard's scaling).
 __global__ __launch_bounds__(256) void k_win_assemble(WinProblem P, WinBuf W, const double* __restrict__ Hpan,
                                                       const double* __restrict__ r, const double* __restrict__ x,
-                                                      const unsigned char* __restrict__ constant, int first) {
+                                                      const unsigned char* __restrict__ constant, int first,
+                                                      const double* __restrict__ x_left, const double* __restrict__ scale_halo) {
   __shared__ double sA[NP * (NP + 1)];
   __shared__ double sg[NP], ss[NP], ssn[NP], red[4];
   const int f = blockIdx.x, tid = threadIdx.x, F = P.F;
   const double* H = Hpan + (size_t)f * kHRows * kHLd;
   const double lam2 = P.lambda_t * P.lambda_t, bp2 = P.beta_pose * P.beta_pose;
-  const int npairs = (P.lambda_t > 0.0) ? ((f + 1 < F) + (f > 0)) : 0;
+  const bool pair_right = f + 1 < F || P.halo, pair_left = f > 0 || x_left != nullptr;
+  const int npairs = (P.lambda_t > 0.0) ? ((int)pair_right + (int)pair_left) : 0;
   for (int e = tid; e < NP * NP; e += 256) {
     const int i = e / NP, j = e % NP, lo = i > j ? i : j, hi = i > j ? j : i;
     double v = H[(size_t)lo * kHLd + hi];
@@ -170,8 +189,9 @@ __global__ __launch_bounds__(256) void k_win_assemble(WinProblem P, WinBuf W, co
     if (tid >= 7 && P.prior_rows > 0) g += P.beta_pose * r[P.row_prior + (size_t)f * P.prior_rows + tid - 7];
     if (tid >= 1 && P.lambda_t > 0.0) {
       const int ti = temporal_row_of(tid);
-      if (f + 1 < F) g += P.lambda_t * r[P.row_temporal + (size_t)f * 75 + ti];
+      if (pair_right) g += P.lambda_t * r[P.row_temporal + (size_t)f * 75 + ti];
       if (f > 0) g -= P.lambda_t * r[P.row_temporal + (size_t)(f - 1) * 75 + ti];
+      else if (x_left) g -= P.lambda_t * (P.lambda_t * (x_left[tid] - x[tid]));   // the previous shard's last pair
     }
     sg[tid] = g;
   }
@@ -184,16 +204,17 @@ __global__ __launch_bounds__(256) void k_win_assemble(WinProblem P, WinBuf W, co
       if (f + 1 < F) {   // the next frame's scale, from its diagonal entry alone (its workgroup may not have run yet)
         double dn = Hpan[(size_t)(f + 1) * kHRows * kHLd + (size_t)tid * kHLd + tid];
         if (tid >= 7 && P.prior_rows > 0) dn += bp2;
-        if (tid >= 1 && P.lambda_t > 0.0) dn += lam2 * (1 + (f + 2 < F));
+        if (tid >= 1 && P.lambda_t > 0.0) dn += lam2 * (1 + (int)(f + 2 < F || P.halo));
         sn = 1.0 / (1.0 + sqrt(dn));
       }
     } else {
       s = W.scale[(size_t)f * NP + tid];
       if (f + 1 < F) sn = W.scale[(size_t)(f + 1) * NP + tid];
     }
+    if (f + 1 == F && P.halo && scale_halo) sn = scale_halo[tid];
     ss[tid] = s; ssn[tid] = sn;
     W.graw[(size_t)f * NP + tid] = sg[tid];
-    W.Eraw[(size_t)f * NP + tid] = (tid >= 1 && f + 1 < F && P.lambda_t > 0.0) ? -lam2 : 0.0;
+    W.Eraw[(size_t)f * NP + tid] = (tid >= 1 && pair_right && P.lambda_t > 0.0) ? -lam2 : 0.0;
   }
   __syncthreads();
   const double inv_radius = 1.0 / W.status[kWsRadius];
@@ -208,7 +229,7 @@ __global__ __launch_bounds__(256) void k_win_assemble(WinProblem P, WinBuf W, co
         v = sA[i * (NP + 1) + j] * ss[i] * ss[j];
         if (i == j) {
           v += fmin(fmax(v, 1e-6), 1e32) * inv_radius;
-          if (i >= 1 && f + 1 < F && P.lambda_t > 0.0) u = -lam2 * ss[i] * ssn[i];
+          if (i >= 1 && pair_right && P.lambda_t > 0.0) u = -lam2 * ss[i] * ssn[i];
         }
       }
     }
@@ -576,16 +597,21 @@ __global__ __launch_bounds__(128) void k_win_schur_part(WinProblem P, WinBuf W) 
   }
 }
 
+// mode 0: all; 1: this shard's sums of the Schur partials -> W.sred[110] only; 2: solve from W.sred (summed over the shards)
 __global__ __launch_bounds__(128) void k_win_beta_solve(WinProblem P, WinBuf W, const double* __restrict__ beta,
-                                                        double* __restrict__ beta_new) {
+                                                        double* __restrict__ beta_new, int mode) {
   __shared__ double S[NBETA * NBETA], rb[NBETA];
   const int tid = threadIdx.x, F = P.F;
   if (P.nb == 0) return;
   if (tid < NBETA * NBETA + NBETA) {
     double s = 0.0;
-    for (int f = 0; f < F; ++f) s += W.part[(size_t)f * kWinPart + tid];
+    if (mode == 2) s = W.sred[tid];
+    else
+      for (int f = 0; f < F; ++f) s += W.part[(size_t)f * kWinPart + tid];
+    if (mode == 1) W.sred[tid] = s;
     if (tid < NBETA * NBETA) S[tid] = W.Cs[tid] - s; else rb[tid - NBETA * NBETA] = W.rhsb[tid - NBETA * NBETA] - s;
   }
+  if (mode == 1) return;
   __syncthreads();
   if (tid == 0) {
     bool ok = true;
@@ -645,12 +671,13 @@ __global__ __launch_bounds__(128) void k_win_step(WinProblem P, WinBuf W, const 
 }
 
 // ---- model cost change  -d^T g - 1/2 d^T H d  with the undamped, unscaled system: per-frame partials --------------------
-__global__ __launch_bounds__(128) void k_win_model(WinProblem P, WinBuf W, const double* __restrict__ x) {
+__global__ __launch_bounds__(128) void k_win_model(WinProblem P, WinBuf W, const double* __restrict__ x,
+                                                   const double* __restrict__ d_halo) {
   __shared__ double sd[NP], sdn[NP], sdb[NBETA], red[2];
   const int f = blockIdx.x, tid = threadIdx.x, F = P.F;
   if (tid < NP) {
     sd[tid] = W.d[(size_t)f * NP + tid];
-    sdn[tid] = (f + 1 < F) ? W.d[(size_t)(f + 1) * NP + tid] : 0.0;
+    sdn[tid] = (f + 1 < F) ? W.d[(size_t)(f + 1) * NP + tid] : ((P.halo && d_halo) ? d_halo[tid] : 0.0);
   }
   if (tid < NBETA) sdb[tid] = (tid < P.nb) ? W.d[(size_t)F * NP + tid] : 0.0;
   __syncthreads();
@@ -676,22 +703,34 @@ __global__ __launch_bounds__(128) void k_win_model(WinProblem P, WinBuf W, const
 }
 
 // ---- decide: gradient tolerance, failed factorisation, parameter tolerance, or a candidate --------------------------------
+// mode 0: all; 1: this shard's sums -> W.fin[0..3] = {model, |d|^2, |x|^2, max |g_frames|}, W.fin[4] = fail flag, only;
+// 2: decide from W.fin (the first three summed, the last two maximised over the shards)
 __global__ __launch_bounds__(256) void k_win_finish(WinProblem P, WinBuf W, const double* __restrict__ x,
                                                     const double* __restrict__ beta, double* __restrict__ x_new,
-                                                    double* __restrict__ beta_new) {
+                                                    double* __restrict__ beta_new, int mode) {
   __shared__ double red[4];
   const int tid = threadIdx.x, F = P.F;
   double pm = 0.0, dn = 0.0, xn = 0.0, gm = 0.0;
-  for (int f = tid; f < F; f += 256) {
-    const double* o = W.part + (size_t)f * kWinPart + 112;
-    pm += o[0]; dn += o[1]; xn += o[2];
-    gm = fmax(gm, W.gmaxp[f]);
+  if (mode != 2) {
+    for (int f = tid; f < F; f += 256) {
+      const double* o = W.part + (size_t)f * kWinPart + 112;
+      pm += o[0]; dn += o[1]; xn += o[2];
+      gm = fmax(gm, W.gmaxp[f]);
+    }
+    pm = block_sum_n(pm, red, tid, 4);
+    dn = block_sum_n(dn, red, tid, 4);
+    xn = block_sum_n(xn, red, tid, 4);
+    gm = block_max_n(gm, red, tid, 4);
+    if (mode == 1) {
+      if (tid == 0) { W.fin[0] = pm; W.fin[1] = dn; W.fin[2] = xn; W.fin[3] = gm; W.fin[4] = *W.fail ? 1.0 : 0.0; }
+      return;
+    }
+  } else {
+    pm = W.fin[0]; dn = W.fin[1]; xn = W.fin[2]; gm = W.fin[3];
+    if (tid == 0 && W.fin[4] != 0.0) *W.fail = 1;
   }
   if (tid == 0) gm = fmax(gm, W.gmaxp[F]);
-  pm = block_sum_n(pm, red, tid, 4);
-  dn = block_sum_n(dn, red, tid, 4);
-  xn = block_sum_n(xn, red, tid, 4);
-  gm = block_max_n(gm, red, tid, 4);
+  __syncthreads();
   __shared__ int no_cand;
   if (tid == 0) {
     double* st = W.status;
@@ -731,15 +770,22 @@ __global__ __launch_bounds__(256) void k_win_finish(WinProblem P, WinBuf W, cons
 }
 
 // ---- accept / reject the candidate (Ceres' step quality and radius rules, host_solver.cpp) ------------------------------
+// mode 0: all; 1: this shard's cost at the candidate -> W.fin[0] only; 2: decide with W.fin[0] (summed over the shards)
 __global__ __launch_bounds__(1024) void k_win_accept(WinProblem P, WinBuf W, const double* __restrict__ r_new,
                                                      double* __restrict__ x, double* __restrict__ beta,
-                                                     const double* __restrict__ x_new, const double* __restrict__ beta_new) {
+                                                     const double* __restrict__ x_new, const double* __restrict__ beta_new,
+                                                     int mode) {
   __shared__ double red[16];
   __shared__ int acc_flag;
   const int tid = threadIdx.x;
   double* st = W.status;
+  if (mode == 1) {
+    const double c = window_cost(P, r_new, red, tid, 1024);
+    if (tid == 0) W.fin[0] = c;
+    return;
+  }
   if (st[kWsHasCand] == 0.0) return;
-  const double new_cost = window_cost(P, r_new, red, tid, 1024);
+  const double new_cost = (mode == 2) ? W.fin[0] : window_cost(P, r_new, red, tid, 1024);
   if (tid == 0) {
     const double cost = st[kWsCost], model = st[kWsModel];
     const double change = cost - new_cost, rho = change / model;
@@ -775,13 +821,18 @@ size_t win_factor_lds_bytes() { return (size_t)(kCrRowsMax * LD + WB + 8) * size
 size_t win_update_lds_bytes() { return (size_t)(2 * WB * LD + WR * LD) * sizeof(double); }
 size_t win_back_lds_bytes() { return (size_t)(WB * LD + 3 * WR * LD + 5 * 16 * 17) * sizeof(double); }
 
-void launch_win_init(const WinProblem& P, const WinBuf& W, const double* d_r, hipStream_t s) {
-  hipLaunchKernelGGL(k_win_init, dim3(1), dim3(1024), 0, s, P, W, d_r);
+void launch_win_init(const WinProblem& P, const WinBuf& W, const double* d_r, int mode, hipStream_t s) {
+  hipLaunchKernelGGL(k_win_init, dim3(1), dim3(1024), 0, s, P, W, d_r, mode);
+}
+void launch_win_beta(const WinProblem& P, const WinBuf& W, const double* d_Hpan, const double* d_r, int first, int mode,
+                     hipStream_t s) {
+  hipLaunchKernelGGL(k_win_beta, dim3(1), dim3(256), 0, s, P, W, d_Hpan, d_r, first, mode);
 }
 void launch_win_assemble(const WinProblem& P, const WinBuf& W, const double* d_Hpan, const double* d_r, const double* d_x,
-                         const unsigned char* d_constant, int first, hipStream_t s) {
-  hipLaunchKernelGGL(k_win_beta, dim3(1), dim3(256), 0, s, P, W, d_Hpan, d_r, first);
-  hipLaunchKernelGGL(k_win_assemble, dim3(P.F), dim3(256), 0, s, P, W, d_Hpan, d_r, d_x, d_constant, first);
+                         const unsigned char* d_constant, int first, const double* d_x_left, const double* d_scale_halo,
+                         hipStream_t s) {
+  hipLaunchKernelGGL(k_win_assemble, dim3(P.F), dim3(256), 0, s, P, W, d_Hpan, d_r, d_x, d_constant, first, d_x_left,
+                     d_scale_halo);
 }
 void launch_cr_factor(const WinBuf& W, const int* d_elim, int n_elim, hipStream_t s) {
   static bool attr = false;
@@ -802,17 +853,25 @@ void launch_cr_update(const WinBuf& W, const int* d_surv, int n_surv, hipStream_
 void launch_cr_back(const WinBuf& W, const int* d_elim, int n_elim, hipStream_t s) {
   if (n_elim > 0) hipLaunchKernelGGL(k_cr_back, dim3(n_elim), dim3(kCrThreads), win_back_lds_bytes(), s, W, d_elim, n_elim);
 }
-void launch_win_step(const WinProblem& P, const WinBuf& W, const double* d_x, const double* d_beta, double* d_x_new,
-                     double* d_beta_new, hipStream_t s) {
+void launch_win_schur_part(const WinProblem& P, const WinBuf& W, hipStream_t s) {
   hipLaunchKernelGGL(k_win_schur_part, dim3(P.F), dim3(128), 0, s, P, W);
-  hipLaunchKernelGGL(k_win_beta_solve, dim3(1), dim3(128), 0, s, P, W, d_beta, d_beta_new);
+}
+void launch_win_beta_solve(const WinProblem& P, const WinBuf& W, const double* d_beta, double* d_beta_new, int mode, hipStream_t s) {
+  hipLaunchKernelGGL(k_win_beta_solve, dim3(1), dim3(128), 0, s, P, W, d_beta, d_beta_new, mode);
+}
+void launch_win_step(const WinProblem& P, const WinBuf& W, const double* d_x, double* d_x_new, hipStream_t s) {
   hipLaunchKernelGGL(k_win_step, dim3(P.F), dim3(128), 0, s, P, W, d_x, d_x_new);
-  hipLaunchKernelGGL(k_win_model, dim3(P.F), dim3(128), 0, s, P, W, d_x);
-  hipLaunchKernelGGL(k_win_finish, dim3(1), dim3(256), 0, s, P, W, d_x, d_beta, d_x_new, d_beta_new);
+}
+void launch_win_model(const WinProblem& P, const WinBuf& W, const double* d_x, const double* d_halo_step, hipStream_t s) {
+  hipLaunchKernelGGL(k_win_model, dim3(P.F), dim3(128), 0, s, P, W, d_x, d_halo_step);
+}
+void launch_win_finish(const WinProblem& P, const WinBuf& W, const double* d_x, const double* d_beta, double* d_x_new,
+                       double* d_beta_new, int mode, hipStream_t s) {
+  hipLaunchKernelGGL(k_win_finish, dim3(1), dim3(256), 0, s, P, W, d_x, d_beta, d_x_new, d_beta_new, mode);
 }
 void launch_win_accept(const WinProblem& P, const WinBuf& W, const double* d_r_new, double* d_x, double* d_beta,
-                       const double* d_x_new, const double* d_beta_new, hipStream_t s) {
-  hipLaunchKernelGGL(k_win_accept, dim3(1), dim3(1024), 0, s, P, W, d_r_new, d_x, d_beta, d_x_new, d_beta_new);
+                       const double* d_x_new, const double* d_beta_new, int mode, hipStream_t s) {
+  hipLaunchKernelGGL(k_win_accept, dim3(1), dim3(1024), 0, s, P, W, d_r_new, d_x, d_beta, d_x_new, d_beta_new, mode);
 }
 
 }  // namespace bodyfit

@@ -19,7 +19,7 @@ int bodyfit_internal_solve_batched_device(bodyfit_problem* p, double* frame_para
 /* Device-resident LM for one shared-beta window (k_window_lm.hip). */
 int bodyfit_internal_solve_window_device(bodyfit_problem* p, double* frame_params, double* beta,
                                          const unsigned char* param_constant, const bodyfit_fit_options* opt,
-                                         bodyfit_fit_summary* summary);
+                                         bodyfit_fit_summary* summary, const bodyfit_comm* comm /* NULL: one GPU */);
 /* Window solver: evaluate at (frame_params, beta) and return the residual vector, the GMM components and, per frame,
  * the reprojection part of the normal equations built on the device (k_frame_normal): H [F][87][88], lower triangle of
  * J^T rho' J over the frame's n columns, gradient J^T rho' r in row n.  Needs <= 32 keypoints per frame. */

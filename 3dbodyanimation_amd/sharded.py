@@ -117,3 +117,65 @@ class HipLocal:
         self.prob.reduce_shared_device(self.buf.data_ptr(), stream)
         torch.cuda.current_stream(self.device).synchronize()
         return self.buf
+
+
+class TorchComm:
+    """bodyfit_comm over torch.distributed for bodyfit_solve_sharded (include/bodyfit.h): the two collectives the sharded LM
+    needs, on small host buffers.  backend "gloo": CPU tensors as they are; backend "nccl" (= RCCL over xGMI): through a
+    device staging tensor, since RCCL reduces device memory."""
+
+    def __init__(self, api, dist, rank: int, world: int, device=None):
+        import ctypes as C
+        import torch
+        self.dist, self.rank, self.world, self.device = dist, rank, world, device
+
+        def _tensor(ptr, n):
+            a = np.ctypeslib.as_array(ptr, shape=(n,))
+            return a, torch.from_numpy(a)
+
+        def allreduce(ctx, buf, n, op):
+            try:
+                a, t = _tensor(buf, n)
+                rop = dist.ReduceOp.SUM if op == 0 else dist.ReduceOp.MAX
+                if self.device is not None:
+                    g = t.to(self.device)
+                    dist.all_reduce(g, op=rop)
+                    t.copy_(g.cpu())
+                else:
+                    dist.all_reduce(t, op=rop)
+                return 0
+            except Exception:   # never raise through the C ABI
+                return 1
+
+        def allgather(ctx, send, recv, n):
+            try:
+                _, ts = _tensor(send, n)
+                _, tr = _tensor(recv, n * world)
+                if self.device is not None:
+                    out = torch.empty(n * world, dtype=torch.float64, device=self.device)
+                    dist.all_gather_into_tensor(out, ts.to(self.device))
+                    tr.copy_(out.cpu())
+                else:
+                    parts = [torch.empty(n, dtype=torch.float64) for _ in range(world)]
+                    dist.all_gather(parts, ts.clone())
+                    tr.copy_(torch.cat(parts))
+                return 0
+            except Exception:
+                return 1
+
+        self._cbs = (api._ALLREDUCE_CB(allreduce), api._ALLGATHER_CB(allgather))   # keep the thunks alive
+        self.c = api.Comm(rank, world, None, self._cbs[0], self._cbs[1])
+
+
+def solve_window_sharded(api, gpu_model, seq, n_frames, dist, rank, world, init_params, beta0, beta_pose=5.0, beta_shape=25.0,
+                         lambda_temporal=3.0, max_iters=100, device=None, constant=None):
+    """One window of `n_frames` frames fitted by `world` ranks (one process per GPU): every rank builds the problem of its
+    shard and calls bodyfit_solve_sharded.  Returns (x_local [f0:f1], beta, summary, shard)."""
+    shard = make_shard(n_frames, world, rank)
+    sl = slice_sequence(seq, shard)
+    prob = api.Problem(gpu_model, sl["kp_offset"], sl["kp_id"], sl["kp_uv"], sl["intr"], sl["R0"], n_cols=86, use_shape=True,
+                       beta_pose=beta_pose, beta_shape=beta_shape if shard.owns_shape_prior else 0.0,
+                       lambda_temporal=lambda_temporal, temporal_halo=shard.halo)
+    comm = TorchComm(api, dist, rank, world, device=device)
+    x, b, summ = prob.solve_sharded(local_params(init_params, shard), beta0, comm.c, constant=constant, max_iters=max_iters)
+    return x, b, summ, shard

@@ -233,6 +233,26 @@ int bodyfit_solve(bodyfit_problem* p, double* frame_params, double* beta, const 
                   int independent_frames, const bodyfit_fit_options* options, bodyfit_fit_summary* summaries,
                   int n_summaries);
 
+/* ---- one window sharded over several GPUs (frames = the data-parallel axis of OptimizeMultiFrame) -----------
+ * One process per GPU.  Rank r creates a bodyfit_problem over ITS contiguous frames (temporal_halo = 1 on every rank but
+ * the last: the temporal pair that leaves the shard is evaluated by the shard it leaves; beta_shape > 0 on exactly one
+ * rank) and calls bodyfit_solve_sharded with a communicator.  The LM state is replicated by construction (every rank
+ * takes the same decisions from the same reduced scalars); the linear solve is substructured: cyclic reduction of the
+ * local chain down to its two end frames, an all-gather of those 2 N interface blocks, the interface system solved by
+ * every rank, local back-substitution.  The shared-shape terms [H_bb, g_beta] cross the ranks ONCE per LM iteration.
+ * The communicator works on HOST buffers (the payloads are small: <= 225 KB per rank and iteration); with
+ * torch.distributed that is gloo on CPU tensors or RCCL ("nccl") through a device staging tensor
+ * (3dbodyanimation_amd/sharded.py: TorchComm).  Both callbacks return 0 on success.
+ *   frame_params [F_local (+1 halo row)][76] in/out: the halo row is refreshed from the neighbour by the solve. */
+typedef struct bodyfit_comm {
+  int rank, size;
+  void* ctx;
+  int (*allreduce)(void* ctx, double* buf, int n, int op /* 0 sum, 1 max */);            /* in place, every rank gets the result */
+  int (*allgather)(void* ctx, const double* send, double* recv /* [size][n] */, int n);
+} bodyfit_comm;
+int bodyfit_solve_sharded(bodyfit_problem* p, double* frame_params, double* beta, const unsigned char* param_constant,
+                          const bodyfit_comm* comm, const bodyfit_fit_options* options, bodyfit_fit_summary* summary);
+
 /* Normal equations of the reprojection blocks, built on the device (window solvers: bodyfit_solve's host loop,
  * 3dbodyanimation_amd/sharded_lm.py): evaluate at (frame_params, beta) and return the residual vector [total_rows], the
  * GMM components [F] (may be NULL) and, per frame, the lower triangle of J^T rho' J over its n_cols columns with the

@@ -1,0 +1,56 @@
+"""bodyfit_solve_sharded (C ABI): one window fitted by several ranks, one bodyfit_problem per shard, collectives through a
+bodyfit_comm (torch.distributed, gloo).  The ranks share the box's one GPU here; on a node every rank has its own.  The
+result must be the unsharded device window LM's (same iterates up to rounding: the elimination order differs)."""
+import importlib
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, F, iters, out_path):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    api = importlib.import_module("3dbodyanimation_amd.api")
+    synth = importlib.import_module("3dbodyanimation_amd.synth")
+    sharded = importlib.import_module("3dbodyanimation_amd.sharded")
+    model = synth.make_model(0)
+    seq = synth.make_sequence(model, F, seed=6)
+    gm = api.Model(model, device=0)
+    x, b, summ, shard = sharded.solve_window_sharded(api, gm, seq, F, dist, rank, world, seq.init_params, np.zeros(10),
+                                                     max_iters=iters)
+    parts = [None] * world
+    dist.all_gather_object(parts, (shard.f0, shard.f1, x, b, summ.iterations, summ.n_successful, summ.final_cost,
+                                   summ.initial_cost))
+    if rank == 0:
+        xs = np.concatenate([p[2] for p in sorted(parts)], axis=0)
+        # every rank holds the same beta and took the same decisions
+        for p in parts:
+            assert np.array_equal(p[3], parts[0][3]) and p[4:] == parts[0][4:]
+        prob = api.Problem.from_sequence(gm, seq, n_cols=86, use_shape=True, beta_pose=5.0, beta_shape=25.0, lambda_temporal=3.0)
+        x2, b2, s2 = prob.solve(seq.init_params, np.zeros(10), independent=False, max_iters=iters,
+                                scale_bounds=(-1e300, 1e300), solver=3)
+        np.savez(out_path, x=xs, b=parts[0][3], it=parts[0][4], ok=parts[0][5], cost=parts[0][6], c0=parts[0][7],
+                 x2=x2, b2=b2, it2=s2[0].iterations, ok2=s2[0].n_successful, cost2=s2[0].final_cost, c02=s2[0].initial_cost)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,F,iters", [(2, 9, 12), (3, 14, 12), (2, 40, 8)])
+def test_sharded_solve_equals_unsharded(tmp_path, world, F, iters):
+    out = str(tmp_path / "res.npz")
+    port = 29700 + (os.getpid() % 1500) + world * 11 + F
+    mp.spawn(_worker, args=(world, port, F, iters, out), nprocs=world, join=True)
+    g = np.load(out)
+    assert (int(g["it"]), int(g["ok"])) == (int(g["it2"]), int(g["ok2"]))
+    assert abs(float(g["c0"]) - float(g["c02"])) <= 1e-12 * float(g["c02"])
+    assert abs(float(g["cost"]) - float(g["cost2"])) <= 1e-9 * float(g["cost2"])
+    assert np.abs(g["x"][:, 1:] - g["x2"][:, 1:]).max() < 1e-7 and np.abs(g["b"] - g["b2"]).max() < 1e-7
