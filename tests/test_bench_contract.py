@@ -51,3 +51,22 @@ def test_bench_two_ranks_rehearsal(workload, scaling):
     assert out.returncode == 0, out.stderr[-2000:]
     d = _last_json(out.stdout)
     assert d["n_gpus"] == 2 and d["scaling"] == scaling and d["value"] > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [1, 2])
+def test_bench_c5_fit_line(world):
+    """--workload c5 --fit: a step is one complete fit of the window; N = 2 rehearsed with both ranks on cuda:0 over gloo."""
+    env = dict(os.environ, BENCH_SHARE_DEVICE0="1", BENCH_BACKEND="gloo")
+    base = ["bench.py", "--gpus", str(world), "--workload", "c5", "--fit", "--window", "64", "--steps", "2", "--warmup", "1"]
+    if world == 1:
+        cmd = [sys.executable] + base
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr",
+               "127.0.0.1", "--master-port", "29547"] + base
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = _last_json(out.stdout)
+    assert KEYS <= set(d)
+    assert d["n_gpus"] == world and d["scaling"] == "strong" and d["unit"] == "frames/s" and d["value"] > 0
+    assert d["fit"]["termination"] == 0 and d["fit"]["final_cost"] < 0.05 * d["fit"]["initial_cost"]
