@@ -418,8 +418,11 @@ __device__ __forceinline__ void frame_part(const DevModel& M, const DevProblem& 
       for (int a = 0; a < 3; ++a) sLm[l * LM_STRIDE + LM_VP + a] = sPart[l * 3 + a] + part[a];
     }
   };
+  // (waves whose two landmark slots are both beyond nL skip the loads and the 108 products per lane altogether: with 11
+  //  landmarks that is waves 6-7, which carry the chain walks, this phase's longest items)
+  const bool lm_wave0 = 2 * wave < nL, lm_wave1 = 2 * wave + 16 < nL;
   double pdv0[27];
-  lm_load(lm_l, pdv0);
+  if (lm_wave0) lm_load(lm_l, pdv0);
   for (int i = tid; i < 208; i += kThreads) {
     double v = 0.0;
     if (i < 9 * (nJ - 1)) v = sR[9 + i] - (((i % 9) % 4 == 0) ? 1.0 : 0.0);
@@ -466,8 +469,8 @@ __device__ __forceinline__ void frame_part(const DevModel& M, const DevProblem& 
     if (tid >= 16 && tid < 19) sP[tid - 16] = 0.0;
     if (tid >= 32 && tid - 32 < 3 * nS) { sB[tid - 32] = 0.0; sT[tid - 32] = 0.0; }
   }
-  lm_terms(lm_l, pdv0);
-  if (nL > 16) {   // landmarks 16..31: second pass
+  if (lm_wave0) lm_terms(lm_l, pdv0);
+  if (lm_wave1) {   // landmarks 16..31: second pass
     double pdv1[27];
     lm_load(lm_l + 16, pdv1);
     lm_terms(lm_l + 16, pdv1);
