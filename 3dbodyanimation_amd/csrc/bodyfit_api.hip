@@ -1259,10 +1259,18 @@ int bodyfit_internal_solve_window_device(bodyfit_problem* p, double* frame_param
       if ((rc = allreduce_dev(W.fin, 1, 0))) return rc;
       launch_win_accept(P, W, d_rn, d_x, d_b, d_xn, d_bn, 2, st);
     }
+    first = false;
+    if (!sharded && !opt->verbose && (it & 3) != 3 && it + 1 < opt->max_iters) {
+      // One GPU: the device takes every decision itself, so the host only looks at the status record every fourth
+      // iteration (a read-back drains the launch pipeline: ~30 us of a ~450 us iteration at 20 frames).  The Jacobian sweep
+      // is then issued unconditionally (after a rejected step it recomputes the same normals), and iterations launched
+      // after the solve has terminated leave the state untouched (every kernel checks the active / candidate flags).
+      need_jac = true;
+      continue;
+    }
     HIP_TRY(hipMemcpyAsync(status, W.status, sizeof(status), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
-    first = false;
-    need_jac = status[kWsAccepted] != 0.0;
+    need_jac = sharded ? status[kWsAccepted] != 0.0 : true;
     if (sharded && need_jac) {   // the accepted point's boundary rows become the current ones
       if (halo) HIP_TRY(hipMemcpyAsync(d_x + (size_t)F * npose, d_xn + (size_t)F * npose, npose * sizeof(double), hipMemcpyDeviceToDevice, st));
       if (has_left) { x_left = x_left_new; HIP_TRY(hipMemcpyAsync(d_xl, x_left.data(), npose * sizeof(double), hipMemcpyHostToDevice, st)); }

@@ -14,6 +14,7 @@
 // Algorithm = host_solver.cpp's (Ceres 1.14 defaults); the host only launches
 // {sweep, step, residual sweep, accept} per iteration and polls the active-frame counter now and then.
 #include "bodyfit_device.h"
+#include "dense_inl.h"
 
 namespace bodyfit {
 #ifdef BODYFIT_STAMPS
@@ -334,39 +335,26 @@ __global__ __launch_bounds__(kStepThreads) void k_lm_step(LmProblem P, LmState S
     const int c0 = 16 * p;
     unsigned long long ta0 = 0, ta1 = 0, ta2 = 0, ta3 = 0;
     LTIME(ta0);
-    // (a) diagonal block in registers of wave 0: lane r holds row r; column values travel by v_readlane
+    // (a) diagonal block in registers of wave 0: lane r holds row r; column values travel by v_readlane (dense_inl.h:
+    //     the next pivot's reciprocal square root runs under the current pivot's updates)
     if (wave == 0) {
       const int rr = lane & 15;
-      double a[16];
+      double a[16], iv[16];
 #pragma unroll
       for (int k = 0; k < 16; ++k) a[k] = M[(c0 + rr) * kMLd + c0 + k];
-      bool okp = true;
-#pragma unroll
-      for (int c = 0; c < 16; ++c) {
-        if (c0 + c >= n) continue;                    // identity padding: nothing to factor, nothing to update (uniform branch)
-        const double piv = readlane_f64(a[c], c);
-        if (!(piv > 0.0)) okp = false;
-        // 1 / sqrt(piv): hardware estimate + two Newton steps (full f64 precision for the normal range the damped,
-        // Jacobi-scaled pivots live in) instead of a software sqrt and a software division on the serial path
-        double inv = __builtin_amdgcn_rsq(piv);
-        inv = inv * (1.5 - 0.5 * piv * inv * inv);
-        inv = inv * (1.5 - 0.5 * piv * inv * inv);
-        const double rt = piv * inv;
-        if (lane == 0) invd[c0 + c] = inv;            // 1 / L_cc: the panel solve and the back substitution multiply
-        const double l = (rr == c) ? rt : a[c] * inv;
-        a[c] = l;
-#pragma unroll
-        for (int k = c + 1; k < 16; ++k) {
-          const double lk = readlane_f64(l, k);
-          if (rr >= k) a[k] -= l * lk;
-        }
-      }
+      // (identity padding beyond n: unit pivots, zero couplings: the factorisation passes through it unchanged)
+      const bool okp = diag_factor16(a, rr, true, iv);
       if (lane < 16) {
 #pragma unroll
         for (int k = 0; k < 16; ++k)
           if (k <= rr) M[(c0 + rr) * kMLd + c0 + k] = a[k];
       }
-      if (lane == 0 && !okp) red[8] = 0.0;
+      if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
+          if (c0 + k < n) invd[c0 + k] = iv[k];
+        if (!okp) red[8] = 0.0;
+      }
     }
     __syncthreads();
     LTIME(ta1);

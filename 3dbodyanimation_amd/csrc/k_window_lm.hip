@@ -17,6 +17,7 @@
 // Blocks are padded to 80 x 80 (identity on the padding), right-hand sides to 16 rows, all stored row-major; "t" buffers
 // hold transposes (Pt[i][k] = P[k][i]) so that every product is  C[i][i'] = sum_k X[i][k] Y[i'][k]  with k contiguous.
 #include "bodyfit_device.h"
+#include "dense_inl.h"
 
 namespace bodyfit {
 namespace {
@@ -33,12 +34,6 @@ __device__ inline double huber_rho_w(double delta, double s) {
   const double b = delta * delta;
   if (delta > 0.0 && s > b) return 2.0 * delta * sqrt(s) - b;
   return s;
-}
-__device__ inline double readlane_f64w(double v, int src) {
-  const long long b = __double_as_longlong(v);
-  const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), src);
-  const int hi = __builtin_amdgcn_readlane((int)(b >> 32), src);
-  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 __device__ inline double block_sum_n(double v, double* red, int tid, int nwaves) {
 #pragma unroll
@@ -312,56 +307,39 @@ __global__ __launch_bounds__(kCrThreads) void k_cr_factor(WinBuf W, const int* _
   if (tid == 0) stat[0] = 1.0;
   __syncthreads();
   constexpr int NPAN = WB / 16;   // 5
+  double* Linv = stat + 8;        // [16][17]: L_pp^-T of the current panel
   for (int p = 0; p < NPAN; ++p) {
     const int c0 = 16 * p;
-    if (wave == 0) {   // (a) diagonal block: lane r holds row r, columns travel by v_readlane
-      const int rr = lane & 15;
-      double av[16];
+    if (wave == 0) {   // (a) diagonal block + identity below it: lanes 0-15 rows of the block, lanes 16-31 rows of I
+      const int rr = lane & 15, grp = lane >> 4;
+      double av[16], iv[16];
 #pragma unroll
-      for (int k = 0; k < 16; ++k) av[k] = M[(c0 + rr) * LD + c0 + k];
-      bool okp = true;
-#pragma unroll
-      for (int c = 0; c < 16; ++c) {
-        const double piv = readlane_f64w(av[c], c);
-        if (!(piv > 0.0) || !(piv < 1e300)) okp = false;
-        double inv = __builtin_amdgcn_rsq(piv);
-        inv = inv * (1.5 - 0.5 * piv * inv * inv);
-        inv = inv * (1.5 - 0.5 * piv * inv * inv);
-        const double rt = piv * inv;
-        if (lane == 0) invd[c0 + c] = inv;
-        const double l = (rr == c) ? rt : av[c] * inv;
-        av[c] = l;
-#pragma unroll
-        for (int k = c + 1; k < 16; ++k) {
-          const double lk = readlane_f64w(l, k);
-          if (rr >= k) av[k] -= l * lk;
-        }
-      }
-      if (lane < 16) {
+      for (int k = 0; k < 16; ++k) av[k] = (grp == 1) ? (k == rr ? 1.0 : 0.0) : M[(c0 + rr) * LD + c0 + k];
+      const bool okp = diag_factor16(av, rr, grp != 1, iv);
+      if (grp == 0) {
 #pragma unroll
         for (int k = 0; k < 16; ++k)
           if (k <= rr) M[(c0 + rr) * LD + c0 + k] = av[k];
+      } else if (grp == 1) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) Linv[rr * 17 + k] = av[k];   // row rr of L_pp^-T
       }
       if (lane == 0 && !okp) stat[0] = 0.0;
     }
     __syncthreads();
-    // (b) panel solve: every row below the diagonal block (matrix rows and appended rows) x <- x L_pp^-T
+    // (b) panel solve on the matrix cores: every 16-row tile below the diagonal block  X = A L_pp^-T
     {
-      const int nbelow = nRows - (c0 + 16);
-      if (tid < nbelow) {
-        const int i = c0 + 16 + tid;
-        double xv[16];
+      const int m = lane & 15, kk = lane >> 4;
+      const int nRowTiles = nRows / 16;
+      for (int I = p + 1 + wave; I < nRowTiles; I += kCrWaves) {
+        double a4[4];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) xv[k] = M[i * LD + c0 + k];
+        for (int s4 = 0; s4 < 4; ++s4) a4[s4] = M[(16 * I + m) * LD + c0 + 4 * s4 + kk];
+        d4 acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int c = 0; c < 16; ++c) {
-          double v = xv[c];
+        for (int s4 = 0; s4 < 4; ++s4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a4[s4], Linv[(4 * s4 + kk) * 17 + m], acc, 0, 0, 0);
 #pragma unroll
-          for (int k = 0; k < c; ++k) v -= xv[k] * M[(c0 + c) * LD + c0 + k];
-          xv[c] = v * invd[c0 + c];
-        }
-#pragma unroll
-        for (int k = 0; k < 16; ++k) M[i * LD + c0 + k] = xv[k];
+        for (int q = 0; q < 4; ++q) M[(16 * I + kk + 4 * q) * LD + c0 + m] = acc[q];
       }
     }
     __syncthreads();
@@ -817,7 +795,7 @@ __global__ __launch_bounds__(1024) void k_win_accept(WinProblem P, WinBuf W, con
 
 }  // namespace
 
-size_t win_factor_lds_bytes() { return (size_t)(kCrRowsMax * LD + WB + 8) * sizeof(double); }
+size_t win_factor_lds_bytes() { return (size_t)(kCrRowsMax * LD + WB + 8 + 16 * 17) * sizeof(double); }
 size_t win_update_lds_bytes() { return (size_t)(2 * WB * LD + WR * LD) * sizeof(double); }
 size_t win_back_lds_bytes() { return (size_t)(WB * LD + 3 * WR * LD + 5 * 16 * 17) * sizeof(double); }
 
