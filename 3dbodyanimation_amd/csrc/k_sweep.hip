@@ -152,17 +152,6 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
   const unsigned char* dirs = reinterpret_cast<const unsigned char*>(A->M.dirsB) + (size_t)(has_tile ? b : 0) * kBBytes;
   const unsigned epoch = A->sy.epoch;
   const int test_skip = A->sy.test_skip;
-  {
-    // touch the whole argument block now (scalar cache), so the frame part's argument loads a call later are hits
-    typedef __attribute__((ext_vector_type(16))) unsigned int u32x16_;
-    constexpr int kChunks = (int)((sizeof(FusedArgs) + 63) / 64);
-#pragma unroll
-    for (int i = 0; i < kChunks - 1; ++i) {   // (the last, partial chunk is reached by the field loads above)
-      u32x16_ t = *reinterpret_cast<const __attribute__((address_space(4))) u32x16_*>(
-          reinterpret_cast<const __attribute__((address_space(4))) char*>(A) + i * 64);
-      asm volatile("" ::"s"(t));
-    }
-  }
   FSTAMP(0);
 
   // ---- frames: this workgroup's own first, then (only while the counter is short after a grace period) adopted ones ---
@@ -180,6 +169,9 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
     staged = true;
   }
   unsigned long long t_enter = 0;
+  uint32_t widx_pre = 0;
+  float4 wv_pre = float4{0.f, 0.f, 0.f, 0.f};
+  bool have_w = false;
   for (;;) {
     if (f >= 0) {
       // (a workgroup with a frame of its own stages its tile under it)
@@ -189,6 +181,12 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
       FSTAMP(1);
     }
     if (!has_tile) break;   // no mesh part: nothing to wait for (the prior tiles below ride on these workgroups)
+    if (!have_w) {          // the mesh part's per-lane constants: requested here, they arrive under the wait
+      const int col = lane & 31;
+      widx_pre = A->M.wIdx[(size_t)b * 32 + col];
+      wv_pre = reinterpret_cast<const float4*>(A->M.wVal)[(size_t)b * 32 + col];
+      have_w = true;
+    }
     // wait until every frame's mesh operands have been handed over; adopt an unclaimed frame after a grace period
     if (wave == 0) {
       // every lane polls four flags with one 16-byte sc1 load (256 flags per wave-instruction); lane 0 runs the adoption scan
@@ -257,7 +255,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
     const DevModel M = A4->M;
     const DevProblem Pb = A4->Pb;
     const MeshCoef mc = A4->mc;
-    mesh_part<true>(M, Pb, mc, A4->cloud_f, b, ldsB, lds + kBBytes);
+    mesh_part<true>(M, Pb, mc, A4->cloud_f, b, ldsB, lds + kBBytes, widx_pre, wv_pre);
   }
   FSTAMP(3);
 #endif

@@ -235,7 +235,8 @@ __device__ __forceinline__ void skin_step(const Lane& L, unsigned char* sSkin, i
 // inside the launch; the caller has waited for both (counter poll, workgroup barrier) before this is entered.
 template <bool kFused>
 __device__ __forceinline__ void mesh_part(const DevModel& M, const DevProblem& Pb, const MeshCoef& mc, float* __restrict__ cloud_f,
-                                          int vtile, unsigned char* sB, unsigned char* sSkinBase) {
+                                          int vtile, unsigned char* sB, unsigned char* sSkinBase, uint32_t widx_pre = 0,
+                                          float4 wv_pre = float4{0.f, 0.f, 0.f, 0.f}) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int col = lane & 31, h = lane >> 5;
   const int v = vtile * kVTile + col;
@@ -255,8 +256,9 @@ __device__ __forceinline__ void mesh_part(const DevModel& M, const DevProblem& P
   }
   Lane L;
   {
-    const uint32_t widx = M.wIdx[(size_t)vtile * 32 + col];
-    const float4 wv = reinterpret_cast<const float4*>(M.wVal)[(size_t)vtile * 32 + col];
+    // (fused sweep: the caller requested the lane's skinning weights before its wait for the hand-off)
+    const uint32_t widx = kFused ? widx_pre : M.wIdx[(size_t)vtile * 32 + col];
+    const float4 wv = kFused ? wv_pre : reinterpret_cast<const float4*>(M.wVal)[(size_t)vtile * 32 + col];
     const float wgt[4] = {wv.x, wv.y, wv.z, wv.w};
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
