@@ -20,7 +20,8 @@ __device__ __forceinline__ double readlane_f64w(double v, int src) {
 // Software-pipelined by hand: pivot c + 1 is final after the FIRST update of step c, so its broadcast and its reciprocal
 // square root (hardware estimate + two Newton steps: the long dependent chain of a step) are issued there and run under the
 // remaining updates of step c.  inv_out[c] (lane-uniform) = 1 / L_cc.
-__device__ __forceinline__ bool diag_factor16(double (&av)[16], int rr, bool own_rows, double (&inv_out)[16]) {
+// nvalid: pivots to process; the columns beyond are identity padding (unit pivots, zero couplings) and are passed through.
+__device__ __forceinline__ bool diag_factor16(double (&av)[16], int rr, bool own_rows, double (&inv_out)[16], int nvalid = 16) {
   auto rsq_nr = [](double piv) {
     double inv = __builtin_amdgcn_rsq(piv);
     inv = inv * (1.5 - 0.5 * piv * inv * inv);
@@ -31,6 +32,7 @@ __device__ __forceinline__ bool diag_factor16(double (&av)[16], int rr, bool own
   double inv = rsq_nr(piv);
 #pragma unroll
   for (int c = 0; c < 16; ++c) {
+    if (c >= nvalid) { inv_out[c] = 1.0; continue; }   // (uniform)
     if (!(piv > 0.0) || !(piv < 1e300)) okp = false;
     inv_out[c] = inv;
     const double l = (own_rows && rr == c) ? piv * inv : av[c] * inv;

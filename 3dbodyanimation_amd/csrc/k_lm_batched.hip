@@ -338,44 +338,48 @@ __global__ __launch_bounds__(kStepThreads) void k_lm_step(LmProblem P, LmState S
     // (a) diagonal block in registers of wave 0: lane r holds row r; column values travel by v_readlane (dense_inl.h:
     //     the next pivot's reciprocal square root runs under the current pivot's updates)
     if (wave == 0) {
-      const int rr = lane & 15;
+      // lanes 0-15: rows of the block; lanes 16-31: rows of the identity, which come out as L_pp^-T (kept in the unused
+      // strict upper triangle of the block, its diagonal 1 / L_cc in invd): the panel solve and the back substitution
+      // become products on the matrix cores
+      const int rr = lane & 15, grp = lane >> 4;
       double a[16], iv[16];
 #pragma unroll
-      for (int k = 0; k < 16; ++k) a[k] = M[(c0 + rr) * kMLd + c0 + k];
-      // (identity padding beyond n: unit pivots, zero couplings: the factorisation passes through it unchanged)
-      const bool okp = diag_factor16(a, rr, true, iv);
-      if (lane < 16) {
+      for (int k = 0; k < 16; ++k) a[k] = (grp == 1) ? (k == rr ? 1.0 : 0.0) : M[(c0 + rr) * kMLd + c0 + k];
+      const bool okp = diag_factor16(a, rr, grp != 1, iv, min(16, n - c0));
+      if (grp == 0) {
 #pragma unroll
         for (int k = 0; k < 16; ++k)
           if (k <= rr) M[(c0 + rr) * kMLd + c0 + k] = a[k];
+      } else if (grp == 1) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
+          if (k > rr) M[(c0 + rr) * kMLd + c0 + k] = a[k];
       }
       if (lane == 0) {
 #pragma unroll
-        for (int k = 0; k < 16; ++k)
-          if (c0 + k < n) invd[c0 + k] = iv[k];
+        for (int k = 0; k < 16; ++k) invd[c0 + k] = iv[k];
         if (!okp) red[8] = 0.0;
       }
     }
     __syncthreads();
     LTIME(ta1);
     if (red[8] == 0.0) break;
-    // (b) panel solve  X = A_below L_pp^{-T}: one row per thread (rows c0+16 .. npad incl. the rhs row)
+    // (b) panel solve  X = A_below L_pp^-T  on the matrix cores: 16-row tiles below the diagonal block incl. the rhs tile
     {
-      const int nbelow = npad - (c0 + 16) + 1;
-      if (tid < nbelow) {
-        const int i = c0 + 16 + tid;
-        double x[16];
+      const int m = lane & 15, kk = lane >> 4;
+      for (int I = p + 1 + wave; I <= NB; I += kStepWaves) {
+        double a4[4], b4[4];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) x[k] = M[i * kMLd + c0 + k];
-#pragma unroll
-        for (int c = 0; c < 16; ++c) {
-          double v = x[c];
-#pragma unroll
-          for (int k = 0; k < c; ++k) v -= x[k] * M[(c0 + c) * kMLd + c0 + k];
-          x[c] = v * invd[c0 + c];
+        for (int s4 = 0; s4 < 4; ++s4) {
+          const int k = 4 * s4 + kk;   // B[k][j = m] = (L^-T)[k][m]
+          a4[s4] = M[(16 * I + m) * kMLd + c0 + k];
+          b4[s4] = (k < m) ? M[(c0 + k) * kMLd + c0 + m] : (k == m ? invd[c0 + k] : 0.0);
         }
+        d4 acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int k = 0; k < 16; ++k) M[i * kMLd + c0 + k] = x[k];
+        for (int s4 = 0; s4 < 4; ++s4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a4[s4], b4[s4], acc, 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) M[(16 * I + kk + 4 * q) * kMLd + c0 + m] = acc[q];
       }
     }
     __syncthreads();
@@ -421,34 +425,35 @@ __global__ __launch_bounds__(kStepThreads) void k_lm_step(LmProblem P, LmState S
     return;
   }
   LSTAMP(5);
-  // ---- backward substitution ds = L^{-T} y by wave 0 alone: two unknowns per lane, x_j broadcast by v_readlane ----
+  // ---- backward substitution ds = L^-T y on the matrix cores, wave 0: in row form  X L = Z  with the rhs tile (rows npad ..,
+  //      row 0 = y) as Z, panel by panel from the last:  X_p = (Z_p - sum_{q > p} X_q L[q][p]) L_pp^-1  -----------------------
   if (wave == 0) {
-    double d0 = M[npad * kMLd + lane];
-    double d1 = (lane + 64 < npad) ? M[npad * kMLd + lane + 64] : 0.0;
-    // npad is a multiple of 16: four columns per pass, their factor rows and pivots are read before the dependent
-    // chain (fma -> readlane -> mul) starts, so LDS latency stays off it
-    for (int j4 = ((n + 3) & ~3) - 1; j4 >= 0; j4 -= 4) {   // padded unknowns stay 0 (zero right-hand side, unit pivots)
-      double ij[4], r0[4], r1[4];
+    const int m = lane & 15, kk = lane >> 4;
+    double* Z = M + npad * kMLd;
+    for (int p = NB - 1; p >= 0; --p) {
+      d4 acc;
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int j = j4 - u;
-        ij[u] = invd[j];
-        r0[u] = M[j * kMLd + lane];
-        r1[u] = (lane + 64 < npad) ? M[j * kMLd + lane + 64] : 0.0;
+      for (int q = 0; q < 4; ++q) acc[q] = Z[(kk + 4 * q) * kMLd + 16 * p + m];
+      for (int qp = p + 1; qp < NB; ++qp) {
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4)
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-Z[m * kMLd + 16 * qp + 4 * s4 + kk], M[(16 * qp + 4 * s4 + kk) * kMLd + 16 * p + m],
+                                                     acc, 0, 0, 0);
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int j = j4 - u;
-        const double dj = (j < 64) ? readlane_f64(d0, j) : readlane_f64(d1, j - 64);
-        const double xj = dj * ij[u];
-        if (lane < j) d0 -= r0[u] * xj;
-        if (lane == j) d0 = xj;
-        if (lane + 64 < j) d1 -= r1[u] * xj;
-        if (lane + 64 == j) d1 = xj;
+      for (int q = 0; q < 4; ++q) Z[(kk + 4 * q) * kMLd + 16 * p + m] = acc[q];
+      d4 xo = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+        const int k = 4 * s4 + kk;   // B[k][n = m] = (L_pp^-1)[k][m] = (L_pp^-T)[m][k]
+        const double li = (m < k) ? M[(16 * p + m) * kMLd + 16 * p + k] : (m == k ? invd[16 * p + k] : 0.0);
+        xo = __builtin_amdgcn_mfma_f64_16x16x4f64(Z[m * kMLd + 16 * p + k], li, xo, 0, 0, 0);
       }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) Z[(kk + 4 * q) * kMLd + 16 * p + m] = xo[q];
     }
-    ds[lane] = d0;
-    if (lane + 64 < npad) ds[lane + 64] = d1;
+    ds[lane] = Z[lane];
+    if (lane + 64 < npad) ds[lane + 64] = Z[lane + 64];
   }
   __syncthreads();
   LSTAMP(6);

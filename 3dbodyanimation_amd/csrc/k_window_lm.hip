@@ -315,7 +315,7 @@ __global__ __launch_bounds__(kCrThreads) void k_cr_factor(WinBuf W, const int* _
       double av[16], iv[16];
 #pragma unroll
       for (int k = 0; k < 16; ++k) av[k] = (grp == 1) ? (k == rr ? 1.0 : 0.0) : M[(c0 + rr) * LD + c0 + k];
-      const bool okp = diag_factor16(av, rr, grp != 1, iv);
+      const bool okp = diag_factor16(av, rr, grp != 1, iv, min(16, NP - c0));
       if (grp == 0) {
 #pragma unroll
         for (int k = 0; k < 16; ++k)
