@@ -368,7 +368,7 @@ def main():
             fit = {"unit": "frames/s", "c2": fit_bench.fit_c2(api, synth, model, gm),
                    "c3": fit_bench.fit_c3(api, synth, model, gm), "c4": fit_bench.fit_c4(api, synth, model, gm)}
             if not args.no_cpu_baseline:
-                fit["cpu_baseline"] = fit_bench.cpu_fit_baseline(synth, model)
+                fit["cpu_baseline"] = fit_bench.cpu_fit_baseline(synth, model, threads=os.cpu_count() or 0)
             out["fit"] = fit
         print(json.dumps(out))
     if world > 1:

@@ -121,18 +121,18 @@ def fit_c5(api, synth, model, gm, F=1024):
                 stage1_sweeps=res["stage1"].n_sweeps, mean_px_fk=float(px[F // 10 + 1:].mean()))
 
 
-def cpu_fit_baseline(synth, model, budget_s=20.0):
+def cpu_fit_baseline(synth, model, budget_s=20.0, threads=0):
     """The checker's own fits (oracle evaluator, reference-like stride-4 dual-number Jacobians, under the dense numpy LM
     of oracle/lm_dense.py) on a bounded sample of c2 / c3 / c4: one c2 frame, as many c3 frames as fit a third of the
     budget, and ONE 20-frame c4 window (60 iterations, beta locked)."""
     from oracle import lm_dense, oracle
     om = oracle.OracleModel(model)
-    nthr = oracle.max_threads()
+    nthr = threads or oracle.max_threads()
     out = {"kind": "port", "cores": nthr, "unit": "frames/s",
            "sample": "oracle evaluator (stride-4 dual-number Jacobian, OpenMP) under oracle/lm_dense.py (numpy dense LM)"}
     # c2
     seq = synth.make_sequence(model, 1, seed=0, beta_fixed=True)
-    om.evaluate_batch(seq, seq.init_params, np.zeros(10), 76, False, True, mode=1)   # start the OpenMP pool untimed
+    om.evaluate_batch(seq, seq.init_params, np.zeros(10), 76, False, True, mode=1, nthreads=nthr)   # start the OpenMP pool untimed, on all cores
     t0 = time.perf_counter()
     _, _, info = lm_dense.solve(om, seq, seq.init_params, None, n_cols=76, use_shape=False, beta_pose=20.0,
                                 constant=pose_only_constant(), max_iters=100, jac_mode=1)
