@@ -167,7 +167,7 @@ int fused_check(bodyfit_problem* p) {
 int sweep(bodyfit_problem* p, const double* d_params, const double* d_beta, int want_jac, bool mesh,
           hipStream_t st, hipEvent_t* ev = nullptr, double* r_base = nullptr, int* comp_out = nullptr,
           const int* frame_flags = nullptr, int frame_mask = 0, const double* R0_override = nullptr,
-          bool skip_priors = false) {
+          bool skip_priors = false, double* J_base = nullptr) {
   const bodyfit_model* m = p->m;
   DevProblem dp = p->d;
   if (R0_override) dp.R0 = R0_override;
@@ -177,6 +177,7 @@ int sweep(bodyfit_problem* p, const double* d_params, const double* d_beta, int 
   dp.frame_flags = frame_flags;
   dp.frame_mask = frame_mask;
   double* d_r = r_base ? r_base : p->d_r;
+  double* d_J = J_base ? J_base : p->d_J;
   int* d_comp = comp_out ? comp_out : p->d_comp;
   MeshCoef mc = p->mc;
   if (!mesh) mc = MeshCoef{};
@@ -211,10 +212,10 @@ int sweep(bodyfit_problem* p, const double* d_params, const double* d_beta, int 
     sy.epoch = ++p->fused_epoch;
     sy.test_skip = p->fused_test_skip;
     p->fused_unchecked = true;
-    launch_sweep_fused(m->d, dp, d_params, d_beta, d_r, want_jac ? p->d_J : nullptr, p->d_joints, mc, want_jac, pa,
+    launch_sweep_fused(m->d, dp, d_params, d_beta, d_r, want_jac ? d_J : nullptr, p->d_joints, mc, want_jac, pa,
                        p->d_cloud, sy, st, ev ? ev[4] : nullptr, ev ? ev[5] : nullptr);
   } else {
-    launch_frame_resjac(m->d, dp, d_params, d_beta, d_r, want_jac ? p->d_J : nullptr, p->d_joints, mc, want_jac,
+    launch_frame_resjac(m->d, dp, d_params, d_beta, d_r, want_jac ? d_J : nullptr, p->d_joints, mc, want_jac,
                         mesh ? none : pa, st, ev ? ev[0] : nullptr, ev ? ev[1] : nullptr);
     if (mesh) launch_mesh(m->d, p->d, p->mc, p->d_cloud, pa, d_params, st, ev ? ev[2] : nullptr, ev ? ev[3] : nullptr);
   }
@@ -867,6 +868,7 @@ int bodyfit_internal_solve_batched_device(bodyfit_problem* p, double* frame_para
   P.prec = p->has_gmm ? p->gmm.prec : nullptr; P.prec_cho = p->has_gmm ? p->gmm.prec_cho : nullptr;
   P.gmm_mean = p->has_gmm ? p->gmm.mean : nullptr; P.gmm_scale = p->has_gmm ? p->gmm.resid_scale : 0.0;
   double* d_r_new = nullptr;
+  double* d_J_new = nullptr;
   int* d_comp_new = nullptr;
   unsigned char* d_const = nullptr;
   {
@@ -880,7 +882,8 @@ int bodyfit_internal_solve_batched_device(bodyfit_problem* p, double* frame_para
                  o_cost = take((size_t)F * 8), o_ic = take((size_t)F * 8), o_model = take((size_t)F * 8),
                  o_scale = take((size_t)F * 86 * 8), o_flags = take((size_t)F * 4), o_iters = take((size_t)F * 4),
                  o_ok = take((size_t)F * 4), o_bad = take((size_t)F * 4), o_act = take(4),
-                 o_rn = take((size_t)std::max(1, p->lay.total_rows) * 8), o_cn = take((size_t)F * 4), o_const = take((size_t)npose);
+                 o_rn = take((size_t)std::max(1, p->lay.total_rows) * 8), o_cn = take((size_t)F * 4), o_const = take((size_t)npose),
+                 o_Jn = take((size_t)std::max(1, p->lay.reproj_rows) * p->lay.n_cols * 8);
     if (!p->lm_pool) HIP_TRY(p->mem.alloc(&p->lm_pool, off));
     unsigned char* B = p->lm_pool;
     S.x = reinterpret_cast<double*>(B + o_x); S.beta = reinterpret_cast<double*>(B + o_b);
@@ -892,6 +895,7 @@ int bodyfit_internal_solve_batched_device(bodyfit_problem* p, double* frame_para
     S.n_ok = reinterpret_cast<int*>(B + o_ok); S.n_bad = reinterpret_cast<int*>(B + o_bad);
     S.active_count = reinterpret_cast<int*>(B + o_act);
     d_r_new = reinterpret_cast<double*>(B + o_rn); d_comp_new = reinterpret_cast<int*>(B + o_cn);
+    d_J_new = reinterpret_cast<double*>(B + o_Jn);
     if (param_constant) d_const = B + o_const;
   }
   if (!p->lm_stream) HIP_TRY(hipStreamCreateWithFlags(&p->lm_stream, hipStreamNonBlocking));
@@ -905,8 +909,18 @@ int bodyfit_internal_solve_batched_device(bodyfit_problem* p, double* frame_para
   if (rc) return rc;
   launch_lm_init(P, S, p->d_r, st);
   int n_sweeps = 1;
+  // Speculative iteration (default): the sweep at the candidate also produces its Jacobian (into second buffers), and the
+  // next k_lm_step judges the candidate before it builds its system from whichever point won: two launches per iteration
+  // (step, sweep) instead of four (step, residual sweep, accept, Jacobian sweep).  A rejected candidate's Jacobian is
+  // wasted work that costs no time (the sweep is latency-bound).  BODYFIT_LM_PLAIN=1 keeps the four-launch form.
+  const bool plain = [] { const char* e = std::getenv("BODYFIT_LM_PLAIN"); return e && e[0] == '1'; }();
   auto iteration = [&](int first) -> int {
-    launch_lm_step(P, S, p->d_r, p->d_J, p->d_comp, d_const, first, st);
+    if (!plain) {
+      launch_lm_step(P, S, p->d_r, p->d_J, p->d_comp, d_r_new, d_J_new, d_comp_new, d_const, first, st);
+      return sweep(p, S.x_new, nb ? S.beta_new : nullptr, 1, false, st, nullptr, d_r_new, d_comp_new, S.flags, kLmHasCand,
+                   nullptr, false, d_J_new);
+    }
+    launch_lm_step(P, S, p->d_r, p->d_J, p->d_comp, nullptr, nullptr, nullptr, d_const, first, st);
     // candidate residuals only for frames that have a candidate; fresh Jacobians only for frames still active
     int rc2 = sweep(p, S.x_new, nb ? S.beta_new : nullptr, 0, false, st, nullptr, d_r_new, d_comp_new, S.flags, kLmHasCand);
     if (rc2) return rc2;
@@ -919,14 +933,16 @@ int bodyfit_internal_solve_batched_device(bodyfit_problem* p, double* frame_para
   for (int it = 0; it < opt->max_iters; ++it) {
     rc = iteration(it == 0 ? 1 : 0);
     if (rc) return rc;
-    n_sweeps += 2;
-    if ((it & 7) == 7 || it + 1 == opt->max_iters) {   // poll the number of frames still iterating
-      int active = 0;
+    n_sweeps += plain ? 2 : 1;
+    if ((it & 7) == 7 || it + 1 == opt->max_iters) {   // poll the number of frames still iterating (speculative form:
+      int active = 0;                                  // as of the previous iteration's candidates)
       HIP_TRY(hipMemcpyAsync(&active, S.active_count, sizeof(int), hipMemcpyDeviceToHost, st));
       HIP_TRY(hipStreamSynchronize(st));
       if (active <= 0) break;
     }
   }
+  // the last candidates are still unjudged in the speculative form (no further step: only x, cost and the counters matter)
+  if (!plain) launch_lm_accept(P, S, d_r_new, p->d_r, d_comp_new, p->d_comp, st);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(hipMemcpy(frame_params, S.x, (size_t)F * npose * sizeof(double), hipMemcpyDeviceToHost));

@@ -130,8 +130,9 @@ struct LmState {              // all device pointers, one entry (or row) per fra
 
 size_t lm_step_lds_bytes();
 void launch_lm_init(const LmProblem& P, const LmState& S, const double* d_r, hipStream_t s);
-void launch_lm_step(const LmProblem& P, const LmState& S, const double* d_r, const double* d_J, const int* d_comp,
-                    const unsigned char* d_constant, int first_iter, hipStream_t s);
+void launch_lm_step(const LmProblem& P, const LmState& S, double* d_r, double* d_J, int* d_comp, const double* d_r_cand,
+                    const double* d_J_cand, const int* d_comp_cand, const unsigned char* d_constant, int first_iter,
+                    hipStream_t s);
 void launch_lm_accept(const LmProblem& P, const LmState& S, const double* d_r_new, double* d_r_cur, const int* d_comp_new,
                       int* d_comp_cur, hipStream_t s);
 constexpr int kNormalRows = 87, kNormalLd = 88;   // per-frame normal-equation panel of k_frame_normal: (n + 1) x 88, lower

@@ -69,6 +69,7 @@ __device__ inline double block_sum(double v, double* red, int tid) {
 }
 
 // cost of one frame from a residual vector: 1/2 sum rho(|r_kp|^2) + 1/2 |prior rows|^2 + 1/2 |shape rows|^2
+// (256 threads: k_lm_init / k_lm_accept; the 512-thread form is frame_cost8 below)
 __device__ double frame_cost(const LmProblem& P, int f, const double* __restrict__ r, double* red, int tid) {
   double acc = 0.0;
   for (int k = P.kp_offset[f] + tid; k < P.kp_offset[f + 1]; k += 256) {
@@ -125,8 +126,106 @@ __device__ inline double block_sum8(double v, double* red, int tid) {
 
 // k_lm_step runs 512 threads = two waves per SIMD: its serial parts (diagonal blocks, back substitution) belong to wave 0,
 // every other part is spread over all eight waves so that LDS and L2 latency of one wave is covered by its neighbour.
-__global__ __launch_bounds__(kStepThreads) void k_lm_step(LmProblem P, LmState S, const double* __restrict__ r,
-                                                  const double* __restrict__ J, const int* __restrict__ comp,
+// Judge the candidate of frame f (cost at the candidate `new_cost` known to every thread): step quality, accept / reject,
+// trust-region radius, Ceres' termination tests.  Accepted: x <- x_new, and the frame's prior rows (all rows when
+// `all_rows`: the speculative iteration keeps the candidate's reprojection rows too) and GMM component become the current
+// ones.  Returns the frame's new flags in *flags_io; true when the step was accepted.
+struct TrustState { double cost, model, radius, dec; };
+// (loaded by every thread BEFORE the barriers of the cost reduction: thread 0 rewrites these words after it)
+__device__ __forceinline__ TrustState load_trust(const LmState& S, int f) {
+  return TrustState{S.cost[f], S.model[f], S.radius[f], S.dec[f]};
+}
+__device__ __forceinline__ bool judge_candidate(const LmProblem& P, const LmState& S, int f, int tid, const TrustState& T,
+                                                double new_cost,
+                                                const double* __restrict__ r_new, double* __restrict__ r_cur,
+                                                const int* __restrict__ comp_new, int* __restrict__ comp_cur, bool all_rows,
+                                                int* flags_io) {
+  const int flags = *flags_io;
+  const int npose = kFrameParams, nb = P.ncols - npose;
+  const double cost = T.cost, model = T.model;
+  const double change = cost - new_cost;
+  const double rho = change / model;
+  const bool accept = (new_cost == new_cost) && new_cost < 1e300 && model > 0.0 && rho > 1e-3;
+  int fl = flags & ~kLmHasCand;
+  if (accept) {
+    if (tid < npose) S.x[(size_t)f * npose + tid] = S.x_new[(size_t)f * npose + tid];
+    else if (tid - npose < nb) S.beta[(size_t)f * nb + tid - npose] = S.beta_new[(size_t)f * nb + tid - npose];
+    // the prior rows (and the GMM component) at the accepted point were computed by the residual sweep: they become
+    // the current ones here, so the Jacobian sweep that follows launches no prior workgroups
+    if (r_cur) {
+      if (tid < P.prior_rows) {
+        const size_t o = P.row_prior + (size_t)f * P.prior_rows + tid;
+        r_cur[o] = r_new[o];
+      } else if (tid >= 128 && tid - 128 < P.shape_rows_per_frame) {
+        const size_t o = P.row_shape + (size_t)f * P.shape_rows_per_frame + tid - 128;
+        r_cur[o] = r_new[o];
+      }
+      if (tid == 255 && comp_cur && comp_new) comp_cur[f] = comp_new[f];
+      if (all_rows && tid >= 256) {
+        const int k0 = P.kp_offset[f], nr = 2 * (P.kp_offset[f + 1] - k0);
+        for (int i = tid - 256; i < nr; i += 256) r_cur[2 * (size_t)k0 + i] = r_new[2 * (size_t)k0 + i];
+      }
+    }
+    if (fabs(change) < 1e-6 * cost) fl &= ~(kLmActive | kLmTermMask);   // function tolerance
+  } else {
+    if (T.radius / T.dec < 1e-32) fl = (fl & ~(kLmActive | kLmTermMask)) | (2 << kLmTermShift);
+  }
+  if (tid == 0) {
+    S.iters[f] += 1;
+    if (accept) {
+      S.cost[f] = new_cost;
+      const double t = 2.0 * rho - 1.0;
+      S.radius[f] = fmin(1e16, T.radius / fmax(1.0 / 3.0, 1.0 - t * t * t));
+      S.dec[f] = 2.0;
+      S.n_ok[f] += 1;
+    } else {
+      S.radius[f] = T.radius / T.dec;
+      S.dec[f] = T.dec * 2.0;
+      S.n_bad[f] += 1;
+    }
+    if ((flags & kLmActive) && !(fl & kLmActive)) atomicSub(S.active_count, 1);
+    S.flags[f] = fl;
+  }
+  *flags_io = fl;
+  return accept;
+}
+
+// 512-thread form of frame_cost: the first four waves carry exactly frame_cost's terms and the sum is formed in the same
+// order, so the cost (and with it every decision of the trust region) is bit-identical in both forms of the iteration
+__device__ double frame_cost8(const LmProblem& P, int f, const double* __restrict__ r, double* red, int tid) {
+  double acc = 0.0;
+  if (tid < 256) {
+    for (int k = P.kp_offset[f] + tid; k < P.kp_offset[f + 1]; k += 256) {
+      const double r0 = r[2 * (size_t)k], r1 = r[2 * (size_t)k + 1];
+      double r1d;
+      acc += 0.5 * huber_rho(P.huber, r0 * r0 + r1 * r1, &r1d);
+    }
+    for (int i = tid; i < P.prior_rows; i += 256) {
+      const double v = r[P.row_prior + (size_t)f * P.prior_rows + i];
+      acc += 0.5 * v * v;
+    }
+    if (P.shape_rows_per_frame > 0)
+      for (int i = tid; i < P.shape_rows_per_frame; i += 256) {
+        const double v = r[P.row_shape + (size_t)f * P.shape_rows_per_frame + i];
+        acc += 0.5 * v * v;
+      }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+  __syncthreads();
+  if ((tid & 63) == 0) red[tid >> 6] = acc;
+  __syncthreads();
+  return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// Speculative iteration (cand.r != nullptr): the sweep before this launch evaluated residuals AND Jacobian at the
+// candidate of the previous step into cand.{r, J, comp}.  The kernel first judges that candidate (what k_lm_accept does as a
+// launch of its own in the plain iteration); an accepted frame builds its next system straight from the candidate's
+// buffers and copies them into the current ones on the way (fire-and-forget stores under the Gram product), a rejected
+// frame rebuilds from the current ones.  One launch and one sweep less per iteration.
+struct LmCandidate { const double* r; const double* J; const int* comp; };
+__global__ __launch_bounds__(kStepThreads) void k_lm_step(LmProblem P, LmState S, double* r_cur, double* J_cur, int* comp_cur,
+                                                  LmCandidate cand,
                                                   const unsigned char* __restrict__ constant, int first_iter) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   double* M = sm;                          // kMRows x kMLd : damped scaled system (+ rhs row), factored in place
@@ -143,6 +242,16 @@ __global__ __launch_bounds__(kStepThreads) void k_lm_step(LmProblem P, LmState S
   const int n = P.ncols, npose = kFrameParams, nb = n - npose;
   const int npad = (n + 15) & ~15, NB = npad >> 4;     // 80 / 96 unknowns padded to whole 16-column panels
   int flags = S.flags[f];
+  bool use_cand = false;
+  if (cand.r && (flags & kLmHasCand)) {
+    const TrustState T = load_trust(S, f);
+    const double new_cost = frame_cost8(P, f, cand.r, red, tid);
+    use_cand = judge_candidate(P, S, f, tid, T, new_cost, cand.r, r_cur, cand.comp, comp_cur, true, &flags);
+    __syncthreads();   // x, beta, radius of the new point are read by other threads below (same CU: L1 is shared)
+  }
+  const double* __restrict__ r = use_cand ? cand.r : r_cur;
+  const double* __restrict__ J = use_cand ? cand.J : J_cur;
+  const int* __restrict__ comp = use_cand ? cand.comp : comp_cur;
   // frames that leave without a candidate still hand the residual sweep (its prior workgroups read every frame) a
   // well-defined point: x_new = x
   auto no_candidate = [&]() {
@@ -180,6 +289,13 @@ __global__ __launch_bounds__(kStepThreads) void k_lm_step(LmProblem P, LmState S
     for (int u = 0; u < 11; ++u) {
       const int i = tid + u * kStepThreads, row = i / 88, c = i % 88;
       jv[u] = (row < nrows && c < n) ? J[(size_t)(2 * k0 + row) * n + c] : 0.0;
+    }
+    if (use_cand) {
+#pragma unroll
+      for (int u = 0; u < 11; ++u) {
+        const int i = tid + u * kStepThreads, row = i / 88, c = i % 88;
+        if (row < nrows && c < n) J_cur[(size_t)(2 * k0 + row) * n + c] = jv[u];
+      }
     }
 #pragma unroll
     for (int u = 0; u < 11; ++u) {
@@ -331,37 +447,42 @@ __global__ __launch_bounds__(kStepThreads) void k_lm_step(LmProblem P, LmState S
   LSTAMP(4);
   if (tid >= n && tid < npad) invd[tid] = 1.0;       // padded unknowns: unit pivots
   // ---- blocked right-looking Cholesky, 16-column panels; the rhs row rides along as one more row below ----------
+  // (a) diagonal block p in registers of wave 0: lane r holds row r; column values travel by v_readlane (dense_inl.h:
+  //     the next pivot's reciprocal square root runs under the current pivot's updates).
+  //     lanes 0-15: rows of the block; lanes 16-31: rows of the identity, which come out as L_pp^-T (kept in the unused
+  //     strict upper triangle of the block, its diagonal 1 / L_cc in invd): the panel solve and the back substitution
+  //     become products on the matrix cores
+  auto diag_block = [&](int p) {
+    const int c0 = 16 * p;
+    const int rr = lane & 15, grp = lane >> 4;
+    double a[16], iv[16];
+    const double* src = M + (c0 + rr) * kMLd + c0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) a[k] = src[k];                     // (unconditional: a predicated read is a branch each)
+    if (grp == 1) {
+#pragma unroll
+      for (int k = 0; k < 16; ++k) a[k] = (k == rr) ? 1.0 : 0.0;
+    }
+    const bool okp = diag_factor16(a, rr, grp != 1, iv, min(16, n - c0));
+    // lower triangle (block rows) and strict upper triangle (identity rows) in one pass of unconditional stores per column
+    if (grp < 2) {
+      double* dst = M + (c0 + rr) * kMLd + c0;
+#pragma unroll
+      for (int k = 0; k < 16; ++k)
+        if ((grp == 0) == (k <= rr)) dst[k] = a[k];
+    }
+    if (lane == 0) {
+#pragma unroll
+      for (int k = 0; k < 16; ++k) invd[c0 + k] = iv[k];
+      if (!okp) red[8] = 0.0;
+    }
+  };
+  if (wave == 0) diag_block(0);
+  __syncthreads();
   for (int p = 0; p < NB; ++p) {
     const int c0 = 16 * p;
     unsigned long long ta0 = 0, ta1 = 0, ta2 = 0, ta3 = 0;
     LTIME(ta0);
-    // (a) diagonal block in registers of wave 0: lane r holds row r; column values travel by v_readlane (dense_inl.h:
-    //     the next pivot's reciprocal square root runs under the current pivot's updates)
-    if (wave == 0) {
-      // lanes 0-15: rows of the block; lanes 16-31: rows of the identity, which come out as L_pp^-T (kept in the unused
-      // strict upper triangle of the block, its diagonal 1 / L_cc in invd): the panel solve and the back substitution
-      // become products on the matrix cores
-      const int rr = lane & 15, grp = lane >> 4;
-      double a[16], iv[16];
-#pragma unroll
-      for (int k = 0; k < 16; ++k) a[k] = (grp == 1) ? (k == rr ? 1.0 : 0.0) : M[(c0 + rr) * kMLd + c0 + k];
-      const bool okp = diag_factor16(a, rr, grp != 1, iv, min(16, n - c0));
-      if (grp == 0) {
-#pragma unroll
-        for (int k = 0; k < 16; ++k)
-          if (k <= rr) M[(c0 + rr) * kMLd + c0 + k] = a[k];
-      } else if (grp == 1) {
-#pragma unroll
-        for (int k = 0; k < 16; ++k)
-          if (k > rr) M[(c0 + rr) * kMLd + c0 + k] = a[k];
-      }
-      if (lane == 0) {
-#pragma unroll
-        for (int k = 0; k < 16; ++k) invd[c0 + k] = iv[k];
-        if (!okp) red[8] = 0.0;
-      }
-    }
-    __syncthreads();
     LTIME(ta1);
     if (red[8] == 0.0) break;
     // (b) panel solve  X = A_below L_pp^-T  on the matrix cores: 16-row tiles below the diagonal block incl. the rhs tile
@@ -384,25 +505,38 @@ __global__ __launch_bounds__(kStepThreads) void k_lm_step(LmProblem P, LmState S
     }
     __syncthreads();
     LTIME(ta2);
-    // (c) trailing update  A[I][Kc] -= X_I X_Kc^T  on the f64 matrix cores (tiles at and below the diagonal)
-    if (p + 1 <= NB) {
+    // (c) trailing update  A[I][Kc] -= X_I X_Kc^T  on the f64 matrix cores (tiles at and below the diagonal).
+    //     Look-ahead: wave 0 updates the next diagonal tile first and factors it at once (the long serial part of a
+    //     panel) while the other seven waves update the rest of the trailing matrix.
+    {
       const int m = lane & 15, kk = lane >> 4;
-      int t = 0;
-      for (int I = p + 1; I <= NB; ++I)
-        for (int Kc = p + 1; Kc <= I && Kc < NB; ++Kc, ++t) {
-          if (t % kStepWaves != wave) continue;
-          d4 acc;
+      auto tile_update = [&](int I, int Kc) {
+        d4 acc;
 #pragma unroll
-          for (int q = 0; q < 4; ++q) acc[q] = M[(16 * I + kk + 4 * q) * kMLd + 16 * Kc + m];
+        for (int q = 0; q < 4; ++q) acc[q] = M[(16 * I + kk + 4 * q) * kMLd + 16 * Kc + m];
 #pragma unroll
-          for (int s4 = 0; s4 < 4; ++s4) {
-            const double av = -M[(16 * I + m) * kMLd + c0 + 4 * s4 + kk];
-            const double bv = M[(16 * Kc + m) * kMLd + c0 + 4 * s4 + kk];
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
-          }
-#pragma unroll
-          for (int q = 0; q < 4; ++q) M[(16 * I + kk + 4 * q) * kMLd + 16 * Kc + m] = acc[q];
+        for (int s4 = 0; s4 < 4; ++s4) {
+          const double av = -M[(16 * I + m) * kMLd + c0 + 4 * s4 + kk];
+          const double bv = M[(16 * Kc + m) * kMLd + c0 + 4 * s4 + kk];
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
         }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) M[(16 * I + kk + 4 * q) * kMLd + 16 * Kc + m] = acc[q];
+      };
+      if (wave == 0) {
+        if (p + 1 < NB) {
+          tile_update(p + 1, p + 1);
+          diag_block(p + 1);
+        }
+      } else {
+        int t = 0;
+        for (int I = p + 1; I <= NB; ++I)
+          for (int Kc = p + 1; Kc <= I && Kc < NB; ++Kc) {
+            if (I == p + 1 && Kc == p + 1) continue;                 // wave 0's
+            if (t++ % (kStepWaves - 1) != wave - 1) continue;
+            tile_update(I, Kc);
+          }
+      }
     }
     __syncthreads();
     LTIME(ta3);
@@ -532,6 +666,7 @@ __global__ __launch_bounds__(kStepThreads) void k_frame_normal(int F, int n, con
       const int i = tid + u * kStepThreads, row = i / 88, c = i % 88;
       jv[u] = (row < nrows && c < n) ? J[(size_t)(2 * k0 + row) * n + c] : 0.0;
     }
+
 #pragma unroll
     for (int u = 0; u < 11; ++u) {
       const int i = tid + u * kStepThreads, row = i / 88, c = i % 88;
@@ -565,50 +700,11 @@ __global__ __launch_bounds__(256) void k_lm_accept(LmProblem P, LmState S, const
                                                     int* __restrict__ comp_cur) {
   __shared__ double red[4];
   const int f = blockIdx.x, tid = threadIdx.x;
-  const int flags = S.flags[f];
+  int flags = S.flags[f];
   if (!(flags & kLmHasCand)) return;
+  const TrustState T = load_trust(S, f);
   const double new_cost = frame_cost(P, f, r_new, red, tid);
-  const int npose = kFrameParams, nb = P.ncols - npose;
-  const double cost = S.cost[f], model = S.model[f];
-  const double change = cost - new_cost;
-  const double rho = change / model;
-  const bool accept = (new_cost == new_cost) && new_cost < 1e300 && model > 0.0 && rho > 1e-3;
-  if (accept) {
-    if (tid < npose) S.x[(size_t)f * npose + tid] = S.x_new[(size_t)f * npose + tid];
-    else if (tid - npose < nb) S.beta[(size_t)f * nb + tid - npose] = S.beta_new[(size_t)f * nb + tid - npose];
-    // the prior rows (and the GMM component) at the accepted point were computed by the residual sweep: they become
-    // the current ones here, so the Jacobian sweep that follows launches no prior workgroups
-    if (r_cur) {
-      if (tid < P.prior_rows) {
-        const size_t o = P.row_prior + (size_t)f * P.prior_rows + tid;
-        r_cur[o] = r_new[o];
-      } else if (tid >= 128 && tid - 128 < P.shape_rows_per_frame) {
-        const size_t o = P.row_shape + (size_t)f * P.shape_rows_per_frame + tid - 128;
-        r_cur[o] = r_new[o];
-      }
-      if (tid == 255 && comp_cur && comp_new) comp_cur[f] = comp_new[f];
-    }
-  }
-  if (tid == 0) {
-    int fl = flags & ~kLmHasCand;
-    S.iters[f] += 1;
-    if (accept) {
-      S.cost[f] = new_cost;
-      const double t = 2.0 * rho - 1.0;
-      S.radius[f] = fmin(1e16, S.radius[f] / fmax(1.0 / 3.0, 1.0 - t * t * t));
-      S.dec[f] = 2.0;
-      S.n_ok[f] += 1;
-      if (fabs(change) < 1e-6 * cost) { fl &= ~(kLmActive | kLmTermMask); atomicSub(S.active_count, 1); }   // function tolerance
-    } else {
-      const double dec = S.dec[f];
-      const double rad = S.radius[f] / dec;
-      S.radius[f] = rad;
-      S.dec[f] = dec * 2.0;
-      S.n_bad[f] += 1;
-      if (rad < 1e-32) { fl = (fl & ~(kLmActive | kLmTermMask)) | (2 << kLmTermShift); atomicSub(S.active_count, 1); }
-    }
-    S.flags[f] = fl;
-  }
+  judge_candidate(P, S, f, tid, T, new_cost, r_new, r_cur, comp_new, comp_cur, false, &flags);
 }
 
 }  // namespace
@@ -618,15 +714,17 @@ size_t lm_step_lds_bytes() { return (size_t)(kMRows * kMLd + (kN + 1) * kLd + 51
 void launch_lm_init(const LmProblem& P, const LmState& S, const double* d_r, hipStream_t s) {
   hipLaunchKernelGGL(k_lm_init, dim3(P.F), dim3(256), 0, s, P, S, d_r);
 }
-void launch_lm_step(const LmProblem& P, const LmState& S, const double* d_r, const double* d_J, const int* d_comp,
-                    const unsigned char* d_constant, int first_iter, hipStream_t s) {
+void launch_lm_step(const LmProblem& P, const LmState& S, double* d_r, double* d_J, int* d_comp, const double* d_r_cand,
+                    const double* d_J_cand, const int* d_comp_cand, const unsigned char* d_constant, int first_iter,
+                    hipStream_t s) {
   static bool attr = false;
   const size_t lds = lm_step_lds_bytes();
   if (!attr) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_lm_step), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr = true;
   }
-  hipLaunchKernelGGL(k_lm_step, dim3(P.F), dim3(kStepThreads), lds, s, P, S, d_r, d_J, d_comp, d_constant, first_iter);
+  hipLaunchKernelGGL(k_lm_step, dim3(P.F), dim3(kStepThreads), lds, s, P, S, d_r, d_J, d_comp,
+                     LmCandidate{d_r_cand, d_J_cand, d_comp_cand}, d_constant, first_iter);
 }
 void launch_lm_accept(const LmProblem& P, const LmState& S, const double* d_r_new, double* d_r_cur, const int* d_comp_new,
                       int* d_comp_cur, hipStream_t s) {

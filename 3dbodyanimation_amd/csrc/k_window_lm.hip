@@ -308,29 +308,38 @@ __global__ __launch_bounds__(kCrThreads) void k_cr_factor(WinBuf W, const int* _
   __syncthreads();
   constexpr int NPAN = WB / 16;   // 5
   double* Linv = stat + 8;        // [16][17]: L_pp^-T of the current panel
+  // (a) diagonal block p + identity below it, in the registers of wave 0: lanes 0-15 rows of the block, lanes 16-31 rows of I
+  auto diag_block = [&](int p) {
+    const int c0 = 16 * p;
+    const int rr = lane & 15, grp = lane >> 4;
+    double av[16], iv[16];
+    const double* src = M + (c0 + rr) * LD + c0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) av[k] = src[k];                    // (unconditional: a predicated read is a branch each)
+    if (grp == 1) {
+#pragma unroll
+      for (int k = 0; k < 16; ++k) av[k] = (k == rr) ? 1.0 : 0.0;
+    }
+    const bool okp = diag_factor16(av, rr, grp != 1, iv, min(16, NP - c0));
+    if (grp == 0) {
+      double* dst = M + (c0 + rr) * LD + c0;
+#pragma unroll
+      for (int k = 0; k < 16; ++k)
+        if (k <= rr) dst[k] = av[k];
+    } else if (grp == 1) {
+#pragma unroll
+      for (int k = 0; k < 16; ++k) Linv[rr * 17 + k] = av[k];   // row rr of L_pp^-T
+    }
+    if (lane == 0 && !okp) stat[0] = 0.0;
+  };
+  if (wave == 0) diag_block(0);
+  __syncthreads();
+  const int nRowTiles = nRows / 16;
   for (int p = 0; p < NPAN; ++p) {
     const int c0 = 16 * p;
-    if (wave == 0) {   // (a) diagonal block + identity below it: lanes 0-15 rows of the block, lanes 16-31 rows of I
-      const int rr = lane & 15, grp = lane >> 4;
-      double av[16], iv[16];
-#pragma unroll
-      for (int k = 0; k < 16; ++k) av[k] = (grp == 1) ? (k == rr ? 1.0 : 0.0) : M[(c0 + rr) * LD + c0 + k];
-      const bool okp = diag_factor16(av, rr, grp != 1, iv, min(16, NP - c0));
-      if (grp == 0) {
-#pragma unroll
-        for (int k = 0; k < 16; ++k)
-          if (k <= rr) M[(c0 + rr) * LD + c0 + k] = av[k];
-      } else if (grp == 1) {
-#pragma unroll
-        for (int k = 0; k < 16; ++k) Linv[rr * 17 + k] = av[k];   // row rr of L_pp^-T
-      }
-      if (lane == 0 && !okp) stat[0] = 0.0;
-    }
-    __syncthreads();
     // (b) panel solve on the matrix cores: every 16-row tile below the diagonal block  X = A L_pp^-T
     {
       const int m = lane & 15, kk = lane >> 4;
-      const int nRowTiles = nRows / 16;
       for (int I = p + 1 + wave; I < nRowTiles; I += kCrWaves) {
         double a4[4];
 #pragma unroll
@@ -343,26 +352,36 @@ __global__ __launch_bounds__(kCrThreads) void k_cr_factor(WinBuf W, const int* _
       }
     }
     __syncthreads();
-    // (c) trailing update on the matrix cores: rows of tile I, columns of panel Kc > p:  M[I][Kc] -= X_I X_Kc^T
+    // (c) trailing update on the matrix cores: rows of tile I, columns of panel Kc > p:  M[I][Kc] -= X_I X_Kc^T.
+    //     Look-ahead: wave 0 updates the next diagonal tile first and factors it at once (the serial part of a panel)
+    //     while the other seven waves update the rest.
     if (p + 1 < NPAN) {
       const int m = lane & 15, kk = lane >> 4;
-      const int nRowTiles = nRows / 16;
-      int t = 0;
-      for (int I = p + 1; I < nRowTiles; ++I) {
-        const int kcmax = (I < NPAN) ? I : NPAN - 1;
-        for (int Kc = p + 1; Kc <= kcmax; ++Kc, ++t) {
-          if (t % kCrWaves != wave) continue;
-          d4 acc;
+      auto tile_update = [&](int I, int Kc) {
+        d4 acc;
 #pragma unroll
-          for (int q = 0; q < 4; ++q) acc[q] = M[(16 * I + kk + 4 * q) * LD + 16 * Kc + m];
+        for (int q = 0; q < 4; ++q) acc[q] = M[(16 * I + kk + 4 * q) * LD + 16 * Kc + m];
 #pragma unroll
-          for (int s4 = 0; s4 < 4; ++s4) {
-            const double av = -M[(16 * I + m) * LD + c0 + 4 * s4 + kk];
-            const double bv = M[(16 * Kc + m) * LD + c0 + 4 * s4 + kk];
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+        for (int s4 = 0; s4 < 4; ++s4) {
+          const double av = -M[(16 * I + m) * LD + c0 + 4 * s4 + kk];
+          const double bv = M[(16 * Kc + m) * LD + c0 + 4 * s4 + kk];
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) M[(16 * I + kk + 4 * q) * LD + 16 * Kc + m] = acc[q];
+      };
+      if (wave == 0) {
+        tile_update(p + 1, p + 1);
+        diag_block(p + 1);
+      } else {
+        int t = 0;
+        for (int I = p + 1; I < nRowTiles; ++I) {
+          const int kcmax = (I < NPAN) ? I : NPAN - 1;
+          for (int Kc = p + 1; Kc <= kcmax; ++Kc) {
+            if (I == p + 1 && Kc == p + 1) continue;               // wave 0's
+            if (t++ % (kCrWaves - 1) != wave - 1) continue;
+            tile_update(I, Kc);
           }
-#pragma unroll
-          for (int q = 0; q < 4; ++q) M[(16 * I + kk + 4 * q) * LD + 16 * Kc + m] = acc[q];
         }
       }
     }

@@ -67,6 +67,37 @@ def test_c3_batched_independent_frames_shape_and_gmm(api, synth, model, gpu_mode
         assert d < TOL and ok_s and np.abs(b[f] - bo).max() < TOL
 
 
+@pytest.mark.parametrize("F,shape", [(1, False), (40, True), (256, True)])
+def test_speculative_iteration_equals_four_launch_iteration(api, synth, model, gpu_model, monkeypatch, F, shape):
+    """The batched device LM judges a candidate in the prologue of the next k_lm_step and takes the Jacobian from the
+    candidate sweep (two launches per iteration); BODYFIT_LM_PLAIN=1 keeps step / residual sweep / accept / Jacobian sweep.
+    Same arithmetic in another launch order: same decisions, same iteration counts, same iterates."""
+    seq = synth.make_sequence(model, F, seed=4, beta_fixed=not shape)
+    w, mu, cov = synth.make_gmm(0)
+
+    def fit(plain):
+        monkeypatch.setenv("BODYFIT_LM_PLAIN", "1" if plain else "0")
+        if shape:
+            prob = api.Problem.from_sequence(gpu_model, seq, n_cols=86, use_shape=True, beta_per_frame=True, beta_pose=20.0,
+                                             gmm=api.Gmm(w, mu, cov), beta_shape=30.0)
+            return prob.solve(seq.init_params, np.zeros((F, 10)), independent=True, max_iters=100)
+        prob = api.Problem.from_sequence(gpu_model, seq, n_cols=76, use_shape=False, beta_pose=20.0)
+        return prob.solve(seq.init_params, None, independent=True, max_iters=100)
+
+    xs, bs, ss = fit(False)
+    xp, bp, sp = fit(True)
+    # same arithmetic in the same order (the cost reduction of the prologue sums like k_lm_accept): identical decisions
+    for f in range(F):
+        a, b = ss[f], sp[f]
+        assert (a.iterations, a.n_successful, a.n_unsuccessful, a.termination) == \
+               (b.iterations, b.n_successful, b.n_unsuccessful, b.termination), f
+        assert a.final_cost == b.final_cost
+    assert np.array_equal(xs, xp)
+    if shape:
+        assert np.array_equal(bs, bp)
+    assert ss[0].n_sweeps < sp[0].n_sweeps   # one sweep per iteration instead of two
+
+
 def test_c4_multi_frame_window_shared_beta(api, synth, model, gpu_model, oracle_mod, omodel):
     """OptimizeMultiFrame on one 20-frame window: shared beta, L2 pose prior 5, shape prior 25, temporal 3."""
     F = 20
