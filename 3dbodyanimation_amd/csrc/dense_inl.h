@@ -31,22 +31,25 @@ __device__ __forceinline__ bool diag_factor16(double (&av)[16], int rr, bool own
   double piv = readlane_f64w(av[0], 0);
   double inv = rsq_nr(piv);
 #pragma unroll
-  for (int c = 0; c < 16; ++c) {
-    if (c >= nvalid) { inv_out[c] = 1.0; continue; }   // (uniform)
-    if (!(piv > 0.0) || !(piv < 1e300)) okp = false;
-    inv_out[c] = inv;
-    const double l = (own_rows && rr == c) ? piv * inv : av[c] * inv;
-    av[c] = l;
-    double piv_n = 1.0, inv_n = 1.0;
-    if (c + 1 < 16) {
-      av[c + 1] -= l * readlane_f64w(l, c + 1);
-      piv_n = readlane_f64w(av[c + 1], c + 1);
-      inv_n = rsq_nr(piv_n);
-    }
-    // (no row predicate: above the diagonal this writes values nothing reads)
+  for (int c = 0; c < 16; ++c) inv_out[c] = 1.0;
 #pragma unroll
-    for (int k = c + 2; k < 16; ++k) av[k] -= l * readlane_f64w(l, k);
-    piv = piv_n; inv = inv_n;
+  for (int c = 0; c < 16; ++c) {
+    if (c < nvalid) {   // (uniform)
+      if (!(piv > 0.0) || !(piv < 1e300)) okp = false;
+      inv_out[c] = inv;
+      const double l = (own_rows && rr == c) ? piv * inv : av[c] * inv;
+      av[c] = l;
+      double piv_n = 1.0, inv_n = 1.0;
+      if (c + 1 < 16) {
+        av[c + 1] -= l * readlane_f64w(l, c + 1);
+        piv_n = readlane_f64w(av[c + 1], c + 1);
+        inv_n = rsq_nr(piv_n);
+      }
+      // (no row predicate: above the diagonal this writes values nothing reads)
+#pragma unroll
+      for (int k = c + 2; k < 16; ++k) av[k] -= l * readlane_f64w(l, k);
+      piv = piv_n; inv = inv_n;
+    }
   }
   return okp;
 }

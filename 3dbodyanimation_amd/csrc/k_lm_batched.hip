@@ -29,7 +29,7 @@ constexpr int kRowsMax = 64;       // reprojection rows per frame handled on the
 constexpr int kJLd = 96;           // Jhat leading dimension: 6 column tiles of 16 (86 columns + rhat + pad)
 constexpr int kMRows = 112;        // panel layout of the damped system: 96 padded unknowns + one tile row for the rhs
 constexpr int kMLd = 98;
-static_assert(kRowsMax * kJLd <= kMRows * kMLd, "Jhat must fit in the region it shares with the damped system");
+static_assert(kRowsMax * kJLd + 69 * 69 <= kMRows * kMLd, "Jhat and the GMM precision matrix share the damped system's region");
 
 #ifdef BODYFIT_STAMPS
 #define LSTAMP(i)                                                                                   \
@@ -171,18 +171,16 @@ __device__ __forceinline__ bool judge_candidate(const LmProblem& P, const LmStat
     if (T.radius / T.dec < 1e-32) fl = (fl & ~(kLmActive | kLmTermMask)) | (2 << kLmTermShift);
   }
   if (tid == 0) {
-    S.iters[f] += 1;
-    if (accept) {
-      S.cost[f] = new_cost;
-      const double t = 2.0 * rho - 1.0;
-      S.radius[f] = fmin(1e16, T.radius / fmax(1.0 / 3.0, 1.0 - t * t * t));
-      S.dec[f] = 2.0;
-      S.n_ok[f] += 1;
-    } else {
-      S.radius[f] = T.radius / T.dec;
-      S.dec[f] = T.dec * 2.0;
-      S.n_bad[f] += 1;
-    }
+    // (straight-line: a branch that picks between S.n_ok and S.n_bad becomes a pointer table in scratch memory)
+    const int it0 = S.iters[f], ok0 = S.n_ok[f], bad0 = S.n_bad[f];
+    const double t = 2.0 * rho - 1.0;
+    const double rad_ok = fmin(1e16, T.radius / fmax(1.0 / 3.0, 1.0 - t * t * t));
+    S.iters[f] = it0 + 1;
+    S.n_ok[f] = ok0 + (accept ? 1 : 0);
+    S.n_bad[f] = bad0 + (accept ? 0 : 1);
+    S.cost[f] = accept ? new_cost : T.cost;
+    S.radius[f] = accept ? rad_ok : T.radius / T.dec;
+    S.dec[f] = accept ? 2.0 : T.dec * 2.0;
     if ((flags & kLmActive) && !(fl & kLmActive)) atomicSub(S.active_count, 1);
     S.flags[f] = fl;
   }
@@ -249,9 +247,15 @@ __global__ __launch_bounds__(kStepThreads) void k_lm_step(LmProblem P, LmState S
     use_cand = judge_candidate(P, S, f, tid, T, new_cost, cand.r, r_cur, cand.comp, comp_cur, true, &flags);
     __syncthreads();   // x, beta, radius of the new point are read by other threads below (same CU: L1 is shared)
   }
-  const double* __restrict__ r = use_cand ? cand.r : r_cur;
-  const double* __restrict__ J = use_cand ? cand.J : J_cur;
-  const int* __restrict__ comp = use_cand ? cand.comp : comp_cur;
+  // (bit arithmetic instead of ?: — hipcc turns a select between two kernel-argument pointers into a two-entry table
+  //  in scratch memory with an indexed load on the kernel's critical path)
+  auto pick = [&](const void* cur, const void* cnd) {
+    const unsigned long long a = (unsigned long long)cur, b = (unsigned long long)cnd;
+    return a ^ ((a ^ b) & (0ull - (unsigned long long)use_cand));
+  };
+  const double* __restrict__ r = reinterpret_cast<const double*>(pick(r_cur, cand.r));
+  const double* __restrict__ J = reinterpret_cast<const double*>(pick(J_cur, cand.J));
+  const int* __restrict__ comp = reinterpret_cast<const int*>(pick(comp_cur, cand.comp));
   // frames that leave without a candidate still hand the residual sweep (its prior workgroups read every frame) a
   // well-defined point: x_new = x
   auto no_candidate = [&]() {
@@ -266,141 +270,194 @@ __global__ __launch_bounds__(kStepThreads) void k_lm_step(LmProblem P, LmState S
   const int k0 = P.kp_offset[f], nrows = 2 * (P.kp_offset[f + 1] - k0);
   LSTAMP(0);
 
-  // ---- Jhat = sqrt(rho') [J | r], zero padded to 6 column tiles of 16 and a multiple of 4 rows -------------
-  const int nrows4 = (nrows + 3) & ~3;
-  if (tid < kRowsMax) {   // per-row robust weight sqrt(rho') and weighted residual (one round trip)
+  // ---- every global operand of the step is requested here, in one go (one L2 round trip instead of five) ---------------
+  //   J (11 values per thread), the residual rows, the selected GMM component's precision matrix (10 per thread),
+  //   x - mu, the prior / shape residual rows, the constant mask, the Jacobi scaling of the first iterate.
+  //   Unconditional loads from clamped addresses, masked afterwards (a predicated load is a branch with its own wait).
+  const int nrows4 = (nrows + 3) & ~3;             // Jhat is zero-padded to whole k-steps of the matrix cores
+  const int D = npose - 7;
+  const double bp = P.beta_pose, bs = P.beta_shape;
+  const bool has_prior = P.prior_rows > 0, has_gmm = has_prior && P.prec != nullptr;
+  const bool has_shape = P.shape_rows_per_frame > 0;
+  double* Pl = sm + kRowsMax * kJLd;       // [D][D] precision matrix of the frame's component, beside Jhat in M's region
+  double* gp = invd;                       // [88] prior part of the gradient (invd is free until the factorisation)
+  double* dx = dd;                         // [69] x - mu (dd is free until the step)
+  double* cf = vec + 504;                  // [88] 1.0 = parameter held constant
+  double jv[11];
+#pragma unroll
+  for (int u = 0; u < 11; ++u) {
+    const int i = tid + u * kStepThreads, row = i / 88, c = i % 88;
+    const bool on = row < nrows && c < n;
+    jv[u] = J[on ? (size_t)(2 * k0 + row) * n + c : (size_t)2 * k0 * n];
+    if (!on) jv[u] = 0.0;
+  }
+  double r_own, r_other;     // this row's residual and the other coordinate of its keypoint
+  {
+    const int row = min(tid, max(nrows, 1) - 1);
+    r_own = r[2 * (size_t)k0 + row]; r_other = r[2 * (size_t)k0 + (row ^ 1)];
+  }
+  double pv[10];
+  double dxv = 0.0, gpv = 0.0, scv = 1.0, cfv = 0.0;
+  if (has_gmm) {
+    const int kc = comp[f];
+    const double* Pm = P.prec + (size_t)kc * D * D;       // L L^T of the selected component
+#pragma unroll
+    for (int u = 0; u < 10; ++u) pv[u] = Pm[min(tid + u * kStepThreads, D * D - 1)];   // 69 * 69 = 4761 <= 10 * 512
+    const int t = min(tid, D - 1);
+    dxv = S.x[(size_t)f * npose + 7 + t] - P.gmm_mean[(size_t)kc * D + t];
+  } else if (has_prior) {               // L2 pose prior: J^T r = beta_p r_prior on the 69 joint columns
+    gpv = bp * r[P.row_prior + (size_t)f * P.prior_rows + min(max(tid - 7, 0), P.prior_rows - 1)];
+    if (tid < 7 || tid >= npose) gpv = 0.0;
+  }
+  if (has_shape && tid >= npose && tid < n)                  // (ten threads: a branch of its own is cheap here)
+    gpv = bs * r[P.row_shape + (size_t)f * P.shape_rows_per_frame + tid - npose];
+  if (constant) cfv = constant[min(tid, npose - 1)] ? 1.0 : 0.0;
+  if (!first_iter) scv = S.scale[(size_t)f * kN + min(tid, n - 1)];
+  if (use_cand) {     // the accepted candidate's Jacobian becomes the current one (fire-and-forget)
+#pragma unroll
+    for (int u = 0; u < 11; ++u) {
+      const int i = tid + u * kStepThreads, row = i / 88, c = i % 88;
+      if (row < nrows && c < n) J_cur[(size_t)(2 * k0 + row) * n + c] = jv[u];
+    }
+  }
+  // ---- Jhat = sqrt(rho') [J | r], zero padded to 6 column tiles of 16 and a multiple of 4 rows --------------------------------
+  if (tid < kRowsMax) {   // per-row robust weight sqrt(rho') and weighted residual
     double sw = 0.0, rr = 0.0;
     if (tid < nrows) {
-      const int k = k0 + (tid >> 1);
-      const double r0 = r[2 * (size_t)k], r1 = r[2 * (size_t)k + 1];
       double rho1;
-      huber_rho(P.huber, r0 * r0 + r1 * r1, &rho1);
+      huber_rho(P.huber, (tid & 1) ? r_other * r_other + r_own * r_own : r_own * r_own + r_other * r_other, &rho1);
       sw = sqrt(rho1);
-      rr = sw * ((tid & 1) ? r1 : r0);
+      rr = sw * r_own;
     }
     ds[tid] = sw;                 // ds is free until the solve
     Jh[tid * kJLd + n] = rr;      // column n = rhat
   }
-  __syncthreads();
-  {
-    // fixed trip count (kRowsMax * 88 / 512 = 11 predicated passes): all loads of J in flight together
-    double jv[11];
+  if (tid < 88) {
+    cf[tid] = (tid < npose) ? cfv : 0.0;
+    gp[tid] = gpv;
+    if (tid < D) dx[tid] = dxv;
+  }
+  if (has_gmm) {
 #pragma unroll
-    for (int u = 0; u < 11; ++u) {
-      const int i = tid + u * kStepThreads, row = i / 88, c = i % 88;
-      jv[u] = (row < nrows && c < n) ? J[(size_t)(2 * k0 + row) * n + c] : 0.0;
+    for (int u = 0; u < 10; ++u) {
+      const int e = tid + u * kStepThreads;
+      if (e < D * D) Pl[e] = pv[u];
     }
-    if (use_cand) {
-#pragma unroll
-      for (int u = 0; u < 11; ++u) {
-        const int i = tid + u * kStepThreads, row = i / 88, c = i % 88;
-        if (row < nrows && c < n) J_cur[(size_t)(2 * k0 + row) * n + c] = jv[u];
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < 11; ++u) {
-      const int i = tid + u * kStepThreads, row = i / 88, c = i % 88;
-      if (row < nrows4 && c != n) Jh[row * kJLd + c] = (row < nrows && c < n) ? ds[row] * jv[u] : 0.0;
-    }
-    for (int i = tid; i < nrows4 * (kJLd - 88); i += kStepThreads) Jh[(i / (kJLd - 88)) * kJLd + 88 + i % (kJLd - 88)] = 0.0;
   }
   __syncthreads();
+  LSTAMP(11);
+#pragma unroll
+  for (int u = 0; u < 11; ++u) {
+    const int i = tid + u * kStepThreads, row = i / 88, c = i % 88;
+    if (row < nrows4 && c != n) Jh[row * kJLd + c] = ds[row] * jv[u];   // (jv is zero outside J; ds is zero past nrows)
+  }
+  for (int i = tid; i < nrows4 * (kJLd - 88); i += kStepThreads) Jh[(i / (kJLd - 88)) * kJLd + 88 + i % (kJLd - 88)] = 0.0;
+  __syncthreads();
   LSTAMP(1);
-  // ---- Gram matrix on the f64 matrix cores: 21 lower tile pairs dealt to the 4 waves -----------------------
+  // ---- Gram matrix on the f64 matrix cores: 21 lower tile pairs dealt to the 8 waves; every tile leaves with its prior
+  //      terms added and is stored in both triangles (the model cost change needs H d with the full matrix) ---------
   {
     const int m = lane & 15, kk = lane >> 4;
+    const double bp2 = bp * bp, bs2 = bs * bs;
+    const int nsteps = nrows4 / 4;
     int pair = 0;
     for (int ti = 0; ti < 6; ++ti)
       for (int tj = 0; tj <= ti; ++tj, ++pair) {
         if (pair % kStepWaves != wave) continue;
+        // k loop software-pipelined by hand, four k-steps deep: the operands of step s + 4 are requested right after the
+        // product of step s (left to itself the compiler reads two steps, waits for them, multiplies, and so on: every
+        // pair of products then pays a full LDS latency).  The uniform branch around each product keeps the order.
         d4 acc = {0.0, 0.0, 0.0, 0.0};
-        const int nsteps = nrows4 / 4;
-        for (int s0 = 0; s0 < nsteps; s0 += 8) {      // eight k-steps per batch: their 16 LDS reads are in flight together
-          double av[8], bv[8];
+        const double* pa = Jh + kk * kJLd + 16 * ti + m;
+        const double* pb = Jh + kk * kJLd + 16 * tj + m;
+        double av[4], bv[4];
 #pragma unroll
-          for (int u = 0; u < 8; ++u) {
-            const bool on = s0 + u < nsteps;
-            const int row = on ? 4 * (s0 + u) + kk : 0;
-            av[u] = on ? Jh[row * kJLd + 16 * ti + m] : 0.0;
-            bv[u] = on ? Jh[row * kJLd + 16 * tj + m] : 0.0;
+        for (int u = 0; u < 4; ++u) { av[u] = pa[4 * u * kJLd]; bv[u] = pb[4 * u * kJLd]; }
+        for (int s0 = 0; s0 < nsteps; s0 += 4) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            if (s0 + u < nsteps) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], acc, 0, 0, 0);
+            const int sn = min(s0 + 4 + u, kRowsMax / 4 - 1);     // (past the last step: a row nothing multiplies)
+            av[u] = pa[4 * sn * kJLd]; bv[u] = pb[4 * sn * kJLd];
           }
-#pragma unroll
-          for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], acc, 0, 0, 0);
         }
-        // D: column = lane & 15 (B side, tile tj), row = (lane >> 4) + 4 q (A side, tile ti)
+        if (pair == 0) {
+          LSTAMP(14);
+          asm volatile("s_nop 0" ::"v"(acc[0]), "v"(acc[3]));
+          LSTAMP(8);
+        }
+        // D: column = lane & 15 (B side, tile tj), row = (lane >> 4) + 4 q (A side, tile ti).  Branch-free up to the
+        // stores: the prior terms are read from clamped addresses and masked (row n, the rhat column, is the gradient
+        // and takes none; its mirror image lands in column n of H0, which nothing reads)
+        double pl[4];
+        const int j = 16 * tj + m;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const int i = 16 * ti + kk + 4 * q, j = 16 * tj + m;
-          if (i <= n && j < n && j <= i) H0[i * kLd + j] = acc[q];   // row n (the rhat column) is the gradient
+          const int i = 16 * ti + kk + 4 * q;
+          pl[q] = has_gmm ? Pl[min(max(i - 7, 0), 68) * 69 + min(max(j - 7, 0), 68)] : ((i == j) ? 1.0 : 0.0);
         }
+        if (pair == 0) LSTAMP(9);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int i = 16 * ti + kk + 4 * q;
+          double v = acc[q];
+          if (has_prior && j >= 7 && i < npose) v += bp2 * pl[q];
+          if (has_shape && i == j && i >= npose && i < n) v += bs2;
+          if (i <= n && j < n && j <= i) {
+            H0[i * kLd + j] = v;
+            H0[j * kLd + i] = v;
+          }
+        }
+        if (pair == 0) LSTAMP(15);
       }
+    // prior part of the gradient for the GMM: J^T r = beta_p^2 s Prec (x - mu); Prec is symmetric, so thread j reads
+    // column j (consecutive lanes, consecutive words).  Waves 6 and 7 carry one Gram tile less than the others.
+    if (has_gmm && tid >= 384 + 7 && tid < 384 + npose) {
+      const int j = tid - 384 - 7;
+      double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+      static_assert(kFrameParams - 7 == 69, "three batches of 23");
+#pragma unroll
+      for (int kb = 0; kb < 69; kb += 23) {       // 23 elements per batch, their 46 LDS reads in flight together
+        double pw[23], dw[23];
+#pragma unroll
+        for (int u = 0; u < 23; ++u) { pw[u] = Pl[(kb + u) * 69 + j]; dw[u] = dx[kb + u]; }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u + 2 < 23; u += 3) { a0 += pw[u] * dw[u]; a1 += pw[u + 1] * dw[u + 1]; a2 += pw[u + 2] * dw[u + 2]; }
+        a0 += pw[21] * dw[21]; a1 += pw[22] * dw[22];
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      gp[7 + j] = bp2 * P.gmm_scale * ((a0 + a1) + a2);
+    }
   }
+  LSTAMP(13);
   __syncthreads();
   LSTAMP(2);
-  // ---- priors: pose prior on the 69 joint columns, shape prior on beta ---------------------------------------
-  const int D = npose - 7;
-  if (P.prior_rows > 0) {
-    const double* rp = r + P.row_prior + (size_t)f * P.prior_rows;
-    const double bp = P.beta_pose;
-    if (P.prec) {
-      const int kc = comp[f];
-      const double* Pm = P.prec + (size_t)kc * D * D;       // L L^T of the selected component
-      {
-        double pv[10];   // 69 * 69 = 4761 <= 10 * 512
-#pragma unroll
-        for (int u = 0; u < 10; ++u) {
-          const int e = tid + u * kStepThreads;
-          pv[u] = (e < D * D) ? Pm[e] : 0.0;
-        }
-#pragma unroll
-        for (int u = 0; u < 10; ++u) {
-          const int e = tid + u * kStepThreads, i = e / D, j = e % D;
-          if (e < D * D && j <= i) H0[(7 + i) * kLd + 7 + j] += bp * bp * pv[u];
-        }
-      }
-      if (tid < D) {
-        // J^T r = beta_p L r[0:69] with r[0:69] = beta_p s L^T (x - mu)  ->  beta_p^2 s Prec (x - mu):
-        // one row of the precision matrix per thread, 69 independent loads
-        const double* xq = S.x + (size_t)f * npose + 7;
-        double a = 0.0;
-#pragma unroll
-        for (int k = 0; k < 69; ++k) a += (k < D) ? Pm[(size_t)tid * D + k] * (xq[k] - P.gmm_mean[(size_t)kc * D + k]) : 0.0;
-        H0[n * kLd + 7 + tid] += bp * bp * P.gmm_scale * a;
-      }
-    } else if (tid < D) {
-      H0[(7 + tid) * kLd + 7 + tid] += bp * bp;
-      H0[n * kLd + 7 + tid] += bp * rp[tid];
-    }
-  }
-  if (P.shape_rows_per_frame > 0 && tid >= 128 && tid - 128 < nb) {
-    const int i = tid - 128;
-    H0[(npose + i) * kLd + npose + i] += P.beta_shape * P.beta_shape;
-    H0[n * kLd + npose + i] += P.beta_shape * r[P.row_shape + (size_t)f * P.shape_rows_per_frame + i];
-  }
-  __syncthreads();
   LSTAMP(3);
   // ---- gradient, Jacobi scaling (fixed at the first iterate) ----------------------------------------------------
+  double gm = 0.0;
   if (tid < n) {
-    g[tid] = H0[n * kLd + tid];
-    const double s0 = first_iter ? 1.0 / (1.0 + sqrt(H0[tid * kLd + tid])) : S.scale[(size_t)f * kN + tid];
+    const double gi0 = H0[n * kLd + tid] + gp[tid];
+    g[tid] = gi0;
+    const double s0 = first_iter ? 1.0 / (1.0 + sqrt(H0[tid * kLd + tid])) : scv;
     if (first_iter) S.scale[(size_t)f * kN + tid] = s0;
     sc[tid] = s0;
-  }
-  // gradient tolerance (projected on the scale bounds), Ceres gradient_tolerance = 1e-10
-  double gm = 0.0;
-  if (tid < n && !(tid < npose && constant && constant[tid])) {
-    double gi = H0[n * kLd + tid];
-    if (tid == 0) {
-      const double s0 = S.x[(size_t)f * npose];
-      gi = s0 - fmin(fmax(s0 - gi, P.scale_lo), P.scale_hi);
+    // gradient tolerance (projected on the scale bounds), Ceres gradient_tolerance = 1e-10
+    if (cf[tid] == 0.0) {
+      double gi = gi0;
+      if (tid == 0) {
+        const double x0 = S.x[(size_t)f * npose];
+        gi = x0 - fmin(fmax(x0 - gi, P.scale_lo), P.scale_hi);
+      }
+      gm = fabs(gi);
     }
-    gm = fabs(gi);
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) gm = fmax(gm, __shfl_xor(gm, off, 64));
   if (lane == 0) red[wave] = gm;
   __syncthreads();
-  gm = fmax(fmax(fmax(red[0], red[1]), fmax(red[2], red[3])), fmax(fmax(red[4], red[5]), fmax(red[6], red[7])));
+  gm = fmax(red[0], red[1]);        // (n <= 86: waves 0 and 1 hold every entry)
+  LSTAMP(12);
   if (gm <= 1e-10) {
     if (tid == 0) {
       S.flags[f] = (flags & ~(kLmActive | kLmHasCand | kLmTermMask));   // termination 0: convergence
@@ -412,37 +469,53 @@ __global__ __launch_bounds__(kStepThreads) void k_lm_step(LmProblem P, LmState S
   // ---- scaled, damped system in panel layout: unknowns padded with identity to npad, rhs = row npad -------------
   const double radius = S.radius[f];
   const double inv_radius = 1.0 / radius;
-  for (int ii = 0; ii < (kMRows + 15) / 16; ++ii) {         // 32 columns x 16 rows per pass, no integer division
-    const int i = (tid >> 5) + 16 * ii;
-    if (i >= npad + 16) continue;
-    const bool ci = i < npose && constant && constant[i];
+  {
+    // 112 x 96 entries, 21 per thread: columns j = (tid & 31) + 32 jj, rows i = (tid >> 5) + 16 ii.  Straight-line code:
+    // the per-column and per-row factors first, then the 21 matrix reads in flight together, then the 21 stores.
+    double scj[3], cfj[3], gj[3], sci[7], cfi[7];
 #pragma unroll
     for (int jj = 0; jj < 3; ++jj) {
-      const int j = (tid & 31) + 32 * jj;
-      if (j >= npad) continue;
-      double v = 0.0;
-      if (i < n && j <= i) {
-        const bool cj = j < npose && constant && constant[j];
-        if (ci || cj) v = (i == j) ? 1.0 : 0.0;
-        else {
-          v = H0[i * kLd + j] * sc[i] * sc[j];
-          if (i == j) v += fmin(fmax(v, 1e-6), 1e32) * inv_radius;
-        }
-      } else if (i < npad) {
-        v = (i == j) ? 1.0 : 0.0;                                  // identity padding keeps the system SPD
-      } else if (i == npad && j < n) {
-        v = (j < npose && constant && constant[j]) ? 0.0 : -g[j] * sc[j];   // rhs = -S g
+      const int j = min((tid & 31) + 32 * jj, n - 1);
+      scj[jj] = sc[j]; cfj[jj] = cf[j]; gj[jj] = g[j];
+    }
+#pragma unroll
+    for (int ii = 0; ii < 7; ++ii) {
+      const int i = min((tid >> 5) + 16 * ii, n - 1);
+      sci[ii] = sc[i]; cfi[ii] = cf[i];
+    }
+    double hv[7][3];
+#pragma unroll
+    for (int ii = 0; ii < 7; ++ii)
+#pragma unroll
+      for (int jj = 0; jj < 3; ++jj) {
+        const int i = min((tid >> 5) + 16 * ii, n - 1), j = min((tid & 31) + 32 * jj, n - 1);
+        hv[ii][jj] = H0[i * kLd + j];
       }
-      M[i * kMLd + j] = v;
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ii = 0; ii < 7; ++ii) {
+      const int i = (tid >> 5) + 16 * ii;
+#pragma unroll
+      for (int jj = 0; jj < 3; ++jj) {
+        const int j = (tid & 31) + 32 * jj;
+        double v = 0.0;
+        if (i < n && j <= i) {
+          if (cfi[ii] != 0.0 || cfj[jj] != 0.0) v = (i == j) ? 1.0 : 0.0;
+          else {
+            v = hv[ii][jj] * sci[ii] * scj[jj];
+            if (i == j) v += fmin(fmax(v, 1e-6), 1e32) * inv_radius;
+          }
+        } else if (i < npad) {
+          v = (i == j) ? 1.0 : 0.0;                                  // identity padding keeps the system SPD
+        } else if (i == npad && j < n) {
+          v = (cfj[jj] != 0.0) ? 0.0 : -gj[jj] * scj[jj];            // rhs = -S g
+        }
+        if (i < npad + 16 && j < npad) M[i * kMLd + j] = v;
+      }
     }
   }
   if (tid == 0) red[8] = 1.0;   // factorisation status
   __syncthreads();
-  // H0 becomes the full symmetric undamped matrix (model cost change needs H d)
-  for (int e = tid; e < n * n; e += kStepThreads) {
-    const int i = e / n, j = e % n;
-    if (j > i) H0[i * kLd + j] = H0[j * kLd + i];
-  }
 
   LSTAMP(4);
   if (tid >= n && tid < npad) invd[tid] = 1.0;       // padded unknowns: unit pivots
@@ -540,7 +613,7 @@ __global__ __launch_bounds__(kStepThreads) void k_lm_step(LmProblem P, LmState S
     }
     __syncthreads();
     LTIME(ta3);
-    LACC(8, ta1 - ta0); LACC(9, ta2 - ta1); LACC(10, ta3 - ta2);
+    LACC(10, ta3 - ta2);
     (void)ta0; (void)ta1; (void)ta2; (void)ta3;
   }
   if (red[8] == 0.0) {
@@ -559,35 +632,60 @@ __global__ __launch_bounds__(kStepThreads) void k_lm_step(LmProblem P, LmState S
     return;
   }
   LSTAMP(5);
-  // ---- backward substitution ds = L^-T y on the matrix cores, wave 0: in row form  X L = Z  with the rhs tile (rows npad ..,
-  //      row 0 = y) as Z, panel by panel from the last:  X_p = (Z_p - sum_{q > p} X_q L[q][p]) L_pp^-1  -----------------------
+  // ---- backward substitution ds = L^-T y, wave 0, on the vector pipe: ONE right-hand side makes a 16 x 16 x 4 f64 matrix
+  //      instruction (64 cycles on gfx950, fifteen of its sixteen rows idle) four times dearer than the four FMAs per
+  //      lane it replaces.  Row form  X L = Z  (Z = y, the rhs row):  X_p = (Z_p - sum_{q > p} X_q L[q][p]) L_pp^-1, panel by
+  //      panel from the last, right-looking: as soon as X_p is known every Z_q, q < p, takes its update.
+  //      lane = (kk = lane >> 4, m = lane & 15): partial sums over k = 4 s + kk, reduced across kk by two shuffles. ----------
   if (wave == 0) {
     const int m = lane & 15, kk = lane >> 4;
-    double* Z = M + npad * kMLd;
+    const double* Zr = M + npad * kMLd;          // row 0 of the rhs tile = y
+    double z[6];                                  // Z_p[m], replicated over kk
+#pragma unroll
+    for (int q = 0; q < 6; ++q) z[q] = Zr[min(16 * q, npad - 16) + m];
     for (int p = NB - 1; p >= 0; --p) {
-      d4 acc;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) acc[q] = Z[(kk + 4 * q) * kMLd + 16 * p + m];
-      for (int qp = p + 1; qp < NB; ++qp) {
-#pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4)
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-Z[m * kMLd + 16 * qp + 4 * s4 + kk], M[(16 * qp + 4 * s4 + kk) * kMLd + 16 * p + m],
-                                                     acc, 0, 0, 0);
-      }
-#pragma unroll
-      for (int q = 0; q < 4; ++q) Z[(kk + 4 * q) * kMLd + 16 * p + m] = acc[q];
-      d4 xo = {0.0, 0.0, 0.0, 0.0};
+      // operands of this panel: L_pp^-1 (strict upper triangle of the diagonal tile holds L_pp^-T, invd its diagonal) and
+      // the tiles L[p][q], q < p — none depends on the chain, all are requested before the first product
+      double li[4], lt[5][4];
 #pragma unroll
       for (int s4 = 0; s4 < 4; ++s4) {
-        const int k = 4 * s4 + kk;   // B[k][n = m] = (L_pp^-1)[k][m] = (L_pp^-T)[m][k]
-        const double li = (m < k) ? M[(16 * p + m) * kMLd + 16 * p + k] : (m == k ? invd[16 * p + k] : 0.0);
-        xo = __builtin_amdgcn_mfma_f64_16x16x4f64(Z[m * kMLd + 16 * p + k], li, xo, 0, 0, 0);
+        const int k = 4 * s4 + kk;
+        const double up = M[(16 * p + min(m, k)) * kMLd + 16 * p + max(m, k)];
+        const double dg = invd[16 * p + k];
+        li[s4] = (m < k) ? up : (m == k ? dg : 0.0);
       }
 #pragma unroll
-      for (int q = 0; q < 4; ++q) Z[(kk + 4 * q) * kMLd + 16 * p + m] = xo[q];
+      for (int q = 0; q < 5; ++q) {
+        const int qc = min(q, max(p - 1, 0));
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) lt[q][s4] = M[(16 * p + 4 * s4 + kk) * kMLd + 16 * qc + m];
+      }
+      double zp = z[0];
+#pragma unroll
+      for (int q = 1; q < 6; ++q) zp = (q == p) ? z[q] : zp;
+      // X_p[m] = sum_k Z_p[k] (L_pp^-1)[k][m]
+      double xp = 0.0;
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) xp += __shfl(zp, 4 * s4 + kk, 64) * li[s4];   // Z_p[4 s + kk] lives in lane 4 s + kk
+      xp += __shfl_xor(xp, 16, 64);
+      xp += __shfl_xor(xp, 32, 64);
+      if (kk == 0) ds[16 * p + m] = xp;
+      // Z_q[m] -= sum_k X_p[k] L[p][q][k][m]
+      double xk[4];
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) xk[s4] = __shfl(xp, 4 * s4 + kk, 64);
+#pragma unroll
+      for (int q = 0; q < 5; ++q) {
+        if (q < p) {      // (uniform)
+          double a = 0.0;
+#pragma unroll
+          for (int s4 = 0; s4 < 4; ++s4) a += xk[s4] * lt[q][s4];
+          a += __shfl_xor(a, 16, 64);
+          a += __shfl_xor(a, 32, 64);
+          z[q] -= a;
+        }
+      }
     }
-    ds[lane] = Z[lane];
-    if (lane + 64 < npad) ds[lane + 64] = Z[lane + 64];
   }
   __syncthreads();
   LSTAMP(6);
@@ -604,16 +702,44 @@ __global__ __launch_bounds__(kStepThreads) void k_lm_step(LmProblem P, LmState S
   __syncthreads();
   double part = 0.0, dn = 0.0, xn = 0.0;
   if (tid < n) {
-    double hd = 0.0;
-    for (int j = 0; j < n; ++j) hd += H0[tid * kLd + j] * dd[j];
+    // (H0 is stored in both triangles: thread i walks COLUMN i, consecutive lanes read consecutive words)
+    double h0 = 0.0, h1 = 0.0;
+    double h2 = 0.0, h3 = 0.0;
+    const int nfull = n & ~15;
+#pragma unroll 1
+    for (int jb = 0; jb < nfull; jb += 16) {     // 16 columns per batch, their 32 LDS reads in flight together
+      const double* hp = H0 + jb * kLd + tid;
+      const double* dp = dd + jb;
+      double hw[16], dw[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) { hw[u] = hp[u * kLd]; dw[u] = dp[u]; }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < 16; u += 4) {
+        h0 += hw[u] * dw[u]; h1 += hw[u + 1] * dw[u + 1]; h2 += hw[u + 2] * dw[u + 2]; h3 += hw[u + 3] * dw[u + 3];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    for (int j = nfull; j < n; ++j) h0 += H0[j * kLd + tid] * dd[j];
+    h0 += h2; h1 += h3;
+    const double hd = h0 + h1;
     part = -dd[tid] * g[tid] - 0.5 * dd[tid] * hd;
     dn = dd[tid] * dd[tid];
     const double xv = (tid < npose) ? xf[tid] : S.beta[(size_t)f * nb + tid - npose];
     xn = xv * xv;
   }
-  const double model = block_sum8(part, red, tid);
-  const double dnorm = sqrt(block_sum8(dn, red, tid));
-  const double xnorm = sqrt(block_sum8(xn, red, tid));
+  // three sums in one pass (n <= 86: waves 0 and 1 hold every term)
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    part += __shfl_xor(part, off, 64);
+    dn += __shfl_xor(dn, off, 64);
+    xn += __shfl_xor(xn, off, 64);
+  }
+  if (lane == 0 && wave < 2) { red[wave] = part; red[2 + wave] = dn; red[4 + wave] = xn; }
+  __syncthreads();
+  const double model = red[0] + red[1];
+  const double dnorm = sqrt(red[2] + red[3]);
+  const double xnorm = sqrt(red[4] + red[5]);
   if (dnorm <= 1e-8 * (xnorm + 1e-8)) {      // Ceres parameter_tolerance
     if (tid == 0) {
       S.flags[f] = (flags & ~(kLmActive | kLmHasCand | kLmTermMask));
@@ -709,7 +835,7 @@ __global__ __launch_bounds__(256) void k_lm_accept(LmProblem P, LmState S, const
 
 }  // namespace
 
-size_t lm_step_lds_bytes() { return (size_t)(kMRows * kMLd + (kN + 1) * kLd + 512) * sizeof(double); }
+size_t lm_step_lds_bytes() { return (size_t)(kMRows * kMLd + (kN + 1) * kLd + 640) * sizeof(double); }
 
 void launch_lm_init(const LmProblem& P, const LmState& S, const double* d_r, hipStream_t s) {
   hipLaunchKernelGGL(k_lm_init, dim3(P.F), dim3(256), 0, s, P, S, d_r);
