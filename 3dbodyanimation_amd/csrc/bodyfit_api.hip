@@ -980,14 +980,17 @@ static void build_cr_schedule(int n, bool pinned, std::vector<int>& sched, std::
     const int na = (int)active.size();
     std::vector<char> el(na, 0);
     int ne = 0;
-    for (int pos = 1; pos < na; pos += 2)
+    // every other node goes; with an odd number of free-ended nodes the EVEN positions (one more of them) go, so that
+    // 20 frames take 20 -> 10 -> 5 -> 2 -> 1 -> root, one level less than always eliminating the odd positions
+    const int first = (!pinned && (na & 1) && na > 1) ? 0 : 1;
+    for (int pos = first; pos < na; pos += 2)
       if (!(pinned && pos == na - 1)) { el[pos] = 1; ++ne; }
     if (ne == 0) break;
     CrLevel lv{};
     lv.elim_off = (int)sched.size();
     for (int pos = 0; pos < na; ++pos)
       if (el[pos]) {
-        sched.push_back(active[pos]); sched.push_back(active[pos - 1]); sched.push_back(pos + 1 < na ? active[pos + 1] : -1);
+        sched.push_back(active[pos]); sched.push_back(pos > 0 ? active[pos - 1] : -1); sched.push_back(pos + 1 < na ? active[pos + 1] : -1);
         ++lv.n_elim;
       }
     lv.surv_off = (int)sched.size();
@@ -1018,11 +1021,12 @@ static size_t carve_cr(unsigned char* base, size_t off, int n, WinBuf& W, bool d
   const size_t blk = (size_t)kWinBlock * kWinBlock * 8, rhs = (size_t)kWinRhs * kWinBlock * 8;
   auto take = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
   const size_t o_D = take(n * blk), o_U = take(n * blk), o_L = take(n * blk), o_P = take(n * blk), o_Q = take(n * blk),
-               o_R = take(n * rhs), o_R0 = take(n * rhs), o_Y = take(n * rhs), o_X = take(n * rhs), o_fail = take(8);
+               o_R = take(n * rhs), o_R0 = take(n * rhs), o_Y = take(n * rhs), o_X = take(n * rhs),
+               o_Li = take((size_t)n * (kWinBlock / 16) * 256 * 8), o_fail = take(8);
   if (!dry) {
     auto dp = [&](size_t o) { return reinterpret_cast<double*>(base + o); };
     W.D = dp(o_D); W.U = dp(o_U); W.L = dp(o_L); W.Pt = dp(o_P); W.Qt = dp(o_Q); W.Rt = dp(o_R); W.Rt0 = dp(o_R0);
-    W.Yt = dp(o_Y); W.Xt = dp(o_X); W.fail = reinterpret_cast<int*>(base + o_fail);
+    W.Yt = dp(o_Y); W.Xt = dp(o_X); W.Li = dp(o_Li); W.fail = reinterpret_cast<int*>(base + o_fail);
   }
   return off;
 }

@@ -156,6 +156,7 @@ struct WinProblem {
 struct WinBuf {
   double *D, *U, *L, *Pt, *Qt;      // [F][80][80]: diagonal blocks, couplings, factors, solved couplings (transposed)
   double *Rt, *Rt0, *Yt, *Xt;       // [F][16][80]: right-hand sides (working copy, as assembled), L^-1 R, solution
+  double *Li;                       // [F][5][16][16]: L_pp^-T of the factor's diagonal blocks (k_cr_factor -> k_cr_back)
   double *Araw, *Braw, *graw, *Eraw;   // undamped, unscaled blocks for the model cost change: [F][76][76], [F][76][10], [F][76] x 2
   double *scale;                    // [F * 76 + 10] Jacobi scaling, fixed at the first iterate
   double *Cs, *rhsb, *Craw, *gbraw, *dsb;   // beta block: scaled damped C, scaled rhs, raw C, raw gradient, scaled step

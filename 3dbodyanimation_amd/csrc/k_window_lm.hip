@@ -329,6 +329,11 @@ __global__ __launch_bounds__(kCrThreads) void k_cr_factor(WinBuf W, const int* _
     } else if (grp == 1) {
 #pragma unroll
       for (int k = 0; k < 16; ++k) Linv[rr * 17 + k] = av[k];   // row rr of L_pp^-T
+      if (side == 0) {                                           // kept for the way down (k_cr_back)
+        double* Lg = W.Li + ((size_t)j * (WB / 16) + p) * 256 + rr * 16;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) Lg[k] = (k >= rr) ? av[k] : 0.0;
+      }
     }
     if (lane == 0 && !okp) stat[0] = 0.0;
   };
@@ -532,19 +537,11 @@ __global__ __launch_bounds__(kCrThreads) void k_cr_back(WinBuf W, const int* __r
 #pragma unroll
     for (int q = 0; q < 4; ++q) Zt[(kk + 4 * q) * LD + 16 * tj + m] = acc[q];
   } else if (wave == 5 || wave == 6) {
-    // inverses of the five 16 x 16 diagonal blocks of L: lane = (block, column c): forward substitution on e_c
-    for (int it = lane + 64 * (wave - 5); it < 5 * 16; it += 128) {
-      const int blk = it >> 4, c = it & 15, o = 16 * blk;
-      double x[16];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        double v = (r == c) ? 1.0 : 0.0;
-#pragma unroll
-        for (int k = 0; k < r; ++k) v -= Ls[(o + r) * LD + o + k] * x[k];
-        x[r] = (r >= c) ? v / Ls[(o + r) * LD + o + r] : 0.0;
-      }
-#pragma unroll
-      for (int r = 0; r < 16; ++r) Li[(blk * 16 + r) * 17 + c] = x[r];
+    // inverses of the five 16 x 16 diagonal blocks of L, as k_cr_factor left them: (L_pp^-T)[c][r] = (L_pp^-1)[r][c]
+    const double* Lg = W.Li + (size_t)j * (WB / 16) * 256;
+    for (int it = tid - 320; it < 5 * 256; it += 128) {
+      const int blk = it >> 8, c = (it >> 4) & 15, r = it & 15;
+      Li[(blk * 16 + r) * 17 + c] = Lg[it];
     }
   }
   __syncthreads();
@@ -595,57 +592,64 @@ __global__ __launch_bounds__(128) void k_win_schur_part(WinProblem P, WinBuf W) 
 }
 
 // mode 0: all; 1: this shard's sums of the Schur partials -> W.sred[110] only; 2: solve from W.sred (summed over the shards)
-__global__ __launch_bounds__(128) void k_win_beta_solve(WinProblem P, WinBuf W, const double* __restrict__ beta,
-                                                        double* __restrict__ beta_new, int mode) {
+__global__ __launch_bounds__(1024) void k_win_beta_solve(WinProblem P, WinBuf W, const double* __restrict__ beta,
+                                                         double* __restrict__ beta_new, int mode) {
+  __shared__ double red[8][128];
   __shared__ double S[NBETA * NBETA], rb[NBETA];
   const int tid = threadIdx.x, F = P.F;
   if (P.nb == 0) return;
+  // sums over the frames: 110 words, eight frame lanes of 128 threads, four independent loads per pass
+  const int w = tid & 127, g = tid >> 7;
+  if (mode != 2) {
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    if (w < NBETA * NBETA + NBETA) {
+      int f = g;
+      for (; f + 24 < F; f += 32) {
+        s0 += W.part[(size_t)f * kWinPart + w];
+        s1 += W.part[(size_t)(f + 8) * kWinPart + w];
+        s2 += W.part[(size_t)(f + 16) * kWinPart + w];
+        s3 += W.part[(size_t)(f + 24) * kWinPart + w];
+      }
+      for (; f < F; f += 8) s0 += W.part[(size_t)f * kWinPart + w];
+    }
+    red[g][w] = (s0 + s1) + (s2 + s3);
+  }
+  __syncthreads();
   if (tid < NBETA * NBETA + NBETA) {
-    double s = 0.0;
+    double s;
     if (mode == 2) s = W.sred[tid];
-    else
-      for (int f = 0; f < F; ++f) s += W.part[(size_t)f * kWinPart + tid];
+    else s = ((red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid])) + ((red[4][tid] + red[5][tid]) + (red[6][tid] + red[7][tid]));
     if (mode == 1) W.sred[tid] = s;
     if (tid < NBETA * NBETA) S[tid] = W.Cs[tid] - s; else rb[tid - NBETA * NBETA] = W.rhsb[tid - NBETA * NBETA] - s;
   }
   if (mode == 1) return;
   __syncthreads();
-  if (tid == 0) {
-    bool ok = true;
-    for (int j = 0; j < NBETA && ok; ++j) {
-      double d = S[j * NBETA + j];
-      for (int k = 0; k < j; ++k) d -= S[j * NBETA + k] * S[j * NBETA + k];
-      if (!(d > 0.0) || !(d < 1e300)) { ok = false; break; }
-      d = sqrt(d);
-      S[j * NBETA + j] = d;
-      for (int i = j + 1; i < NBETA; ++i) {
-        double v = S[i * NBETA + j];
-        for (int k = 0; k < j; ++k) v -= S[i * NBETA + k] * S[j * NBETA + k];
-        S[i * NBETA + j] = v / d;
-      }
+  if (tid < 64) {
+    // 10 x 10 Cholesky + both substitutions in the registers of one wave (dense_inl.h): lanes 0-15 the rows of S padded with
+    // the identity, lane 16 the right-hand side as one more row (comes out as y^T = rb^T L^-T), lanes 32-47 the identity
+    // (comes out as L^-T);  x = L^-T y
+    const int rr = tid & 15, grp = tid >> 4;
+    double av[16], iv[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      double v = 0.0;
+      if (grp == 0) v = (rr < NBETA && k < NBETA) ? ((k <= rr) ? S[rr * NBETA + k] : 0.0) : (rr == k ? 1.0 : 0.0);
+      else if (grp == 1) v = (rr == 0 && k < NBETA) ? rb[k] : 0.0;
+      else if (grp == 2) v = (rr == k) ? 1.0 : 0.0;
+      av[k] = v;
     }
-    if (!ok) {
-      *W.fail = 1;
-      for (int i = 0; i < NBETA; ++i) W.dsb[i] = 0.0;
-    } else {
-      double y[NBETA];
-      for (int i = 0; i < NBETA; ++i) {
-        double v = rb[i];
-        for (int k = 0; k < i; ++k) v -= S[i * NBETA + k] * y[k];
-        y[i] = v / S[i * NBETA + i];
-      }
-      for (int i = NBETA - 1; i >= 0; --i) {
-        double v = y[i];
-        for (int k = i + 1; k < NBETA; ++k) v -= S[k * NBETA + i] * y[k];
-        y[i] = v / S[i * NBETA + i];
-      }
-      for (int i = 0; i < NBETA; ++i) W.dsb[i] = y[i];
+    const bool ok = diag_factor16(av, rr, grp == 0, iv, NBETA);
+    double x = 0.0;
+#pragma unroll
+    for (int k = 0; k < NBETA; ++k) x += av[k] * readlane_f64w(av[k], 16);     // lanes 32 + r: sum_k (L^-T)[r][k] y[k]
+    if (grp == 2 && rr < NBETA) {
+      const double dsb = ok ? x : 0.0;
+      W.dsb[rr] = dsb;
+      const double di = dsb * W.scale[(size_t)F * NP + rr];
+      W.d[(size_t)F * NP + rr] = di;
+      beta_new[rr] = beta[rr] + di;
     }
-    for (int i = 0; i < NBETA; ++i) {
-      const double di = W.dsb[i] * W.scale[(size_t)F * NP + i];
-      W.d[(size_t)F * NP + i] = di;
-      beta_new[i] = beta[i] + di;
-    }
+    if (tid == 0 && !ok) *W.fail = 1;
   }
 }
 
@@ -854,7 +858,7 @@ void launch_win_schur_part(const WinProblem& P, const WinBuf& W, hipStream_t s) 
   hipLaunchKernelGGL(k_win_schur_part, dim3(P.F), dim3(128), 0, s, P, W);
 }
 void launch_win_beta_solve(const WinProblem& P, const WinBuf& W, const double* d_beta, double* d_beta_new, int mode, hipStream_t s) {
-  hipLaunchKernelGGL(k_win_beta_solve, dim3(1), dim3(128), 0, s, P, W, d_beta, d_beta_new, mode);
+  hipLaunchKernelGGL(k_win_beta_solve, dim3(1), dim3(1024), 0, s, P, W, d_beta, d_beta_new, mode);
 }
 void launch_win_step(const WinProblem& P, const WinBuf& W, const double* d_x, double* d_x_new, hipStream_t s) {
   hipLaunchKernelGGL(k_win_step, dim3(P.F), dim3(128), 0, s, P, W, d_x, d_x_new);
