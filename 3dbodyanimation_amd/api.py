@@ -30,7 +30,8 @@ class BodyfitError(RuntimeError):
 class _ModelDesc(C.Structure):
     _fields_ = [("n_verts", C.c_int), ("n_joints", C.c_int), ("n_shape", C.c_int), ("n_pose_feat", C.c_int),
                 ("v_template", _dp), ("shapedirs", _dp), ("posedirs", _dp), ("j_regressor", _dp),
-                ("weights", _dp), ("parent", _ip), ("n_landmarks", C.c_int), ("landmark_vid", _ip)]
+                ("weights", _dp), ("parent", _ip), ("n_landmarks", C.c_int), ("landmark_vid", _ip),
+                ("n_kp_regressors", C.c_int), ("kpreg_offset", _ip), ("kpreg_vid", _ip), ("kpreg_weight", _dp)]
 
 
 class _ProblemDesc(C.Structure):
@@ -224,8 +225,14 @@ class Model:
         k = self._keep
         self.n_verts, self.n_joints, self.n_shape = m.v_template.shape[0], len(m.parent), m.shapedirs.shape[2]
         self.n_landmarks = len(m.landmark_vid)
+        self.n_kp_regressors = getattr(m, "n_kp_regressors", 0)
+        if self.n_kp_regressors:
+            self._keep += [_c32i(m.kpreg_offset), _c32i(m.kpreg_vid), _c64(m.kpreg_weight)]
+            reg = (self.n_kp_regressors, _i(self._keep[-3]), _i(self._keep[-2]), _d(self._keep[-1]))
+        else:
+            reg = (0, None, None, None)
         desc = _ModelDesc(self.n_verts, self.n_joints, self.n_shape, m.posedirs.shape[2] if pose_blend_data else 0,
-                          _d(k[0]), _d(k[1]), _d(k[2]), _d(k[3]), _d(k[4]), _i(k[5]), self.n_landmarks, _i(k[6]))
+                          _d(k[0]), _d(k[1]), _d(k[2]), _d(k[3]), _d(k[4]), _i(k[5]), self.n_landmarks, _i(k[6]), *reg)
         h = C.c_void_p()
         _check(lib.bodyfit_model_create(C.byref(desc), device, C.byref(h)))
         self.h = h

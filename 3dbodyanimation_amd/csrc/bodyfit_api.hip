@@ -64,7 +64,9 @@ struct Allocs {
 struct bodyfit_model {
   int device = 0;
   int n_cus = 0;
-  int V = 0, nJ = 0, nS = 0, P = 0, nL = 0;
+  int V = 0, nJ = 0, nS = 0, P = 0, nL = 0;   // nL: the caller's one-hot landmarks (the device model's nL counts slots)
+  int nReg = 0;                               // sparse keypoint regressors over posed vertices
+  std::vector<int> reg_slot;                  // [nReg] first landmark slot of the row's pseudo-vertices
   bool mesh_ok = true;
   DevModel d{};
   std::vector<int> parent;
@@ -257,6 +259,15 @@ int bodyfit_model_create(const bodyfit_model_desc* desc, int device, bodyfit_mod
       return fail(BODYFIT_ERR_INVALID, "kintree must be topologically ordered with a single root");
   for (int l = 0; l < nL; ++l)
     if (desc->landmark_vid[l] < 0 || desc->landmark_vid[l] >= V) return fail(BODYFIT_ERR_INVALID, "landmark vertex id");
+  const int nReg = desc->n_kp_regressors;
+  if (nReg < 0 || (nReg > 0 && (!desc->kpreg_offset || !desc->kpreg_vid || !desc->kpreg_weight)))
+    return fail(BODYFIT_ERR_INVALID, "keypoint regressors: missing arrays");
+  for (int r = 0; r < nReg; ++r) {
+    if (desc->kpreg_offset[r + 1] <= desc->kpreg_offset[r] || desc->kpreg_offset[0] != 0)
+      return fail(BODYFIT_ERR_INVALID, "keypoint regressors: offsets must start at 0 and every row needs an entry");
+    for (int e = desc->kpreg_offset[r]; e < desc->kpreg_offset[r + 1]; ++e)
+      if (desc->kpreg_vid[e] < 0 || desc->kpreg_vid[e] >= V) return fail(BODYFIT_ERR_INVALID, "keypoint regressor vertex id");
+  }
 
   HIP_TRY(hipSetDevice(device));
   bodyfit_model* m = new bodyfit_model();
@@ -335,33 +346,74 @@ int bodyfit_model_create(const bodyfit_model_desc* desc, int device, bodyfit_mod
   HIP_TRY(m->mem.upload(&d.Jc0, Jc0));
   HIP_TRY(m->mem.upload(&d.Sc, Sc));
 
-  // landmarks
+  // landmark slots of the frame kernel: the caller's one-hot landmarks, then the pseudo-vertices of the regressor rows.
+  // A row  k = sum_i a_i posed(v_i),  posed(v) = sum_j W_vj (A_j (rest_v - Jc_j) + P_j),  collapses per skinning joint j to
+  //   s_j (A_j (r_j - Jc_j) + P_j),   s_j = sum_i a_i W_ij,   r_j = sum_i a_i W_ij rest_i / s_j
+  // (rest_i = template + shapedirs beta + posedirs feat is linear in the vertex rows, and the coefficients a_i W_ij / s_j
+  // sum to one, so r_j is itself a "vertex" with rows combined the same way): one slot per joint with s_j != 0, skinned to
+  // that joint alone with weight s_j.  The kernel adds the slots of a row up (position and Jacobian terms) into the first.
   {
-    // fixed-stride skinning weights per landmark: kMaxLmNnz slots padded with weight 0; woff[l] = count
-    std::vector<int> woff(nL + 1, 0), wj((size_t)std::max(nL, 1) * kMaxLmNnz, 0);
-    std::vector<double> ww((size_t)std::max(nL, 1) * kMaxLmNnz, 0.0), vt((size_t)nL * 3),
-        sd((size_t)nL * 3 * std::max(nS, 1), 0.0), pd((size_t)std::max(nL, 1) * 27 * 32, 0.0);
+    struct Slot { std::vector<std::pair<int, double>> w; std::vector<std::pair<int, double>> src; };   // (joint, weight), (vertex, coefficient)
+    std::vector<Slot> slots;
+    std::vector<int> gcount;
     for (int l = 0; l < nL; ++l) {
+      Slot sl;
       const int vid = desc->landmark_vid[l];
-      int cnt = 0;
       for (int j = 0; j < nJ; ++j) {
         const double w = desc->weights[(size_t)vid * nJ + j];
-        if (w == 0.0) continue;
-        if (cnt >= kMaxLmNnz) return fail(BODYFIT_ERR_INVALID, "landmark vertex has more than 8 skinning weights");
-        wj[(size_t)l * kMaxLmNnz + cnt] = j;
-        ww[(size_t)l * kMaxLmNnz + cnt] = w;
-        ++cnt;
+        if (w != 0.0) sl.w.emplace_back(j, w);
       }
-      woff[l] = cnt;
-      for (int a = 0; a < 3; ++a) {
-        vt[l * 3 + a] = desc->v_template[(size_t)vid * 3 + a] - J0[a];
-        for (int k = 0; k < nS; ++k)
-          sd[(size_t)(l * 3 + a) * nS + k] = desc->shapedirs[((size_t)vid * 3 + a) * nS + k] - S[(size_t)a * nS + k];
-        // [l][a * 9 + e][k - 1]: the 9 (k - 1) + e pose-feature column of joint k, joint-minor, so that the lanes of a
-        // half-wave (one joint each) read 184 contiguous bytes per (a, e)
-        for (int k = 0; k < P; ++k)
-          pd[((size_t)l * 27 + a * 9 + k % 9) * 32 + k / 9] = desc->posedirs[((size_t)vid * 3 + a) * P + k];
+      if ((int)sl.w.size() > kMaxLmNnz) return fail(BODYFIT_ERR_INVALID, "landmark vertex has more than 8 skinning weights");
+      sl.src.emplace_back(vid, 1.0);
+      slots.push_back(std::move(sl));
+      gcount.push_back(1);
+    }
+    m->nReg = nReg;
+    for (int r = 0; r < nReg; ++r) {
+      m->reg_slot.push_back((int)slots.size());
+      const int first = (int)slots.size();
+      for (int j = 0; j < nJ; ++j) {
+        double sj = 0.0;
+        for (int e = desc->kpreg_offset[r]; e < desc->kpreg_offset[r + 1]; ++e)
+          sj += desc->kpreg_weight[e] * desc->weights[(size_t)desc->kpreg_vid[e] * nJ + j];
+        if (sj == 0.0) continue;
+        Slot sl;
+        sl.w.emplace_back(j, sj);
+        for (int e = desc->kpreg_offset[r]; e < desc->kpreg_offset[r + 1]; ++e) {
+          const double c = desc->kpreg_weight[e] * desc->weights[(size_t)desc->kpreg_vid[e] * nJ + j];
+          if (c != 0.0) sl.src.emplace_back(desc->kpreg_vid[e], c / sj);
+        }
+        slots.push_back(std::move(sl));
+        gcount.push_back(0);
       }
+      if ((int)slots.size() == first) return fail(BODYFIT_ERR_INVALID, "keypoint regressor row without skinning weight");
+      gcount[first] = (int)slots.size() - first;
+    }
+    const int nSlots = (int)slots.size();
+    if (nSlots > kMaxLandmarks)
+      return fail(BODYFIT_ERR_INVALID, "landmarks + regressor pseudo-vertices (one per row and skinning joint) must be <= 32");
+    d.nL = nSlots;
+    // fixed-stride skinning weights per slot: kMaxLmNnz entries padded with weight 0; woff[l] = count
+    std::vector<int> woff(nSlots + 1, 0), wj((size_t)std::max(nSlots, 1) * kMaxLmNnz, 0);
+    std::vector<double> ww((size_t)std::max(nSlots, 1) * kMaxLmNnz, 0.0), vt((size_t)nSlots * 3, 0.0),
+        sd((size_t)nSlots * 3 * std::max(nS, 1), 0.0), pd((size_t)std::max(nSlots, 1) * 27 * 32, 0.0);
+    for (int l = 0; l < nSlots; ++l) {
+      const Slot& sl = slots[l];
+      for (size_t i = 0; i < sl.w.size(); ++i) {
+        wj[(size_t)l * kMaxLmNnz + i] = sl.w[i].first;
+        ww[(size_t)l * kMaxLmNnz + i] = sl.w[i].second;
+      }
+      woff[l] = (int)sl.w.size();
+      for (const auto& [vid, c] : sl.src)
+        for (int a = 0; a < 3; ++a) {
+          vt[l * 3 + a] += c * (desc->v_template[(size_t)vid * 3 + a] - J0[a]);
+          for (int k = 0; k < nS; ++k)
+            sd[(size_t)(l * 3 + a) * nS + k] += c * (desc->shapedirs[((size_t)vid * 3 + a) * nS + k] - S[(size_t)a * nS + k]);
+          // [l][a * 9 + e][k - 1]: the 9 (k - 1) + e pose-feature column of joint k, joint-minor, so that the lanes of a
+          // half-wave (one joint each) read 184 contiguous bytes per (a, e)
+          for (int k = 0; k < P; ++k)
+            pd[((size_t)l * 27 + a * 9 + k % 9) * 32 + k / 9] += c * desc->posedirs[((size_t)vid * 3 + a) * P + k];
+        }
     }
     HIP_TRY(m->mem.upload(&d.lm_woff, woff));
     HIP_TRY(m->mem.upload(&d.lm_wj, wj));
@@ -369,6 +421,11 @@ int bodyfit_model_create(const bodyfit_model_desc* desc, int device, bodyfit_mod
     HIP_TRY(m->mem.upload(&d.lm_vt, vt));
     HIP_TRY(m->mem.upload(&d.lm_sd, sd));
     HIP_TRY(m->mem.upload(&d.lm_pd, pd));
+    d.lm_gcount = nullptr;
+    if (nReg > 0) {
+      gcount.resize(kMaxLandmarks, 0);
+      HIP_TRY(m->mem.upload(&d.lm_gcount, gcount));
+    }
   }
 
   // mesh operands in MFMA fragment order
@@ -578,7 +635,7 @@ int bodyfit_problem_create(const bodyfit_model* m, const bodyfit_problem_desc* d
   const int K = desc->kp_offset[F];
   if (K > 0 && (!desc->kp_id || !desc->kp_uv)) return fail(BODYFIT_ERR_INVALID, "missing keypoints");
   for (int k = 0; k < K; ++k)
-    if (desc->kp_id[k] < 0 || desc->kp_id[k] >= nJ + m->nL) return fail(BODYFIT_ERR_INVALID, "keypoint id out of range");
+    if (desc->kp_id[k] < 0 || desc->kp_id[k] >= nJ + m->nL + m->nReg) return fail(BODYFIT_ERR_INVALID, "keypoint id out of range");
   if (desc->gmm && desc->gmm->d.D != 3 * (nJ - 1)) return fail(BODYFIT_ERR_INVALID, "GMM dimension must be 3 (n_joints - 1)");
   if (desc->want_mesh && (size_t)((F + kFTile - 1) / kFTile) * kFTile * m->d.nVTiles * kVTile * 12 >= ((size_t)1 << 32))
     return fail(BODYFIT_ERR_INVALID, "mesh path: the cloud of one problem must stay below 4 GiB (split the frames)");
@@ -627,6 +684,8 @@ int bodyfit_problem_create(const bodyfit_model* m, const bodyfit_problem_desc* d
     // the device copies carry one keypoint chunk (32 entries) of zero padding: k_frame_resjac prefetches a frame's first
     // chunk with unconditional loads
     std::vector<int> ids(p->kp_id);
+    for (int& id : ids)        // a regressor row is addressed by the first of its landmark slots on the device
+      if (id >= nJ + m->nL) id = nJ + m->reg_slot[id - nJ - m->nL];
     std::vector<double> uv(p->kp_uv);
     ids.resize(ids.size() + 32, 0);
     uv.resize(uv.size() + 64, 0.0);

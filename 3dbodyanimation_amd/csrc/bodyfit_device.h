@@ -36,6 +36,8 @@ struct DevModel {
   const double* lm_vt;         // [nL][3]       v_template - J0_root
   const double* lm_sd;         // [nL][3][nS]   shapedirs  - S_root
   const double* lm_pd;         // [nL][27 = 3 coords x 9 entries][32 >= nJ - 1] posedirs of the landmark vertex, joint-minor
+  const int* lm_gcount;        // [32] or NULL: slots of a keypoint regressor row are summed into its first slot, whose entry is the
+                               // row's slot count (other entries: 1 = plain landmark, 0 = member of a row)
   // mesh operands (packed in MFMA fragment order at upload)
   const uint16_t* dirsB;       // [nVTiles][kBlendKSteps][3][2 hi/lo][64][8] bf16: posedirs, then shapedirs - S_root
   const float* vtB;            // [nVTiles][3][32] f32

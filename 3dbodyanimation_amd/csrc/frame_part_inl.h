@@ -546,6 +546,20 @@ __device__ __forceinline__ void frame_part(const DevModel& M, const DevProblem& 
 #pragma unroll
     for (int e = 0; e < 9; ++e) L[LM_A + e] = Ab[e];
   }
+  if (wave == 2 && M.lm_gcount) {
+    // keypoint regressor rows: the position of a row is the sum over its slots, left in the first one (LDS serves a wave in
+    // order: the stores above are complete for every lane)
+    const int cnt = (lane < nL) ? M.lm_gcount[lane] : 0;
+    if (cnt > 1) {
+      double* L = sLm + lane * LM_STRIDE;
+      double q0 = L[LM_Q], q1 = L[LM_Q + 1], q2 = L[LM_Q + 2];
+      for (int i = 1; i < cnt; ++i) {
+        const double* Li = L + i * LM_STRIDE;
+        q0 += Li[LM_Q]; q1 += Li[LM_Q + 1]; q2 += Li[LM_Q + 2];
+      }
+      L[LM_Q] = q0; L[LM_Q + 1] = q1; L[LM_Q + 2] = q2;
+    }
+  }
   if (wave == 3 && lane < 36) {
     // Rr0 = R_root R0, dRr0_c = dR_root,c R0
     const double* R0 = Pb.R0 + (size_t)f * 9;
@@ -714,6 +728,23 @@ __device__ __forceinline__ void frame_part(const DevModel& M, const DevProblem& 
     frame_sync<true>();
     if (tid == kThreads - 1) __hip_atomic_store(fu.flag + f, fu.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     STAMP_REAL(12);
+  }
+  if (M.lm_gcount && want_jac && nL > 0) {
+    // keypoint regressor rows: d q / d theta (69 x 3) and d q / d beta (10 x 3) of a row are the sums over its slots, left in
+    // the first one.  item = (slot, word of [LM_BETA, LM_PD + 207)); only models with regressor rows pay the two barriers.
+    frame_sync<kFused>();
+    constexpr int kWords = LM_PD + 207 - LM_BETA;     // 237 contiguous words: LM_BETA (30) then LM_PD (207)
+    static_assert(LM_PD == LM_BETA + 30, "LM_BETA and LM_PD are adjacent");
+    for (int it = tid; it < nL * kWords; it += kThreads) {
+      const int l = it / kWords, w = it - l * kWords;
+      const int cnt = M.lm_gcount[l];
+      if (cnt > 1) {
+        double* o = sLm + l * LM_STRIDE + LM_BETA + w;
+        double v = o[0];
+        for (int i = 1; i < cnt; ++i) v += o[i * LM_STRIDE];
+        o[0] = v;
+      }
+    }
   }
   // ---- F. keypoints of this frame, KC at a time: stage per-keypoint data, then the flat (keypoint, column)
   //         sweep over all 512 threads (consecutive threads on consecutive columns of the row-major panel) ------

@@ -95,6 +95,15 @@ class SynthModel:
     J0: np.ndarray = field(default=None)
     S: np.ndarray = field(default=None)
     faces: np.ndarray = field(default=None)  # [nF,3] int32 triangles (AvatarModel::mesh); optional
+    # sparse keypoint regressors over the POSED vertices (CSR; keypoint id n_joints + n_landmarks + r): OpenPose-style extra
+    # keypoints that are a weighted mean of a few surface vertices instead of one vertex
+    kpreg_offset: np.ndarray = field(default=None)  # [nR + 1] int32
+    kpreg_vid: np.ndarray = field(default=None)     # [nnz] int32
+    kpreg_weight: np.ndarray = field(default=None)  # [nnz] float64
+
+    @property
+    def n_kp_regressors(self):
+        return 0 if self.kpreg_offset is None else len(self.kpreg_offset) - 1
 
     @property
     def n_verts(self):
@@ -112,6 +121,27 @@ class SynthModel:
         self.J0 = self.j_regressor @ self.v_template
         self.S = np.einsum("jv,vak->jak", self.j_regressor, self.shapedirs).reshape(3 * self.n_joints, -1)
         return self
+
+
+def add_kp_regressors(model: "SynthModel", n_rows: int = 3, support: int = 12, seed: int = 0) -> "SynthModel":
+    """Attach `n_rows` sparse regressor rows: each is a convex combination of the `support` vertices nearest to a landmark
+    vertex (so a row spans several skinning joints), weights drawn once from a seeded generator."""
+    from scipy.spatial import cKDTree
+
+    rng = np.random.default_rng(seed)
+    tree = cKDTree(model.v_template)
+    off, vid, w = [0], [], []
+    for r in range(n_rows):
+        centre = model.v_template[model.landmark_vid[(3 * r + 1) % len(model.landmark_vid)]]
+        _, nn = tree.query(centre, k=support)
+        c = rng.uniform(0.2, 1.0, support)
+        vid += [int(i) for i in nn]
+        w += list(c / c.sum())
+        off.append(len(vid))
+    model.kpreg_offset = np.asarray(off, np.int32)
+    model.kpreg_vid = np.asarray(vid, np.int32)
+    model.kpreg_weight = np.asarray(w, np.float64)
+    return model
 
 
 N_FACES = 13776  # SMPL: 2 V - 4
@@ -312,14 +342,28 @@ def make_sequence(model: SynthModel, n_frames: int, seed: int = 0, kp_ids=BODY25
     intr = camera_intrinsics(W, H)
     R0 = np.tile(R0_DEFAULT.reshape(1, 9), (F, 1))
     kp_ids = np.asarray(kp_ids, dtype=np.int32)
-    lm = kp_ids[kp_ids >= nJ] - nJ
+    nL = len(model.landmark_vid)
+    is_lm = (kp_ids >= nJ) & (kp_ids < nJ + nL)
+    is_reg = kp_ids >= nJ + nL                       # sparse regressor rows over the posed vertices
+    lm = kp_ids[is_lm] - nJ
+    reg_rows = kp_ids[is_reg] - nJ - nL
+    reg_vid = (np.concatenate([model.kpreg_vid[model.kpreg_offset[r]:model.kpreg_offset[r + 1]] for r in reg_rows])
+               if len(reg_rows) else np.zeros(0, np.int32))
     offs, ids, uvs = [0], [], []
     for f in range(F):
-        joints, lmk = forward_numpy(model, gt[f], beta, R0_DEFAULT, True, model.landmark_vid[lm] if len(lm) else [])
+        vids = np.concatenate([model.landmark_vid[lm], reg_vid]).astype(np.int64) if (len(lm) or len(reg_vid)) else []
+        joints, lmk = forward_numpy(model, gt[f], beta, R0_DEFAULT, True, vids)
         pts = np.empty((len(kp_ids), 3))
         pts[kp_ids < nJ] = joints[kp_ids[kp_ids < nJ]]
         if len(lm):
-            pts[kp_ids >= nJ] = lmk
+            pts[is_lm] = lmk[:len(lm)]
+        if len(reg_rows):
+            o, rp = len(lm), []
+            for r in reg_rows:
+                e0, e1 = model.kpreg_offset[r], model.kpreg_offset[r + 1]
+                rp.append(model.kpreg_weight[e0:e1] @ lmk[o:o + e1 - e0])
+                o += e1 - e0
+            pts[is_reg] = np.array(rp)
         uv = project(pts, intr) + rng.normal(scale=noise_px, size=(len(kp_ids), 2))
         keep = np.ones(len(kp_ids), bool)
         if ragged:  # drop a few keypoints per frame (visibility < 0.5 in the reference loader)

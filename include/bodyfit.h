@@ -70,6 +70,17 @@ typedef struct bodyfit_model_desc {
   const int* parent;         /* [n_joints], root = -1 (scripts/npz_fixer.py) */
   int n_landmarks;           /* vertex-landmark keypoints (0 = none) */
   const int* landmark_vid;   /* [n_landmarks] vertex ids  */
+  /* Sparse keypoint regressors over the POSED vertices (0 = none): keypoint id n_joints + n_landmarks + r is
+   *   sum_i kpreg_weight[i] * posed_vertex(kpreg_vid[i]),  i in [kpreg_offset[r], kpreg_offset[r + 1])
+   * (OpenPose-style extra keypoints: a weighted mean of a few surface vertices; the avatar library's keypoints of this
+   * kind are what the reference's PixelKP::jid would address past the 24 SMPL joints, include/Sim3BA.h:28-33).
+   * Evaluated exactly, with its Jacobian, in the frame kernel: per skinning joint j the row collapses to ONE pseudo-vertex
+   * (sum_i w_i W_ij [v_i ; 1] is linear in the vertex rows), so a row costs as many landmark slots as its vertices have
+   * distinct joints.  Landmarks + slots of all rows <= 32.                                                               */
+  int n_kp_regressors;
+  const int* kpreg_offset;    /* [n_kp_regressors + 1] */
+  const int* kpreg_vid;       /* [nnz] vertex ids      */
+  const double* kpreg_weight; /* [nnz]                 */
 } bodyfit_model_desc;
 
 int bodyfit_model_create(const bodyfit_model_desc* desc, int device, bodyfit_model** out);
@@ -95,7 +106,8 @@ typedef struct bodyfit_problem_desc {
   int n_frames;
   const int* kp_offset;   /* [n_frames+1] CSR over keypoints (frames may be empty)            */
   const int* kp_id;       /* [K] id < n_joints: SMPL joint (PixelKP::jid);
-                                 id >= n_joints: vertex landmark id - n_joints                */
+                                 n_joints <= id < n_joints + n_landmarks: vertex landmark id - n_joints;
+                                 above: keypoint regressor row id - n_joints - n_landmarks    */
   const double* kp_uv;    /* [K][2] observed pixels (PixelKP::u,v)                            */
   double fx, fy, cx, cy;
   const double* R0;       /* [n_frames][9] row-major fixed root orientation (avatar.r[0])     */

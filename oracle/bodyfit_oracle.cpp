@@ -129,6 +129,9 @@ struct Model {
   std::vector<double> weights;      // [V][nJ]
   std::vector<int> parent;          // [nJ]
   std::vector<int> landmark_vid;    // [nL]
+  // sparse keypoint regressors over the POSED vertices (keypoint id >= nJ + nL): position = sum_i w_i posed(v_i)
+  std::vector<int> kpreg_off, kpreg_vid;
+  std::vector<double> kpreg_w;
   // derived
   std::vector<double> J0;      // [nJ][3]   initialJointPos = j_regressor . v_template
   std::vector<double> S;       // [3 nJ][nS] jointShapeReg   = j_regressor . shapedirs
@@ -311,7 +314,17 @@ bool kp_functor(const KpCtx& c, T const* const* params, T* residuals) {
   } else {
     std::vector<T> A, Pj, Jc, Rl;
     body_skeleton(c, params, A, Pj, Jc, Rl);
-    vertex_body(c, params, m.landmark_vid[c.id - m.nJ], A, Pj, Jc, Rl, pos);
+    if (c.id < m.nJ + m.nL) {
+      vertex_body(c, params, m.landmark_vid[c.id - m.nJ], A, Pj, Jc, Rl, pos);
+    } else {   // sparse regressor row over the posed vertices
+      const int r = c.id - m.nJ - m.nL;
+      for (int a = 0; a < 3; ++a) pos[a] = T(0.0);
+      for (int e = m.kpreg_off[r]; e < m.kpreg_off[r + 1]; ++e) {
+        T pv[3];
+        vertex_body(c, params, m.kpreg_vid[e], A, Pj, Jc, Rl, pv);
+        for (int a = 0; a < 3; ++a) pos[a] += T(m.kpreg_w[e]) * pv[a];
+      }
+    }
   }
   // include/Sim3BA.h:210-213
   T cam[3];
@@ -518,78 +531,83 @@ void kp_analytic(const KpCtx& c, const FrameGeom& g, const double* x, const doub
       }
     }
   } else {
-    // vertex landmark through blend + LBS, body frame
-    const int vid = m.landmark_vid[c.id - nJ];
-    double vp[3];
-    for (int a = 0; a < 3; ++a) {
-      double s = m.v_template[(size_t)vid * 3 + a] - m.J0[a];
-      if (c.use_shape)
-        for (int k = 0; k < nS; ++k)
-          s += (m.shapedirs[((size_t)vid * 3 + a) * nS + k] - m.S[(size_t)a * nS + k]) * beta[k];
-      if (c.pose_blend && P > 0) {
-        const double* pd = &m.posedirs[((size_t)vid * 3 + a) * P];
-        for (int j = 1; j < nJ; ++j)
-          for (int e = 0; e < 9; ++e)
-            s += pd[9 * (j - 1) + e] * (g.R[j * 9 + e] - ((e % 4 == 0) ? 1.0 : 0.0));
-      }
-      vp[a] = s;
-    }
-    double Ablend[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    for (int j = 0; j < nJ; ++j) {
-      const double w = m.weights[(size_t)vid * nJ + j];
-      if (w == 0.0) continue;
-      double loc[3] = {vp[0] - g.Jc[j * 3], vp[1] - g.Jc[j * 3 + 1], vp[2] - g.Jc[j * 3 + 2]};
-      double xj[3];
-      mat3vec(&g.A[j * 9], loc, xj);
-      for (int a = 0; a < 3; ++a) { xj[a] += g.Pj[j * 3 + a]; q[a] += w * xj[a]; }
-      for (int i = 0; i < 9; ++i) Ablend[i] += w * g.A[j * 9 + i];
-      // pose columns: joint k in {j and its ancestors}, k != root, rotates (x_j - P_k)
-      for (int k = j; k > 0; k = m.parent[k]) {
-        const int pk = m.parent[k];
-        double rel[3] = {xj[0] - g.Pj[k * 3], xj[1] - g.Pj[k * 3 + 1], xj[2] - g.Pj[k * 3 + 2]};
-        double Ak[9], lk[3];
-        mat3mul(&g.A[pk * 9], &g.R[k * 9], Ak);
-        for (int i = 0; i < 3; ++i) lk[i] = Ak[i] * rel[0] + Ak[3 + i] * rel[1] + Ak[6 + i] * rel[2];
-        for (int cc = 0; cc < 3; ++cc) {
-          double t[3];
-          mat3vec(&g.dR[(k * 3 + cc) * 9], lk, t);
-          mat3vec(&g.A[pk * 9], t, t);
-          for (int a = 0; a < 3; ++a) DQ(a, 7 + 3 * (k - 1) + cc) += w * t[a];
+    // vertex keypoint through blend + LBS, body frame: one vertex (landmark) or a sparse regressor row over posed vertices
+    const bool is_reg = c.id >= nJ + m.nL;
+    const int e0 = is_reg ? m.kpreg_off[c.id - nJ - m.nL] : 0, e1 = is_reg ? m.kpreg_off[c.id - nJ - m.nL + 1] : 1;
+    for (int ee = e0; ee < e1; ++ee) {
+      const int vid = is_reg ? m.kpreg_vid[ee] : m.landmark_vid[c.id - nJ];
+      const double coef = is_reg ? m.kpreg_w[ee] : 1.0;
+      double vp[3];
+      for (int a = 0; a < 3; ++a) {
+        double s = m.v_template[(size_t)vid * 3 + a] - m.J0[a];
+        if (c.use_shape)
+          for (int k = 0; k < nS; ++k)
+            s += (m.shapedirs[((size_t)vid * 3 + a) * nS + k] - m.S[(size_t)a * nS + k]) * beta[k];
+        if (c.pose_blend && P > 0) {
+          const double* pd = &m.posedirs[((size_t)vid * 3 + a) * P];
+          for (int j = 1; j < nJ; ++j)
+            for (int e = 0; e < 9; ++e)
+              s += pd[9 * (j - 1) + e] * (g.R[j * 9 + e] - ((e % 4 == 0) ? 1.0 : 0.0));
         }
+        vp[a] = s;
       }
-      if (c.use_shape && shape_cols) {
-        // d/d beta of A_j (vp - Jc_j) + P_j
-        for (int k = 0; k < nS; ++k) {
-          double d[3], t[3];
-          for (int a = 0; a < 3; ++a)
-            d[a] = (m.shapedirs[((size_t)vid * 3 + a) * nS + k] - m.S[(size_t)a * nS + k]) -
-                   (m.S[(size_t)(3 * j + a) * nS + k] - m.S[(size_t)a * nS + k]);
-          mat3vec(&g.A[j * 9], d, t);
-          for (int a = 0; a < 3; ++a) DQ(a, 7 + 3 * (nJ - 1) + k) += w * t[a];
-          for (int cnode = j; cnode > 0; cnode = m.parent[cnode]) {
-            const int pc = m.parent[cnode];
+      double Ablend[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+      for (int j = 0; j < nJ; ++j) {
+        const double w = m.weights[(size_t)vid * nJ + j];
+        if (w == 0.0) continue;
+        double loc[3] = {vp[0] - g.Jc[j * 3], vp[1] - g.Jc[j * 3 + 1], vp[2] - g.Jc[j * 3 + 2]};
+        double xj[3];
+        mat3vec(&g.A[j * 9], loc, xj);
+        for (int a = 0; a < 3; ++a) { xj[a] += g.Pj[j * 3 + a]; q[a] += coef * w * xj[a]; }
+        for (int i = 0; i < 9; ++i) Ablend[i] += w * g.A[j * 9 + i];
+        // pose columns: joint k in {j and its ancestors}, k != root, rotates (x_j - P_k)
+        for (int k = j; k > 0; k = m.parent[k]) {
+          const int pk = m.parent[k];
+          double rel[3] = {xj[0] - g.Pj[k * 3], xj[1] - g.Pj[k * 3 + 1], xj[2] - g.Pj[k * 3 + 2]};
+          double Ak[9], lk[3];
+          mat3mul(&g.A[pk * 9], &g.R[k * 9], Ak);
+          for (int i = 0; i < 3; ++i) lk[i] = Ak[i] * rel[0] + Ak[3 + i] * rel[1] + Ak[6 + i] * rel[2];
+          for (int cc = 0; cc < 3; ++cc) {
+            double t[3];
+            mat3vec(&g.dR[(k * 3 + cc) * 9], lk, t);
+            mat3vec(&g.A[pk * 9], t, t);
+            for (int a = 0; a < 3; ++a) DQ(a, 7 + 3 * (k - 1) + cc) += coef * w * t[a];
+          }
+        }
+        if (c.use_shape && shape_cols) {
+          // d/d beta of A_j (vp - Jc_j) + P_j
+          for (int k = 0; k < nS; ++k) {
+            double d[3], t[3];
             for (int a = 0; a < 3; ++a)
-              d[a] = m.S[(size_t)(3 * cnode + a) * nS + k] - m.S[(size_t)(3 * pc + a) * nS + k];
-            mat3vec(&g.A[pc * 9], d, t);
-            for (int a = 0; a < 3; ++a) DQ(a, 7 + 3 * (nJ - 1) + k) += w * t[a];
+              d[a] = (m.shapedirs[((size_t)vid * 3 + a) * nS + k] - m.S[(size_t)a * nS + k]) -
+                     (m.S[(size_t)(3 * j + a) * nS + k] - m.S[(size_t)a * nS + k]);
+            mat3vec(&g.A[j * 9], d, t);
+            for (int a = 0; a < 3; ++a) DQ(a, 7 + 3 * (nJ - 1) + k) += coef * w * t[a];
+            for (int cnode = j; cnode > 0; cnode = m.parent[cnode]) {
+              const int pc = m.parent[cnode];
+              for (int a = 0; a < 3; ++a)
+                d[a] = m.S[(size_t)(3 * cnode + a) * nS + k] - m.S[(size_t)(3 * pc + a) * nS + k];
+              mat3vec(&g.A[pc * 9], d, t);
+              for (int a = 0; a < 3; ++a) DQ(a, 7 + 3 * (nJ - 1) + k) += coef * w * t[a];
+            }
           }
         }
       }
-    }
-    if (c.pose_blend && P > 0) {
-      // d vp / d a_k,c = posedirs[:, 9(k-1):9k] . vec(dR_k,c), carried by the blended rotation
-      for (int k = 1; k < nJ; ++k)
-        for (int cc = 0; cc < 3; ++cc) {
-          double d[3], t[3];
-          for (int a = 0; a < 3; ++a) {
-            const double* pd = &m.posedirs[((size_t)vid * 3 + a) * P + 9 * (k - 1)];
-            double s = 0;
-            for (int e = 0; e < 9; ++e) s += pd[e] * g.dR[(k * 3 + cc) * 9 + e];
-            d[a] = s;
+      if (c.pose_blend && P > 0) {
+        // d vp / d a_k,c = posedirs[:, 9(k-1):9k] . vec(dR_k,c), carried by the blended rotation
+        for (int k = 1; k < nJ; ++k)
+          for (int cc = 0; cc < 3; ++cc) {
+            double d[3], t[3];
+            for (int a = 0; a < 3; ++a) {
+              const double* pd = &m.posedirs[((size_t)vid * 3 + a) * P + 9 * (k - 1)];
+              double s = 0;
+              for (int e = 0; e < 9; ++e) s += pd[e] * g.dR[(k * 3 + cc) * 9 + e];
+              d[a] = s;
+            }
+            mat3vec(Ablend, d, t);
+            for (int a = 0; a < 3; ++a) DQ(a, 7 + 3 * (k - 1) + cc) += coef * t[a];
           }
-          mat3vec(Ablend, d, t);
-          for (int a = 0; a < 3; ++a) DQ(a, 7 + 3 * (k - 1) + cc) += t[a];
-        }
+      }
     }
   }
 
@@ -679,6 +697,13 @@ void* oracle_model_create(int V, int nJ, int nS, int P, const double* v_template
   return m;
 }
 void oracle_model_destroy(void* h) { delete static_cast<Model*>(h); }
+// sparse keypoint regressors (CSR): keypoint id nJ + nL + r = sum_i weight_i posed(vertex_i)
+void oracle_model_set_kp_regressors(void* h, int n, const int* offset, const int* vid, const double* weight) {
+  Model* m = static_cast<Model*>(h);
+  m->kpreg_off.assign(offset, offset + n + 1);
+  m->kpreg_vid.assign(vid, vid + offset[n]);
+  m->kpreg_w.assign(weight, weight + offset[n]);
+}
 
 void oracle_model_derived(void* h, double* J0, double* S, double* offset) {
   Model* m = static_cast<Model*>(h);

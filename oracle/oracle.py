@@ -66,6 +66,10 @@ class OracleModel:
         self.h = C.c_void_p(lib().oracle_model_create(self.V, self.nJ, self.nS, self.P, _d(k[0]), _d(k[1]),
                                                       _d(k[2]), _d(k[3]), _d(k[4]), _i(k[5]),
                                                       len(model.landmark_vid), _i(k[6])))
+        if getattr(model, "n_kp_regressors", 0):
+            self._keep += [_c32i(model.kpreg_offset), _c32i(model.kpreg_vid), _c64(model.kpreg_weight)]
+            lib().oracle_model_set_kp_regressors(self.h, model.n_kp_regressors, _i(self._keep[-3]), _i(self._keep[-2]),
+                                                 _d(self._keep[-1]))
 
     def __del__(self):
         if getattr(self, "h", None):

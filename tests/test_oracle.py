@@ -1,5 +1,6 @@
 """CPU suite: the oracle against itself (analytic == dual-number autodiff == finite differences),
 hand-derivable known answers, and the committed golden fixtures."""
+import importlib
 import os
 
 import numpy as np
@@ -308,3 +309,36 @@ def test_dense_lm_answer_is_a_minimum_for_an_independent_solver(oracle_mod, omod
     # gauge-free comparison (the Sim3 scale is a null direction of the reprojection): rotations, joint angles, t / s
     assert np.abs(sp2.x[1:4] - xd[0, 1:4]).max() < 2e-3 and np.abs(sp2.x[7:] - xd[0, 7:]).max() < 2e-3
     assert np.abs(sp2.x[4:7] / sp2.x[0] - xd[0, 4:7] / xd[0, 0]).max() < 2e-3
+
+
+def test_kp_regressor_rows_analytic_dual_and_cloud(model, oracle_mod):
+    """Sparse keypoint regressor rows over the posed vertices (oracle extension beside the HIP feature, tests/test_gpu_kp_regressor.py):
+    the analytic Jacobian against the dual-number one, and the residual against the definition evaluated on the oracle's own posed
+    cloud (sum_i w_i cloud[v_i], projected)."""
+    import copy
+    synth = importlib.import_module("3dbodyanimation_amd.synth")
+    m = synth.add_kp_regressors(copy.copy(model), n_rows=3, support=12, seed=2)
+    om = oracle_mod.OracleModel(m)
+    nJ, nL = m.n_joints, len(m.landmark_vid)
+    ids = [3, nJ + 2] + [nJ + nL + r for r in range(3)]
+    seq = synth.make_sequence(m, 2, seed=7, kp_ids=ids, noise_px=0.0)
+    rng = np.random.default_rng(0)
+    x = seq.gt_params + 0.05 * rng.standard_normal(seq.gt_params.shape)
+    beta = seq.gt_beta + 0.3
+    ra, Ja = om.evaluate_batch(seq, x, beta, 86, True, True, mode=0)
+    rb, Jb = om.evaluate_batch(seq, x, beta, 86, True, True, mode=1)
+    assert np.abs(ra - rb).max() < 1e-9
+    assert np.abs(Ja - Jb).max() < 1e-8 * max(1.0, np.abs(Jb).max())
+    # the definition on the posed cloud
+    fx, fy, cx, cy = seq.intr
+    for f in range(2):
+        _, cloud = om.forward(x[f], beta, seq.R0[f])
+        for r in range(3):
+            e0, e1 = m.kpreg_offset[r], m.kpreg_offset[r + 1]
+            p = m.kpreg_weight[e0:e1] @ cloud[m.kpreg_vid[e0:e1]]
+            uv = np.array([fx * p[0] / p[2] + cx, fy * p[1] / p[2] + cy])
+            k = seq.kp_offset[f] + 2 + r
+            assert np.abs(uv - seq.kp_uv[k] - ra[2 * k:2 * k + 2]).max() < 1e-8
+    # at the ground truth the noise-free observations are reproduced (synth.forward_numpy is a third implementation)
+    r0, _ = om.evaluate_batch(seq, seq.gt_params, seq.gt_beta, 86, True, True, mode=0, want_jac=False)
+    assert np.abs(r0).max() < 1e-6
