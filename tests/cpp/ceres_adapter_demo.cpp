@@ -1,0 +1,123 @@
+// Drives include/bodyfit_ceres.h the way ceres::Problem::Evaluate would (tests/cpp/ceres_double is an interface double, not
+// Ceres): every residual block of a shared-beta window is added to a Problem, the evaluation callback runs one device sweep,
+// every block is evaluated with Ceres' pointer conventions, and the assembled residual vector / Jacobian is compared with
+// bodyfit_evaluate_batch's.  Input blob: the format of tests/test_gpu_cpp_api.py.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "bodyfit_ceres.h"
+
+void ceres::HuberLoss::Evaluate(double s, double rho[3]) const {
+  if (s > b_) { const double r = std::sqrt(s); rho[0] = 2 * a_ * r - b_; rho[1] = a_ / r; rho[2] = -rho[1] / (2 * s); }
+  else { rho[0] = s; rho[1] = 1; rho[2] = 0; }
+}
+
+template <typename T>
+static std::vector<T> rd(FILE* f, size_t n) {
+  std::vector<T> v(n);
+  if (n && fread(v.data(), sizeof(T), n, f) != n) { std::fprintf(stderr, "short read\n"); std::exit(2); }
+  return v;
+}
+
+int main(int argc, char** argv) {
+  if (argc < 2) return 2;
+  FILE* f = std::fopen(argv[1], "rb");
+  if (!f) return 2;
+  auto hdr = rd<int>(f, 7);
+  const int V = hdr[0], nJ = hdr[1], nS = hdr[2], P = hdr[3], nL = hdr[4], F = hdr[5], K = hdr[6];
+  auto vt = rd<double>(f, (size_t)V * 3), sd = rd<double>(f, (size_t)V * 3 * nS), pd = rd<double>(f, (size_t)V * 3 * P),
+       jr = rd<double>(f, (size_t)nJ * V), w = rd<double>(f, (size_t)V * nJ);
+  auto parent = rd<int>(f, nJ), lvid = rd<int>(f, nL), koff = rd<int>(f, F + 1), kid = rd<int>(f, K);
+  auto uv = rd<double>(f, (size_t)2 * K), intr = rd<double>(f, 4);
+  std::fclose(f);
+
+  bodyfit_model_desc md{V, nJ, nS, P, vt.data(), sd.data(), pd.data(), jr.data(), w.data(), parent.data(), nL, lvid.data()};
+  bodyfit_model* model = nullptr;
+  if (bodyfit_model_create(&md, 0, &model) != BODYFIT_OK) { std::fprintf(stderr, "%s\n", bodyfit_last_error()); return 1; }
+  std::vector<double> R0((size_t)F * 9, 0.0);
+  for (int i = 0; i < F; ++i) R0[i * 9] = R0[i * 9 + 4] = R0[i * 9 + 8] = -1.0;
+  bodyfit_problem_desc pdsc{};
+  pdsc.n_frames = F; pdsc.kp_offset = koff.data(); pdsc.kp_id = kid.data(); pdsc.kp_uv = uv.data();
+  pdsc.fx = intr[0]; pdsc.fy = intr[1]; pdsc.cx = intr[2]; pdsc.cy = intr[3];
+  pdsc.R0 = R0.data(); pdsc.n_cols = 86; pdsc.use_shape = 1; pdsc.pose_blend = 1;
+  pdsc.beta_pose = 5.0; pdsc.beta_shape = 25.0; pdsc.lambda_temporal = 3.0; pdsc.huber_delta = 3.0;
+  bodyfit_problem* bp = nullptr;
+  if (bodyfit_problem_create(model, &pdsc, &bp) != BODYFIT_OK) { std::fprintf(stderr, "%s\n", bodyfit_last_error()); return 1; }
+  bodyfit_layout L;
+  bodyfit_problem_layout(bp, &L);
+
+  // the parameters Ceres would own: FramePoseParams per frame, one shared beta
+  std::vector<double> x((size_t)F * 76, 0.0), beta(10, 0.0);
+  for (int i = 0; i < F; ++i) {
+    x[(size_t)i * 76] = 1.0 + 0.01 * i; x[(size_t)i * 76 + 6] = 3.0;
+    for (int c = 1; c < 76; ++c)
+      if (c != 6) x[(size_t)i * 76 + c] += 0.05 * std::sin(0.37 * c + 1.3 * i);
+  }
+  for (int k = 0; k < 10; ++k) beta[k] = 0.3 * std::cos(1.1 * k);
+
+  ceres::Problem problem;
+  const int n_blocks = bodyfit_ceres::AddResidualBlocks(&problem, bp, F, koff.data(), x.data(), beta.data());
+  const int expect_blocks = K + F + 1 + 25 * (F - 1);
+  bodyfit_ceres::SweepCallback cb(bp, x.data(), beta.data());
+
+  // what ceres::Problem::Evaluate does: callback, then every block with its parameter pointers and Jacobian buffers
+  cb.PrepareForEvaluation(true, true);
+  const int ncol = F * 76 + 10;
+  std::vector<double> r_all, J_all;   // rows in block order, dense columns [F x 76 | beta]
+  int bad = 0;
+  for (const auto& rec : problem.records()) {
+    const ceres::CostFunction& cf = *rec->cost;
+    const int nr = cf.num_residuals();
+    const auto& sizes = cf.parameter_block_sizes();
+    if (sizes.size() != rec->blocks.size()) ++bad;
+    std::vector<double> r(nr);
+    std::vector<std::vector<double>> jb(sizes.size());
+    std::vector<double*> jp(sizes.size());
+    for (size_t b = 0; b < sizes.size(); ++b) { jb[b].assign((size_t)nr * sizes[b], 0.0); jp[b] = jb[b].data(); }
+    if (sizes.size() > 5) jp[5] = nullptr;          // a constant parameter block: jacobians[b] == NULL
+    if (!cf.Evaluate(rec->blocks.data(), r.data(), jp.data())) ++bad;
+    const size_t row0 = r_all.size();
+    r_all.insert(r_all.end(), r.begin(), r.end());
+    J_all.resize((row0 + nr) * (size_t)ncol, 0.0);
+    for (size_t b = 0; b < sizes.size(); ++b) {
+      if (!jp[b]) continue;
+      const double* base = rec->blocks[b];
+      const size_t col = (base >= beta.data() && base < beta.data() + 10) ? (size_t)F * 76 + (base - beta.data()) : (size_t)(base - x.data());
+      for (int i = 0; i < nr; ++i)
+        for (int c = 0; c < sizes[b]; ++c) J_all[(row0 + i) * ncol + col + c] = jb[b][(size_t)i * sizes[b] + c];
+    }
+  }
+  // reference: the batched evaluation of the same point
+  std::vector<double> r_ref(L.total_rows), J_ref((size_t)L.reproj_rows * 86);
+  if (bodyfit_evaluate_batch(bp, x.data(), beta.data(), r_ref.data(), J_ref.data(), nullptr, 1) != BODYFIT_OK) return 1;
+  double dr = 0.0, dj = 0.0;
+  if ((int)r_all.size() != L.total_rows) ++bad;
+  for (size_t i = 0; i < r_all.size() && i < r_ref.size(); ++i) dr = std::fmax(dr, std::fabs(r_all[i] - r_ref[i]));
+  for (int fr = 0; fr < F; ++fr)
+    for (int k = koff[fr]; k < koff[fr + 1]; ++k)
+      for (int i = 0; i < 2; ++i)
+        for (int c = 0; c < 86; ++c) {
+          if (c >= 7 + 3 * 2 && c < 10 + 3 * 2) continue;   // block 5 (joint 3) was held constant above
+          const size_t col = c < 76 ? (size_t)fr * 76 + c : (size_t)F * 76 + (c - 76);
+          dj = std::fmax(dj, std::fabs(J_all[((size_t)2 * k + i) * ncol + col] - J_ref[((size_t)2 * k + i) * 86 + c]));
+        }
+  // a second call at the same point costs no sweep and gives the same numbers; a moved point is re-evaluated
+  cb.PrepareForEvaluation(false, false);
+  x[4] += 0.01;
+  cb.PrepareForEvaluation(false, true);
+  std::vector<double> r2(2);
+  const auto& rec0 = *problem.records()[0];
+  rec0.cost->Evaluate(rec0.blocks.data(), r2.data(), nullptr);
+  std::vector<double> r_ref2(L.total_rows);
+  bodyfit_evaluate_batch(bp, x.data(), beta.data(), r_ref2.data(), nullptr, nullptr, 0);
+  const double dr2 = std::fmax(std::fabs(r2[0] - r_ref2[0]), std::fabs(r2[1] - r_ref2[1]));
+  std::printf("blocks %d (expected %d) rows %zu (layout %d) max|dr| %.3e max|dJ| %.3e moved %.3e bad %d\n", n_blocks,
+              expect_blocks, r_all.size(), L.total_rows, dr, dj, dr2, bad);
+  const bool ok = n_blocks == expect_blocks && bad == 0 && dr == 0.0 && dj == 0.0 && dr2 == 0.0 && cb.ok();
+  std::printf(ok ? "ceres adapter: OK\n" : "ceres adapter: MISMATCH\n");
+  bodyfit_problem_destroy(bp);
+  bodyfit_model_destroy(model);
+  return ok ? 0 : 1;
+}

@@ -39,3 +39,13 @@ def test_cpp_mirror_header_compiles():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     subprocess.check_call(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-I", os.path.join(root, "include"),
                            os.path.join(root, "tests", "cpp", "optimize_api_demo.cpp")])
+
+
+def test_ceres_adapter_header_compiles_against_the_interface_double():
+    """include/bodyfit_ceres.h + its driver compile (no link, no GPU): the adapter uses only CostFunction / EvaluationCallback /
+    LossFunction / Problem members that tests/cpp/ceres_double declares with Ceres 1.14's signatures."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-fsyntax-only", "-I", os.path.join(root, "include"),
+                           "-I", os.path.join(root, "tests", "cpp", "ceres_double"),
+                           os.path.join(root, "tests", "cpp", "ceres_adapter_demo.cpp")])

@@ -1,1 +1,1 @@
-timeout -k 10 600 python -m pytest tests/test_gpu_kp_regressor.py -x -q 2>&1 | tail -25
+timeout -k 10 600 python -m pytest tests/test_gpu_cpp_api.py -x -q 2>&1 | tail -25
