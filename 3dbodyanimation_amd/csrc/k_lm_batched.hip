@@ -526,23 +526,21 @@ __global__ __launch_bounds__(kStepThreads) void k_lm_step(LmProblem P, LmState S
   //     strict upper triangle of the block, its diagonal 1 / L_cc in invd): the panel solve and the back substitution
   //     become products on the matrix cores
   auto diag_block = [&](int p) {
+    // every 16-lane group holds the block (row rr per lane) and, as the appended row of the same lane, row rr of the identity
+    // (dense_inl.h: column values travel by DPP row broadcast)
     const int c0 = 16 * p;
     const int rr = lane & 15, grp = lane >> 4;
-    double a[16], iv[16];
+    double a[16], b[16], iv[16];
     const double* src = M + (c0 + rr) * kMLd + c0;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) a[k] = src[k];                     // (unconditional: a predicated read is a branch each)
-    if (grp == 1) {
-#pragma unroll
-      for (int k = 0; k < 16; ++k) a[k] = (k == rr) ? 1.0 : 0.0;
-    }
-    const bool okp = diag_factor16(a, rr, grp != 1, iv, min(16, n - c0));
-    // lower triangle (block rows) and strict upper triangle (identity rows) in one pass of unconditional stores per column
+    for (int k = 0; k < 16; ++k) { a[k] = src[k]; b[k] = (k == rr) ? 1.0 : 0.0; }
+    const bool okp = diag_factor16_dpp(a, b, iv, min(16, n - c0));
+    // lower triangle: rows of L (group 0 stores); strict upper triangle: rows of L_pp^-T (group 1 stores its copy)
     if (grp < 2) {
       double* dst = M + (c0 + rr) * kMLd + c0;
 #pragma unroll
       for (int k = 0; k < 16; ++k)
-        if ((grp == 0) == (k <= rr)) dst[k] = a[k];
+        if ((grp == 0) == (k <= rr)) dst[k] = (grp == 0) ? a[k] : b[k];
     }
     if (lane == 0) {
 #pragma unroll

@@ -310,17 +310,14 @@ __global__ __launch_bounds__(kCrThreads) void k_cr_factor(WinBuf W, const int* _
   double* Linv = stat + 8;        // [16][17]: L_pp^-T of the current panel
   // (a) diagonal block p + identity below it, in the registers of wave 0: lanes 0-15 rows of the block, lanes 16-31 rows of I
   auto diag_block = [&](int p) {
+    // every 16-lane group holds the block (row rr per lane) and, as the appended row of the same lane, row rr of the identity
     const int c0 = 16 * p;
     const int rr = lane & 15, grp = lane >> 4;
-    double av[16], iv[16];
+    double av[16], bv[16], iv[16];
     const double* src = M + (c0 + rr) * LD + c0;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) av[k] = src[k];                    // (unconditional: a predicated read is a branch each)
-    if (grp == 1) {
-#pragma unroll
-      for (int k = 0; k < 16; ++k) av[k] = (k == rr) ? 1.0 : 0.0;
-    }
-    const bool okp = diag_factor16(av, rr, grp != 1, iv, min(16, NP - c0));
+    for (int k = 0; k < 16; ++k) { av[k] = src[k]; bv[k] = (k == rr) ? 1.0 : 0.0; }
+    const bool okp = diag_factor16_dpp(av, bv, iv, min(16, NP - c0));
     if (grp == 0) {
       double* dst = M + (c0 + rr) * LD + c0;
 #pragma unroll
@@ -328,12 +325,11 @@ __global__ __launch_bounds__(kCrThreads) void k_cr_factor(WinBuf W, const int* _
         if (k <= rr) dst[k] = av[k];
     } else if (grp == 1) {
 #pragma unroll
-      for (int k = 0; k < 16; ++k) Linv[rr * 17 + k] = av[k];   // row rr of L_pp^-T
-      if (side == 0) {                                           // kept for the way down (k_cr_back)
-        double* Lg = W.Li + ((size_t)j * (WB / 16) + p) * 256 + rr * 16;
+      for (int k = 0; k < 16; ++k) Linv[rr * 17 + k] = bv[k];   // row rr of L_pp^-T
+    } else if (grp == 2 && side == 0) {                          // kept for the way down (k_cr_back)
+      double* Lg = W.Li + ((size_t)j * (WB / 16) + p) * 256 + rr * 16;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) Lg[k] = (k >= rr) ? av[k] : 0.0;
-      }
+      for (int k = 0; k < 16; ++k) Lg[k] = (k >= rr) ? bv[k] : 0.0;
     }
     if (lane == 0 && !okp) stat[0] = 0.0;
   };
