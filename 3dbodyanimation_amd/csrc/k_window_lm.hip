@@ -61,12 +61,30 @@ __device__ inline int temporal_row_of(int s) { return (s >= 7) ? (s - 7 + 6) : (
 
 // ---- cost of a residual vector: 1/2 sum rho(|r_kp|^2) over the keypoints + 1/2 |other rows|^2 -----------------------
 __device__ double window_cost(const WinProblem& P, const double* __restrict__ r, double* red, int tid, int nthreads) {
-  double acc = 0.0;
-  for (int k = tid; k < P.K; k += nthreads) {
-    const double r0 = r[2 * (size_t)k], r1 = r[2 * (size_t)k + 1];
-    acc += 0.5 * huber_rho_w(P.huber, r0 * r0 + r1 * r1);
+  // four independent partial sums per thread: the loads of a pass are in flight together (a 1024-frame window has 170 rows
+  // per thread, and one dependent load per pass made this the second longest kernel of an iteration)
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+  int k = tid;
+  for (; k + 3 * nthreads < P.K; k += 4 * nthreads) {
+    const double* q = r + 2 * (size_t)k;
+    const double x0 = q[0], y0 = q[1], x1 = q[2 * (size_t)nthreads], y1 = q[2 * (size_t)nthreads + 1];
+    const double x2 = q[4 * (size_t)nthreads], y2 = q[4 * (size_t)nthreads + 1], x3 = q[6 * (size_t)nthreads], y3 = q[6 * (size_t)nthreads + 1];
+    a0 += 0.5 * huber_rho_w(P.huber, x0 * x0 + y0 * y0);
+    a1 += 0.5 * huber_rho_w(P.huber, x1 * x1 + y1 * y1);
+    a2 += 0.5 * huber_rho_w(P.huber, x2 * x2 + y2 * y2);
+    a3 += 0.5 * huber_rho_w(P.huber, x3 * x3 + y3 * y3);
   }
-  for (int i = 2 * P.K + tid; i < P.total_rows; i += nthreads) acc += 0.5 * r[i] * r[i];
+  for (; k < P.K; k += nthreads) {
+    const double r0 = r[2 * (size_t)k], r1 = r[2 * (size_t)k + 1];
+    a0 += 0.5 * huber_rho_w(P.huber, r0 * r0 + r1 * r1);
+  }
+  int i = 2 * P.K + tid;
+  for (; i + 3 * nthreads < P.total_rows; i += 4 * nthreads) {
+    const double v0 = r[i], v1 = r[i + nthreads], v2 = r[i + 2 * nthreads], v3 = r[i + 3 * nthreads];
+    a0 += 0.5 * v0 * v0; a1 += 0.5 * v1 * v1; a2 += 0.5 * v2 * v2; a3 += 0.5 * v3 * v3;
+  }
+  for (; i < P.total_rows; i += nthreads) a0 += 0.5 * r[i] * r[i];
+  const double acc = (a0 + a1) + (a2 + a3);
   return block_sum_n(acc, red, tid, nthreads / 64);
 }
 
@@ -92,34 +110,46 @@ __global__ __launch_bounds__(1024) void k_win_init(WinProblem P, WinBuf W, const
 // ---- beta block: C = sum_f C_f (+ shape prior), g_beta; scaling; damped scaled copy ------------------------------------
 // mode 0: all; 1: this shard's sums -> W.Craw, W.gbraw only; 2: scaling and the damped copy from W.Craw, W.gbraw (summed
 // over the shards by the caller)
-__global__ __launch_bounds__(256) void k_win_beta(WinProblem P, WinBuf W, const double* __restrict__ Hpan,
-                                                  const double* __restrict__ r, int first, int mode) {
+__global__ __launch_bounds__(1024) void k_win_beta(WinProblem P, WinBuf W, const double* __restrict__ Hpan,
+                                                   const double* __restrict__ r, int first, int mode) {
   __shared__ double sC[NBETA * NBETA], sg[NBETA], ssc[NBETA];
+  __shared__ double part[8][128];
   const int tid = threadIdx.x, F = P.F;
   if (tid == 0 && mode != 2) *W.fail = 0;
   if (P.nb == 0) return;
   if (mode == 2) {
     if (tid < NBETA * NBETA) sC[tid] = W.Craw[tid];
     if (tid < NBETA) sg[tid] = W.gbraw[tid];
-  } else if (tid < NBETA * NBETA + NBETA) {
-    size_t off;
-    if (tid < NBETA * NBETA) {
-      const int a = tid / NBETA, b = tid % NBETA, lo = a > b ? a : b, hi = a > b ? b : a;
-      off = (size_t)(NP + lo) * kHLd + NP + hi;
-    } else {
-      off = (size_t)(NP + NBETA) * kHLd + NP + (tid - NBETA * NBETA);
-    }
+  } else {
+    // C = sum_f H_f[beta, beta], g_beta = sum_f H_f[rhs row, beta]: 110 words, eight frame lanes of 128 threads, four
+    // independent loads per pass
+    const int w = tid & 127, g = tid >> 7;
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-    int f = 0;
-    for (; f + 4 <= F; f += 4) {
-      a0 += Hpan[(size_t)f * kHRows * kHLd + off];
-      a1 += Hpan[(size_t)(f + 1) * kHRows * kHLd + off];
-      a2 += Hpan[(size_t)(f + 2) * kHRows * kHLd + off];
-      a3 += Hpan[(size_t)(f + 3) * kHRows * kHLd + off];
+    if (w < NBETA * NBETA + NBETA) {
+      size_t off;
+      if (w < NBETA * NBETA) {
+        const int a = w / NBETA, b = w % NBETA, lo = a > b ? a : b, hi = a > b ? b : a;
+        off = (size_t)(NP + lo) * kHLd + NP + hi;
+      } else {
+        off = (size_t)(NP + NBETA) * kHLd + NP + (w - NBETA * NBETA);
+      }
+      const size_t fs = (size_t)kHRows * kHLd;
+      int f = g;
+      for (; f + 24 < F; f += 32) {
+        a0 += Hpan[(size_t)f * fs + off];
+        a1 += Hpan[(size_t)(f + 8) * fs + off];
+        a2 += Hpan[(size_t)(f + 16) * fs + off];
+        a3 += Hpan[(size_t)(f + 24) * fs + off];
+      }
+      for (; f < F; f += 8) a0 += Hpan[(size_t)f * fs + off];
     }
-    for (; f < F; ++f) a0 += Hpan[(size_t)f * kHRows * kHLd + off];
-    const double v = (a0 + a1) + (a2 + a3);
-    if (tid < NBETA * NBETA) sC[tid] = v; else sg[tid - NBETA * NBETA] = v;
+    part[g][w] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (tid < NBETA * NBETA + NBETA) {
+      const double v = ((part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid])) +
+                       ((part[4][tid] + part[5][tid]) + (part[6][tid] + part[7][tid]));
+      if (tid < NBETA * NBETA) sC[tid] = v; else sg[tid - NBETA * NBETA] = v;
+    }
   }
   __syncthreads();
   if (mode != 2 && tid < NBETA && P.shape_rows > 0) {   // ShapePriorL2Analytic: r = beta_s w, J = beta_s I (include/Sim3BA.h:336-340)
@@ -823,7 +853,7 @@ void launch_win_init(const WinProblem& P, const WinBuf& W, const double* d_r, in
 }
 void launch_win_beta(const WinProblem& P, const WinBuf& W, const double* d_Hpan, const double* d_r, int first, int mode,
                      hipStream_t s) {
-  hipLaunchKernelGGL(k_win_beta, dim3(1), dim3(256), 0, s, P, W, d_Hpan, d_r, first, mode);
+  hipLaunchKernelGGL(k_win_beta, dim3(1), dim3(1024), 0, s, P, W, d_Hpan, d_r, first, mode);
 }
 void launch_win_assemble(const WinProblem& P, const WinBuf& W, const double* d_Hpan, const double* d_r, const double* d_x,
                          const unsigned char* d_constant, int first, const double* d_x_left, const double* d_scale_halo,
