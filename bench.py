@@ -368,7 +368,10 @@ def main():
             fit = {"unit": "frames/s", "c2": fit_bench.fit_c2(api, synth, model, gm),
                    "c3": fit_bench.fit_c3(api, synth, model, gm), "c4": fit_bench.fit_c4(api, synth, model, gm)}
             if not args.no_cpu_baseline:
-                fit["cpu_baseline"] = fit_bench.cpu_fit_baseline(synth, model, threads=os.cpu_count() or 0)
+                # eight threads: what the reference itself configures (options.num_threads = 8, include/MultiFrameBA.h:148;
+                # 4 in include/Sim3BA.h:476) — and what these small problems can use: 25 to 500 residual blocks per evaluation
+                # on all 256 hardware threads of the box is ten times SLOWER (fork/join of the OpenMP pool per evaluation)
+                fit["cpu_baseline"] = fit_bench.cpu_fit_baseline(synth, model, threads=min(8, os.cpu_count() or 8))
             out["fit"] = fit
         print(json.dumps(out))
     if world > 1:

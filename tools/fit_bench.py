@@ -129,7 +129,8 @@ def cpu_fit_baseline(synth, model, budget_s=20.0, threads=0):
     om = oracle.OracleModel(model)
     nthr = threads or oracle.max_threads()
     out = {"kind": "port", "cores": nthr, "unit": "frames/s",
-           "sample": "oracle evaluator (stride-4 dual-number Jacobian, OpenMP) under oracle/lm_dense.py (numpy dense LM)"}
+           "sample": "oracle evaluator (stride-4 dual-number Jacobian, OpenMP on `cores` threads: the reference's own "
+                     "options.num_threads = 8) under oracle/lm_dense.py (numpy dense LM)"}
     # c2
     seq = synth.make_sequence(model, 1, seed=0, beta_fixed=True)
     om.evaluate_batch(seq, seq.init_params, np.zeros(10), 76, False, True, mode=1, nthreads=nthr)   # start the OpenMP pool untimed, on all cores
