@@ -296,13 +296,53 @@ __global__ __launch_bounds__(256) void k_win_assemble(WinProblem P, WinBuf W, co
   if (tid == 0) W.gmaxp[f] = gm;
 }
 
+// Staging of 80 x 80 (or 16 x 80) blocks between HBM/L2 and LDS.  A plain `for (idx = tid; idx < n; idx += threads) lds[..] =
+// g[idx]` compiles to load -> s_waitcnt vmcnt(0) -> ds_write per trip: thirteen DEPENDENT L2 round trips per block (k_cr_factor
+// spent 9 of its 27 us in them).  Here every load of a block is issued before the first is used (fixed trip count, clamped
+// index, predicated use).
+constexpr int kCrThreads = 512, kCrWaves = 8;
+template <int ROWS>
+struct BlockRegs { static constexpr int kPasses = (ROWS * WB + kCrThreads - 1) / kCrThreads; double v[kPasses]; };
+template <int ROWS>
+__device__ __forceinline__ void block_load(BlockRegs<ROWS>& r, const double* __restrict__ src, int tid) {
+#pragma unroll
+  for (int u = 0; u < BlockRegs<ROWS>::kPasses; ++u) r.v[u] = src[min(tid + u * kCrThreads, ROWS * WB - 1)];
+}
+// dst[row][col] (leading dimension LD); transposed: the element (i, k) of the source lands at row k, column i
+template <int ROWS, bool kTransposed = false, bool kLowerOnly = false>
+__device__ __forceinline__ void block_to_lds(const BlockRegs<ROWS>& r, double* dst, int tid) {
+#pragma unroll
+  for (int u = 0; u < BlockRegs<ROWS>::kPasses; ++u) {
+    const int idx = tid + u * kCrThreads;
+    if (idx < ROWS * WB) {
+      const int i = idx / WB, k = idx % WB;
+      const double v = (kLowerOnly && k > i) ? 0.0 : r.v[u];
+      dst[kTransposed ? k * LD + i : i * LD + k] = v;
+    }
+  }
+}
+// LDS [ROWS][LD] -> global [ROWS][WB]: the LDS reads of the block first, then its stores
+template <int ROWS, bool kLowerOnly = false>
+__device__ __forceinline__ void block_from_lds(double* __restrict__ dst, const double* src, int tid) {
+  BlockRegs<ROWS> r;
+#pragma unroll
+  for (int u = 0; u < BlockRegs<ROWS>::kPasses; ++u) {
+    const int idx = min(tid + u * kCrThreads, ROWS * WB - 1);
+    r.v[u] = src[(idx / WB) * LD + idx % WB];
+  }
+#pragma unroll
+  for (int u = 0; u < BlockRegs<ROWS>::kPasses; ++u) {
+    const int idx = tid + u * kCrThreads;
+    if (idx < ROWS * WB) dst[idx] = (kLowerOnly && idx % WB > idx / WB) ? 0.0 : r.v[u];
+  }
+}
+
 // ---- cyclic reduction: factor one eliminated block, solve its appended rows -------------------------------------------
 // Two workgroups per eliminated frame j (side = blockIdx.x & 1): both factor D_j = L L^T (right-looking, 16-column
 // panels, the k_lm_step scheme: diagonal block in the registers of wave 0, panel solve one row per thread, trailing update
 // on the f64 matrix cores) with rows appended below that receive L^-T from the right:
 //   side 0:  rows of U_a (-> Pt_j)  and the 16 rows of Rt_j (-> Yt_j);  writes L_j
 //   side 1:  rows of U_j^T (-> Qt_j)
-constexpr int kCrThreads = 512, kCrWaves = 8;
 constexpr int kCrRowsMax = WB + WB + WR;   // 176
 __global__ __launch_bounds__(kCrThreads) void k_cr_factor(WinBuf W, const int* __restrict__ elim, int n_elim) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
@@ -316,23 +356,19 @@ __global__ __launch_bounds__(kCrThreads) void k_cr_factor(WinBuf W, const int* _
   const int nU = (side == 0) ? (a >= 0 ? WB : 0) : WB;       // appended coupling rows
   const int nApp = nU + (side == 0 ? WR : 0);
   const int nRows = WB + nApp;
-  const double* D = W.D + (size_t)j * WB * WB;
-  for (int idx = tid; idx < WB * WB; idx += kCrThreads) {
-    const int i = idx / WB, k = idx % WB;
-    M[i * LD + k] = (k <= i) ? D[idx] : 0.0;
-  }
-  if (nU) {
-    if (side == 0) {
-      const double* Ua = W.U + (size_t)a * WB * WB;          // row i of U_a
-      for (int idx = tid; idx < WB * WB; idx += kCrThreads) M[(WB + idx / WB) * LD + idx % WB] = Ua[idx];
-    } else {
-      const double* Uj = W.U + (size_t)j * WB * WB;          // row i of U_j^T = column i of U_j
-      for (int idx = tid; idx < WB * WB; idx += kCrThreads) M[(WB + idx % WB) * LD + idx / WB] = Uj[idx];
+  {
+    // the node's blocks: all three requested before any lands in LDS (one round trip)
+    BlockRegs<WB> rD, rU;
+    BlockRegs<WR> rR;
+    block_load<WB>(rD, W.D + (size_t)j * WB * WB, tid);
+    if (nU) block_load<WB>(rU, W.U + (size_t)(side == 0 ? a : j) * WB * WB, tid);
+    if (side == 0) block_load<WR>(rR, W.Rt + (size_t)j * WR * WB, tid);
+    block_to_lds<WB, false, true>(rD, M, tid);
+    if (nU) {
+      if (side == 0) block_to_lds<WB>(rU, M + WB * LD, tid);              // row i of U_a
+      else block_to_lds<WB, true>(rU, M + WB * LD, tid);                  // row i of U_j^T = column i of U_j
     }
-  }
-  if (side == 0) {
-    const double* Rt = W.Rt + (size_t)j * WR * WB;
-    for (int idx = tid; idx < WR * WB; idx += kCrThreads) M[(WB + nU + idx / WB) * LD + idx % WB] = Rt[idx];
+    if (side == 0) block_to_lds<WR>(rR, M + (WB + nU) * LD, tid);
   }
   if (tid == 0) stat[0] = 1.0;
   __syncthreads();
@@ -420,20 +456,11 @@ __global__ __launch_bounds__(kCrThreads) void k_cr_factor(WinBuf W, const int* _
   }
   if (tid == 0 && stat[0] == 0.0) *W.fail = 1;
   if (side == 0) {
-    double* L = W.L + (size_t)j * WB * WB;
-    for (int idx = tid; idx < WB * WB; idx += kCrThreads) {
-      const int i = idx / WB, k = idx % WB;
-      L[idx] = (k <= i) ? M[i * LD + k] : 0.0;
-    }
-    if (nU) {
-      double* Pt = W.Pt + (size_t)j * WB * WB;
-      for (int idx = tid; idx < WB * WB; idx += kCrThreads) Pt[idx] = M[(WB + idx / WB) * LD + idx % WB];
-    }
-    double* Yt = W.Yt + (size_t)j * WR * WB;
-    for (int idx = tid; idx < WR * WB; idx += kCrThreads) Yt[idx] = M[(WB + nU + idx / WB) * LD + idx % WB];
+    block_from_lds<WB, true>(W.L + (size_t)j * WB * WB, M, tid);
+    if (nU) block_from_lds<WB>(W.Pt + (size_t)j * WB * WB, M + WB * LD, tid);
+    block_from_lds<WR>(W.Yt + (size_t)j * WR * WB, M + (WB + nU) * LD, tid);
   } else {
-    double* Qt = W.Qt + (size_t)j * WB * WB;
-    for (int idx = tid; idx < WB * WB; idx += kCrThreads) Qt[idx] = M[(WB + idx / WB) * LD + idx % WB];
+    block_from_lds<WB>(W.Qt + (size_t)j * WB * WB, M + WB * LD, tid);
   }
 }
 
@@ -449,9 +476,6 @@ __device__ __forceinline__ d4 tile_xyT(const double* X, const double* Y, int ti,
   }
   return acc;
 }
-__device__ inline void stage_block(double* dst, const double* __restrict__ src, int rows, int tid, int nthreads) {
-  for (int idx = tid; idx < rows * WB; idx += nthreads) dst[(idx / WB) * LD + idx % WB] = src[idx];
-}
 
 // ---- cyclic reduction: Schur updates of one remaining frame a (left eliminated neighbour jl, right one jr, next
 //      remaining frame b).  Three workgroups per frame (part = blockIdx.x % 3): diagonal block, coupling block, rhs. -----
@@ -459,37 +483,49 @@ __global__ __launch_bounds__(kCrThreads) void k_cr_update(WinBuf W, const int* _
   extern __shared__ __attribute__((aligned(16))) double sm[];
   double* X0 = sm;                 // [WB][LD]
   double* X1 = sm + WB * LD;       // [WB][LD]
-  double* Ys = X1 + WB * LD;       // [WR][LD]
+  double* Ys = X1 + WB * LD;       // [2][WR][LD]
   const int sidx = blockIdx.x / 3, part = blockIdx.x % 3;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int a = surv[4 * sidx], jl = surv[4 * sidx + 1], jr = surv[4 * sidx + 2], b = surv[4 * sidx + 3];
   const int m = lane & 15, kk = lane >> 4;
+  // Every operand of the part is requested before the first is used: the source blocks (13 loads per thread each) and the
+  // accumulator tiles of the wave (read-modify-write of global memory), one round trip instead of one per trip / per tile.
   if (part == 0) {
-    // D_a -= Qt_jl Qt_jl^T + Pt_jr Pt_jr^T  (lower tiles)
+    // D_a -= Qt_jl Qt_jl^T + Pt_jr Pt_jr^T  (15 lower tiles over 8 waves: tiles wave and wave + 8)
     double* D = W.D + (size_t)a * WB * WB;
-    for (int src = 0; src < 2; ++src) {
-      const int j = src == 0 ? jl : jr;
-      if (j < 0) continue;
-      __syncthreads();
-      stage_block(X0, (src == 0 ? W.Qt : W.Pt) + (size_t)j * WB * WB, WB, tid, kCrThreads);
-      __syncthreads();
-      int t = 0;
-      for (int ti = 0; ti < 5; ++ti)
-        for (int tj = 0; tj <= ti; ++tj, ++t) {
-          if (t % kCrWaves != wave) continue;
-          d4 acc;
+    BlockRegs<WB> r0, r1;
+    if (jl >= 0) block_load<WB>(r0, W.Qt + (size_t)jl * WB * WB, tid);
+    if (jr >= 0) block_load<WB>(r1, W.Pt + (size_t)jr * WB * WB, tid);
+    int tis[2], tjs[2];
+    d4 acc[2];
 #pragma unroll
-          for (int q = 0; q < 4; ++q) acc[q] = D[(size_t)(16 * ti + kk + 4 * q) * WB + 16 * tj + m];
-          acc = tile_xyT(X0, X0, ti, tj, lane, acc, -1.0);
+    for (int u = 0; u < 2; ++u) {
+      const int t = min(wave + 8 * u, 14);
+      int ti = 0, rem = t;
+      while (rem > ti) { rem -= ti + 1; ++ti; }       // t -> (ti, tj) of the lower triangle, row-major
+      tis[u] = ti; tjs[u] = rem;
 #pragma unroll
-          for (int q = 0; q < 4; ++q) D[(size_t)(16 * ti + kk + 4 * q) * WB + 16 * tj + m] = acc[q];
-        }
+      for (int q = 0; q < 4; ++q) acc[u][q] = D[(size_t)(16 * ti + kk + 4 * q) * WB + 16 * rem + m];
+    }
+    if (jl >= 0) block_to_lds<WB>(r0, X0, tid);
+    if (jr >= 0) block_to_lds<WB>(r1, X1, tid);
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      if (wave + 8 * u > 14) continue;
+      if (jl >= 0) acc[u] = tile_xyT(X0, X0, tis[u], tjs[u], lane, acc[u], -1.0);
+      if (jr >= 0) acc[u] = tile_xyT(X1, X1, tis[u], tjs[u], lane, acc[u], -1.0);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) D[(size_t)(16 * tis[u] + kk + 4 * q) * WB + 16 * tjs[u] + m] = acc[u][q];
     }
   } else if (part == 1) {
     // U_a := -Pt_jr Qt_jr^T  (coupling of a with the next remaining frame b)
     if (jr < 0 || b < 0) return;
-    stage_block(X0, W.Pt + (size_t)jr * WB * WB, WB, tid, kCrThreads);
-    stage_block(X1, W.Qt + (size_t)jr * WB * WB, WB, tid, kCrThreads);
+    BlockRegs<WB> r0, r1;
+    block_load<WB>(r0, W.Pt + (size_t)jr * WB * WB, tid);
+    block_load<WB>(r1, W.Qt + (size_t)jr * WB * WB, tid);
+    block_to_lds<WB>(r0, X0, tid);
+    block_to_lds<WB>(r1, X1, tid);
     __syncthreads();
     double* U = W.U + (size_t)a * WB * WB;
     for (int t = wave; t < 25; t += kCrWaves) {
@@ -500,24 +536,24 @@ __global__ __launch_bounds__(kCrThreads) void k_cr_update(WinBuf W, const int* _
       for (int q = 0; q < 4; ++q) U[(size_t)(16 * ti + kk + 4 * q) * WB + 16 * tj + m] = acc[q];
     }
   } else {
-    // Rt_a -= Yt_jl Qt_jl^T + Yt_jr Pt_jr^T   ([16 x 80])
+    // Rt_a -= Yt_jl Qt_jl^T + Yt_jr Pt_jr^T   ([16 x 80]: one column tile per wave, waves 0-4)
     double* Rt = W.Rt + (size_t)a * WR * WB;
-    for (int src = 0; src < 2; ++src) {
-      const int j = src == 0 ? jl : jr;
-      if (j < 0) continue;
-      __syncthreads();
-      stage_block(X0, (src == 0 ? W.Qt : W.Pt) + (size_t)j * WB * WB, WB, tid, kCrThreads);
-      stage_block(Ys, W.Yt + (size_t)j * WR * WB, WR, tid, kCrThreads);
-      __syncthreads();
-      if (wave < 5) {
-        const int tj = wave;
-        d4 acc;
+    BlockRegs<WB> r0, r1;
+    BlockRegs<WR> y0, y1;
+    if (jl >= 0) { block_load<WB>(r0, W.Qt + (size_t)jl * WB * WB, tid); block_load<WR>(y0, W.Yt + (size_t)jl * WR * WB, tid); }
+    if (jr >= 0) { block_load<WB>(r1, W.Pt + (size_t)jr * WB * WB, tid); block_load<WR>(y1, W.Yt + (size_t)jr * WR * WB, tid); }
+    const int tj = min(wave, 4);
+    d4 acc;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) acc[q] = Rt[(size_t)(kk + 4 * q) * WB + 16 * tj + m];
-        acc = tile_xyT(Ys, X0, 0, tj, lane, acc, -1.0);
+    for (int q = 0; q < 4; ++q) acc[q] = Rt[(size_t)(kk + 4 * q) * WB + 16 * tj + m];
+    if (jl >= 0) { block_to_lds<WB>(r0, X0, tid); block_to_lds<WR>(y0, Ys, tid); }
+    if (jr >= 0) { block_to_lds<WB>(r1, X1, tid); block_to_lds<WR>(y1, Ys + WR * LD, tid); }
+    __syncthreads();
+    if (wave < 5) {
+      if (jl >= 0) acc = tile_xyT(Ys, X0, 0, tj, lane, acc, -1.0);
+      if (jr >= 0) acc = tile_xyT(Ys + WR * LD, X1, 0, tj, lane, acc, -1.0);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) Rt[(size_t)(kk + 4 * q) * WB + 16 * tj + m] = acc[q];
-      }
+      for (int q = 0; q < 4; ++q) Rt[(size_t)(kk + 4 * q) * WB + 16 * tj + m] = acc[q];
     }
   }
 }
@@ -537,9 +573,16 @@ __global__ __launch_bounds__(kCrThreads) void k_cr_back(WinBuf W, const int* __r
   const int e = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int m = lane & 15, kk = lane >> 4;
   const int j = elim[3 * e], a = elim[3 * e + 1], b = elim[3 * e + 2];
-  stage_block(Ls, W.L + (size_t)j * WB * WB, WB, tid, kCrThreads);
-  if (a >= 0) stage_block(Xa, W.Xt + (size_t)a * WR * WB, WR, tid, kCrThreads);
-  if (b >= 0) stage_block(Xb, W.Xt + (size_t)b * WR * WB, WR, tid, kCrThreads);
+  {
+    BlockRegs<WB> rL;
+    BlockRegs<WR> rA, rB;
+    block_load<WB>(rL, W.L + (size_t)j * WB * WB, tid);
+    if (a >= 0) block_load<WR>(rA, W.Xt + (size_t)a * WR * WB, tid);
+    if (b >= 0) block_load<WR>(rB, W.Xt + (size_t)b * WR * WB, tid);
+    block_to_lds<WB>(rL, Ls, tid);
+    if (a >= 0) block_to_lds<WR>(rA, Xa, tid);
+    if (b >= 0) block_to_lds<WR>(rB, Xb, tid);
+  }
   __syncthreads();
   if (wave < 5) {
     // Zt tile (all 16 rows, columns 16 wave ..): accumulate -X P and -X Q on top of Yt
@@ -845,7 +888,7 @@ __global__ __launch_bounds__(1024) void k_win_accept(WinProblem P, WinBuf W, con
 }  // namespace
 
 size_t win_factor_lds_bytes() { return (size_t)(kCrRowsMax * LD + WB + 8 + 16 * 17) * sizeof(double); }
-size_t win_update_lds_bytes() { return (size_t)(2 * WB * LD + WR * LD) * sizeof(double); }
+size_t win_update_lds_bytes() { return (size_t)(2 * WB * LD + 2 * WR * LD) * sizeof(double); }
 size_t win_back_lds_bytes() { return (size_t)(WB * LD + 3 * WR * LD + 5 * 16 * 17) * sizeof(double); }
 
 void launch_win_init(const WinProblem& P, const WinBuf& W, const double* d_r, int mode, hipStream_t s) {
