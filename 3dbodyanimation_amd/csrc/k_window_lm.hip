@@ -189,34 +189,73 @@ __global__ __launch_bounds__(1024) void k_win_beta(WinProblem P, WinBuf W, const
 // Shards of a window (bodyfit_solve_sharded): x_left = parameters of the frame in front of the shard's first one (null: none),
 // P.halo: a temporal pair leaves the shard behind its last frame (its residual rows are this shard's), scale_halo = Jacobi
 // scaling of that next frame (null on the first pass of the first iteration, which only produces this shard's scaling).
-__global__ __launch_bounds__(256) void k_win_assemble(WinProblem P, WinBuf W, const double* __restrict__ Hpan,
+constexpr int kAsmThreads = 1024;
+__global__ __launch_bounds__(kAsmThreads) void k_win_assemble(WinProblem P, WinBuf W, const double* __restrict__ Hpan,
                                                       const double* __restrict__ r, const double* __restrict__ x,
                                                       const unsigned char* __restrict__ constant, int first,
                                                       const double* __restrict__ x_left, const double* __restrict__ scale_halo) {
   __shared__ double sA[NP * (NP + 1)];
-  __shared__ double sg[NP], ss[NP], ssn[NP], red[4];
+  __shared__ double sB[NBETA * NP];           // H[beta rows][pose columns]: the frame's B block
+  __shared__ double sg[NP], ss[NP], ssn[NP], scf[WB], sbs[NBETA], red[kAsmThreads / 64];
   const int f = blockIdx.x, tid = threadIdx.x, F = P.F;
   const double* H = Hpan + (size_t)f * kHRows * kHLd;
   const double lam2 = P.lambda_t * P.lambda_t, bp2 = P.beta_pose * P.beta_pose;
   const bool pair_right = f + 1 < F || P.halo, pair_left = f > 0 || x_left != nullptr;
   const int npairs = (P.lambda_t > 0.0) ? ((int)pair_right + (int)pair_left) : 0;
-  for (int e = tid; e < NP * NP; e += 256) {
+  // Every global operand of the frame is requested before the first is used (a load-store loop compiles to one dependent
+  // L2 round trip per trip: 23 of them for the 76 x 76 block alone)
+  constexpr int kAPasses = (NP * NP + kAsmThreads - 1) / kAsmThreads, kBPasses = (NBETA * NP + kAsmThreads - 1) / kAsmThreads;
+  double av[kAPasses], bv[kBPasses];
+#pragma unroll
+  for (int u = 0; u < kAPasses; ++u) {
+    const int e = min(tid + u * kAsmThreads, NP * NP - 1);
     const int i = e / NP, j = e % NP, lo = i > j ? i : j, hi = i > j ? j : i;
-    double v = H[(size_t)lo * kHLd + hi];
-    if (i == j) {
-      if (i >= 7 && P.prior_rows > 0) v += bp2;       // PosePriorAAAnalytic, L2 branch (include/Sim3BA.h:304-310)
-      if (i >= 1) v += lam2 * npairs;                 // Vec3DiffCost on rootT, rootAA, joints (include/MultiFrameBA.h:121-142)
-    }
-    sA[i * (NP + 1) + j] = v;
+    av[u] = H[(size_t)lo * kHLd + hi];
   }
+#pragma unroll
+  for (int u = 0; u < kBPasses; ++u) {
+    const int e = min(tid + u * kAsmThreads, NBETA * NP - 1);
+    bv[u] = H[(size_t)(NP + e / NP) * kHLd + e % NP];
+  }
+  const int tc = min(tid, NP - 1);
+  double g_in = H[(size_t)(NP + NBETA) * kHLd + tc];
+  const double rp_in = (P.prior_rows > 0) ? r[P.row_prior + (size_t)f * P.prior_rows + max(tc - 7, 0)] : 0.0;
+  const int ti_c = temporal_row_of(max(tc, 1));
+  const double rt_r = (P.lambda_t > 0.0 && pair_right) ? r[P.row_temporal + (size_t)f * 75 + ti_c] : 0.0;
+  const double rt_l = (P.lambda_t > 0.0 && f > 0) ? r[P.row_temporal + (size_t)(f - 1) * 75 + ti_c] : 0.0;
+  const double xl_in = (f == 0 && x_left) ? x_left[tc] - x[tc] : 0.0;
+  const double cf_in = (constant && constant[tc]) ? 1.0 : 0.0;
+  const double sc_in = first ? 0.0 : W.scale[(size_t)f * NP + tc];
+  const double scn_in = (!first && f + 1 < F) ? W.scale[(size_t)(f + 1) * NP + tc] : 0.0;
+  double dn_in = (first && f + 1 < F) ? Hpan[(size_t)(f + 1) * kHRows * kHLd + (size_t)tc * kHLd + tc] : 0.0;
+  const double sh_in = (f + 1 == F && P.halo && scale_halo) ? scale_halo[tc] : 0.0;
+  const double sbeta_in = W.scale[(size_t)F * NP + min(tid, NBETA - 1)];
+  const double inv_radius = 1.0 / W.status[kWsRadius];
+#pragma unroll
+  for (int u = 0; u < kAPasses; ++u) {
+    const int e = tid + u * kAsmThreads;
+    if (e < NP * NP) {
+      const int i = e / NP, j = e % NP;
+      double v = av[u];
+      if (i == j) {
+        if (i >= 7 && P.prior_rows > 0) v += bp2;       // PosePriorAAAnalytic, L2 branch (include/Sim3BA.h:304-310)
+        if (i >= 1) v += lam2 * npairs;                 // Vec3DiffCost on rootT, rootAA, joints (include/MultiFrameBA.h:121-142)
+      }
+      sA[i * (NP + 1) + j] = v;
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < kBPasses; ++u)
+    if (tid + u * kAsmThreads < NBETA * NP) sB[tid + u * kAsmThreads] = bv[u];
+  if (tid < WB) scf[tid] = (tid < NP) ? cf_in : 0.0;
+  if (tid < NBETA) sbs[tid] = sbeta_in;
   if (tid < NP) {
-    double g = H[(size_t)(NP + NBETA) * kHLd + tid];
-    if (tid >= 7 && P.prior_rows > 0) g += P.beta_pose * r[P.row_prior + (size_t)f * P.prior_rows + tid - 7];
+    double g = g_in;
+    if (tid >= 7 && P.prior_rows > 0) g += P.beta_pose * rp_in;
     if (tid >= 1 && P.lambda_t > 0.0) {
-      const int ti = temporal_row_of(tid);
-      if (pair_right) g += P.lambda_t * r[P.row_temporal + (size_t)f * 75 + ti];
-      if (f > 0) g -= P.lambda_t * r[P.row_temporal + (size_t)(f - 1) * 75 + ti];
-      else if (x_left) g -= P.lambda_t * (P.lambda_t * (x_left[tid] - x[tid]));   // the previous shard's last pair
+      if (pair_right) g += P.lambda_t * rt_r;
+      if (f > 0) g -= P.lambda_t * rt_l;
+      else if (x_left) g -= P.lambda_t * (P.lambda_t * xl_in);   // the previous shard's last pair
     }
     sg[tid] = g;
   }
@@ -227,30 +266,28 @@ __global__ __launch_bounds__(256) void k_win_assemble(WinProblem P, WinBuf W, co
       s = 1.0 / (1.0 + sqrt(sA[tid * (NP + 1) + tid]));
       W.scale[(size_t)f * NP + tid] = s;
       if (f + 1 < F) {   // the next frame's scale, from its diagonal entry alone (its workgroup may not have run yet)
-        double dn = Hpan[(size_t)(f + 1) * kHRows * kHLd + (size_t)tid * kHLd + tid];
+        double dn = dn_in;
         if (tid >= 7 && P.prior_rows > 0) dn += bp2;
         if (tid >= 1 && P.lambda_t > 0.0) dn += lam2 * (1 + (int)(f + 2 < F || P.halo));
         sn = 1.0 / (1.0 + sqrt(dn));
       }
     } else {
-      s = W.scale[(size_t)f * NP + tid];
-      if (f + 1 < F) sn = W.scale[(size_t)(f + 1) * NP + tid];
+      s = sc_in;
+      if (f + 1 < F) sn = scn_in;
     }
-    if (f + 1 == F && P.halo && scale_halo) sn = scale_halo[tid];
+    if (f + 1 == F && P.halo && scale_halo) sn = sh_in;
     ss[tid] = s; ssn[tid] = sn;
     W.graw[(size_t)f * NP + tid] = sg[tid];
     W.Eraw[(size_t)f * NP + tid] = (tid >= 1 && pair_right && P.lambda_t > 0.0) ? -lam2 : 0.0;
   }
   __syncthreads();
-  const double inv_radius = 1.0 / W.status[kWsRadius];
   double* D = W.D + (size_t)f * WB * WB;
   double* U = W.U + (size_t)f * WB * WB;
-  for (int e = tid; e < WB * WB; e += 256) {
+  for (int e = tid; e < WB * WB; e += kAsmThreads) {
     const int i = e / WB, j = e % WB;
     double v = (i == j) ? 1.0 : 0.0, u = 0.0;
     if (i < NP && j < NP) {
-      const bool ci = constant && constant[i], cj = constant && constant[j];
-      if (!ci && !cj) {
+      if (scf[i] == 0.0 && scf[j] == 0.0) {
         v = sA[i * (NP + 1) + j] * ss[i] * ss[j];
         if (i == j) {
           v += fmin(fmax(v, 1e-6), 1e32) * inv_radius;
@@ -261,30 +298,26 @@ __global__ __launch_bounds__(256) void k_win_assemble(WinProblem P, WinBuf W, co
     D[e] = v;
     U[e] = u;
   }
-  for (int e = tid; e < NP * NP; e += 256) W.Araw[(size_t)f * NP * NP + e] = sA[(e / NP) * (NP + 1) + e % NP];
+  for (int e = tid; e < NP * NP; e += kAsmThreads) W.Araw[(size_t)f * NP * NP + e] = sA[(e / NP) * (NP + 1) + e % NP];
   double* Rt = W.Rt + (size_t)f * WR * WB;
   double* Rt0 = W.Rt0 + (size_t)f * WR * WB;
-  for (int e = tid; e < WR * WB; e += 256) {
+  for (int e = tid; e < WR * WB; e += kAsmThreads) {
     const int c = e / WB, i = e % WB;
     double v = 0.0;
-    if (i < NP && !(constant && constant[i])) {
-      if (c < P.nb) {
-        const double b = H[(size_t)(NP + c) * kHLd + i];
-        v = b * ss[i] * W.scale[(size_t)F * NP + c];
-      } else if (c == NBETA) {
-        v = -sg[i] * ss[i];
-      }
+    if (i < NP && scf[i] == 0.0) {
+      if (c < P.nb) v = sB[c * NP + i] * ss[i] * sbs[c];
+      else if (c == NBETA) v = -sg[i] * ss[i];
     }
     Rt[e] = v;
     Rt0[e] = v;
   }
-  for (int e = tid; e < NP * NBETA; e += 256) {
+  for (int e = tid; e < NP * NBETA; e += kAsmThreads) {
     const int i = e / NBETA, c = e % NBETA;
-    W.Braw[(size_t)f * NP * NBETA + e] = (c < P.nb) ? H[(size_t)(NP + c) * kHLd + i] : 0.0;
+    W.Braw[(size_t)f * NP * NBETA + e] = (c < P.nb) ? sB[c * NP + i] : 0.0;
   }
   // gradient tolerance test: max |g_i| over the free parameters, the bounded scale projected (Ceres gradient_tolerance)
   double gm = 0.0;
-  if (tid < NP && !(constant && constant[tid])) {
+  if (tid < NP && scf[tid] == 0.0) {
     double gi = sg[tid];
     if (tid == 0) {
       const double s0 = x[(size_t)f * NP];
@@ -292,7 +325,7 @@ __global__ __launch_bounds__(256) void k_win_assemble(WinProblem P, WinBuf W, co
     }
     gm = fabs(gi);
   }
-  gm = block_max_n(gm, red, tid, 4);
+  gm = block_max_n(gm, red, tid, kAsmThreads / 64);
   if (tid == 0) W.gmaxp[f] = gm;
 }
 
@@ -648,15 +681,27 @@ __global__ __launch_bounds__(kCrThreads) void k_cr_back(WinBuf W, const int* __r
 
 // ---- beta Schur complement: per-frame partials, then the 10 x 10 solve ---------------------------------------------------
 __global__ __launch_bounds__(128) void k_win_schur_part(WinProblem P, WinBuf W) {
+  __shared__ double sBt[(NBETA + 1) * WB], sXt[(NBETA + 1) * WB];
   const int f = blockIdx.x, tid = threadIdx.x;
   const double* B = W.Rt0 + (size_t)f * WR * WB;     // scaled [B | rhs]^T as assembled
   const double* X = W.Xt + (size_t)f * WR * WB;
+  {
+    // both 11 x 80 operands into LDS, every load issued before the first is used
+    constexpr int kN = (NBETA + 1) * WB, kPasses = (kN + 127) / 128;
+    double bv[kPasses], xv[kPasses];
+#pragma unroll
+    for (int u = 0; u < kPasses; ++u) { const int e = min(tid + u * 128, kN - 1); bv[u] = B[e]; xv[u] = X[e]; }
+#pragma unroll
+    for (int u = 0; u < kPasses; ++u) { const int e = tid + u * 128; if (e < kN) { sBt[e] = bv[u]; sXt[e] = xv[u]; } }
+  }
+  __syncthreads();
   if (tid < NBETA * NBETA + NBETA) {
     const int a = (tid < NBETA * NBETA) ? tid / NBETA : tid - NBETA * NBETA;
     const int c = (tid < NBETA * NBETA) ? tid % NBETA : NBETA;
-    double s = 0.0;
-    for (int i = 0; i < NP; ++i) s += B[a * WB + i] * X[c * WB + i];
-    W.part[(size_t)f * kWinPart + tid] = s;
+    double s0 = 0.0, s1 = 0.0;
+#pragma unroll 4
+    for (int i = 0; i + 1 < NP; i += 2) { s0 += sBt[a * WB + i] * sXt[c * WB + i]; s1 += sBt[a * WB + i + 1] * sXt[c * WB + i + 1]; }
+    W.part[(size_t)f * kWinPart + tid] = s0 + s1;
   }
 }
 
@@ -728,10 +773,15 @@ __global__ __launch_bounds__(128) void k_win_step(WinProblem P, WinBuf W, const 
   const int f = blockIdx.x, tid = threadIdx.x;
   if (tid >= NP) return;
   const double* X = W.Xt + (size_t)f * WR * WB;
+  double xc[NBETA], dc[NBETA];
+#pragma unroll
+  for (int c = 0; c < NBETA; ++c) { xc[c] = X[c * WB + tid]; dc[c] = W.dsb[c]; }   // (dsb is zero past nb)
   double ds = X[NBETA * WB + tid];
-  for (int c = 0; c < P.nb; ++c) ds -= X[c * WB + tid] * W.dsb[c];
-  double di = ds * W.scale[(size_t)f * NP + tid];
+  const double sc = W.scale[(size_t)f * NP + tid];
   const double xi = x[(size_t)f * NP + tid];
+#pragma unroll
+  for (int c = 0; c < NBETA; ++c) ds -= (c < P.nb) ? xc[c] * dc[c] : 0.0;
+  double di = ds * sc;
   if (tid == 0) {
     const double s_new = fmin(fmax(xi + di, P.scale_lo), P.scale_hi);
     di = s_new - xi;
@@ -739,8 +789,6 @@ __global__ __launch_bounds__(128) void k_win_step(WinProblem P, WinBuf W, const 
   W.d[(size_t)f * NP + tid] = di;
   x_new[(size_t)f * NP + tid] = xi + di;
 }
-
-// ---- model cost change  -d^T g - 1/2 d^T H d  with the undamped, unscaled system: per-frame partials --------------------
 __global__ __launch_bounds__(128) void k_win_model(WinProblem P, WinBuf W, const double* __restrict__ x,
                                                    const double* __restrict__ d_halo) {
   __shared__ double sd[NP], sdn[NP], sdb[NBETA], red[2];
@@ -753,10 +801,25 @@ __global__ __launch_bounds__(128) void k_win_model(WinProblem P, WinBuf W, const
   __syncthreads();
   double pm = 0.0, dn = 0.0, xn = 0.0;
   if (tid < NP) {
-    const double* Ar = W.Araw + ((size_t)f * NP + tid) * NP;
-    double hd = 0.0;
-    for (int jj = 0; jj < NP; ++jj) hd += Ar[jj] * sd[jj];
-    for (int c = 0; c < NBETA; ++c) hd += 2.0 * W.Braw[((size_t)f * NP + tid) * NBETA + c] * sdb[c];
+    // A is symmetric: thread i walks COLUMN i (consecutive threads read consecutive words), 19 loads in flight per batch
+    const double* Ac = W.Araw + (size_t)f * NP * NP + tid;
+    double hd = 0.0, h1 = 0.0;
+#pragma unroll 1
+    for (int jb = 0; jb < NP; jb += 19) {
+      double aw[19];
+#pragma unroll
+      for (int u = 0; u < 19; ++u) aw[u] = Ac[(size_t)(jb + u) * NP];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u + 1 < 19; u += 2) { hd += aw[u] * sd[jb + u]; h1 += aw[u + 1] * sd[jb + u + 1]; }
+      hd += aw[18] * sd[jb + 18];
+    }
+    hd += h1;
+    double bw[NBETA];
+#pragma unroll
+    for (int c = 0; c < NBETA; ++c) bw[c] = W.Braw[((size_t)f * NP + tid) * NBETA + c];
+#pragma unroll
+    for (int c = 0; c < NBETA; ++c) hd += 2.0 * bw[c] * sdb[c];
     hd += 2.0 * W.Eraw[(size_t)f * NP + tid] * sdn[tid];
     pm = -sd[tid] * W.graw[(size_t)f * NP + tid] - 0.5 * sd[tid] * hd;
     dn = sd[tid] * sd[tid];
@@ -800,18 +863,27 @@ __global__ __launch_bounds__(256) void k_win_finish(WinProblem P, WinBuf W, cons
     if (tid == 0 && W.fin[4] != 0.0) *W.fail = 1;
   }
   if (tid == 0) gm = fmax(gm, W.gmaxp[F]);
+  // the beta block's operands into LDS first (one round trip; thread 0 walking global memory made this an 11 us kernel)
+  __shared__ double sCr[NBETA * NBETA], sdb2[NBETA], sgb[NBETA], sbt[NBETA];
+  if (tid < NBETA * NBETA) sCr[tid] = W.Craw[tid];
+  if (tid >= 128 && tid < 128 + NBETA) {
+    const int a = tid - 128;
+    sdb2[a] = (a < P.nb) ? W.d[(size_t)F * NP + a] : 0.0;
+    sgb[a] = W.gbraw[a];
+    sbt[a] = (a < P.nb) ? beta[a] : 0.0;
+  }
   __syncthreads();
   __shared__ int no_cand;
   if (tid == 0) {
     double* st = W.status;
     for (int a = 0; a < P.nb; ++a) {
-      const double da = W.d[(size_t)F * NP + a];
-      pm -= da * W.gbraw[a];
+      const double da = sdb2[a];
+      pm -= da * sgb[a];
       double h = 0.0;
-      for (int c = 0; c < P.nb; ++c) h += W.Craw[a * NBETA + c] * W.d[(size_t)F * NP + c];
+      for (int c = 0; c < P.nb; ++c) h += sCr[a * NBETA + c] * sdb2[c];
       pm -= 0.5 * da * h;
       dn += da * da;
-      xn += beta[a] * beta[a];
+      xn += sbt[a] * sbt[a];
     }
     st[kWsGmax] = gm;
     st[kWsHasCand] = 0.0;
@@ -901,7 +973,7 @@ void launch_win_beta(const WinProblem& P, const WinBuf& W, const double* d_Hpan,
 void launch_win_assemble(const WinProblem& P, const WinBuf& W, const double* d_Hpan, const double* d_r, const double* d_x,
                          const unsigned char* d_constant, int first, const double* d_x_left, const double* d_scale_halo,
                          hipStream_t s) {
-  hipLaunchKernelGGL(k_win_assemble, dim3(P.F), dim3(256), 0, s, P, W, d_Hpan, d_r, d_x, d_constant, first, d_x_left,
+  hipLaunchKernelGGL(k_win_assemble, dim3(P.F), dim3(kAsmThreads), 0, s, P, W, d_Hpan, d_r, d_x, d_constant, first, d_x_left,
                      d_scale_halo);
 }
 void launch_cr_factor(const WinBuf& W, const int* d_elim, int n_elim, hipStream_t s) {
