@@ -250,33 +250,27 @@ __device__ __forceinline__ void frame_part(const DevModel& M, const DevProblem& 
   if (Pb.frame_flags && !(Pb.frame_flags[f] & Pb.frame_mask)) return;   // frame already converged (device LM)
   constexpr int kLoaders = kThreads;
   constexpr bool loader = true;
-  // ---- A. small model tables, landmark weights and the frame's parameters into LDS --------------------
-  if (tid < nJ) { sParent[tid] = M.parent[tid]; sAnc[tid] = M.anc_mask[tid]; }
-  for (int it = tid; loader && it < nL * kMaxLmNnz; it += kThreads) {
-    // landmark skinning weights, fixed stride (padded with weight 0) -> one round trip
-    const int l = it / kMaxLmNnz, i = it % kMaxLmNnz;
-    double* L = sLm + l * LM_STRIDE;
-    L[LM_W + i] = M.lm_ww[it];
-    reinterpret_cast<int*>(L + LM_J)[i] = M.lm_wj[it];
-    if (i == 0) L[LM_NW] = (double)M.lm_woff[l];   // weight count
-  }
-  for (int it = tid; loader && it < nL * 3 * nS; it += kThreads) sLmSd[it] = M.lm_sd[it];
-  {
-    // 720 = 24 x 3 x 10 doubles each: fixed predicated passes so all the loads are in flight together
-    constexpr int kPasses = (720 + kLoaders - 1) / kLoaders;
-    double t0[kPasses], t1[kPasses];
-    const int nds = nJ * 3 * nS;
+  // ---- A. small model tables, landmark weights and the frame's parameters into LDS: every load of the phase is issued
+  //      before the first of them is used (unconditional loads from clamped indices; the stores, before the barrier, are
+  //      predicated).  Written as load-store loops the phase compiled to one dependent L2 round trip per loop trip. --------
+  constexpr int kSdPasses = (kMaxLandmarks * 3 * kMaxShape + kThreads - 1) / kThreads;   // 2
+  constexpr int kPasses = (720 + kLoaders - 1) / kLoaders;                                 // 24 x 3 x 10 doubles: 2
+  const int tj_c = min(tid, nJ - 1);
+  const int par_in = M.parent[tj_c];
+  const unsigned anc_in = M.anc_mask[tj_c];
+  const int nlw = nL * kMaxLmNnz, lw_i = min(tid, max(nlw, 1) - 1);          // <= 256 items: one pass
+  const double lww_in = M.lm_ww[lw_i];
+  const int lwj_in = M.lm_wj[lw_i];
+  const int lwo_in = M.lm_woff[lw_i / kMaxLmNnz];
+  const int nsd = nL * 3 * nS, nds = nJ * 3 * nS;
+  double sd_in[kSdPasses], t0[kPasses], t1[kPasses];
 #pragma unroll
-    for (int u = 0; u < kPasses; ++u) {
-      const int i = tid + u * kLoaders;
-      t0[u] = (loader && i < nds) ? M.dS[i] : 0.0;
-      t1[u] = (loader && i < nds) ? M.Sc[i] : 0.0;
-    }
+  for (int u = 0; u < kSdPasses; ++u) sd_in[u] = M.lm_sd[min(tid + u * kThreads, max(nsd, 1) - 1)];
 #pragma unroll
-    for (int u = 0; u < kPasses; ++u) {
-      const int i = tid + u * kLoaders;
-      if (loader && i < nds) { sDS[i] = t0[u]; sSc[i] = t1[u]; }
-    }
+  for (int u = 0; u < kPasses; ++u) {
+    const int i = min(tid + u * kLoaders, max(nds, 1) - 1);
+    t0[u] = M.dS[i];
+    t1[u] = M.Sc[i];
   }
   // the first keypoint chunk depends on kp_offset[f] (a second round trip): its loads are issued here but land in LDS
   // only after the barrier, so phase A waits for one round trip, not two (the staged keypoints are first read in F)
@@ -300,6 +294,22 @@ __device__ __forceinline__ void frame_part(const DevModel& M, const DevProblem& 
     kp_id0 = Pb.kp_id[k_begin0 + (tid & (KC - 1))];
     kp_u0 = Pb.kp_uv[2 * (size_t)(k_begin0 + (tid & (KC - 1)))];
     kp_v0 = Pb.kp_uv[2 * (size_t)(k_begin0 + (tid & (KC - 1))) + 1];
+  }
+  if (tid < nJ) { sParent[tid] = par_in; sAnc[tid] = anc_in; }
+  if (tid < nlw) {   // landmark skinning weights, fixed stride (padded with weight 0)
+    const int l = tid / kMaxLmNnz, i = tid % kMaxLmNnz;
+    double* L = sLm + l * LM_STRIDE;
+    L[LM_W + i] = lww_in;
+    reinterpret_cast<int*>(L + LM_J)[i] = lwj_in;
+    if (i == 0) L[LM_NW] = (double)lwo_in;   // weight count
+  }
+#pragma unroll
+  for (int u = 0; u < kSdPasses; ++u)
+    if (tid + u * kThreads < nsd) sLmSd[tid + u * kThreads] = sd_in[u];
+#pragma unroll
+  for (int u = 0; u < kPasses; ++u) {
+    const int i = tid + u * kLoaders;
+    if (i < nds) { sDS[i] = t0[u]; sSc[i] = t1[u]; }
   }
   if (x_lane) sx[tid - 128] = x_in;
   if (b_lane) sx[npose + tid - 224] = x_in;
