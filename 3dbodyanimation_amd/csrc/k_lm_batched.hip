@@ -769,47 +769,60 @@ __global__ __launch_bounds__(kStepThreads) void k_frame_normal(int F, int n, con
   const int f = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int k0 = kp_offset[f], nrows = 2 * (kp_offset[f + 1] - k0);
   const int nrows4 = (nrows + 3) & ~3;
+  // J and the residual rows in one round trip (unconditional loads from clamped addresses, masked afterwards)
+  double jv[11];
+#pragma unroll
+  for (int u = 0; u < 11; ++u) {
+    const int i = tid + u * kStepThreads, row = i / 88, c = i % 88;
+    const bool on = row < nrows && c < n;
+    jv[u] = J[on ? (size_t)(2 * k0 + row) * n + c : (size_t)2 * k0 * n];
+    if (!on) jv[u] = 0.0;
+  }
+  double r_own, r_other;
+  {
+    const int row = min(tid, max(nrows, 1) - 1);
+    r_own = r[2 * (size_t)k0 + row]; r_other = r[2 * (size_t)k0 + (row ^ 1)];
+  }
   if (tid < kRowsMax) {
     double sw = 0.0, rr = 0.0;
     if (tid < nrows) {
-      const int k = k0 + (tid >> 1);
-      const double r0 = r[2 * (size_t)k], r1 = r[2 * (size_t)k + 1];
       double rho1;
-      huber_rho(huber, r0 * r0 + r1 * r1, &rho1);
+      huber_rho(huber, (tid & 1) ? r_other * r_other + r_own * r_own : r_own * r_own + r_other * r_other, &rho1);
       sw = sqrt(rho1);
-      rr = sw * ((tid & 1) ? r1 : r0);
+      rr = sw * r_own;
     }
     ds[tid] = sw;
     Jh[tid * kJLd + n] = rr;
   }
   __syncthreads();
-  {
-    double jv[11];
 #pragma unroll
-    for (int u = 0; u < 11; ++u) {
-      const int i = tid + u * kStepThreads, row = i / 88, c = i % 88;
-      jv[u] = (row < nrows && c < n) ? J[(size_t)(2 * k0 + row) * n + c] : 0.0;
-    }
-
-#pragma unroll
-    for (int u = 0; u < 11; ++u) {
-      const int i = tid + u * kStepThreads, row = i / 88, c = i % 88;
-      if (row < nrows4 && c != n) Jh[row * kJLd + c] = (row < nrows && c < n) ? ds[row] * jv[u] : 0.0;
-    }
-    for (int i = tid; i < nrows4 * (kJLd - 88); i += kStepThreads) Jh[(i / (kJLd - 88)) * kJLd + 88 + i % (kJLd - 88)] = 0.0;
+  for (int u = 0; u < 11; ++u) {
+    const int i = tid + u * kStepThreads, row = i / 88, c = i % 88;
+    if (row < nrows4 && c != n) Jh[row * kJLd + c] = ds[row] * jv[u];
   }
+  for (int i = tid; i < nrows4 * (kJLd - 88); i += kStepThreads) Jh[(i / (kJLd - 88)) * kJLd + 88 + i % (kJLd - 88)] = 0.0;
   __syncthreads();
   double* H = out + (size_t)f * (kN + 1) * kLd;
   const int m = lane & 15, kk = lane >> 4;
+  const int nsteps = nrows4 / 4;
   int pair = 0;
   for (int ti = 0; ti < 6; ++ti)
     for (int tj = 0; tj <= ti; ++tj, ++pair) {
       if (pair % kStepWaves != wave) continue;
+      // k loop software-pipelined four steps deep (see k_lm_step)
       d4 acc = {0.0, 0.0, 0.0, 0.0};
-      for (int s = 0; s < nrows4 / 4; ++s) {
-        const double a = Jh[(4 * s + kk) * kJLd + 16 * ti + m];
-        const double b = Jh[(4 * s + kk) * kJLd + 16 * tj + m];
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+      const double* pa = Jh + kk * kJLd + 16 * ti + m;
+      const double* pb = Jh + kk * kJLd + 16 * tj + m;
+      double av[4], bv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { av[u] = pa[4 * u * kJLd]; bv[u] = pb[4 * u * kJLd]; }
+      for (int s0 = 0; s0 < nsteps; s0 += 4) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (s0 + u < nsteps) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], acc, 0, 0, 0);
+          const int sn = min(s0 + 4 + u, kRowsMax / 4 - 1);
+          av[u] = pa[4 * sn * kJLd]; bv[u] = pb[4 * sn * kJLd];
+        }
       }
 #pragma unroll
       for (int q = 0; q < 4; ++q) {

@@ -1,2 +1,2 @@
-timeout -k 10 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fused.py tests/test_gpu_kp_regressor.py -x -q 2>&1 | tail -3
-for i in 1 2; do timeout -k 10 300 python bench.py --no-fit --no-cpu-baseline 2>&1 | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], [ (k,round(v['avg_launch_ms']*1e3,2)) for k,v in d['roofline']['kernels'].items()])"; done
+timeout -k 10 900 python -m pytest tests/test_gpu_window_lm.py tests/test_gpu_fit.py tests/test_gpu_parity.py -x -q 2>&1 | tail -4
+timeout -k 10 200 python tools/fit_bench.py 2>&1 | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print({k:(round(v['seconds'],5), round(v['frames_per_s'])) for k,v in d.items()})"
