@@ -169,6 +169,7 @@ struct WinBuf {
   double *d;                        // [F * 76 + 10] the step
   double *status;                   // [kWsCount]
   int* fail;                        // a factorisation met a non-positive pivot
+  int* ticket;                      // k_win_tail: workgroups that have delivered their partial (reset by the last one)
 };
 size_t win_factor_lds_bytes();
 // (mode 0: single GPU, everything in the kernel; 1: this shard's partial sums only; 2: finish from the sums the host reduced)
@@ -183,6 +184,8 @@ void launch_cr_update(const WinBuf& W, const int* d_surv, int n_surv, hipStream_
 void launch_cr_back(const WinBuf& W, const int* d_elim, int n_elim, hipStream_t s);
 void launch_win_schur_part(const WinProblem& P, const WinBuf& W, hipStream_t s);
 void launch_win_beta_solve(const WinProblem& P, const WinBuf& W, const double* d_beta, double* d_beta_new, int mode, hipStream_t s);
+void launch_win_tail(const WinProblem& P, const WinBuf& W, const double* d_x, const double* d_beta, double* d_x_new, double* d_beta_new,
+                     hipStream_t s);
 void launch_win_step(const WinProblem& P, const WinBuf& W, const double* d_x, double* d_x_new, hipStream_t s);
 void launch_win_model(const WinProblem& P, const WinBuf& W, const double* d_x, const double* d_halo_step, hipStream_t s);
 void launch_win_finish(const WinProblem& P, const WinBuf& W, const double* d_x, const double* d_beta, double* d_x_new,

@@ -838,30 +838,12 @@ __global__ __launch_bounds__(128) void k_win_model(WinProblem P, WinBuf W, const
 // ---- decide: gradient tolerance, failed factorisation, parameter tolerance, or a candidate --------------------------------
 // mode 0: all; 1: this shard's sums -> W.fin[0..3] = {model, |d|^2, |x|^2, max |g_frames|}, W.fin[4] = fail flag, only;
 // 2: decide from W.fin (the first three summed, the last two maximised over the shards)
-__global__ __launch_bounds__(256) void k_win_finish(WinProblem P, WinBuf W, const double* __restrict__ x,
-                                                    const double* __restrict__ beta, double* __restrict__ x_new,
-                                                    double* __restrict__ beta_new, int mode) {
-  __shared__ double red[4];
-  const int tid = threadIdx.x, F = P.F;
-  double pm = 0.0, dn = 0.0, xn = 0.0, gm = 0.0;
-  if (mode != 2) {
-    for (int f = tid; f < F; f += 256) {
-      const double* o = W.part + (size_t)f * kWinPart + 112;
-      pm += o[0]; dn += o[1]; xn += o[2];
-      gm = fmax(gm, W.gmaxp[f]);
-    }
-    pm = block_sum_n(pm, red, tid, 4);
-    dn = block_sum_n(dn, red, tid, 4);
-    xn = block_sum_n(xn, red, tid, 4);
-    gm = block_max_n(gm, red, tid, 4);
-    if (mode == 1) {
-      if (tid == 0) { W.fin[0] = pm; W.fin[1] = dn; W.fin[2] = xn; W.fin[3] = gm; W.fin[4] = *W.fail ? 1.0 : 0.0; }
-      return;
-    }
-  } else {
-    pm = W.fin[0]; dn = W.fin[1]; xn = W.fin[2]; gm = W.fin[3];
-    if (tid == 0 && W.fin[4] != 0.0) *W.fail = 1;
-  }
+// the decision of an iteration from the sums over the frames (256 threads): gradient tolerance, failed factorisation,
+// parameter tolerance, or a candidate
+__device__ __forceinline__ void finish_core(const WinProblem& P, const WinBuf& W, const double* __restrict__ x,
+                                            const double* __restrict__ beta, double* __restrict__ x_new,
+                                            double* __restrict__ beta_new, double pm, double dn, double xn, double gm, int tid) {
+  const int F = P.F;
   if (tid == 0) gm = fmax(gm, W.gmaxp[F]);
   // the beta block's operands into LDS first (one round trip; thread 0 walking global memory made this an 11 us kernel)
   __shared__ double sCr[NBETA * NBETA], sdb2[NBETA], sgb[NBETA], sbt[NBETA];
@@ -909,6 +891,130 @@ __global__ __launch_bounds__(256) void k_win_finish(WinProblem P, WinBuf W, cons
     for (int i = tid; i < F * NP; i += 256) x_new[i] = x[i];
     if (tid < P.nb) beta_new[tid] = beta[tid];
   }
+}
+
+__global__ __launch_bounds__(256) void k_win_finish(WinProblem P, WinBuf W, const double* __restrict__ x,
+                                                    const double* __restrict__ beta, double* __restrict__ x_new,
+                                                    double* __restrict__ beta_new, int mode) {
+  __shared__ double red[4];
+  const int tid = threadIdx.x, F = P.F;
+  double pm = 0.0, dn = 0.0, xn = 0.0, gm = 0.0;
+  if (mode != 2) {
+    for (int f = tid; f < F; f += 256) {
+      const double* o = W.part + (size_t)f * kWinPart + 112;
+      pm += o[0]; dn += o[1]; xn += o[2];
+      gm = fmax(gm, W.gmaxp[f]);
+    }
+    pm = block_sum_n(pm, red, tid, 4);
+    dn = block_sum_n(dn, red, tid, 4);
+    xn = block_sum_n(xn, red, tid, 4);
+    gm = block_max_n(gm, red, tid, 4);
+    if (mode == 1) {
+      if (tid == 0) { W.fin[0] = pm; W.fin[1] = dn; W.fin[2] = xn; W.fin[3] = gm; W.fin[4] = *W.fail ? 1.0 : 0.0; }
+      return;
+    }
+  } else {
+    pm = W.fin[0]; dn = W.fin[1]; xn = W.fin[2]; gm = W.fin[3];
+    if (tid == 0 && W.fin[4] != 0.0) *W.fail = 1;
+  }
+  finish_core(P, W, x, beta, x_new, beta_new, pm, dn, xn, gm, tid);
+}
+
+// ---- single-GPU tail of an iteration in ONE launch: the step of every frame (k_win_step), its share of the model cost
+//      change (k_win_model; the next frame's step, which the temporal term needs, is recomputed here instead of read), and —
+//      by the LAST workgroup to finish, found by a ticket — the decision (k_win_finish).  Two launch floors (~5 us each) and
+//      their boundaries less per iteration.  Sharded solves exchange boundary rows between these steps and keep the three
+//      kernels. ----------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_win_tail(WinProblem P, WinBuf W, const double* __restrict__ x,
+                                                  const double* __restrict__ beta, double* __restrict__ x_new,
+                                                  double* __restrict__ beta_new) {
+  __shared__ double sd[2][NP], sdb[NBETA], red[4];
+  __shared__ int s_last;
+  const int f = blockIdx.x, tid = threadIdx.x, F = P.F;
+  {
+    // d of frame f (threads 0..75, stored) and of frame f + 1 (threads 128..203, kept here)
+    const int h = tid >> 7, i = tid & 127, ff = f + h;
+    if (i < NP) {
+      double di = 0.0;
+      if (ff < F) {
+        const double* X = W.Xt + (size_t)ff * WR * WB;
+        double xc[NBETA], dc[NBETA];
+#pragma unroll
+        for (int c = 0; c < NBETA; ++c) { xc[c] = X[c * WB + i]; dc[c] = W.dsb[c]; }
+        double ds = X[NBETA * WB + i];
+        const double sc = W.scale[(size_t)ff * NP + i];
+        const double xi = x[(size_t)ff * NP + i];
+#pragma unroll
+        for (int c = 0; c < NBETA; ++c) ds -= (c < P.nb) ? xc[c] * dc[c] : 0.0;
+        di = ds * sc;
+        if (i == 0) {
+          const double s_new = fmin(fmax(xi + di, P.scale_lo), P.scale_hi);
+          di = s_new - xi;
+        }
+        if (h == 0) {
+          W.d[(size_t)f * NP + i] = di;
+          x_new[(size_t)f * NP + i] = xi + di;
+        }
+      }
+      sd[h][i] = di;
+    }
+    if (tid >= 224 && tid < 224 + NBETA) sdb[tid - 224] = (tid - 224 < P.nb) ? W.d[(size_t)F * NP + tid - 224] : 0.0;
+  }
+  __syncthreads();
+  double pm = 0.0, dn = 0.0, xn = 0.0;
+  if (tid < NP) {
+    const double* Ac = W.Araw + (size_t)f * NP * NP + tid;
+    double hd = 0.0, h1 = 0.0;
+#pragma unroll 1
+    for (int jb = 0; jb < NP; jb += 19) {
+      double aw[19];
+#pragma unroll
+      for (int u = 0; u < 19; ++u) aw[u] = Ac[(size_t)(jb + u) * NP];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u + 1 < 19; u += 2) { hd += aw[u] * sd[0][jb + u]; h1 += aw[u + 1] * sd[0][jb + u + 1]; }
+      hd += aw[18] * sd[0][jb + 18];
+    }
+    hd += h1;
+    double bw[NBETA];
+#pragma unroll
+    for (int c = 0; c < NBETA; ++c) bw[c] = W.Braw[((size_t)f * NP + tid) * NBETA + c];
+#pragma unroll
+    for (int c = 0; c < NBETA; ++c) hd += 2.0 * bw[c] * sdb[c];
+    hd += 2.0 * W.Eraw[(size_t)f * NP + tid] * sd[1][tid];
+    pm = -sd[0][tid] * W.graw[(size_t)f * NP + tid] - 0.5 * sd[0][tid] * hd;
+    dn = sd[0][tid] * sd[0][tid];
+    const double xv = x[(size_t)f * NP + tid];
+    xn = xv * xv;
+  }
+  pm = block_sum_n(pm, red, tid, 4);
+  dn = block_sum_n(dn, red, tid, 4);
+  xn = block_sum_n(xn, red, tid, 4);
+  if (tid == 0) {
+    double* o = W.part + (size_t)f * kWinPart + 112;
+    o[0] = pm; o[1] = dn; o[2] = xn;
+    __threadfence();                                        // the partial is visible device-wide before the ticket is taken
+    s_last = (atomicAdd(W.ticket, 1) == F - 1) ? 1 : 0;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  // ---- the last workgroup: every frame's partial is in L2 (read past this CU's L1), decide ----
+  __threadfence();
+  if (tid == 0) *W.ticket = 0;
+  pm = 0.0; dn = 0.0; xn = 0.0;
+  double gm = 0.0;
+  for (int g = tid; g < F; g += 256) {
+    const double* o = W.part + (size_t)g * kWinPart + 112;
+    pm += __builtin_nontemporal_load(o);
+    dn += __builtin_nontemporal_load(o + 1);
+    xn += __builtin_nontemporal_load(o + 2);
+    gm = fmax(gm, W.gmaxp[g]);
+  }
+  pm = block_sum_n(pm, red, tid, 4);
+  dn = block_sum_n(dn, red, tid, 4);
+  xn = block_sum_n(xn, red, tid, 4);
+  gm = block_max_n(gm, red, tid, 4);
+  finish_core(P, W, x, beta, x_new, beta_new, pm, dn, xn, gm, tid);
 }
 
 // ---- accept / reject the candidate (Ceres' step quality and radius rules, host_solver.cpp) ------------------------------
@@ -1000,6 +1106,10 @@ void launch_win_schur_part(const WinProblem& P, const WinBuf& W, hipStream_t s) 
 }
 void launch_win_beta_solve(const WinProblem& P, const WinBuf& W, const double* d_beta, double* d_beta_new, int mode, hipStream_t s) {
   hipLaunchKernelGGL(k_win_beta_solve, dim3(1), dim3(1024), 0, s, P, W, d_beta, d_beta_new, mode);
+}
+void launch_win_tail(const WinProblem& P, const WinBuf& W, const double* d_x, const double* d_beta, double* d_x_new, double* d_beta_new,
+                     hipStream_t s) {
+  hipLaunchKernelGGL(k_win_tail, dim3(P.F), dim3(256), 0, s, P, W, d_x, d_beta, d_x_new, d_beta_new);
 }
 void launch_win_step(const WinProblem& P, const WinBuf& W, const double* d_x, double* d_x_new, hipStream_t s) {
   hipLaunchKernelGGL(k_win_step, dim3(P.F), dim3(128), 0, s, P, W, d_x, d_x_new);
