@@ -59,6 +59,19 @@ __device__ inline double block_max_n(double v, double* red, int tid, int nwaves)
 __device__ inline int temporal_src(int i) { return (i < 3) ? (4 + i) : (i < 6 ? (1 + (i - 3)) : (7 + (i - 6))); }
 __device__ inline int temporal_row_of(int s) { return (s >= 7) ? (s - 7 + 6) : (s >= 4 ? (s - 4) : (s - 1 + 3)); }   // s >= 1
 
+// dst[i] = src[i], i in [0, n): eight loads in flight per thread and pass (a load-store loop is one dependent round trip per trip)
+__device__ __forceinline__ void copy_batched(double* __restrict__ dst, const double* __restrict__ src, int n, int tid, int nthreads) {
+  int i = tid;
+  for (; i + 7 * nthreads < n; i += 8 * nthreads) {
+    double v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = src[i + u * nthreads];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) dst[i + u * nthreads] = v[u];
+  }
+  for (; i < n; i += nthreads) dst[i] = src[i];
+}
+
 // ---- cost of a residual vector: 1/2 sum rho(|r_kp|^2) over the keypoints + 1/2 |other rows|^2 -----------------------
 __device__ double window_cost(const WinProblem& P, const double* __restrict__ r, double* red, int tid, int nthreads) {
   // four independent partial sums per thread: the loads of a pass are in flight together (a 1024-frame window has 170 rows
@@ -888,7 +901,7 @@ __device__ __forceinline__ void finish_core(const WinProblem& P, const WinBuf& W
   }
   __syncthreads();
   if (no_cand) {   // the residual sweep that follows still reads a well-defined point
-    for (int i = tid; i < F * NP; i += 256) x_new[i] = x[i];
+    copy_batched(x_new, x, F * NP, tid, 256);
     if (tid < P.nb) beta_new[tid] = beta[tid];
   }
 }
@@ -1058,7 +1071,7 @@ __global__ __launch_bounds__(1024) void k_win_accept(WinProblem P, WinBuf W, con
   }
   __syncthreads();
   if (acc_flag) {
-    for (int i = tid; i < P.F * NP; i += 1024) x[i] = x_new[i];
+    copy_batched(x, x_new, P.F * NP, tid, 1024);
     if (tid < P.nb) beta[tid] = beta_new[tid];
   }
 }
