@@ -1081,7 +1081,7 @@ static size_t carve_cr(unsigned char* base, size_t off, int n, WinBuf& W, bool d
   auto take = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
   const size_t o_D = take(n * blk), o_U = take(n * blk), o_L = take(n * blk), o_P = take(n * blk), o_Q = take(n * blk),
                o_R = take(n * rhs), o_R0 = take(n * rhs), o_Y = take(n * rhs), o_X = take(n * rhs),
-               o_Li = take((size_t)n * (kWinBlock / 16) * 256 * 8), o_fail = take(8), o_ticket = take(8);
+               o_Li = take((size_t)n * (kWinBlock / 16) * 256 * 8), o_fail = take(8), o_ticket = take(4 * (size_t)(2 + n / 32 + 1));
   if (!dry) {
     auto dp = [&](size_t o) { return reinterpret_cast<double*>(base + o); };
     W.D = dp(o_D); W.U = dp(o_U); W.L = dp(o_L); W.Pt = dp(o_P); W.Qt = dp(o_Q); W.Rt = dp(o_R); W.Rt0 = dp(o_R0);
@@ -1303,7 +1303,13 @@ int bodyfit_internal_solve_window_device(bodyfit_problem* p, double* frame_param
     launch_win_schur_part(P, W, st);
     if (!sharded) {
       launch_win_beta_solve(P, W, d_b, d_bn, 0, st);
-      launch_win_tail(P, W, d_x, d_b, d_xn, d_bn, st);      // step + model change + (last workgroup) decision
+      if (F <= 256) {
+        launch_win_tail(P, W, d_x, d_b, d_xn, d_bn, st);      // step + model change + (last workgroup) decision in one launch
+      } else {                                                // (long windows: the three kernels are bandwidth-bound, not
+        launch_win_step(P, W, d_x, d_xn, st);                 //  launch-bound, and their separate grids fill the chip better)
+        launch_win_model(P, W, d_x, nullptr, st);
+        launch_win_finish(P, W, d_x, d_b, d_xn, d_bn, 0, st);
+      }
     } else {
       if (Wi.fail) {   // a failed interface factorisation is everybody's failure
         int hf = 0;

@@ -66,6 +66,7 @@ __device__ __forceinline__ void copy_batched(double* __restrict__ dst, const dou
     double v[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) v[u] = src[i + u * nthreads];
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int u = 0; u < 8; ++u) dst[i + u * nthreads] = v[u];
   }
@@ -74,27 +75,35 @@ __device__ __forceinline__ void copy_batched(double* __restrict__ dst, const dou
 
 // ---- cost of a residual vector: 1/2 sum rho(|r_kp|^2) over the keypoints + 1/2 |other rows|^2 -----------------------
 __device__ double window_cost(const WinProblem& P, const double* __restrict__ r, double* red, int tid, int nthreads) {
-  // four independent partial sums per thread: the loads of a pass are in flight together (a 1024-frame window has 170 rows
-  // per thread, and one dependent load per pass made this the second longest kernel of an iteration)
+  // independent partial sums per thread, sixteen loads in flight per pass (a 1024-frame window has 170 rows per thread: one
+  // dependent load per pass made this the second longest kernel of an iteration, four in flight still left it at 39 us)
   double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
   int k = tid;
-  for (; k + 3 * nthreads < P.K; k += 4 * nthreads) {
-    const double* q = r + 2 * (size_t)k;
-    const double x0 = q[0], y0 = q[1], x1 = q[2 * (size_t)nthreads], y1 = q[2 * (size_t)nthreads + 1];
-    const double x2 = q[4 * (size_t)nthreads], y2 = q[4 * (size_t)nthreads + 1], x3 = q[6 * (size_t)nthreads], y3 = q[6 * (size_t)nthreads + 1];
-    a0 += 0.5 * huber_rho_w(P.huber, x0 * x0 + y0 * y0);
-    a1 += 0.5 * huber_rho_w(P.huber, x1 * x1 + y1 * y1);
-    a2 += 0.5 * huber_rho_w(P.huber, x2 * x2 + y2 * y2);
-    a3 += 0.5 * huber_rho_w(P.huber, x3 * x3 + y3 * y3);
+  for (; k + 7 * nthreads < P.K; k += 8 * nthreads) {
+    double xx[8], yy[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { xx[u] = r[2 * (size_t)(k + u * nthreads)]; yy[u] = r[2 * (size_t)(k + u * nthreads) + 1]; }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < 8; u += 4) {
+      a0 += 0.5 * huber_rho_w(P.huber, xx[u] * xx[u] + yy[u] * yy[u]);
+      a1 += 0.5 * huber_rho_w(P.huber, xx[u + 1] * xx[u + 1] + yy[u + 1] * yy[u + 1]);
+      a2 += 0.5 * huber_rho_w(P.huber, xx[u + 2] * xx[u + 2] + yy[u + 2] * yy[u + 2]);
+      a3 += 0.5 * huber_rho_w(P.huber, xx[u + 3] * xx[u + 3] + yy[u + 3] * yy[u + 3]);
+    }
   }
   for (; k < P.K; k += nthreads) {
     const double r0 = r[2 * (size_t)k], r1 = r[2 * (size_t)k + 1];
     a0 += 0.5 * huber_rho_w(P.huber, r0 * r0 + r1 * r1);
   }
   int i = 2 * P.K + tid;
-  for (; i + 3 * nthreads < P.total_rows; i += 4 * nthreads) {
-    const double v0 = r[i], v1 = r[i + nthreads], v2 = r[i + 2 * nthreads], v3 = r[i + 3 * nthreads];
-    a0 += 0.5 * v0 * v0; a1 += 0.5 * v1 * v1; a2 += 0.5 * v2 * v2; a3 += 0.5 * v3 * v3;
+  for (; i + 15 * nthreads < P.total_rows; i += 16 * nthreads) {
+    double v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) v[u] = r[i + u * nthreads];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < 16; u += 4) { a0 += 0.5 * v[u] * v[u]; a1 += 0.5 * v[u + 1] * v[u + 1]; a2 += 0.5 * v[u + 2] * v[u + 2]; a3 += 0.5 * v[u + 3] * v[u + 3]; }
   }
   for (; i < P.total_rows; i += nthreads) a0 += 0.5 * r[i] * r[i];
   const double acc = (a0 + a1) + (a2 + a3);
@@ -148,11 +157,13 @@ __global__ __launch_bounds__(1024) void k_win_beta(WinProblem P, WinBuf W, const
       }
       const size_t fs = (size_t)kHRows * kHLd;
       int f = g;
-      for (; f + 24 < F; f += 32) {
-        a0 += Hpan[(size_t)f * fs + off];
-        a1 += Hpan[(size_t)(f + 8) * fs + off];
-        a2 += Hpan[(size_t)(f + 16) * fs + off];
-        a3 += Hpan[(size_t)(f + 24) * fs + off];
+      for (; f + 120 < F; f += 128) {        // sixteen loads in flight
+        double v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = Hpan[(size_t)(f + 8 * u) * fs + off];
+        __builtin_amdgcn_sched_barrier(0);     // (without it the scheduler pairs every load with its add again)
+#pragma unroll
+        for (int u = 0; u < 16; u += 4) { a0 += v[u]; a1 += v[u + 1]; a2 += v[u + 2]; a3 += v[u + 3]; }
       }
       for (; f < F; f += 8) a0 += Hpan[(size_t)f * fs + off];
     }
@@ -731,11 +742,13 @@ __global__ __launch_bounds__(1024) void k_win_beta_solve(WinProblem P, WinBuf W,
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
     if (w < NBETA * NBETA + NBETA) {
       int f = g;
-      for (; f + 24 < F; f += 32) {
-        s0 += W.part[(size_t)f * kWinPart + w];
-        s1 += W.part[(size_t)(f + 8) * kWinPart + w];
-        s2 += W.part[(size_t)(f + 16) * kWinPart + w];
-        s3 += W.part[(size_t)(f + 24) * kWinPart + w];
+      for (; f + 120 < F; f += 128) {        // sixteen loads in flight
+        double v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = W.part[(size_t)(f + 8 * u) * kWinPart + w];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 16; u += 4) { s0 += v[u]; s1 += v[u + 1]; s2 += v[u + 2]; s3 += v[u + 3]; }
       }
       for (; f < F; f += 8) s0 += W.part[(size_t)f * kWinPart + w];
     }
@@ -1007,7 +1020,16 @@ __global__ __launch_bounds__(256) void k_win_tail(WinProblem P, WinBuf W, const 
     double* o = W.part + (size_t)f * kWinPart + 112;
     o[0] = pm; o[1] = dn; o[2] = xn;
     __threadfence();                                        // the partial is visible device-wide before the ticket is taken
-    s_last = (atomicAdd(W.ticket, 1) == F - 1) ? 1 : 0;
+    // two-level ticket: groups of 32 frames, then the groups (atomics on ONE word serialise at ~40 ns each: 1024 of them
+    // were two thirds of this kernel at 1024 frames)
+    const int grp = f >> 5, ngrp = (F + 31) >> 5, gsize = min(32, F - 32 * grp);
+    int last = 0;
+    if (atomicAdd(W.ticket + 1 + grp, 1) == gsize - 1) {
+      W.ticket[1 + grp] = 0;
+      __threadfence();
+      last = (atomicAdd(W.ticket, 1) == ngrp - 1) ? 1 : 0;
+    }
+    s_last = last;
   }
   __syncthreads();
   if (!s_last) return;
