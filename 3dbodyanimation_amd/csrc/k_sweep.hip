@@ -64,6 +64,9 @@ __global__ __launch_bounds__(kThreads, 4) void k_frame_resjac(DevModel M, DevPro
     return;
   }
   const FusedFrame none{};
+  // a frame workgroup that shares its CU with a prior workgroup (256 frames + 16 prior tiles on 256 CUs) is the launch's
+  // critical path; the prior workgroup has slack: frame waves win the issue arbitration
+  __builtin_amdgcn_s_setprio(2);
   frame_part<false>(M, Pb, params, beta, r_out, J_out, joints_out, mc, want_jac, sm, (int)blockIdx.x - pa.n_tiles, none);
 }
 

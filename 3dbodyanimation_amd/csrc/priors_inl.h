@@ -70,22 +70,26 @@ __device__ inline void prior_block(const PriorArgs& A, int tile, const double* _
         for (int third = 0; third < 3; ++third) {   // 6 k-steps of fragments in flight (72 VGPRs): the kernel stays
           double2 b[6][3];                          // under 128 VGPRs so a prior workgroup co-resides with a frame one
           double mu[6];
+          // the factor is LOWER triangular (B[r][c] = L[r][c], zero for c > r): column tile nt only meets the k-steps with
+          // 4 ks + 3 >= 16 nt, i.e. ks >= 4 nt — 50 of the 90 tile products (and their fragment loads) remain; all the
+          // conditions below are compile-time after unrolling
 #pragma unroll
           for (int s = 0; s < 6; ++s) {
             const int ks = third * 6 + s, r = 4 * ks + kk;
 #pragma unroll
-            for (int pr = 0; pr < 3; ++pr) b[s][pr] = Lf[(size_t)(ks * 3 + pr) * 64];
+            for (int pr = 0; pr < 3; ++pr)
+              if (ks >= 4 * (2 * pr)) b[s][pr] = Lf[(size_t)(ks * 3 + pr) * 64];
             mu[s] = (r < D) ? g.mean[(size_t)k * D + r] : 0.0;
           }
 #pragma unroll
           for (int s = 0; s < 6; ++s) {
-            const int r = 4 * (third * 6 + s) + kk;
+            const int ks = third * 6 + s, r = 4 * ks + kk;
             const double a = (r < D) ? sx[m * 72 + r] - mu[s] : 0.0;
             acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[s][0].x, acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[s][0].y, acc[1], 0, 0, 0);
-            acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[s][1].x, acc[2], 0, 0, 0);
-            acc[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[s][1].y, acc[3], 0, 0, 0);
-            acc[4] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[s][2].x, acc[4], 0, 0, 0);
+            if (ks >= 4) acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[s][0].y, acc[1], 0, 0, 0);
+            if (ks >= 8) acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[s][1].x, acc[2], 0, 0, 0);
+            if (ks >= 12) acc[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[s][1].y, acc[3], 0, 0, 0);
+            if (ks >= 16) acc[4] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[s][2].x, acc[4], 0, 0, 0);
           }
         }
         // D layout (f64): column = lane & 15, frame row = (lane >> 4) + 4 q

@@ -1,6 +1,6 @@
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
-rocprofv3 --kernel-trace --stats -d gpurun_out/wprof -o w --output-format csv -- python3 tools/window_prof.py 1024 > gpurun_out/wprof.log 2>&1
+rocprofv3 --kernel-trace --stats -d gpurun_out/wprof -o w --output-format csv -- python3 tools/tmp/c3prof.py > gpurun_out/wprof.log 2>&1
 python3 - <<'PY'
 import csv, glob
 f = glob.glob("gpurun_out/wprof/**/*kernel_stats.csv", recursive=True)[0]
