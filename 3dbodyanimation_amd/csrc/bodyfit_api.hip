@@ -1127,7 +1127,7 @@ int bodyfit_internal_solve_window_device(bodyfit_problem* p, double* frame_param
   if (sharded) build_cr_schedule(NI, false, sched, ilevels);
   // ---- one pooled allocation, kept across solves ----
   WinBuf W{}, Wi{};
-  double *d_x, *d_b, *d_xn, *d_bn, *d_rn, *d_xl, *d_sh, *d_dh, *d_io;
+  double *d_x, *d_b, *d_xn, *d_bn, *d_rn, *d_xl, *d_sh, *d_dh;
   int *d_compn, *d_sched;
   unsigned char* d_const = nullptr;
   const size_t io_doubles = (size_t)NI * (3 * kWinBlock * kWinBlock + kWinRhs * kWinBlock);   // gathered interface blocks
@@ -1161,7 +1161,8 @@ int bodyfit_internal_solve_window_device(bodyfit_problem* p, double* frame_param
     d_compn = reinterpret_cast<int*>(Bp + o_cn);
     d_sched = reinterpret_cast<int*>(Bp + o_sched);
     if (param_constant) d_const = Bp + o_const;
-    d_xl = dp(o_xl); d_sh = dp(o_sh); d_dh = dp(o_dh); d_io = dp(o_io);
+    d_xl = dp(o_xl); d_sh = dp(o_sh); d_dh = dp(o_dh);
+    (void)o_io;
   }
   if (!p->d_frame_normal) HIP_TRY(p->mem.alloc(&p->d_frame_normal, (size_t)F * kNormalRows * kNormalLd));
   if (!p->lm_stream) HIP_TRY(hipStreamCreateWithFlags(&p->lm_stream, hipStreamNonBlocking));

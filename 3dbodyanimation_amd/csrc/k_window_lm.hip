@@ -5,7 +5,8 @@
 // term: diagonal off-diagonal blocks) with a 10-wide border (beta).  host_solver.cpp factors the chain frame after frame
 // on the host; here it is solved on the device, parallel in the frames, by BLOCK CYCLIC REDUCTION with the border carried
 // as 11 right-hand sides [B | rhs]:
-//   level l: every second remaining frame j (neighbours a < j < b) is eliminated:
+//   level l: every second remaining frame j (neighbours a < j < b) is eliminated (the larger independent set when the count
+//   is odd: bodyfit_api.hip build_cr_schedule):
 //       D_j = L L^T,  P = L^-1 U_a^T,  Q = L^-1 U_j,  Y = L^-1 R_j                         (k_cr_factor, two workgroups per j)
 //       D_a -= P^T P,  D_b -= Q^T Q,  U_a := -P^T Q,  R_a -= P^T Y,  R_b -= Q^T Y          (k_cr_update, f64 MFMA)
 //   after ceil(log2 F) levels one frame is left: x = D^-1 R; then down again: x_j = L^-T (Y - P x_a - Q x_b)  (k_cr_back)
@@ -13,7 +14,11 @@
 // (U_j: coupling block (j, next remaining frame); at level 0 it is the diagonal temporal block, afterwards dense.)
 // Around it, all of Ceres' trust-region logic as restated in host_solver.cpp (Jacobi scaling fixed at the first iterate,
 // LM damping, projected scale bounds, step quality, radius update, the three termination tests) runs in small kernels on
-// the device: per LM iteration the host launches a fixed sequence and reads back one 16-double status record.
+// the device: per LM iteration the host launches a fixed sequence and reads back one 16-double status record (every fourth
+// iteration on one GPU).  Single-GPU windows of up to 256 frames end an iteration with ONE launch for step, model change and
+// decision (k_win_tail: the last workgroup, found by a ticket, decides).
+// Every block that moves between global memory and LDS does so with all its loads issued before the first is used
+// (BlockRegs): written as load-store loops these kernels spent a third of their time in dependent L2 round trips.
 // Blocks are padded to 80 x 80 (identity on the padding), right-hand sides to 16 rows, all stored row-major; "t" buffers
 // hold transposes (Pt[i][k] = P[k][i]) so that every product is  C[i][i'] = sum_k X[i][k] Y[i'][k]  with k contiguous.
 #include "bodyfit_device.h"
