@@ -51,3 +51,15 @@ for rep in range(30):
 free1 = torch.cuda.mem_get_info()[0]
 assert abs(free0 - free1) < 64 << 20, (free0, free1)
 print("pooled solves + overlay cycles ok", round(time.time() - t0, 1), "s")
+
+# window LM (cyclic reduction, fused tail with its ticket): the same fit repeated must give the same bits
+for F in (13, 20, 103, 300):
+    seq = synth.make_sequence(model, F, seed=F)
+    ref = None
+    for rep in range(12):
+        prob = api.Problem.from_sequence(gm, seq, n_cols=86, use_shape=True, beta_pose=5.0, beta_shape=25.0, lambda_temporal=3.0)
+        x, bb, s = prob.solve(seq.init_params, np.zeros(10), independent=False, max_iters=40, scale_bounds=(-1e300, 1e300), solver=3)
+        cur = (x.copy(), bb.copy(), s[0].iterations, s[0].final_cost)
+        if ref is None: ref = cur
+        assert np.array_equal(ref[0], cur[0]) and np.array_equal(ref[1], cur[1]) and ref[2:] == cur[2:], (F, rep)
+    print("window F", F, "bit-stable over 12 fits,", ref[2], "iterations", flush=True)
