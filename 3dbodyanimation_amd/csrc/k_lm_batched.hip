@@ -360,56 +360,73 @@ __global__ __launch_bounds__(kStepThreads) void k_lm_step(LmProblem P, LmState S
     const int m = lane & 15, kk = lane >> 4;
     const double bp2 = bp * bp, bs2 = bs * bs;
     const int nsteps = nrows4 / 4;
-    int pair = 0;
-    for (int ti = 0; ti < 6; ++ti)
-      for (int tj = 0; tj <= ti; ++tj, ++pair) {
-        if (pair % kStepWaves != wave) continue;
-        // k loop software-pipelined by hand, four k-steps deep: the operands of step s + 4 are requested right after the
-        // product of step s (left to itself the compiler reads two steps, waits for them, multiplies, and so on: every
-        // pair of products then pays a full LDS latency).  The uniform branch around each product keeps the order.
-        d4 acc = {0.0, 0.0, 0.0, 0.0};
-        const double* pa = Jh + kk * kJLd + 16 * ti + m;
-        const double* pb = Jh + kk * kJLd + 16 * tj + m;
-        double av[4], bv[4];
+    // The wave's (up to) three tiles t = wave, wave + 8, wave + 16 run their k loops INTERLEAVED: three independent
+    // accumulator chains keep the matrix pipe fed, and the three epilogues (prior terms from LDS, stores in both triangles)
+    // are issued together.  The k loop is software-pipelined by hand, two k-steps deep per tile: operands of step s + 2 are
+    // requested right after the products of step s (left to itself the compiler reads, waits, multiplies, and every product
+    // pays a full LDS latency); the uniform branches keep the order.
+    int tis[3], tjs[3];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { av[u] = pa[4 * u * kJLd]; bv[u] = pb[4 * u * kJLd]; }
-        for (int s0 = 0; s0 < nsteps; s0 += 4) {
+    for (int u = 0; u < 3; ++u) {
+      const int t = min(wave + 8 * u, 20);
+      int ti = 0, rem = t;
+      while (rem > ti) { rem -= ti + 1; ++ti; }       // t -> (ti, tj) of the lower triangle, row-major
+      tis[u] = ti; tjs[u] = rem;
+    }
+    const bool third = wave + 16 < 21;                 // waves 0-4 carry three tiles, waves 5-7 two
+    d4 acc[3];
+    const double* pa[3];
+    const double* pb[3];
+    double av[3][2], bv[3][2];
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            if (s0 + u < nsteps) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], acc, 0, 0, 0);
-            const int sn = min(s0 + 4 + u, kRowsMax / 4 - 1);     // (past the last step: a row nothing multiplies)
-            av[u] = pa[4 * sn * kJLd]; bv[u] = pb[4 * sn * kJLd];
-          }
-        }
-        if (pair == 0) {
-          LSTAMP(14);
-          asm volatile("s_nop 0" ::"v"(acc[0]), "v"(acc[3]));
-          LSTAMP(8);
-        }
-        // D: column = lane & 15 (B side, tile tj), row = (lane >> 4) + 4 q (A side, tile ti).  Branch-free up to the
-        // stores: the prior terms are read from clamped addresses and masked (row n, the rhat column, is the gradient
-        // and takes none; its mirror image lands in column n of H0, which nothing reads)
-        double pl[4];
-        const int j = 16 * tj + m;
+    for (int u = 0; u < 3; ++u) {
+      acc[u] = d4{0.0, 0.0, 0.0, 0.0};
+      pa[u] = Jh + kk * kJLd + 16 * tis[u] + m;
+      pb[u] = Jh + kk * kJLd + 16 * tjs[u] + m;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int i = 16 * ti + kk + 4 * q;
-          pl[q] = has_gmm ? Pl[min(max(i - 7, 0), 68) * 69 + min(max(j - 7, 0), 68)] : ((i == j) ? 1.0 : 0.0);
-        }
-        if (pair == 0) LSTAMP(9);
+      for (int w = 0; w < 2; ++w) { av[u][w] = pa[u][4 * w * kJLd]; bv[u][w] = pb[u][4 * w * kJLd]; }
+    }
+    for (int s0 = 0; s0 < nsteps; s0 += 2) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int i = 16 * ti + kk + 4 * q;
-          double v = acc[q];
-          if (has_prior && j >= 7 && i < npose) v += bp2 * pl[q];
-          if (has_shape && i == j && i >= npose && i < n) v += bs2;
-          if (i <= n && j < n && j <= i) {
-            H0[i * kLd + j] = v;
-            H0[j * kLd + i] = v;
-          }
+      for (int w = 0; w < 2; ++w) {
+        const bool on = s0 + w < nsteps;
+        const int sn = min(s0 + 2 + w, kRowsMax / 4 - 1);     // (past the last step: a row nothing multiplies)
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+          if (on && (u < 2 || third)) acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u][w], bv[u][w], acc[u], 0, 0, 0);
+          av[u][w] = pa[u][4 * sn * kJLd]; bv[u][w] = pb[u][4 * sn * kJLd];
         }
-        if (pair == 0) LSTAMP(15);
       }
+    }
+    // D: column = lane & 15 (B side, tile tj), row = (lane >> 4) + 4 q (A side, tile ti).  Branch-free up to the
+    // stores: the prior terms are read from clamped addresses and masked (row n, the rhat column, is the gradient
+    // and takes none; its mirror image lands in column n of H0, which nothing reads)
+    double pl[3][4];
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      const int j = 16 * tjs[u] + m;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int i = 16 * tis[u] + kk + 4 * q;
+        pl[u][q] = has_gmm ? Pl[min(max(i - 7, 0), 68) * 69 + min(max(j - 7, 0), 68)] : ((i == j) ? 1.0 : 0.0);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      if (u == 2 && !third) continue;
+      const int j = 16 * tjs[u] + m;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int i = 16 * tis[u] + kk + 4 * q;
+        double v = acc[u][q];
+        if (has_prior && j >= 7 && i < npose) v += bp2 * pl[u][q];
+        if (has_shape && i == j && i >= npose && i < n) v += bs2;
+        if (i <= n && j < n && j <= i) {
+          H0[i * kLd + j] = v;
+          H0[j * kLd + i] = v;
+        }
+      }
+    }
     // prior part of the gradient for the GMM: J^T r = beta_p^2 s Prec (x - mu); Prec is symmetric, so thread j reads
     // column j (consecutive lanes, consecutive words).  Waves 6 and 7 carry one Gram tile less than the others.
     if (has_gmm && tid >= 384 + 7 && tid < 384 + npose) {

@@ -35,7 +35,6 @@ for i, n in enumerate(names):
     print(f"  {n:36s} {np.median(d[:, i]):9.0f}")
 print("  total", np.median(raw[ok, 7] - raw[ok, 0]))
 print("  staging: operands arrived + first LDS pass", np.median(raw[ok, 11] - raw[ok, 0]), " Gram: wave 0's own tiles",
-      np.median(raw[ok, 13] - raw[ok, 1]), " (first tile: k loop", np.median(raw[ok, 14] - raw[ok, 1]), "mfma drain", np.median(raw[ok, 8] - raw[ok, 14]), "Pl reads", np.median(raw[ok, 9] - raw[ok, 8]), "store",
-      np.median(raw[ok, 15] - raw[ok, 9]), ")  gradient + scaling up to the tolerance test", np.median(raw[ok, 12] - raw[ok, 3]))
+      np.median(raw[ok, 13] - raw[ok, 1]), " gradient + scaling up to the tolerance test", np.median(raw[ok, 12] - raw[ok, 3]))
 print("  Cholesky parts summed over the solve's iterations / iterations: (a) diagonal blocks, (b) panel solves, (c) trailing updates:",
       np.median(raw[ok, 8:11], axis=0) / max(1, int(max(q.iterations for q in s))))
