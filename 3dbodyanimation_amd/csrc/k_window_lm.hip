@@ -540,13 +540,19 @@ __device__ __forceinline__ d4 tile_xyT(const double* X, const double* Y, int ti,
 }
 
 // ---- cyclic reduction: Schur updates of one remaining frame a (left eliminated neighbour jl, right one jr, next
-//      remaining frame b).  Three workgroups per frame (part = blockIdx.x % 3): diagonal block, coupling block, rhs. -----
-__global__ __launch_bounds__(kCrThreads) void k_cr_update(WinBuf W, const int* __restrict__ surv, int n_surv) {
+//      remaining frame b).  Four workgroups per frame: diagonal block (two halves of its tiles), coupling block, rhs. -----
+__global__ __launch_bounds__(kCrThreads) void k_cr_update(WinBuf W, const int* __restrict__ surv, int n_surv, int split) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   double* X0 = sm;                 // [WB][LD]
   double* X1 = sm + WB * LD;       // [WB][LD]
   double* Ys = X1 + WB * LD;       // [2][WR][LD]
-  const int sidx = blockIdx.x / 3, part = blockIdx.x % 3;
+  // four workgroups per remaining frame: the diagonal block's 15 lower tiles in two halves (its 600 f64 matrix
+  // instructions were the longest part by 2x: one tile per wave now), the coupling block, the right-hand sides
+  // (split = 1, levels that do not fill the chip; on the throughput-bound levels of a long window one workgroup takes both
+  //  halves: three workgroups per frame)
+  const int sidx = split ? (int)(blockIdx.x >> 2) : (int)(blockIdx.x / 3), part4 = split ? (int)(blockIdx.x & 3) : -1;
+  const int part = split ? (part4 < 2 ? 0 : part4 - 1) : (int)(blockIdx.x % 3);
+  const int h0 = split ? (part4 & 1) : 0, h1 = split ? h0 + 1 : 2;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int a = surv[4 * sidx], jl = surv[4 * sidx + 1], jr = surv[4 * sidx + 2], b = surv[4 * sidx + 3];
   const int m = lane & 15, kk = lane >> 4;
@@ -561,24 +567,26 @@ __global__ __launch_bounds__(kCrThreads) void k_cr_update(WinBuf W, const int* _
     int tis[2], tjs[2];
     d4 acc[2];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < 2; ++u) {                         // this wave's tile of each half it carries
       const int t = min(wave + 8 * u, 14);
-      int ti = 0, rem = t;
-      while (rem > ti) { rem -= ti + 1; ++ti; }       // t -> (ti, tj) of the lower triangle, row-major
-      tis[u] = ti; tjs[u] = rem;
+      int ti = 0, tj = t;
+      while (tj > ti) { tj -= ti + 1; ++ti; }             // t -> (ti, tj) of the lower triangle, row-major
+      tis[u] = ti; tjs[u] = tj;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) acc[u][q] = D[(size_t)(16 * ti + kk + 4 * q) * WB + 16 * rem + m];
+      for (int q = 0; q < 4; ++q) acc[u][q] = (u >= h0 && u < h1) ? D[(size_t)(16 * ti + kk + 4 * q) * WB + 16 * tj + m] : 0.0;
     }
     if (jl >= 0) block_to_lds<WB>(r0, X0, tid);
     if (jr >= 0) block_to_lds<WB>(r1, X1, tid);
     __syncthreads();
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-      if (wave + 8 * u > 14) continue;
+      if (u < h0 || u >= h1 || wave + 8 * u > 14) continue;
+      // the two sources as two independent accumulator chains
+      d4 acc2 = {0.0, 0.0, 0.0, 0.0};
       if (jl >= 0) acc[u] = tile_xyT(X0, X0, tis[u], tjs[u], lane, acc[u], -1.0);
-      if (jr >= 0) acc[u] = tile_xyT(X1, X1, tis[u], tjs[u], lane, acc[u], -1.0);
+      if (jr >= 0) acc2 = tile_xyT(X1, X1, tis[u], tjs[u], lane, acc2, -1.0);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) D[(size_t)(16 * tis[u] + kk + 4 * q) * WB + 16 * tjs[u] + m] = acc[u][q];
+      for (int q = 0; q < 4; ++q) D[(size_t)(16 * tis[u] + kk + 4 * q) * WB + 16 * tjs[u] + m] = acc[u][q] + acc2[q];
     }
   } else if (part == 1) {
     // U_a := -Pt_jr Qt_jr^T  (coupling of a with the next remaining frame b)
@@ -1136,7 +1144,10 @@ void launch_cr_factor(const WinBuf& W, const int* d_elim, int n_elim, hipStream_
   if (n_elim > 0) hipLaunchKernelGGL(k_cr_factor, dim3(2 * n_elim), dim3(kCrThreads), win_factor_lds_bytes(), s, W, d_elim, n_elim);
 }
 void launch_cr_update(const WinBuf& W, const int* d_surv, int n_surv, hipStream_t s) {
-  if (n_surv > 0) hipLaunchKernelGGL(k_cr_update, dim3(3 * n_surv), dim3(kCrThreads), win_update_lds_bytes(), s, W, d_surv, n_surv);
+  if (n_surv > 0) {
+    const int split = 4 * n_surv <= 256 ? 1 : 0;        // (the diagonal block in two workgroups where CUs are idle anyway)
+    hipLaunchKernelGGL(k_cr_update, dim3((split ? 4 : 3) * n_surv), dim3(kCrThreads), win_update_lds_bytes(), s, W, d_surv, n_surv, split);
+  }
 }
 void launch_cr_back(const WinBuf& W, const int* d_elim, int n_elim, hipStream_t s) {
   if (n_elim > 0) hipLaunchKernelGGL(k_cr_back, dim3(n_elim), dim3(kCrThreads), win_back_lds_bytes(), s, W, d_elim, n_elim);
