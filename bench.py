@@ -366,7 +366,11 @@ def main():
             sys.path.insert(0, os.path.join(ROOT, "tools"))
             import fit_bench
             fit = {"unit": "frames/s", "c2": fit_bench.fit_c2(api, synth, model, gm),
-                   "c3": fit_bench.fit_c3(api, synth, model, gm), "c4": fit_bench.fit_c4(api, synth, model, gm)}
+                   "c3": fit_bench.fit_c3(api, synth, model, gm), "c4": fit_bench.fit_c4(api, synth, model, gm),
+                   # configs[4] on this one GPU: as the reference stages it (103 anchors + 69 windows of 20 through
+                   # drivers.run_multi, incl. the per-window write-back) and as ONE 1024-frame window (what --workload c5 --fit
+                   # shards over the ranks)
+                   "c5_staged": fit_bench.fit_c5(api, synth, model, gm), "c5_window": fit_bench.fit_c5_window(api, synth, model, gm)}
             if not args.no_cpu_baseline:
                 # eight threads: what the reference itself configures (options.num_threads = 8, include/MultiFrameBA.h:148;
                 # 4 in include/Sim3BA.h:476) — and what these small problems can use: 25 to 500 residual blocks per evaluation

@@ -34,7 +34,7 @@ def test_bench_single_gpu_line():
     # the second half of the metric: frames/sec to convergence of c2 / c3 / c4, with iteration and sweep counts
     fit = d["fit"]
     assert fit["unit"] == "frames/s"
-    for k in ("c2", "c3", "c4"):
+    for k in ("c2", "c3", "c4", "c5_staged", "c5_window"):
         assert fit[k]["frames_per_s"] > 0 and fit[k]["frames"] >= 1
     assert fit["c2"]["iterations"] >= 1 and fit["c2"]["sweeps"] >= 1 and fit["c3"]["converged"] >= 250
     assert fit["c4"]["windows"] == 9 and fit["c4"]["anchors"] == 13

@@ -121,6 +121,23 @@ def fit_c5(api, synth, model, gm, F=1024):
                 stage1_sweeps=res["stage1"].n_sweeps, mean_px_fk=float(px[F // 10 + 1:].mean()))
 
 
+def fit_c5_window(api, synth, model, gm, F=1024, repeats=2):
+    """BASELINE configs[4] as ONE shared-beta window of all 1024 frames, fitted to convergence on one GPU from the reference's
+    initial state (max_iters_s1 = 1000, src/main_multi_frame.cpp:29): the single-GPU form of `bench.py --workload c5 --fit`."""
+    seq = synth.make_sequence(model, F, seed=0)
+    prob = api.Problem.from_sequence(gm, seq, n_cols=86, use_shape=True, beta_pose=5.0, beta_shape=25.0, lambda_temporal=3.0)
+    out = None
+    for _ in range(repeats):
+        t0 = time.perf_counter()
+        x, b, s = prob.solve(seq.init_params, np.zeros(10), independent=False, max_iters=1000, scale_bounds=(-1e300, 1e300), solver=3)
+        dt = time.perf_counter() - t0
+        rec = dict(frames=F, seconds=dt, frames_per_s=F / dt, iterations=s[0].iterations, sweeps=s[0].n_sweeps,
+                   termination=s[0].termination, final_cost=s[0].final_cost)
+        if out is None or dt < out["seconds"]:
+            out = rec
+    return out
+
+
 def cpu_fit_baseline(synth, model, budget_s=20.0, threads=0):
     """The checker's own fits (oracle evaluator, reference-like stride-4 dual-number Jacobians, under the dense numpy LM
     of oracle/lm_dense.py) on a bounded sample of c2 / c3 / c4: one c2 frame, as many c3 frames as fit a third of the
