@@ -52,6 +52,13 @@ __global__ __launch_bounds__(kThreads, 4) void k_frame_resjac(DevModel M, DevPro
     unsigned long long tp0 = 0;
     if (Pb.dbg && threadIdx.x == 0) asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tp0)::"memory");
 #endif
+    if (Pb.frame_flags) {
+      // device LM: a tile none of whose 16 frames has a candidate has nothing to evaluate (every wave reads the same 16
+      // flags, so the decision is uniform over the workgroup) — late iterations of a batch keep only a few tiles
+      const int f = (int)blockIdx.x * kPriorTileF + (int)(threadIdx.x & 15);
+      const int fl = (f < Pb.F) ? Pb.frame_flags[f] : 0;
+      if (__ballot((fl & Pb.frame_mask) != 0) == 0ull) return;
+    }
     prior_block(pa, (int)blockIdx.x, params, sm);   // (dispatched first so they never form the tail of the launch)
 #ifdef BODYFIT_STAMPS
     if (Pb.dbg && threadIdx.x == 0) {
