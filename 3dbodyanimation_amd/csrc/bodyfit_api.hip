@@ -107,10 +107,10 @@ struct bodyfit_problem {
   size_t win_pool_bytes = 0;
   hipStream_t lm_stream = nullptr;
   double* d_writeback = nullptr;
-  // fused sweep (k_sweep_fused): in-launch synchronisation words [error | pad | flag[256] | claim[256]], launch counter
+  // one-launch sweep (k_sweep_roles): in-launch synchronisation words [error | pad | flag[F rounded up to 256]], launch counter
   unsigned char* d_fused = nullptr;
+  size_t fused_bytes = 0;
   unsigned fused_epoch = 0;
-  int fused_test_skip = 0;
   bool fused_enabled = true, fused_unchecked = false;
   double* d_frame_partials = nullptr; // [F][258] per-frame beta partials written by k_frame_resjac (shared-beta problems)
   int partials_tiles = 0;             // prior tiles that added their plain-cost rows behind the frame rows
@@ -145,7 +145,7 @@ bool chol_lower(std::vector<double>& A, int n) {
   return true;
 }
 
-// The bounded waits of the fused sweep set an error word instead of hanging; the synchronous entry points read it after
+// The bounded waits of the one-launch sweep set an error word instead of hanging; the synchronous entry points read it after
 // their stream synchronisation.
 int fused_check(bodyfit_problem* p) {
   if (!p->fused_unchecked || !p->d_fused) return BODYFIT_OK;
@@ -155,14 +155,14 @@ int fused_check(bodyfit_problem* p) {
   if (err) {
     (void)hipMemset(p->d_fused, 0, 4);
     p->fused_enabled = false;   // fall back to the two-launch sweep for the rest of this problem's life
-    return fail(BODYFIT_ERR_HIP, "fused sweep: an in-launch wait timed out (results of that sweep are incomplete); "
+    return fail(BODYFIT_ERR_HIP, "one-launch sweep: an in-launch wait timed out (results of that sweep are incomplete); "
                                  "the problem now uses the two-launch sweep");
   }
   return BODYFIT_OK;
 }
 
-// One evaluation sweep on the caller's stream: ONE launch (k_sweep_fused) when the mesh is on and the frames fit one
-// workgroup per CU, otherwise two launches.  The prior residuals are produced by extra
+// One evaluation sweep on the caller's stream: ONE launch (k_sweep_roles: frame, mesh and prior workgroups side by side)
+// when the mesh is on, otherwise (no mesh, device LM with frame flags, models with more than 12 landmark slots) two.  The prior residuals are produced by extra
 // workgroups (priors_inl.h) of the mesh launch when the mesh is on (its vertex tiles leave 40 CUs idle), otherwise
 // of the k_frame_resjac launch.  ev (optional, 4 events): the dispatches' own begin / end timestamps,
 // [0],[1] k_frame_resjac, [2],[3] k_mesh_blend_lbs.
@@ -201,20 +201,18 @@ int sweep(bodyfit_problem* p, const double* d_params, const double* d_beta, int 
   p->partials_tiles = dp.beta_partials ? pa.n_tiles : 0;
   PriorArgs none = pa;
   none.n_tiles = 0;
-  if (mesh && !frame_flags && p->fused_enabled && p->d_fused && fused_sweep_fits(m->d, dp, pa.n_tiles, m->n_cus)) {
-    // ONE launch: frame part + mesh part per workgroup, operands handed over inside the launch (k_sweep.hip)
+  if (mesh && !frame_flags && p->fused_enabled && p->d_fused && role_sweep_fits(m->d, dp)) {
+    // ONE launch: frame, mesh and prior roles, operands handed over inside the launch (k_sweep.hip)
     FusedSync sy{};
     sy.error = reinterpret_cast<unsigned*>(p->d_fused);
     sy.flag = reinterpret_cast<unsigned*>(p->d_fused + kFusedSyncHeader);
-    sy.claim = sy.flag + kFusedMaxFrames;
     if (p->fused_epoch == 0xffffffffu) {   // the 32-bit launch counter is about to wrap: start over (stream-ordered)
-      (void)hipMemsetAsync(p->d_fused, 0, kFusedSyncHeader + (size_t)2 * kFusedMaxFrames * 4, st);
+      (void)hipMemsetAsync(p->d_fused, 0, p->fused_bytes, st);
       p->fused_epoch = 0;
     }
     sy.epoch = ++p->fused_epoch;
-    sy.test_skip = p->fused_test_skip;
     p->fused_unchecked = true;
-    launch_sweep_fused(m->d, dp, d_params, d_beta, d_r, want_jac ? d_J : nullptr, p->d_joints, mc, want_jac, pa,
+    launch_sweep_roles(m->d, dp, d_params, d_beta, d_r, want_jac ? d_J : nullptr, p->d_joints, mc, want_jac, pa,
                        p->d_cloud, sy, st, ev ? ev[4] : nullptr, ev ? ev[5] : nullptr);
   } else {
     launch_frame_resjac(m->d, dp, d_params, d_beta, d_r, want_jac ? d_J : nullptr, p->d_joints, mc, want_jac,
@@ -721,16 +719,13 @@ int bodyfit_problem_create(const bodyfit_model* m, const bodyfit_problem_desc* d
     // unconditionally, whole 128-byte lines per half-wave
     HIP_TRY(p->mem.alloc(&p->d_cloud, (size_t)d.nFTiles * kFTile * m->d.nVTiles * kVTile * 3));
     HIP_TRY(hipMemset(p->mc.featA, 0, nfa * sizeof(uint16_t)));
-    const size_t nfu = kFusedSyncHeader + (size_t)2 * kFusedMaxFrames * 4;
+    const size_t nfu = kFusedSyncHeader + (size_t)((F + 255) / 256) * 256 * 4;
     HIP_TRY(p->mem.alloc(&p->d_fused, nfu));
     HIP_TRY(hipMemset(p->d_fused, 0, nfu));
-    // The one-launch sweep is opt-in (BODYFIT_FUSED=1): measured on MI355X it is correct but not yet faster than the two
-    // launches it replaces (what the in-launch hand-off saves, the frame part loses beside the tile
-    // transfer and behind the call).
-    const char* fe = std::getenv("BODYFIT_FUSED");
-    p->fused_enabled = fe && fe[0] == '1';
-    const char* ts = std::getenv("BODYFIT_FUSED_TEST_SKIP");   // tests: every n-th workgroup leaves its frame to be adopted
-    p->fused_test_skip = ts ? std::atoi(ts) : 0;
+    p->fused_bytes = nfu;
+    // BODYFIT_ONE_LAUNCH=0 keeps the two-launch sweep (k_frame_resjac, then k_mesh_blend_lbs): A/B measurements, fallback
+    const char* fe = std::getenv("BODYFIT_ONE_LAUNCH");
+    p->fused_enabled = !(fe && fe[0] == '0');
   }
   *out = p.release();
   return BODYFIT_OK;

@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 namespace bodyfit {
 
 constexpr int kMaxJoints = 24;     // SMPL
@@ -47,6 +49,7 @@ struct DevModel {
 
 struct DevProblem {
   int F, K, ncols, use_shape, beta_stride, pose_blend, nFTiles;
+  int feat_perm;          // row order of the blend-coefficient fragments (frame_part_inl.h), set per launch
   const int* kp_offset;   // [F+1]
   const int* kp_id;       // [K]
   const double* kp_uv;    // [K][2]
@@ -92,18 +95,43 @@ struct PriorArgs {
   double* plain_cost;   // optional [n_tiles][258]: entry 257 of row `tile` receives the tile's 1/2 sum r^2 (folded reduction)
 };
 
-// in-launch synchronisation words of the fused sweep (k_sweep.hip), one set per problem, zeroed at creation only
+// in-launch synchronisation words of the one-launch sweep (k_sweep_roles), one set per problem, zeroed at creation only.
 // Per frame f: flag[f] == epoch once the frame's mesh operands have been handed over in launch `epoch` (an idempotent
-// store: no counter, no read-modify-write on the normal path); claim[f] == epoch once a workgroup has started on the frame.
+// store: no counter, no read-modify-write).
 constexpr size_t kFusedSyncHeader = 16;   // error word, pad
 struct FusedSync {
-  unsigned* flag;              // [256]
-  unsigned* claim;             // [256]
+  unsigned* flag;              // [kRoleMaxFrames]
   unsigned* error;             // set when a workgroup's bounded wait ran out
   unsigned epoch;              // launch number, >= 1
-  int test_skip;               // diagnostic (tests): workgroups b % test_skip == 1 leave their frame to be adopted
 };
-constexpr int kFusedMaxFrames = 256;
+constexpr int kRoleMaxFrames = 16384;
+
+// A kernel's dynamic-LDS grant (hipFuncSetAttribute) is an attribute of the kernel ON ONE DEVICE: a process that creates
+// models on several devices needs it on each of them.  Bookkeeping per device, not per process.
+struct DeviceOnce {
+  std::atomic<unsigned long long> done[4] = {};       // bit d of word d / 64: granted on device d (d < 256)
+  bool first(int device) {                             // true exactly once per device
+    const unsigned d = (unsigned)device & 255u;
+    const unsigned long long bit = 1ull << (d & 63u);
+    return (done[d >> 6].fetch_or(bit, std::memory_order_acq_rel) & bit) == 0;
+  }
+};
+struct DeviceMax {                                     // a grant that grows: true when `want` exceeds what device d has
+  std::atomic<size_t> granted[256] = {};
+  bool raise(int device, size_t want, size_t initial) {
+    std::atomic<size_t>& g = granted[(unsigned)device & 255u];
+    size_t cur = g.load(std::memory_order_acquire);
+    if (cur == 0) cur = initial;
+    if (want <= cur) return false;
+    g.store(want, std::memory_order_release);
+    return true;
+  }
+};
+inline int current_device() {
+  int d = 0;
+  (void)hipGetDevice(&d);
+  return d;
+}
 
 // ---- device-resident LM for batches of independent frames (k_lm_batched.hip) ------------------------
 constexpr int kLmActive = 1;        // flags: frame still iterating
@@ -211,8 +239,8 @@ void launch_frame_resjac(const DevModel& M, const DevProblem& P, const double* d
                          const PriorArgs& priors, hipStream_t s, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 void launch_mesh(const DevModel& M, const DevProblem& P, const MeshCoef& mc, float* d_cloud, const PriorArgs& pa,
                  const double* d_params, hipStream_t s, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
-bool fused_sweep_fits(const DevModel& M, const DevProblem& P, int n_prior_tiles, int n_cus);
-void launch_sweep_fused(const DevModel& M, const DevProblem& P, const double* d_params, const double* d_beta, double* d_r,
+bool role_sweep_fits(const DevModel& M, const DevProblem& P);
+void launch_sweep_roles(const DevModel& M, const DevProblem& P, const double* d_params, const double* d_beta, double* d_r,
                         double* d_J, double* d_joints, const MeshCoef& mc, int want_jac, const PriorArgs& pa, float* d_cloud,
                         const FusedSync& sy, hipStream_t s, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 // (ev_start / ev_stop: optional events that take the dispatch's own begin / end timestamps, hipExtLaunchKernelGGL)

@@ -169,11 +169,9 @@ constexpr int TAB_PARENT = 0;                  // 24
 constexpr int TAB_ANC = 24;                    // 24
 constexpr int TAB_KPID = 96;                   // KC
 
-// What the fused sweep adds to the frame part (k_sweep_fused): the workgroup's mesh operands are staged while it runs, and
-// the frame's mesh operands are handed to the other workgroups inside the launch.
+// What the one-launch sweep (k_sweep_roles) adds to the frame part: the frame's mesh operands are handed to the mesh
+// workgroups inside the launch.
 struct FusedFrame {
-  unsigned char* ldsB;            // LDS image of the workgroup's vertex tile operands (null: no tile)
-  const unsigned char* dirsB;     // the tile's operand block in HBM
   unsigned* flag;                 // flag[f] = epoch: this frame's mesh operands are published
   unsigned epoch;                 // this launch's number
 };
@@ -199,15 +197,6 @@ __device__ __forceinline__ void store_operand16(void* p, uint4 v) {
     *reinterpret_cast<uint4*>(p) = v;
   }
 }
-
-// pieces [p0, p1) of the workgroup's 84 KiB tile operand block, HBM -> LDS by LDS-DMA (1 KiB per wave-instruction)
-__device__ __forceinline__ void tile_dma(const FusedFrame& fu, int lane, int p0, int p1) {
-#pragma unroll 1
-  for (int pc = p0; pc < p1; ++pc)
-    __builtin_amdgcn_global_load_lds(fu.dirsB + (size_t)pc * 1024 + lane * 16,
-                                     (__attribute__((address_space(3))) void*)(fu.ldsB + (size_t)pc * 1024), 16, 0, 0);
-}
-constexpr int kTileDmaB = 15, kTileDmaD = 17, kTileDmaE = 84 - 2 * kTileDmaB - 2 * kTileDmaD;   // pieces per issuing wave
 
 template <bool kFused>
 __device__ __forceinline__ void frame_part(const DevModel& M, const DevProblem& Pb, const double* __restrict__ params,
@@ -322,13 +311,6 @@ __device__ __forceinline__ void frame_part(const DevModel& M, const DevProblem& 
   const double* sbeta = sx + npose;
 
   STAMP(1);
-  if constexpr (kFused) {
-    // Fused sweep: the workgroup's vertex tile operands (84 x 1 KiB, HBM -> LDS by LDS-DMA) are requested in the idle issue
-    // slots of the frame part, ~150 cycles of a wave per piece: here by waves 6-7 (idle in this phase; LDS work only until
-    // the hand-off, so nothing of theirs waits behind the transfer: vmcnt retires in order), in phase D by waves 0-1 (least
-    // to do there), in phase E by wave 7 behind its operand stores.
-    if (fu.ldsB && wave >= 6) tile_dma(fu, lane, (wave - 6) * kTileDmaB, (wave - 5) * kTileDmaB);
-  }
   // ---- B. wave 0: Rodrigues + gradient per joint (joint 0 = root angle-axis);
   //         waves 1-3: chain offsets o_j(beta) (include/Sim3BA.h:142-170,179-205), centred rest joints ------
   if (tid < 3 * nJ) {     // (joint, k): wave 0 and a few lanes of wave 1
@@ -489,9 +471,6 @@ __device__ __forceinline__ void frame_part(const DevModel& M, const DevProblem& 
   frame_sync<kFused>();
 
   STAMP(4);
-  if constexpr (kFused) {
-    if (fu.ldsB && wave < 2) tile_dma(fu, lane, 2 * kTileDmaB + wave * kTileDmaD, 2 * kTileDmaB + (wave + 1) * kTileDmaD);
-  }
   // ---- D. wave 0-1: W_{k,c} = A_p (dR_{k,c} R_k^T) A_p^T ; wave 2: landmark LBS ; wave 3: camera matrices ;
   //         waves 4-7: B_j columns (d P_j / d beta) ----
   if (use_shape && want_jac) {
@@ -499,7 +478,11 @@ __device__ __forceinline__ void frame_part(const DevModel& M, const DevProblem& 
   }
   // blend-coefficient fragments of the mesh kernel (pose features from phase C, beta): nothing in this phase's way
   if (mc.featA) {
-    const int ftile = f / kFTile, row = f % kFTile;
+    // MFMA row of this frame inside its 32-frame tile.  feat_perm (k_sweep_roles' mesh role): accumulator register i of the
+    // half-wave h holds frame 2 i + h, so that one register row covers two CONSECUTIVE frames (2,304 contiguous bytes of
+    // transforms); otherwise (k_mesh_blend_lbs) the natural order, register i <-> frames 8 (i >> 2) + (i & 3) + 4 h.
+    const int ftile = f / kFTile, phi = f % kFTile;
+    const int row = Pb.feat_perm ? (8 * (phi >> 3) + 4 * (phi & 1) + ((phi >> 1) & 3)) : phi;
     if (wave == 3 && lane >= 8 && lane - 8 < kBlendKSteps * 4) {   // wave 3 only has the camera matrices in this phase
       const int wl = lane - 8;
       const int kstep = wl >> 2, h = (wl >> 1) & 1, hl = wl & 1;
@@ -661,9 +644,6 @@ __device__ __forceinline__ void frame_part(const DevModel& M, const DevProblem& 
       for (int r = 0; r < 3; ++r) joints_out[((size_t)f * nJ + jj) * 3 + r] = s * t[r] + sx[4 + r];
     }
   }
-  if constexpr (kFused) {
-    if (fu.ldsB && wave == 7) tile_dma(fu, lane, 84 - kTileDmaE, 84);   // behind the stores above: see the counted wait below
-  }
   if (nL > 0 && want_jac) {
     // d q_l / d theta_{k,c} for landmark l, complete, left in LM_PD[l][3 (k - 1) + c] for the Jacobian sweep:
     //   Ablend . (pd[:, 9(k-1):9k] . vec(dR_{k,c}))   the inner products were parked here by phase C (same lane mapping:
@@ -727,14 +707,7 @@ __device__ __forceinline__ void frame_part(const DevModel& M, const DevProblem& 
     // part: write-through stores, every wave drains its own, workgroup barrier, ONE lane stores the frame's flag
     // (cdna guide, Guideline 16 R1).  The flag store is idempotent, so a frame processed twice (adopted, then run by its
     // late owner) is still published exactly as once.
-    // the waves that stored operands drain them: wave 3 everything, wave 7 all but the kTileDmaE DMA pieces it issued behind
-    // its stores (vmcnt retires in order)
-    static_assert(kTileDmaE == 20, "the counted wait below");
-    if (wave == 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (wave == 7) {
-      if (fu.ldsB) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
+    if (wave == 3 || wave == 7) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the waves that stored operands
     frame_sync<true>();
     if (tid == kThreads - 1) __hip_atomic_store(fu.flag + f, fu.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     STAMP_REAL(12);

@@ -871,12 +871,10 @@ void launch_lm_init(const LmProblem& P, const LmState& S, const double* d_r, hip
 void launch_lm_step(const LmProblem& P, const LmState& S, double* d_r, double* d_J, int* d_comp, const double* d_r_cand,
                     const double* d_J_cand, const int* d_comp_cand, const unsigned char* d_constant, int first_iter,
                     hipStream_t s) {
-  static bool attr = false;
+  static DeviceOnce attr;
   const size_t lds = lm_step_lds_bytes();
-  if (!attr) {
+  if (attr.first(current_device()))
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_lm_step), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr = true;
-  }
   hipLaunchKernelGGL(k_lm_step, dim3(P.F), dim3(kStepThreads), lds, s, P, S, d_r, d_J, d_comp,
                      LmCandidate{d_r_cand, d_J_cand, d_comp_cand}, d_constant, first_iter);
 }
@@ -889,11 +887,9 @@ void launch_frame_normal(int F, int n, const int* d_kp_offset, double huber, con
                          double* d_out, hipStream_t s) {
   if (F <= 0) return;
   const size_t lds = (size_t)(kRowsMax * kJLd + kRowsMax) * sizeof(double);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static DeviceOnce attr_set;
+  if (attr_set.first(current_device()))
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_frame_normal), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
   hipLaunchKernelGGL(k_frame_normal, dim3(F), dim3(kStepThreads), lds, s, F, n, d_kp_offset, huber, d_r, d_J, d_out);
 }
 

@@ -326,9 +326,11 @@ def test_many_keypoints_per_frame_and_no_posedirs(api, synth, model, gpu_model, 
 
 
 @pytest.mark.gpu
-def test_writeback_batch_matches_host_composition(api, synth, model, gpu_model, omodel):
-    """bodyfit_writeback_batch against the same steps done on the host: R0' = R(rootAA) R0, forward with
-    s = 1 / zero root angle-axis through the oracle, mean_pixel_error over the FK keypoints; frames without keypoints -> 0."""
+def test_writeback_batch_matches_host_composition(api, synth, model, gpu_model, omodel, oracle_mod):
+    """bodyfit_writeback_batch against the same steps done by the checker: R0' = R(rootAA) R0, forward with
+    s = 1 / zero root angle-axis through the oracle, the ORACLE's mean_pixel_error (include/Utils.h:102-115 restated in
+    oracle/bodyfit_oracle.cpp) over the FK keypoints; frames without keypoints -> 0.  The product's own host function
+    bodyfit_mean_pixel_error is checked against the oracle on the same inputs as well."""
     F = 9
     seq = synth.make_sequence(model, F, seed=21, ragged=True)
     rng = np.random.default_rng(5)
@@ -346,8 +348,10 @@ def test_writeback_batch_matches_host_composition(api, synth, model, gpu_model, 
         k0, k1 = seq.kp_offset[f], seq.kp_offset[f + 1]
         ids, uv = seq.kp_id[k0:k1], seq.kp_uv[k0:k1]
         fk = ids < 24
-        want = api.mean_pixel_error(ids[fk], uv[fk], jo, seq.intr) if fk.any() else 0.0
+        want = oracle_mod.mean_pixel_error(ids[fk], uv[fk], jo, seq.intr) if fk.any() else 0.0
         assert abs(wb["mean_px"][f] - want) < 1e-8 * max(1.0, want)
+        if fk.any():   # the C-ABI host function (mean_pixel_error binding) against the checker too
+            assert abs(api.mean_pixel_error(ids[fk], uv[fk], jo, seq.intr) - want) < 1e-10 * max(1.0, want)
 
 
 @pytest.mark.gpu
