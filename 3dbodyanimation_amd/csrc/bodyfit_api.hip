@@ -107,7 +107,7 @@ struct bodyfit_problem {
   size_t win_pool_bytes = 0;
   hipStream_t lm_stream = nullptr;
   double* d_writeback = nullptr;
-  // one-launch sweep (k_sweep_roles): in-launch synchronisation words [error | pad | flag[F rounded up to 256]], launch counter
+  // one-launch sweep (k_sweep_roles): in-launch synchronisation words [error | pad | one counter per 32-frame unit], launch counter
   unsigned char* d_fused = nullptr;
   size_t fused_bytes = 0;
   unsigned fused_epoch = 0;
@@ -206,7 +206,7 @@ int sweep(bodyfit_problem* p, const double* d_params, const double* d_beta, int 
     FusedSync sy{};
     sy.error = reinterpret_cast<unsigned*>(p->d_fused);
     sy.flag = reinterpret_cast<unsigned*>(p->d_fused + kFusedSyncHeader);
-    if (p->fused_epoch == 0xffffffffu) {   // the 32-bit launch counter is about to wrap: start over (stream-ordered)
+    if (p->fused_epoch >= (1u << 26)) {   // epoch x 32 is about to wrap the 32-bit unit counters: start over (stream-ordered)
       (void)hipMemsetAsync(p->d_fused, 0, p->fused_bytes, st);
       p->fused_epoch = 0;
     }
@@ -719,7 +719,7 @@ int bodyfit_problem_create(const bodyfit_model* m, const bodyfit_problem_desc* d
     // unconditionally, whole 128-byte lines per half-wave
     HIP_TRY(p->mem.alloc(&p->d_cloud, (size_t)d.nFTiles * kFTile * m->d.nVTiles * kVTile * 3));
     HIP_TRY(hipMemset(p->mc.featA, 0, nfa * sizeof(uint16_t)));
-    const size_t nfu = kFusedSyncHeader + (size_t)((F + 255) / 256) * 256 * 4;
+    const size_t nfu = kFusedSyncHeader + (size_t)((F + 255) / 256) * 8 * kUnitCounterStride * 4;
     HIP_TRY(p->mem.alloc(&p->d_fused, nfu));
     HIP_TRY(hipMemset(p->d_fused, 0, nfu));
     p->fused_bytes = nfu;

@@ -96,11 +96,15 @@ struct PriorArgs {
 };
 
 // in-launch synchronisation words of the one-launch sweep (k_sweep_roles), one set per problem, zeroed at creation only.
-// Per frame f: flag[f] == epoch once the frame's mesh operands have been handed over in launch `epoch` (an idempotent
-// store: no counter, no read-modify-write).
-constexpr size_t kFusedSyncHeader = 16;   // error word, pad
+// Per 32-frame unit u: flag[u] == epoch x (frames of the unit) once all of them have handed their mesh operands over in launch
+// `epoch` (every frame workgroup adds 1 per launch; nothing is reset between launches).
+constexpr size_t kFusedSyncHeader = 256;  // error word, pad (the counters start on a line of their own)
+// One counter per 32-frame unit, 256 bytes apart: an agent-scope atomic add executes at the memory side at ~12 ns per add
+// and LINE (measured: 512 adds into one line took 6 us and held back every store queued behind them on that channel), so a
+// unit's 32 adds must not share a line, or a channel, with the other units'.
+constexpr int kUnitCounterStride = 64;    // dwords
 struct FusedSync {
-  unsigned* flag;              // [kRoleMaxFrames]
+  unsigned* flag;              // [frames / 32, rounded up to whole groups of 8][kUnitCounterStride]
   unsigned* error;             // set when a workgroup's bounded wait ran out
   unsigned epoch;              // launch number, >= 1
 };

@@ -44,6 +44,17 @@ namespace {
 __device__ __forceinline__ void store_through(double* p, double v) {
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
+// One-launch sweep (kFused): plain stores.  There the panel is written while other frame workgroups hand their mesh operands
+// over and the mesh workgroups poll for them: 1.1 M eight-byte write-through stores (one fabric write each) kept the
+// memory side busy enough to delay hand-off signals by up to 7 us (tools/stamp_roles.py).
+#ifndef BODYFIT_J_THROUGH
+#define BODYFIT_J_THROUGH 0
+#endif
+template <bool kFused>
+__device__ __forceinline__ void store_J(double* p, double v) {
+  if constexpr (kFused && !BODYFIT_J_THROUGH) *p = v;
+  else store_through(p, v);
+}
 
 
 __device__ inline void mul33(const double* A, const double* B, double* C) {  // C = A B
@@ -172,7 +183,7 @@ constexpr int TAB_KPID = 96;                   // KC
 // What the one-launch sweep (k_sweep_roles) adds to the frame part: the frame's mesh operands are handed to the mesh
 // workgroups inside the launch.
 struct FusedFrame {
-  unsigned* flag;                 // flag[f] = epoch: this frame's mesh operands are published
+  unsigned* flag;                 // counter of 32-frame unit u at flag[u * kUnitCounterStride]: += 1 once a frame's mesh operands are published
   unsigned epoch;                 // this launch's number
 };
 
@@ -271,6 +282,16 @@ __device__ __forceinline__ void frame_part(const DevModel& M, const DevProblem& 
   double o_pre = 0.0, jc_pre = 0.0, vt_pre = 0.0;
   if (o_lane) { o_pre = M.offset[o_i]; jc_pre = M.Jc0[o_i]; }
   if (v_lane) vt_pre = M.lm_vt[v_row];
+  // R0 of this frame for the camera matrices Rr0 = R_root R0, dRr0_c = dR_root,c R0 (36 entries, wave 6 in phase C):
+  // lane's column c of R0, requested here
+  const int cam_lane = tid - 384;
+  const bool cam_on = cam_lane >= 0 && cam_lane < 36;
+  double r0c0 = 0.0, r0c1 = 0.0, r0c2 = 0.0;
+  if (cam_on) {
+    const double* R0 = Pb.R0 + (size_t)f * 9;
+    const int c = cam_lane % 3;
+    r0c0 = R0[c]; r0c1 = R0[3 + c]; r0c2 = R0[6 + c];
+  }
   double x_in = 0.0;
   const bool x_lane = tid >= 128 && tid - 128 < npose, b_lane = tid >= 224 && tid - 224 < nS;
   if (x_lane) x_in = params[(size_t)f * npose + tid - 128];
@@ -285,6 +306,8 @@ __device__ __forceinline__ void frame_part(const DevModel& M, const DevProblem& 
     kp_v0 = Pb.kp_uv[2 * (size_t)(k_begin0 + (tid & (KC - 1))) + 1];
   }
   if (tid < nJ) { sParent[tid] = par_in; sAnc[tid] = anc_in; }
+  volatile int* sWalkDone = reinterpret_cast<volatile int*>(sPart + 104);   // phase C: wave 6's chain quantities are in LDS
+  if (tid == 0) *sWalkDone = 0;
   if (tid < nlw) {   // landmark skinning weights, fixed stride (padded with weight 0)
     const int l = tid / kMaxLmNnz, i = tid % kMaxLmNnz;
     double* L = sLm + l * LM_STRIDE;
@@ -449,17 +472,104 @@ __device__ __forceinline__ void frame_part(const DevModel& M, const DevProblem& 
       sT[(j * 3 + 0) * nS + sel] = v0 - c[0]; sT[(j * 3 + 1) * nS + sel] = v1 - c[1]; sT[(j * 3 + 2) * nS + sel] = v2 - c[2];
     }
   };
+  // blend-coefficient fragments of the mesh kernel: they need R_j (phase B) and beta only, so wave 6 stores them first
+  // thing (it has the least to do in this phase) and they have long left when it signals
+  if (wave == 6 && mc.featA) {
+    // MFMA row of this frame inside its 32-frame tile.  feat_perm (k_sweep_roles' mesh role): accumulator register i of the
+    // half-wave h holds frame 2 i + h, so that one register row covers two CONSECUTIVE frames (2,304 contiguous bytes of
+    // transforms); otherwise (k_mesh_blend_lbs) the natural order, register i <-> frames 8 (i >> 2) + (i & 3) + 4 h.
+    const int ftile = f / kFTile, phi = f % kFTile;
+    const int row = Pb.feat_perm ? (8 * (phi >> 3) + 4 * (phi & 1) + ((phi >> 1) & 3)) : phi;
+    if (lane >= 8 && lane - 8 < kBlendKSteps * 4) {
+      const int wl = lane - 8;
+      const int kstep = wl >> 2, h = (wl >> 1) & 1, hl = wl & 1;
+      uint32_t pk[4];
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        uint16_t b[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int k = kstep * 16 + 8 * h + 2 * jj + u;     // blend coefficient: pose feature vec(R_j - I), then beta
+          float x = 0.0f;
+          if (k < kPoseFeat) x = (Pb.pose_blend && k < 9 * (nJ - 1)) ? (float)(sR[9 + k] - (((k % 9) % 4 == 0) ? 1.0 : 0.0)) : 0.0f;
+          else if (k - kPoseFeat < nS) x = (float)sbeta[k - kPoseFeat];
+          else if (k == kPoseFeat + kMaxShape || k == kPoseFeat + kMaxShape + 1) x = 1.0f;   // the template's two slots
+          const uint16_t hi = f32_to_bf16(x);
+          b[u] = hl == 0 ? hi : f32_to_bf16(x - bf16_to_f32(hi));
+        }
+        pk[jj] = (uint32_t)b[0] | ((uint32_t)b[1] << 16);
+      }
+      uint4* dst = reinterpret_cast<uint4*>(mc.featA + ((((size_t)ftile * kBlendKSteps + kstep) * 2 + hl) * 64 + (h * 32 + row)) * 8);
+      store_operand16<kFused>(dst, make_uint4(pk[0], pk[1], pk[2], pk[3]));
+    }
+  }
+  if (cam_on) {
+    // Rr0 = R_root R0, dRr0_c = dR_root,c R0 (include/Sim3BA.h:210-216 and its derivative): before the chain walks, so that
+    // the mesh operands can be published right behind this phase's barrier
+    const int mtx = cam_lane / 9, e = cam_lane % 9, r = e / 3;
+    const double* Lm = (mtx == 0) ? sR : (sdR + (mtx - 1) * 9);
+    sCam[cam_lane] = Lm[r * 3] * r0c0 + Lm[r * 3 + 1] * r0c1 + Lm[r * 3 + 2] * r0c2;
+  }
   {
-    // A_j columns and P_j (92 items) on waves 6-7, beside the landmark items of waves 0-5 (two landmarks per wave);
-    // the 230 B_j columns nothing needs before phase E are walked in phase D, where most threads are idle
+    // A_j columns and P_j (92 items) on waves 6-7, beside the landmark items of waves 0-5 (two landmarks per wave); each of
+    // the two waves takes half of the A columns and half of the (dearer) P walks.  The 230 B_j columns nothing needs
+    // before phase E are walked in phase D, where most threads are idle
     const int nA = 3 * (nJ - 1), nP = nJ - 1;
-    for (int it = tid - 384; it >= 0 && it < nA + nP; it += 128) {
-      if (it < nA) walk(0, 1 + it / 3, it % 3);
-      else walk(1, 1 + (it - nA), 0);
+    const int nA6 = (nA + 1) / 2, nP6 = (nP + 1) / 2;
+    if (wave == 6) {
+      if (lane < nA6) walk(0, 1 + lane / 3, lane % 3);
+      else if (lane - nA6 < nP6) walk(1, 1 + (lane - nA6), 0);
+    } else if (wave == 7) {
+      if (lane < nA - nA6) walk(0, 1 + (nA6 + lane) / 3, (nA6 + lane) % 3);
+      else if (lane - (nA - nA6) < nP - nP6) walk(1, 1 + nP6 + (lane - (nA - nA6)), 0);
     }
     if (tid < 9) sA[tid] = (tid % 4 == 0) ? 1.0 : 0.0;       // root: A_0 = I, P_0 = 0, B_0 = 0
     if (tid >= 16 && tid < 19) sP[tid - 16] = 0.0;
     if (tid >= 32 && tid - 32 < 3 * nS) { sB[tid - 32] = 0.0; sT[tid - 32] = 0.0; }
+  }
+  // ---- mesh operands (blend-coefficient fragments, skinning transforms) and posed joints: wave 7, still in phase C ----
+  // They need R_j (phase B), the chain quantities A_j, P_j (waves 6 and 7, just above), the root entries (waves 0, above)
+  // and Rr0 (wave 6, above).  Wave 6 and wave 0 say so through one LDS word each wave-program-ordered behind its writes;
+  // everything is stored by this ONE wave, so the in-launch hand-off needs no workgroup barrier (cdna guide, Guideline 16 R1:
+  // one lane signals for all the stores of its workgroup after every STORING wave's vmcnt(0)); the drain and the signal
+  // are wave 7's only work in phase D.
+  if (wave == 6 || wave == 0) {
+    // (LDS serves a wave in order; the wait also keeps hipcc from sinking the writes.)  Wave 6 also waits for its blend-
+    // coefficient stores (requested a chain walk ago) to have left: wave 7, which sees both adds before it signals, then
+    // signals for wave 6's stores too (cdna guide, Guideline 16: "each wave adds to a counter in LDS after its wait and the
+    // wave whose add is last signals")
+    if (kFused && wave == 6) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (lane == 0) __hip_atomic_fetch_add(const_cast<int*>(sWalkDone), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
+  if (wave == 7) {
+    STAMP_REAL(13);
+    for (int spin = 0; spin < (1 << 20) && *sWalkDone < 2; ++spin) __builtin_amdgcn_s_sleep(1);
+    asm volatile("" ::: "memory");
+    STAMP_REAL(14);
+    const double s_ = sx[0];
+    const double* Rr0_ = sCam;
+    if (lane < nJ) {
+      const int jj = lane;
+      double RA[9], t[3], q[3];
+      mul33(Rr0_, sA + jj * 9, RA);
+      mv3(sA + jj * 9, sJc[jj * 3], sJc[jj * 3 + 1], sJc[jj * 3 + 2], q);
+      mv3(Rr0_, sP[jj * 3] - q[0], sP[jj * 3 + 1] - q[1], sP[jj * 3 + 2] - q[2], t);
+      if (mc.skinT) {
+        float4* T = reinterpret_cast<float4*>(mc.skinT + ((size_t)f * nJ + jj) * 12);
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+          store_operand16<kFused>(T + r, make_uint4(__float_as_uint((float)(s_ * RA[r * 3 + 0])), __float_as_uint((float)(s_ * RA[r * 3 + 1])),
+                                                    __float_as_uint((float)(s_ * RA[r * 3 + 2])),
+                                                    __float_as_uint((float)(s_ * t[r] + sx[4 + r]))));
+      }
+      if (joints_out) {
+        mv3(Rr0_, sP[jj * 3], sP[jj * 3 + 1], sP[jj * 3 + 2], t);
+#pragma unroll
+        for (int r = 0; r < 3; ++r) joints_out[((size_t)f * nJ + jj) * 3 + r] = s_ * t[r] + sx[4 + r];
+      }
+    }
+    STAMP_REAL(15);
   }
   if (lm_wave0) lm_terms(lm_l, pdv0);
   if (lm_wave1) {   // landmarks 16..31: second pass
@@ -471,39 +581,20 @@ __device__ __forceinline__ void frame_part(const DevModel& M, const DevProblem& 
   frame_sync<kFused>();
 
   STAMP(4);
-  // ---- D. wave 0-1: W_{k,c} = A_p (dR_{k,c} R_k^T) A_p^T ; wave 2: landmark LBS ; wave 3: camera matrices ;
-  //         waves 4-7: B_j columns (d P_j / d beta) ----
+  // ---- D. wave 0-1: W_{k,c} = A_p (dR_{k,c} R_k^T) A_p^T ; wave 2: landmark LBS ; waves 3-6: B_j columns (d P_j / d beta) ;
+  //         wave 7: the hand-off of the mesh operands it stored in phase C ----
   if (use_shape && want_jac) {
-    for (int it = tid - 256; it >= 0 && it < nS * (nJ - 1); it += 256) walk(2, 1 + it / nS, it % nS);
+    for (int it = tid - 192; it >= 0 && tid < 448 && it < nS * (nJ - 1); it += 256) walk(2, 1 + it / nS, it % nS);
   }
-  // blend-coefficient fragments of the mesh kernel (pose features from phase C, beta): nothing in this phase's way
-  if (mc.featA) {
-    // MFMA row of this frame inside its 32-frame tile.  feat_perm (k_sweep_roles' mesh role): accumulator register i of the
-    // half-wave h holds frame 2 i + h, so that one register row covers two CONSECUTIVE frames (2,304 contiguous bytes of
-    // transforms); otherwise (k_mesh_blend_lbs) the natural order, register i <-> frames 8 (i >> 2) + (i & 3) + 4 h.
-    const int ftile = f / kFTile, phi = f % kFTile;
-    const int row = Pb.feat_perm ? (8 * (phi >> 3) + 4 * (phi & 1) + ((phi >> 1) & 3)) : phi;
-    if (wave == 3 && lane >= 8 && lane - 8 < kBlendKSteps * 4) {   // wave 3 only has the camera matrices in this phase
-      const int wl = lane - 8;
-      const int kstep = wl >> 2, h = (wl >> 1) & 1, hl = wl & 1;
-      uint32_t pk[4];
-#pragma unroll
-      for (int jj = 0; jj < 4; ++jj) {
-        uint16_t b[2];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const int k = kstep * 16 + 8 * h + 2 * jj + u;     // blend coefficient: pose feature, then beta
-          float x = 0.0f;
-          if (k < kPoseFeat) x = Pb.pose_blend ? (float)sFeat[k] : 0.0f;
-          else if (k - kPoseFeat < nS) x = (float)sbeta[k - kPoseFeat];
-          else if (k == kPoseFeat + kMaxShape || k == kPoseFeat + kMaxShape + 1) x = 1.0f;   // the template's two slots
-          const uint16_t hi = f32_to_bf16(x);
-          b[u] = hl == 0 ? hi : f32_to_bf16(x - bf16_to_f32(hi));
-        }
-        pk[jj] = (uint32_t)b[0] | ((uint32_t)b[1] << 16);
-      }
-      uint4* dst = reinterpret_cast<uint4*>(mc.featA + ((((size_t)ftile * kBlendKSteps + kstep) * 2 + hl) * 64 + (h * 32 + row)) * 8);
-      store_operand16<kFused>(dst, make_uint4(pk[0], pk[1], pk[2], pk[3]));
+  if constexpr (kFused) {
+    if (wave == 7) {
+      // hand-off: this wave's operand stores of phase C (the only ones of the workgroup; nothing else of this wave is in
+      // flight) have left, then one agent-scope add to the counter of the frame's 32-frame unit.  The write-through stores
+      // take 1-3 us to be acknowledged; wave 7 has nothing else to do in this phase.
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (lane == 0)
+        (void)__hip_atomic_fetch_add(fu.flag + (size_t)(f / kFTile) * kUnitCounterStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      STAMP_REAL(12);
     }
   }
   if (want_jac && tid < 3 * (nJ - 1)) {
@@ -552,13 +643,6 @@ __device__ __forceinline__ void frame_part(const DevModel& M, const DevProblem& 
       }
       L[LM_Q] = q0; L[LM_Q + 1] = q1; L[LM_Q + 2] = q2;
     }
-  }
-  if (wave == 3 && lane < 36) {
-    // Rr0 = R_root R0, dRr0_c = dR_root,c R0
-    const double* R0 = Pb.R0 + (size_t)f * 9;
-    const int mtx = lane / 9, e = lane % 9, r = e / 3, c = e % 3;
-    const double* L = (mtx == 0) ? sR : (sdR + (mtx - 1) * 9);
-    sCam[lane] = L[r * 3] * R0[c] + L[r * 3 + 1] * R0[3 + c] + L[r * 3 + 2] * R0[6 + c];
   }
   frame_sync<kFused>();
   const double s = sx[0];
@@ -624,26 +708,6 @@ __device__ __forceinline__ void frame_part(const DevModel& M, const DevProblem& 
   STAMP(5);
   // ---- E. independent items: mesh operands + posed joints, landmark Jacobian terms, first keypoint chunk ----------
   if (wave == 6 && lane < min(KC, k_end - k_begin)) stage_kp(lane, k_begin);
-  if (wave == 7 && lane < nJ) {   // (waves 6 and 7 carry no landmark items below unless the model has more than 12)
-    const int jj = lane;
-    double RA[9], t[3], q[3];
-    mul33(Rr0, sA + jj * 9, RA);
-    mv3(sA + jj * 9, sJc[jj * 3], sJc[jj * 3 + 1], sJc[jj * 3 + 2], q);
-    mv3(Rr0, sP[jj * 3] - q[0], sP[jj * 3 + 1] - q[1], sP[jj * 3 + 2] - q[2], t);
-    if (mc.skinT) {
-      float4* T = reinterpret_cast<float4*>(mc.skinT + ((size_t)f * nJ + jj) * 12);
-#pragma unroll
-      for (int r = 0; r < 3; ++r)
-        store_operand16<kFused>(T + r, make_uint4(__float_as_uint((float)(s * RA[r * 3 + 0])), __float_as_uint((float)(s * RA[r * 3 + 1])),
-                                                  __float_as_uint((float)(s * RA[r * 3 + 2])),
-                                                  __float_as_uint((float)(s * t[r] + sx[4 + r]))));
-    }
-    if (joints_out) {
-      mv3(Rr0, sP[jj * 3], sP[jj * 3 + 1], sP[jj * 3 + 2], t);
-#pragma unroll
-      for (int r = 0; r < 3; ++r) joints_out[((size_t)f * nJ + jj) * 3 + r] = s * t[r] + sx[4 + r];
-    }
-  }
   if (nL > 0 && want_jac) {
     // d q_l / d theta_{k,c} for landmark l, complete, left in LM_PD[l][3 (k - 1) + c] for the Jacobian sweep:
     //   Ablend . (pd[:, 9(k-1):9k] . vec(dR_{k,c}))   the inner products were parked here by phase C (same lane mapping:
@@ -702,16 +766,6 @@ __device__ __forceinline__ void frame_part(const DevModel& M, const DevProblem& 
   }
 
   STAMP(6);
-  if constexpr (kFused) {
-    // Hand-off of this frame's mesh operands (blend coefficients: phase D, transforms: phase E) to every workgroup's mesh
-    // part: write-through stores, every wave drains its own, workgroup barrier, ONE lane stores the frame's flag
-    // (cdna guide, Guideline 16 R1).  The flag store is idempotent, so a frame processed twice (adopted, then run by its
-    // late owner) is still published exactly as once.
-    if (wave == 3 || wave == 7) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the waves that stored operands
-    frame_sync<true>();
-    if (tid == kThreads - 1) __hip_atomic_store(fu.flag + f, fu.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    STAMP_REAL(12);
-  }
   if (M.lm_gcount && want_jac && nL > 0) {
     // keypoint regressor rows: d q / d theta (69 x 3) and d q / d beta (10 x 3) of a row are the sums over its slots, left in
     // the first one.  item = (slot, word of [LM_BETA, LM_PD + 207)); only models with regressor rows pay the two barriers.
@@ -773,8 +827,8 @@ __device__ __forceinline__ void frame_part(const DevModel& M, const DevProblem& 
             const double* o = sLm + (id - nJ) * LM_STRIDE + LM_PD + kc * 3;   // complete since phase E
             d0 = o[0]; d1 = o[1]; d2 = o[2];
           }
-          store_through(J_out + (size_t)(2 * kg) * ncols + 7 + kc, G[0] * d0 + G[1] * d1 + G[2] * d2);
-          store_through(J_out + (size_t)(2 * kg + 1) * ncols + 7 + kc, G[3] * d0 + G[4] * d1 + G[5] * d2);
+          store_J<kFused>(J_out + (size_t)(2 * kg) * ncols + 7 + kc, G[0] * d0 + G[1] * d1 + G[2] * d2);
+          store_J<kFused>(J_out + (size_t)(2 * kg + 1) * ncols + 7 + kc, G[3] * d0 + G[4] * d1 + G[5] * d2);
         }
       }
       // (2) Sim3 columns (7) and shape columns (ncols - npose) per keypoint
@@ -820,8 +874,8 @@ __device__ __forceinline__ void frame_part(const DevModel& M, const DevProblem& 
           j0 = G[0] * d0 + G[1] * d1 + G[2] * d2;
           j1 = G[3] * d0 + G[4] * d1 + G[5] * d2;
         }
-        store_through(J_out + (size_t)(2 * kg) * ncols + col, j0);
-        store_through(J_out + (size_t)(2 * kg + 1) * ncols + col, j1);
+        store_J<kFused>(J_out + (size_t)(2 * kg) * ncols + col, j0);
+        store_J<kFused>(J_out + (size_t)(2 * kg + 1) * ncols + col, j1);
         if (fold && c >= 7) { sJb[(2 * kk) * kMaxShape + c - 7] = j0; sJb[(2 * kk + 1) * kMaxShape + c - 7] = j1; }
       }
     }

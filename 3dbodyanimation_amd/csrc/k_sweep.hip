@@ -17,10 +17,10 @@
 //                     halves of the sweep in time instead of running them one after the other.
 //
 // In-launch hand-off (cdna guide, Guideline 16, R1): producers store the operands write-through (sc1), every storing wave
-// drains (s_waitcnt vmcnt(0)), workgroup barrier, one lane stores the frame's flag = the launch's epoch (sc1); consumers
-// poll the group's flags with sc1 loads from one wave (one 16-byte load per lane covers 256 flags), workgroup barrier, then
-// read the operands with sc1 loads only.  Nothing is reset between launches (the flags carry the launch's epoch) and there is
-// no read-modify-write anywhere.
+// (ONE wave per frame workgroup: no barrier needed) drains (s_waitcnt vmcnt(0)), then one lane adds 1 to the counter of the
+// frame's 32-frame unit (agent-scope atomic, executed at the memory side); consumers poll the eight counters of their group
+// (one 32-byte line) with sc1 loads from one wave, workgroup barrier, then read the operands with sc1 loads only.  Nothing is
+// reset between launches: every launch adds exactly the unit's frame count, so a complete unit reads epoch x count.
 //
 // Progress: a mesh workgroup waits only for frame workgroups, which wait for nothing; frame workgroups precede the mesh
 // workgroups that need them in block order, and the hardware dispatches blocks in order.  HIP does not promise that
@@ -150,36 +150,37 @@ __global__ __launch_bounds__(kThreads, 4) void k_sweep_roles(RoleArgs by_value) 
                      reinterpret_cast<double*>(lds), idx, fu);
     return;
   }
-  if (role == 2) {
-    const PriorArgs pa = A->pa;
-    if (idx < pa.n_tiles) prior_block(pa, idx, A->params, reinterpret_cast<double*>(lds));
-    return;
-  }
-  // ---- mesh role ----------------------------------------------------------------------------------------------------------
-  const DevModel M = A->M;
-  const DevProblem Pb = A->Pb;
-  const MeshCoef mc = A->mc;
+  // ---- mesh and prior roles: both start their real work once the group's frames have been handed over ----------------------
   const unsigned epoch = A->sy.epoch;
   unsigned* const flag_base = A->sy.flag;
   unsigned* const error_word = A->sy.error;
+  if (role == 2) grp = (idx * kPriorTileF) / kRoleGroup;
   auto wait_flags = [&]() -> bool {
-    // wave 0 polls the group's flags, four per lane with one 16-byte sc1 load (256 flags per wave-instruction)
+    // wave 0 polls the counters of the group's eight 32-frame units (each on a line of its own: lane u reads counter u with an sc1
+    // load).  Every launch adds exactly the unit's frame count, so after launch `epoch` a complete unit reads epoch x count.
+    // Polling is kept sparse: a few hundred waiting workgroups that hammer one line delay the very stores they wait for
+    // (with 1 KB of per-frame flags polled every 128 cycles the hand-off took 3 us to arrive and the producers' store drain
+    // 3 us instead of 1).  One immediate look (later groups: their frames are long done), then nothing before 3 us after
+    // entry (no frame workgroup is faster), then one look every ~0.25 us.
     volatile unsigned* ctrl = reinterpret_cast<volatile unsigned*>(lds + kRoleCtrlOff);
     const int tid = threadIdx.x, lane = tid & 63;
     if ((tid >> 6) == 0) {
       const int fbeg = grp * kRoleGroup, nf = min(kRoleGroup, F - fbeg);
-      const __amdgpu_buffer_rsrc_t flags = __builtin_amdgcn_make_buffer_rsrc(flag_base + fbeg, 0, kRoleGroup * 4, 0x00020000);
+      const int nu = (nf + kFTile - 1) / kFTile;
+      const unsigned want = epoch * (unsigned)min(kFTile, nf - min(lane, 7) * kFTile);
+      const unsigned* ctr = flag_base + (size_t)(grp * (kRoleGroup / kFTile) + min(lane, 7)) * kUnitCounterStride;
       unsigned action = 0;
       const unsigned long long t_enter = __builtin_amdgcn_s_memrealtime();
-      for (;;) {
-        typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_;
-        const u32x4_ fl = __builtin_amdgcn_raw_buffer_load_b128(flags, (unsigned)lane * 16u, 0, 16);
-        const int f4 = lane * 4;
-        const bool ok = (f4 >= nf || fl.x == epoch) && (f4 + 1 >= nf || fl.y == epoch) && (f4 + 2 >= nf || fl.z == epoch) &&
-                        (f4 + 3 >= nf || fl.w == epoch);
-        if (__all(ok)) break;
-        __builtin_amdgcn_s_sleep(2);
-        if (__builtin_amdgcn_s_memrealtime() - t_enter > kRoleTimeoutTicks) { action = 1; break; }
+      for (int n = 0;; ++n) {
+        const unsigned got = __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (__all(lane >= nu || got == want)) break;
+        const unsigned long long el = __builtin_amdgcn_s_memrealtime() - t_enter;
+        if (el > kRoleTimeoutTicks) { action = 1; break; }
+        if (el < 300) {
+          for (int i = 0; i < 6 && __builtin_amdgcn_s_memrealtime() - t_enter < 300; ++i) __builtin_amdgcn_s_sleep(20);
+        } else {
+          __builtin_amdgcn_s_sleep(9);
+        }
       }
       if (lane == 0) ctrl[0] = action;
     }
@@ -193,6 +194,20 @@ __global__ __launch_bounds__(kThreads, 4) void k_sweep_roles(RoleArgs by_value) 
     }
     return true;
   };
+  if (role == 2) {
+    // The prior residuals depend on nothing the frame workgroups produce; they wait all the same: a prior workgroup is eight
+    // waves of f64 matrix work, and the frame workgroup it shares a CU with reached its hand-off 5 us late beside it (15 us
+    // against 9.6), which every mesh workgroup then waited for.  Behind the hand-off it only meets a Jacobian sweep.
+    const PriorArgs pa = A->pa;
+    if (idx >= pa.n_tiles) return;
+    if (!wait_flags()) return;
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // the control word has been read by every wave
+    prior_block(pa, idx, A->params, reinterpret_cast<double*>(lds));
+    return;
+  }
+  const DevModel M = A->M;
+  const DevProblem Pb = A->Pb;
+  const MeshCoef mc = A->mc;
   mesh_role(M, Pb, mc, A->cloud_f, idx, grp, lds, wait_flags);
 #endif
 }

@@ -46,6 +46,20 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef const __attribute__((address_space(3))) u32x4 lds_u32x4;
 typedef const __attribute__((address_space(3))) f32x4 lds_f32x4;
 
+#ifdef BODYFIT_STAMPS
+// diagnostic build: per-wave s_memrealtime stamps of the mesh role (tools/stamp_roles.py)
+#define RSTAMP(i)                                                                                              \
+  do {                                                                                                         \
+    if (Pb.dbg && C.lane == 0) {                                                                               \
+      unsigned long long t_;                                                                                   \
+      asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                          \
+      Pb.dbg[kStampBase + ((size_t)(group * M.nVTiles + vtile) * 8 + C.wave) * 16 + (i)] = t_;                 \
+    }                                                                                                          \
+  } while (0)
+#else
+#define RSTAMP(i)
+#endif
+
 #define ROLE_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 
 // vector-memory operations a wave issues in blend step t: its piece of slab t + 4, the A fragments (hi, lo) of k-step t + 3
@@ -219,6 +233,7 @@ __device__ __forceinline__ void mesh_role(const DevModel& M, const DevProblem& P
   const int col = C.lane & 31, h = C.lane >> 5;
   const int v = vtile * kVTile + col;
 
+  RSTAMP(0);
   // ---- independent of the frame workgroups: the first four slabs of the operand stream, the lane's skinning weights -----
 #pragma unroll
   for (int s = 0; s < kRingSlabs; ++s) role_dma_slab(C, s);
@@ -241,6 +256,7 @@ __device__ __forceinline__ void mesh_role(const DevModel& M, const DevProblem& P
 
   // ---- the group's frames have been handed over -----------------------------------------------------------------------
   if (!wait_flags()) return;   // (workgroup-uniform; includes the barrier that orders the poll before every operand load)
+  RSTAMP(1);
 
   f32x16 acc[3];
   u32x4 a[3][2], bq[3][2];
@@ -255,6 +271,7 @@ __device__ __forceinline__ void mesh_role(const DevModel& M, const DevProblem& P
     }
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // slabs 0-3, rows 0-2, A fragments 0-2
+  RSTAMP(2);
   if (active) {
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
@@ -266,10 +283,12 @@ __device__ __forceinline__ void mesh_role(const DevModel& M, const DevProblem& P
     RB(0); RB(1); RB(2); RB(3); RB(4); RB(5); RB(6); RB(7); RB(8); RB(9); RB(10); RB(11); RB(12); RB(13);
 #undef RB
     // (the last steps issued nothing: every DMA of the blend has been waited for, rows 0-2 landed long ago)
+    RSTAMP(3);
     const unsigned row0 = (unsigned)f0 * stride;
 #define RS(R) role_skin_row<R>(C, L, acc, cloud, row0 + (unsigned)(2 * (R)) * stride)
     RS(0); RS(1); RS(2); RS(3); RS(4); RS(5); RS(6); RS(7); RS(8); RS(9); RS(10); RS(11); RS(12); RS(13); RS(14); RS(15);
 #undef RS
+    RSTAMP(4);
   } else {
     // a wave without frames (last group of a frame count that is not a multiple of 256) keeps the operand stream and the
     // barriers of the others going

@@ -1,0 +1,64 @@
+"""Diagnostic: timeline of the one-launch sweep (k_sweep_roles) from in-kernel s_memrealtime stamps (10 ns ticks).
+Build: make -C 3dbodyanimation_amd/csrc stamps ; run with BODYFIT_LIB=.../libbodyfit_stamps.so"""
+import ctypes as C
+import importlib
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.getcwd())
+api = importlib.import_module("3dbodyanimation_amd.api")
+synth = importlib.import_module("3dbodyanimation_amd.synth")
+F = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+model = synth.make_model(0)
+seq = synth.make_sequence(model, F, seed=0)
+w, mu, cov = synth.make_gmm(0)
+gm = api.Model(model)
+prob = api.Problem.from_sequence(gm, seq, n_cols=86, use_shape=True, beta_per_frame=True, pose_blend=True, beta_pose=20.0,
+                                 gmm=api.Gmm(w, mu, cov), beta_shape=30.0, want_mesh=True)
+lib = api.load_library()
+nvt = (6890 + 31) // 32
+nG = (F + 255) // 256
+BASE = 1 << 20
+buf = torch.zeros(BASE + nG * nvt * 8 * 16 + 64, dtype=torch.int64, device="cuda")
+lib.bodyfit_debug_set_stamp_buffer.argtypes = [C.c_void_p, C.c_void_p]
+lib.bodyfit_debug_set_stamp_buffer(prob.h, buf.data_ptr())
+x = torch.from_numpy(seq.gt_params + 0.01).cuda()
+b = torch.from_numpy(np.tile(seq.gt_beta, (F, 1))).cuda()
+for _ in range(5):
+    prob.evaluate_device(x.data_ptr(), b.data_ptr(), True, None)
+torch.cuda.synchronize()
+raw = buf.cpu().numpy()
+fr = raw[:F * 8 * 16].reshape(F, 8, 16).astype(np.float64)
+ms = raw[BASE:BASE + nG * nvt * 8 * 16].reshape(nG * nvt, 8, 16).astype(np.float64)
+t0 = min(fr[:, 0, 10].min(), ms[:, :, 0].min())
+us = lambda a: (a - t0) / 100.0
+def q(a):
+    a = np.asarray(a).ravel()
+    return f"min {a.min():6.2f}  med {np.median(a):6.2f}  max {a.max():6.2f}"
+print(f"F = {F}; all times in us after the first workgroup's entry")
+print("frame role: entry              ", q(us(fr[:, 0, 10])))
+print("frame role: hand-off published ", q(us(fr[:, 7, 12])))
+w7 = fr[:, 7, :]
+print("frame role wave 7: walks done", q(us(w7[:, 13])), "| wave 6 + 0 seen", q(us(w7[:, 14])))
+print("                   operands stored", q(us(w7[:, 15])), "| drained + signalled", q(us(w7[:, 12])))
+pub = us(fr[:, 7, 12])
+late = np.argsort(pub)[-24:]
+print("frame role: latest 24 hand-offs (frame: us):", " ".join(f"{int(i)}:{pub[i]:.1f}" for i in late))
+print("frame role: hand-off percentiles 50/90/95/99/100:", np.percentile(pub, [50, 90, 95, 99, 100]).round(2))
+print("frame role: end                ", q(us(fr[:, :, 11].max(1))))
+print("mesh role: entry               ", q(us(ms[:, :, 0])))
+print("mesh role: flags seen          ", q(us(ms[:, :, 1])))
+print("mesh role: blend starts        ", q(us(ms[:, :, 2])))
+print("mesh role: blend done          ", q(us(ms[:, :, 3])))
+print("mesh role: skinning done       ", q(us(ms[:, :, 4])))
+print("mesh role durations: wait", q((ms[:, :, 1] - ms[:, :, 0]) / 100), "| prologue", q((ms[:, :, 2] - ms[:, :, 1]) / 100))
+print("                     blend", q((ms[:, :, 3] - ms[:, :, 2]) / 100), "| skin", q((ms[:, :, 4] - ms[:, :, 3]) / 100))
+cyc = np.diff(fr[:, :, :9], axis=2)
+names = ["A tables", "B rodrigues/offsets", "C chain walks / landmark items", "C barrier", "D", "E", "hand-off + F1", "F2 sweep"]
+print("frame role phases, shader cycles (median over frames of the slowest wave | per wave 0..7):")
+for i, n in enumerate(names):
+    print(f"  {n:32s} {int(np.median(cyc[:, :, i].max(1))):6d} |", np.median(cyc[:, :, i], axis=0).astype(int))
+print("frame role total cycles (median):", int(np.median(fr[:, :, 8].max(1) - fr[:, :, 0].min(1))))
