@@ -74,6 +74,39 @@ class Comm(C.Structure):   # bodyfit_comm (include/bodyfit.h)
                 ("allgather", _ALLGATHER_CB)]
 
 
+class Rccl:
+    """RCCL communicator of a sharded solve (bodyfit_rccl_*): created by the library from a 128-byte id that rank 0 obtains
+    and the application ships to the other ranks (any host channel: here whatever the caller uses, e.g. torch.distributed
+    broadcast_object_list), or wrapped around an ncclComm_t the application already has."""
+
+    def __init__(self, handle):
+        self.h = handle
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = (C.c_ubyte * 128)()
+        _check(load_library().bodyfit_rccl_unique_id(buf))
+        return bytes(buf)
+
+    @classmethod
+    def create(cls, uid: bytes, rank: int, size: int, device: int = 0) -> "Rccl":
+        buf = (C.c_ubyte * 128).from_buffer_copy(uid)
+        h = C.c_void_p()
+        _check(load_library().bodyfit_rccl_create(buf, rank, size, device, C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def wrap(cls, nccl_comm_ptr: int, rank: int, size: int) -> "Rccl":
+        h = C.c_void_p()
+        _check(load_library().bodyfit_rccl_wrap(C.c_void_p(nccl_comm_ptr), rank, size, C.byref(h)))
+        return cls(h)
+
+    def close(self):
+        if self.h:
+            load_library().bodyfit_rccl_destroy(self.h)
+            self.h = None
+
+
 class DeviceViews(C.Structure):
     _fields_ = [("residuals", C.c_void_p), ("jacobian", C.c_void_p), ("gmm_comp", C.c_void_p),
                 ("cloud", C.c_void_p), ("joints", C.c_void_p), ("normal_eq", C.c_void_p),
@@ -126,6 +159,15 @@ def load_library():
                                   C.POINTER(FitSummary), C.c_int]
     lib.bodyfit_solve_sharded.argtypes = [C.c_void_p, _dp, _dp, C.POINTER(C.c_ubyte), C.POINTER(Comm), C.POINTER(FitOptions),
                                           C.POINTER(FitSummary)]
+    lib.bodyfit_solve_sharded_rccl.argtypes = [C.c_void_p, _dp, _dp, C.POINTER(C.c_ubyte), C.c_void_p, C.POINTER(FitOptions),
+                                               C.POINTER(FitSummary)]
+    lib.bodyfit_rccl_unique_id.argtypes = [C.POINTER(C.c_ubyte)]
+    lib.bodyfit_rccl_create.argtypes = [C.POINTER(C.c_ubyte), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+    lib.bodyfit_rccl_wrap.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+    lib.bodyfit_rccl_destroy.argtypes = [C.c_void_p]
+    lib.bodyfit_rccl_destroy.restype = None
+    lib.bodyfit_last_exchange_count.argtypes = [C.c_void_p]
+    lib.bodyfit_last_exchange_count.restype = C.c_long
     lib.bodyfit_forward.argtypes = [C.c_void_p, _dp, _dp, _dp, _fp]
     lib.bodyfit_writeback_batch.argtypes = [C.c_void_p, _dp, _dp, _dp, _dp, _fp, _dp]
     lib.bodyfit_evaluate_block.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(_dp), _dp, C.POINTER(_dp)]
@@ -387,6 +429,25 @@ class Problem:
                                                     cst.ctypes.data_as(C.POINTER(C.c_ubyte)) if cst is not None else None,
                                                     C.byref(comm), C.byref(opt), C.byref(summ)))
         return x.reshape(-1)[:self.n_frames * N_FRAME_PARAMS].reshape(self.n_frames, N_FRAME_PARAMS).copy(), b, summ
+
+    def solve_sharded_rccl(self, frame_params, beta, comm: "Rccl", constant=None, max_iters=100,
+                           scale_bounds=(-1e300, 1e300), verbose=False):
+        """This rank's shard of one window with the exchanges as RCCL all-gathers on the solve's device buffers and stream
+        (bodyfit_solve_sharded_rccl)."""
+        x = _c64(frame_params).copy()
+        b = _c64(beta).copy()
+        assert x.size == self.n_param_rows * N_FRAME_PARAMS
+        cst = np.ascontiguousarray(constant, dtype=np.uint8) if constant is not None else None
+        summ = FitSummary()
+        opt = FitOptions(max_iters, scale_bounds[0], scale_bounds[1], int(verbose), 3)
+        _check(load_library().bodyfit_solve_sharded_rccl(self.h, _d(x), _d(b),
+                                                         cst.ctypes.data_as(C.POINTER(C.c_ubyte)) if cst is not None else None,
+                                                         comm.h, C.byref(opt), C.byref(summ)))
+        return x.reshape(-1)[:self.n_frames * N_FRAME_PARAMS].reshape(self.n_frames, N_FRAME_PARAMS).copy(), b, summ
+
+    def last_exchange_count(self) -> int:
+        """all-gathers issued by the last sharded solve of this problem"""
+        return int(load_library().bodyfit_last_exchange_count(self.h))
 
     def evaluate_block(self, kind: int, index: int, blocks: list[np.ndarray], n_res: int, want=None):
         """ceres::CostFunction::Evaluate on one block.  `want[b]` False -> jacobians[b] = NULL."""

@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "bodyfit_device.h"
+#include "collectives.h"
 #include "solver_view.h"
 
 using namespace bodyfit;
@@ -110,6 +111,7 @@ struct bodyfit_problem {
   // one-launch sweep (k_sweep_roles): in-launch synchronisation words [error | pad | one counter per 32-frame unit], launch counter
   unsigned char* d_fused = nullptr;
   size_t fused_bytes = 0;
+  long last_exchanges = 0;             // all-gathers issued by the last sharded solve (tests: exchanges per iteration)
   unsigned fused_epoch = 0;
   bool fused_enabled = true, fused_unchecked = false;
   double* d_frame_partials = nullptr; // [F][258] per-frame beta partials written by k_frame_resjac (shared-beta problems)
@@ -1094,14 +1096,24 @@ static size_t carve_cr(unsigned char* base, size_t off, int n, WinBuf& W, bool d
 // comm != NULL: this problem is ONE SHARD (contiguous frames) of the window, one process per GPU (bodyfit_solve_sharded).
 // Every rank reduces its own chain down to its two end frames (cyclic reduction with the ends pinned), the 2 N interface
 // blocks are all-gathered and solved redundantly by every rank, then each rank substitutes back through its own levels.
-// What crosses ranks per LM iteration: the beta terms [C, g_beta] (one all-reduce of 110 doubles), the interface blocks
-// (one all-gather of 225 KB per rank), the beta Schur partials (110), three boundary parameter rows, and four scalars.
-int bodyfit_internal_solve_window_device(bodyfit_problem* p, double* frame_params, double* beta,
-                                         const unsigned char* param_constant, const bodyfit_fit_options* opt,
-                                         bodyfit_fit_summary* summary, const bodyfit_comm* comm) {
+// What crosses ranks per LM iteration, as THREE all-gathers of device buffers ordered on the solve's stream (RCCL: nothing
+// touches the host, no stream synchronisation between the host's status reads):
+//   1. the interface blocks of the shard's two end frames (225 KB) with the shard's beta terms [C, g_beta] (110 doubles)
+//      riding on the same buffer;
+//   2. the shard's beta Schur partials (110 doubles) — they need the interface solution, the step needs them;
+//   3. the shard's scalars [model change, |d|^2, |x|^2, max |g|, failure flag, cost at the candidate] (8 doubles): ONE
+//      decision kernel then applies Ceres' tests and the accept / reject rules on every rank, on the same numbers.
+// Sums are taken by every rank in rank order from the gathered partials (bit-identical totals, identical decisions, no
+// broadcast).  The steps of the neighbouring shards' boundary frames — the halo row of the temporal pair this shard owns, the
+// frame in front of its first — are not exchanged at all: every rank holds the whole interface solution and computes them
+// with the neighbour's own arithmetic (k_win_halo_step).  The first iteration has two more small gathers (the beta terms
+// before the first scaling, the boundary frames' Jacobi scaling), the start one (the boundary rows).
+static int solve_window_device(bodyfit_problem* p, double* frame_params, double* beta,
+                               const unsigned char* param_constant, const bodyfit_fit_options* opt,
+                               bodyfit_fit_summary* summary, Transport* comm, bool force_sharded) {
   const bodyfit_model* m = p->m;
   const int F = p->d.F, npose = 7 + 3 * (m->nJ - 1), n = p->lay.n_cols, nb = n - npose;
-  const bool sharded = comm != nullptr && comm->size > 1;
+  const bool sharded = comm != nullptr && (comm->size > 1 || force_sharded);
   const int halo = p->desc.temporal_halo ? 1 : 0;
   if (npose != kFrameParams || nb != kMaxShape || p->desc.beta_per_frame || p->has_gmm)
     return fail(BODYFIT_ERR_INVALID, "device window solver: needs 24 joints, a shared 10-coefficient beta and the L2 pose prior");
@@ -1122,10 +1134,9 @@ int bodyfit_internal_solve_window_device(bodyfit_problem* p, double* frame_param
   if (sharded) build_cr_schedule(NI, false, sched, ilevels);
   // ---- one pooled allocation, kept across solves ----
   WinBuf W{}, Wi{};
-  double *d_x, *d_b, *d_xn, *d_bn, *d_rn, *d_xl, *d_sh, *d_dh;
+  double *d_x, *d_b, *d_xn, *d_bn, *d_rn, *d_xl, *d_sh, *d_dh, *d_xln, *d_sl, *d_cg, *d_send, *d_gath;
   int *d_compn, *d_sched;
   unsigned char* d_const = nullptr;
-  const size_t io_doubles = (size_t)NI * (3 * kWinBlock * kWinBlock + kWinRhs * kWinBlock);   // gathered interface blocks
   {
     size_t off = carve_cr(nullptr, 0, F, W, true);
     if (sharded) off = carve_cr(nullptr, off, NI, Wi, true);
@@ -1138,7 +1149,9 @@ int bodyfit_internal_solve_window_device(bodyfit_problem* p, double* frame_param
                  o_st = take(kWsCount * 8), o_x = take((size_t)(F + 1) * npose * 8), o_b = take(nb * 8),
                  o_xn = take((size_t)(F + 1) * npose * 8), o_bn = take(nb * 8), o_rn = take((size_t)std::max(1, p->lay.total_rows) * 8),
                  o_cn = take((size_t)F * 4), o_sched = take(sched.size() * 4), o_const = take((size_t)npose),
-                 o_xl = take(npose * 8), o_sh = take(npose * 8), o_dh = take(npose * 8), o_io = take(sharded ? io_doubles * 8 : 8);
+                 o_xl = take(npose * 8), o_sh = take(npose * 8), o_dh = take(npose * 8), o_xln = take(npose * 8), o_sl = take(npose * 8),
+                 o_cg = take(112 * 8), o_send = take(sharded ? (size_t)iface_doubles(112) * 8 : 8),
+                 o_gath = take(sharded ? (size_t)N * iface_doubles(112) * 8 : 8);
     if (!p->win_pool || p->win_pool_bytes < off) {
       HIP_TRY(p->mem.alloc(&p->win_pool, off));
       HIP_TRY(hipMemset(p->win_pool, 0, off));
@@ -1156,8 +1169,8 @@ int bodyfit_internal_solve_window_device(bodyfit_problem* p, double* frame_param
     d_compn = reinterpret_cast<int*>(Bp + o_cn);
     d_sched = reinterpret_cast<int*>(Bp + o_sched);
     if (param_constant) d_const = Bp + o_const;
-    d_xl = dp(o_xl); d_sh = dp(o_sh); d_dh = dp(o_dh);
-    (void)o_io;
+    d_xl = dp(o_xl); d_sh = dp(o_sh); d_dh = dp(o_dh); d_xln = dp(o_xln); d_sl = dp(o_sl);
+    d_cg = dp(o_cg); d_send = dp(o_send); d_gath = dp(o_gath);
   }
   if (!p->d_frame_normal) HIP_TRY(p->mem.alloc(&p->d_frame_normal, (size_t)F * kNormalRows * kNormalLd));
   if (!p->lm_stream) HIP_TRY(hipStreamCreateWithFlags(&p->lm_stream, hipStreamNonBlocking));
@@ -1173,42 +1186,25 @@ int bodyfit_internal_solve_window_device(bodyfit_problem* p, double* frame_param
   HIP_TRY(hipMemcpyAsync(d_b, beta, (size_t)nb * sizeof(double), hipMemcpyHostToDevice, st));
   HIP_TRY(hipMemcpyAsync(d_sched, sched.data(), sched.size() * sizeof(int), hipMemcpyHostToDevice, st));
   if (param_constant) HIP_TRY(hipMemcpyAsync(d_const, param_constant, (size_t)npose, hipMemcpyHostToDevice, st));
-  // ---- collectives of a sharded solve: small host buffers through the caller's communicator ----
-  std::vector<double> hb(std::max<size_t>(256, sharded ? io_doubles / NI * 1 : 0)), hg;
-  auto comm_fail = [&](const char* what) { return fail(BODYFIT_ERR_INVALID, std::string("bodyfit_solve_sharded: ") + what + " failed"); };
-  // all-reduce `cnt` device doubles in place (op 0 sum, 1 max)
-  auto allreduce_dev = [&](double* dptr, int cnt, int op) -> int {
-    HIP_TRY(hipMemcpyAsync(hb.data(), dptr, cnt * sizeof(double), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    if (comm->allreduce(comm->ctx, hb.data(), cnt, op)) return comm_fail("allreduce");
-    HIP_TRY(hipMemcpyAsync(dptr, hb.data(), cnt * sizeof(double), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipStreamSynchronize(st));   // (hb is reused by the next collective)
+  // ---- exchanges of a sharded solve: all-gathers of device buffers on the solve's stream (collectives.h) ----
+  auto comm_fail = [&](const char* what) {
+    return fail(BODYFIT_ERR_INVALID, std::string("bodyfit_solve_sharded: ") + what + " failed: " + (comm ? comm->error : ""));
+  };
+  // gather n doubles per rank from d_send into d_gath [N][n]
+  auto gather = [&](const double* d_send, int cnt, const char* what) -> int {
+    if (comm->allgather(d_send, d_gath, cnt, st)) return comm_fail(what);
     return BODYFIT_OK;
   };
-  std::vector<double> bnd(3 * npose), bnd_all, x_left_new(npose, 0.0);
-  // boundary rows of a point: every rank contributes [first row, last row, extra row]; rank r receives its left neighbour's last
-  // row (-> left_out, host) and its right neighbour's first row (-> the halo row of d_pt) and extra row (-> d_extra_halo)
-  auto exchange_boundary = [&](double* d_pt, const double* d_extra_first, double* left_out, double* d_extra_halo) -> int {
-    HIP_TRY(hipMemcpyAsync(bnd.data(), d_pt, npose * sizeof(double), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(bnd.data() + npose, d_pt + (size_t)(F - 1) * npose, npose * sizeof(double), hipMemcpyDeviceToHost, st));
-    if (d_extra_first) HIP_TRY(hipMemcpyAsync(bnd.data() + 2 * npose, d_extra_first, npose * sizeof(double), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    bnd_all.resize((size_t)N * 3 * npose);
-    if (comm->allgather(comm->ctx, bnd.data(), bnd_all.data(), 3 * npose)) return comm_fail("allgather");
-    if (has_left) std::memcpy(left_out, &bnd_all[((size_t)(R - 1) * 3 + 1) * npose], npose * sizeof(double));
-    if (halo) {
-      HIP_TRY(hipMemcpyAsync(d_pt + (size_t)F * npose, &bnd_all[(size_t)(R + 1) * 3 * npose], npose * sizeof(double), hipMemcpyHostToDevice, st));
-      if (d_extra_halo)
-        HIP_TRY(hipMemcpyAsync(d_extra_halo, &bnd_all[((size_t)(R + 1) * 3 + 2) * npose], npose * sizeof(double), hipMemcpyHostToDevice, st));
-    }
-    HIP_TRY(hipStreamSynchronize(st));
-    return BODYFIT_OK;
-  };
-  std::vector<double> x_left(npose, 0.0);
   if (sharded) {
-    int rc0 = exchange_boundary(d_x, nullptr, x_left.data(), nullptr);
-    if (rc0) return rc0;
-    if (has_left) HIP_TRY(hipMemcpyAsync(d_xl, x_left.data(), npose * sizeof(double), hipMemcpyHostToDevice, st));
+    // the boundary rows of the starting point: [first row | last row] of every shard -> the frame in front of this shard's
+    // first (d_xl) and the halo row behind its last
+    HIP_TRY(hipMemcpyAsync(d_send, d_x, npose * sizeof(double), hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_send + npose, d_x + (size_t)(F - 1) * npose, npose * sizeof(double), hipMemcpyDeviceToDevice, st));
+    if (int rcg = gather(d_send, 2 * npose, "allgather (boundary rows)")) return rcg;
+    if (has_left)
+      HIP_TRY(hipMemcpyAsync(d_xl, d_gath + ((size_t)(R - 1) * 2 + 1) * npose, npose * sizeof(double), hipMemcpyDeviceToDevice, st));
+    if (halo)
+      HIP_TRY(hipMemcpyAsync(d_x + (size_t)F * npose, d_gath + (size_t)(R + 1) * 2 * npose, npose * sizeof(double), hipMemcpyDeviceToDevice, st));
   }
   auto jac_sweep = [&]() -> int {
     int rc = sweep(p, d_x, d_b, 1, false, st);
@@ -1222,13 +1218,14 @@ int bodyfit_internal_solve_window_device(bodyfit_problem* p, double* frame_param
     launch_win_init(P, W, p->d_r, 0, st);
   } else {
     launch_win_init(P, W, p->d_r, 1, st);
-    if ((rc = allreduce_dev(W.fin, 1, 0))) return rc;
+    if ((rc = gather(W.fin, 1, "allgather (initial cost)"))) return rc;
+    launch_sum_ranks(d_gath, N, 1, 1, W.fin, st);
     launch_win_init(P, W, p->d_r, 2, st);
   }
   int n_sweeps = 1;
   double status[kWsCount] = {0};
   bool need_jac = false, first = true;
-  const size_t blk = (size_t)kWinBlock * kWinBlock, rhs = (size_t)kWinRhs * kWinBlock;
+  const size_t rhs = (size_t)kWinRhs * kWinBlock;
   for (int it = 0; it < opt->max_iters; ++it) {
     if (need_jac) {
       if ((rc = jac_sweep())) return rc;
@@ -1239,18 +1236,19 @@ int bodyfit_internal_solve_window_device(bodyfit_problem* p, double* frame_param
       launch_win_beta(P, W, p->d_frame_normal, p->d_r, first ? 1 : 0, 0, st);
       launch_win_assemble(P, W, p->d_frame_normal, p->d_r, d_x, d_const, first ? 1 : 0, nullptr, nullptr, st);
     } else {
-      launch_win_beta(P, W, p->d_frame_normal, p->d_r, first ? 1 : 0, 1, st);
-      if ((rc = allreduce_dev(W.Craw, 110, 0))) return rc;       // [C (100) | g_beta (10)]: the beta terms, once per iteration
-      launch_win_beta(P, W, p->d_frame_normal, p->d_r, first ? 1 : 0, 2, st);
+      launch_win_beta(P, W, p->d_frame_normal, p->d_r, first ? 1 : 0, 1, st);   // this shard's [C (100) | g_beta (10)] -> W.Craw
       if (first) {
-        // first pass: this shard's Jacobi scaling; the next shard's first-frame scaling then completes the boundary coupling
+        // first iteration only: the Jacobi scaling needs the complete C before the blocks are assembled, and the boundary
+        // frames' scaling rows (this shard's first and last frame) complete the couplings across the shard boundaries
+        if ((rc = gather(W.Craw, 112, "allgather (beta terms)"))) return rc;
+        launch_sum_ranks(d_gath, N, 112, 110, W.Craw, st);
+        launch_win_beta(P, W, p->d_frame_normal, p->d_r, 1, 2, st);
         launch_win_assemble(P, W, p->d_frame_normal, p->d_r, d_x, d_const, 1, has_left ? d_xl : nullptr, nullptr, st);
-        HIP_TRY(hipMemcpyAsync(bnd.data(), W.scale, npose * sizeof(double), hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
-        bnd_all.resize((size_t)N * npose);
-        if (comm->allgather(comm->ctx, bnd.data(), bnd_all.data(), npose)) return comm_fail("allgather");
-        if (halo) HIP_TRY(hipMemcpyAsync(d_sh, &bnd_all[(size_t)(R + 1) * npose], npose * sizeof(double), hipMemcpyHostToDevice, st));
-        HIP_TRY(hipStreamSynchronize(st));
+        HIP_TRY(hipMemcpyAsync(d_send, W.scale, npose * sizeof(double), hipMemcpyDeviceToDevice, st));
+        HIP_TRY(hipMemcpyAsync(d_send + npose, W.scale + (size_t)(F - 1) * npose, npose * sizeof(double), hipMemcpyDeviceToDevice, st));
+        if ((rc = gather(d_send, 2 * npose, "allgather (scaling rows)"))) return rc;
+        if (halo) HIP_TRY(hipMemcpyAsync(d_sh, d_gath + (size_t)(R + 1) * 2 * npose, npose * sizeof(double), hipMemcpyDeviceToDevice, st));
+        if (has_left) HIP_TRY(hipMemcpyAsync(d_sl, d_gath + ((size_t)(R - 1) * 2 + 1) * npose, npose * sizeof(double), hipMemcpyDeviceToDevice, st));
       }
       launch_win_assemble(P, W, p->d_frame_normal, p->d_r, d_x, d_const, 0, has_left ? d_xl : nullptr, halo ? d_sh : nullptr, st);
     }
@@ -1261,30 +1259,16 @@ int bodyfit_internal_solve_window_device(bodyfit_problem* p, double* frame_param
       launch_cr_update(W, d_sched + lv.surv_off, lv.n_surv, st);
     }
     if (sharded) {
-      // ---- interface system of the 2 N end frames: gathered, solved by every rank ----
-      const size_t per = 3 * blk + 2 * rhs;   // doubles per rank: [D_first, D_last, U_first (-> last), U_last diag block.., R_first, R_last]
-      (void)per;
-      std::vector<double>& hs = hg;
-      const size_t per_rank = 4 * blk + 2 * rhs;
-      hs.resize(per_rank);
-      const int fl = F - 1;
-      HIP_TRY(hipMemcpyAsync(&hs[0], W.D, blk * 8, hipMemcpyDeviceToHost, st));
-      HIP_TRY(hipMemcpyAsync(&hs[blk], W.D + (size_t)fl * blk, blk * 8, hipMemcpyDeviceToHost, st));
-      HIP_TRY(hipMemcpyAsync(&hs[2 * blk], W.U, blk * 8, hipMemcpyDeviceToHost, st));
-      HIP_TRY(hipMemcpyAsync(&hs[3 * blk], W.U + (size_t)fl * blk, blk * 8, hipMemcpyDeviceToHost, st));
-      HIP_TRY(hipMemcpyAsync(&hs[4 * blk], W.Rt, rhs * 8, hipMemcpyDeviceToHost, st));
-      HIP_TRY(hipMemcpyAsync(&hs[4 * blk + rhs], W.Rt + (size_t)fl * rhs, rhs * 8, hipMemcpyDeviceToHost, st));
-      HIP_TRY(hipStreamSynchronize(st));
-      static thread_local std::vector<double> all;
-      all.resize(per_rank * N);
-      if (comm->allgather(comm->ctx, hs.data(), all.data(), (int)per_rank)) return comm_fail("allgather");
-      for (int r2 = 0; r2 < N; ++r2) {
-        const double* src = &all[(size_t)r2 * per_rank];
-        HIP_TRY(hipMemcpyAsync(Wi.D + (size_t)(2 * r2) * blk, src, 2 * blk * 8, hipMemcpyHostToDevice, st));
-        HIP_TRY(hipMemcpyAsync(Wi.U + (size_t)(2 * r2) * blk, src + 2 * blk, 2 * blk * 8, hipMemcpyHostToDevice, st));
-        HIP_TRY(hipMemcpyAsync(Wi.Rt + (size_t)(2 * r2) * rhs, src + 4 * blk, 2 * rhs * 8, hipMemcpyHostToDevice, st));
+      // ---- interface system of the 2 N end frames: ONE all-gather (the shard's beta terms ride on it from the second
+      //      iteration on), then every rank solves the same chain ----
+      const int n_extra = 112;
+      launch_iface_pack(W, F, W.Craw, n_extra, d_send, st);
+      if ((rc = gather(d_send, iface_doubles(n_extra), "allgather (interface blocks)"))) return rc;
+      launch_iface_unpack(Wi, d_gath, N, n_extra, d_cg, st);
+      if (!first) {
+        HIP_TRY(hipMemcpyAsync(W.Craw, d_cg, 110 * sizeof(double), hipMemcpyDeviceToDevice, st));
+        launch_win_beta(P, W, p->d_frame_normal, p->d_r, 0, 2, st);
       }
-      HIP_TRY(hipMemsetAsync(Wi.fail, 0, sizeof(int), st));
       for (size_t l = 0; l < ilevels.size(); ++l) {
         const CrLevel& lv = ilevels[l];
         launch_cr_factor(Wi, d_sched + lv.elim_off, lv.n_elim, st);
@@ -1292,7 +1276,7 @@ int bodyfit_internal_solve_window_device(bodyfit_problem* p, double* frame_param
       }
       for (size_t l = ilevels.size(); l-- > 0;) launch_cr_back(Wi, d_sched + ilevels[l].elim_off, ilevels[l].n_elim, st);
       HIP_TRY(hipMemcpyAsync(W.Xt, Wi.Xt + (size_t)(2 * R) * rhs, rhs * 8, hipMemcpyDeviceToDevice, st));
-      HIP_TRY(hipMemcpyAsync(W.Xt + (size_t)fl * rhs, Wi.Xt + (size_t)(2 * R + 1) * rhs, rhs * 8, hipMemcpyDeviceToDevice, st));
+      HIP_TRY(hipMemcpyAsync(W.Xt + (size_t)(F - 1) * rhs, Wi.Xt + (size_t)(2 * R + 1) * rhs, rhs * 8, hipMemcpyDeviceToDevice, st));
     }
     for (size_t l = levels.size(); l-- > 0;) launch_cr_back(W, d_sched + levels[l].elim_off, levels[l].n_elim, st);
     // ---- beta Schur complement, step, model change, decision ----
@@ -1307,40 +1291,37 @@ int bodyfit_internal_solve_window_device(bodyfit_problem* p, double* frame_param
         launch_win_finish(P, W, d_x, d_b, d_xn, d_bn, 0, st);
       }
     } else {
-      if (Wi.fail) {   // a failed interface factorisation is everybody's failure
-        int hf = 0;
-        HIP_TRY(hipMemcpyAsync(&hf, Wi.fail, sizeof(int), hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
-        if (opt->verbose) {
-          int lf = 0;
-          HIP_TRY(hipMemcpy(&lf, W.fail, sizeof(int), hipMemcpyDeviceToHost));
-          std::printf("[bodyfit-dev r%d] local fail %d interface fail %d\n", R, lf, hf);
-        }
-        if (hf) { const int one = 1; HIP_TRY(hipMemcpyAsync(W.fail, &one, sizeof(int), hipMemcpyHostToDevice, st)); HIP_TRY(hipStreamSynchronize(st)); }
-      }
-      launch_win_beta_solve(P, W, d_b, d_bn, 1, st);
-      if ((rc = allreduce_dev(W.sred, 110, 0))) return rc;
+      // (a failed interface factorisation is everybody's failure: every rank factors the same chain and sees the same flag,
+      //  k_win_finish folds it into the shard's own)
+      launch_win_beta_solve(P, W, d_b, d_bn, 1, st);                     // this shard's Schur partials -> W.sred
+      if ((rc = gather(W.sred, 112, "allgather (Schur partials)"))) return rc;
+      launch_sum_ranks(d_gath, N, 112, 110, W.sred, st);
       launch_win_beta_solve(P, W, d_b, d_bn, 2, st);
       launch_win_step(P, W, d_x, d_xn, st);
-      if ((rc = exchange_boundary(d_xn, W.d, x_left_new.data(), d_dh))) return rc;   // candidate's boundary rows + the next shard's first step
+      // the neighbours' boundary frames move by the steps their own shards compute (same arithmetic, same numbers)
+      launch_win_halo_step(P, Wi.Xt, W.dsb, halo ? 2 * (R + 1) : -1, d_sh, d_x + (size_t)F * npose, d_dh, d_xn + (size_t)F * npose,
+                           has_left ? 2 * R - 1 : -1, d_sl, d_xl, d_xln, st);
       launch_win_model(P, W, d_x, halo ? d_dh : nullptr, st);
-      launch_win_finish(P, W, d_x, d_b, d_xn, d_bn, 1, st);
-      if ((rc = allreduce_dev(W.fin, 3, 0))) return rc;
-      if ((rc = allreduce_dev(W.fin + 3, 2, 1))) return rc;
-      launch_win_finish(P, W, d_x, d_b, d_xn, d_bn, 2, st);
+      launch_win_fold_fail(W, Wi, st);
+      launch_win_finish(P, W, d_x, d_b, d_xn, d_bn, 1, st);              // this shard's scalars -> W.fin[0..4]
     }
-    rc = sweep(p, d_xn, d_bn, 0, false, st, nullptr, d_rn, d_compn);
-    if (rc) return rc;
-    ++n_sweeps;
     if (!sharded) {
+      rc = sweep(p, d_xn, d_bn, 0, false, st, nullptr, d_rn, d_compn);
+      if (rc) return rc;
+      ++n_sweeps;
       launch_win_accept(P, W, d_rn, d_x, d_b, d_xn, d_bn, 0, st);
     } else {
-      launch_win_accept(P, W, d_rn, d_x, d_b, d_xn, d_bn, 1, st);
-      if ((rc = allreduce_dev(W.fin, 1, 0))) return rc;
-      launch_win_accept(P, W, d_rn, d_x, d_b, d_xn, d_bn, 2, st);
+      // the candidate is evaluated whatever the decision will be (it is taken once, below, from everybody's scalars)
+      rc = sweep(p, d_xn, d_bn, 0, false, st, nullptr, d_rn, d_compn);
+      if (rc) return rc;
+      ++n_sweeps;
+      launch_win_accept(P, W, d_rn, d_x, d_b, d_xn, d_bn, 3, st);       // this shard's cost at the candidate -> W.fin[5]
+      if ((rc = gather(W.fin, 8, "allgather (scalars)"))) return rc;
+      launch_win_decide(P, W, d_x, d_b, d_xn, d_bn, d_gath, N, halo ? d_x + (size_t)F * npose : nullptr, d_xn + (size_t)F * npose,
+                        has_left ? d_xl : nullptr, d_xln, st);
     }
     first = false;
-    if (!sharded && !opt->verbose && (it & 3) != 3 && it + 1 < opt->max_iters) {
+    if (!opt->verbose && (it & 3) != 3 && it + 1 < opt->max_iters) {
       // One GPU: the device takes every decision itself, so the host only looks at the status record every fourth
       // iteration (a read-back drains the launch pipeline: ~30 us of a ~450 us iteration at 20 frames).  The Jacobian sweep
       // is then issued unconditionally (after a rejected step it recomputes the same normals), and iterations launched
@@ -1350,12 +1331,7 @@ int bodyfit_internal_solve_window_device(bodyfit_problem* p, double* frame_param
     }
     HIP_TRY(hipMemcpyAsync(status, W.status, sizeof(status), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
-    need_jac = sharded ? status[kWsAccepted] != 0.0 : true;
-    if (sharded && need_jac) {   // the accepted point's boundary rows become the current ones
-      if (halo) HIP_TRY(hipMemcpyAsync(d_x + (size_t)F * npose, d_xn + (size_t)F * npose, npose * sizeof(double), hipMemcpyDeviceToDevice, st));
-      if (has_left) { x_left = x_left_new; HIP_TRY(hipMemcpyAsync(d_xl, x_left.data(), npose * sizeof(double), hipMemcpyHostToDevice, st)); }
-      HIP_TRY(hipStreamSynchronize(st));
-    }
+    need_jac = true;
     if (opt->verbose && R == 0)
       std::printf("[bodyfit-dev] it %3d cost %.6e radius %.3e accepted %d gmax %.2e\n", (int)status[kWsIters], status[kWsCost],
                   status[kWsRadius], (int)status[kWsAccepted], status[kWsGmax]);
@@ -1377,20 +1353,104 @@ int bodyfit_internal_solve_window_device(bodyfit_problem* p, double* frame_param
   return BODYFIT_OK;
 }
 
-// One window sharded over several processes (one per GPU): this rank's shard of the frames, collectives through `comm`.
-int bodyfit_solve_sharded(bodyfit_problem* p, double* frame_params, double* beta, const unsigned char* param_constant,
-                          const bodyfit_comm* comm, const bodyfit_fit_options* opt_in, bodyfit_fit_summary* summary) {
-  if (!p || !frame_params || !beta || !comm || !comm->allreduce || !comm->allgather || comm->size < 1 || comm->rank < 0 ||
-      comm->rank >= comm->size)
-    return fail(BODYFIT_ERR_INVALID, "bodyfit_solve_sharded: bad argument");
+// the unsharded entry (host_solver.cpp's router)
+int bodyfit_internal_solve_window_device(bodyfit_problem* p, double* frame_params, double* beta,
+                                         const unsigned char* param_constant, const bodyfit_fit_options* opt,
+                                         bodyfit_fit_summary* summary, const bodyfit_comm* comm) {
+  (void)comm;
+  return solve_window_device(p, frame_params, beta, param_constant, opt, summary, nullptr, false);
+}
+
+static int sharded_common(bodyfit_problem* p, double* frame_params, double* beta, const unsigned char* param_constant,
+                          Transport* tr, const bodyfit_fit_options* opt_in, bodyfit_fit_summary* summary, long* n_exchanges) {
   bodyfit_fit_options opt;
   opt.max_iters = 100; opt.scale_lo = -1e300; opt.scale_hi = 1e300; opt.verbose = 0; opt.solver = 3;
   if (opt_in) opt = *opt_in;
   int maxk = 0;
   for (int f = 0; f < p->d.F; ++f) maxk = std::max(maxk, p->kp_offset[f + 1] - p->kp_offset[f]);
   if (maxk > 32) return fail(BODYFIT_ERR_INVALID, "bodyfit_solve_sharded: at most 32 keypoints per frame");
-  return bodyfit_internal_solve_window_device(p, frame_params, beta, param_constant, &opt, summary, comm);
+  // BODYFIT_FORCE_SHARDED=1 (tests): a communicator of ONE rank still takes the sharded code path (interface system of its two
+  // end frames, every exchange issued), which is how the RCCL transport is exercised on a box with a single GPU
+  const char* fs = std::getenv("BODYFIT_FORCE_SHARDED");
+  const long before = tr->n_calls;
+  const int rc = solve_window_device(p, frame_params, beta, param_constant, &opt, summary, tr, fs && fs[0] == '1');
+  if (n_exchanges) *n_exchanges = tr->n_calls - before;
+  return rc;
 }
+
+// One window sharded over several processes (one per GPU): this rank's shard of the frames, exchanges through the caller's
+// callbacks on host buffers (the transport of tests and of MPI hosts; bodyfit_solve_sharded_rccl keeps them on the device).
+int bodyfit_solve_sharded(bodyfit_problem* p, double* frame_params, double* beta, const unsigned char* param_constant,
+                          const bodyfit_comm* comm, const bodyfit_fit_options* opt_in, bodyfit_fit_summary* summary) {
+  if (!p || !frame_params || !beta || !comm || !comm->allgather || comm->size < 1 || comm->rank < 0 || comm->rank >= comm->size)
+    return fail(BODYFIT_ERR_INVALID, "bodyfit_solve_sharded: bad argument");
+  HostTransport tr;
+  tr.rank = comm->rank; tr.size = comm->size; tr.cb = comm;
+  long n = 0;
+  const int rc = sharded_common(p, frame_params, beta, param_constant, &tr, opt_in, summary, &n);
+  p->last_exchanges = n;
+  return rc;
+}
+
+// ---- RCCL transport ---------------------------------------------------------------------------------------------------------
+struct bodyfit_rccl {
+  RcclTransport tr;
+  bool owns = false;
+};
+
+int bodyfit_rccl_unique_id(unsigned char* id128) {
+  if (!id128) return fail(BODYFIT_ERR_INVALID, "null argument");
+  RcclApi& A = RcclApi::get();
+  if (!A.ok()) return fail(BODYFIT_ERR_HIP, A.error);
+  RcclApi::unique_id id;
+  const int rc = A.GetUniqueId(&id);
+  if (rc != 0) return fail(BODYFIT_ERR_HIP, std::string("ncclGetUniqueId: ") + A.GetErrorString(rc));
+  std::memcpy(id128, id.internal, 128);
+  return BODYFIT_OK;
+}
+
+int bodyfit_rccl_create(const unsigned char* id128, int rank, int size, int device, bodyfit_rccl** out) {
+  if (!id128 || !out || size < 1 || rank < 0 || rank >= size) return fail(BODYFIT_ERR_INVALID, "bodyfit_rccl_create: bad argument");
+  *out = nullptr;
+  RcclApi& A = RcclApi::get();
+  if (!A.ok()) return fail(BODYFIT_ERR_HIP, A.error);
+  HIP_TRY(hipSetDevice(device));
+  RcclApi::unique_id id;
+  std::memcpy(id.internal, id128, 128);
+  std::unique_ptr<bodyfit_rccl> c(new bodyfit_rccl());
+  const int rc = A.CommInitRank(&c->tr.comm, size, id, rank);
+  if (rc != 0) return fail(BODYFIT_ERR_HIP, std::string("ncclCommInitRank: ") + A.GetErrorString(rc));
+  c->tr.rank = rank; c->tr.size = size; c->owns = true;
+  *out = c.release();
+  return BODYFIT_OK;
+}
+
+int bodyfit_rccl_wrap(void* nccl_comm, int rank, int size, bodyfit_rccl** out) {
+  if (!nccl_comm || !out || size < 1 || rank < 0 || rank >= size) return fail(BODYFIT_ERR_INVALID, "bodyfit_rccl_wrap: bad argument");
+  RcclApi& A = RcclApi::get();
+  if (!A.ok()) return fail(BODYFIT_ERR_HIP, A.error);
+  bodyfit_rccl* c = new bodyfit_rccl();
+  c->tr.comm = nccl_comm; c->tr.rank = rank; c->tr.size = size; c->owns = false;
+  *out = c;
+  return BODYFIT_OK;
+}
+
+void bodyfit_rccl_destroy(bodyfit_rccl* c) {
+  if (!c) return;
+  if (c->owns && c->tr.comm) (void)RcclApi::get().CommDestroy(c->tr.comm);
+  delete c;
+}
+
+int bodyfit_solve_sharded_rccl(bodyfit_problem* p, double* frame_params, double* beta, const unsigned char* param_constant,
+                               bodyfit_rccl* comm, const bodyfit_fit_options* opt_in, bodyfit_fit_summary* summary) {
+  if (!p || !frame_params || !beta || !comm || !comm->tr.comm) return fail(BODYFIT_ERR_INVALID, "bodyfit_solve_sharded_rccl: bad argument");
+  long n = 0;
+  const int rc = sharded_common(p, frame_params, beta, param_constant, &comm->tr, opt_in, summary, &n);
+  p->last_exchanges = n;
+  return rc;
+}
+
+long bodyfit_last_exchange_count(const bodyfit_problem* p) { return p ? p->last_exchanges : 0; }
 
 int bodyfit_internal_fail(int code, const char* msg) { return fail(code, msg ? msg : ""); }
 

@@ -225,6 +225,19 @@ void launch_win_finish(const WinProblem& P, const WinBuf& W, const double* d_x, 
 void launch_win_accept(const WinProblem& P, const WinBuf& W, const double* d_r_new, double* d_x, double* d_beta,
                        const double* d_x_new, const double* d_beta_new, int mode, hipStream_t s);
 
+// sharded solves (bodyfit_solve_sharded*): the exchange steps
+void launch_sum_ranks(const double* d_g, int N, int stride, int n, double* d_out, hipStream_t s);
+int iface_doubles(int n_extra);
+void launch_iface_pack(const WinBuf& W, int F, const double* d_extra, int n_extra, double* d_send, hipStream_t s);
+void launch_iface_unpack(const WinBuf& Wi, const double* d_g, int N, int n_extra, double* d_extra_sum, hipStream_t s);
+void launch_win_halo_step(const WinProblem& P, const double* d_Xi, const double* d_dsb, int node_right, const double* d_scale_right,
+                          const double* d_x_right, double* d_d_right, double* d_xn_right, int node_left,
+                          const double* d_scale_left, const double* d_x_left, double* d_xn_left, hipStream_t s);
+void launch_win_fold_fail(const WinBuf& W, const WinBuf& Wi, hipStream_t s);
+void launch_win_decide(const WinProblem& P, const WinBuf& W, double* d_x, double* d_beta, double* d_x_new, double* d_beta_new,
+                       const double* d_g, int N, double* d_x_halo, const double* d_xn_halo, double* d_x_left,
+                       const double* d_xn_left, hipStream_t s);
+
 // f32 -> bf16 round-to-nearest-even (finite inputs)
 __host__ __device__ inline uint16_t f32_to_bf16(float x) {
   union { float f; uint32_t u; } c;

@@ -247,6 +247,13 @@ __device__ __forceinline__ void frame_part(const DevModel& M, const DevProblem& 
 
   STAMP_REAL(10);
   STAMP(0);
+#ifdef BODYFIT_STAMPS
+  if (Pb.dbg && tid == 0) {   // which XCD this workgroup runs on (HW_REG_XCC_ID = 20, low 4 bits)
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    Pb.dbg[((size_t)f * 8) * 16 + 9] = xcc & 0xf;
+  }
+#endif
   if (Pb.frame_flags && !(Pb.frame_flags[f] & Pb.frame_mask)) return;   // frame already converged (device LM)
   constexpr int kLoaders = kThreads;
   constexpr bool loader = true;
@@ -483,17 +490,28 @@ __device__ __forceinline__ void frame_part(const DevModel& M, const DevProblem& 
     if (lane >= 8 && lane - 8 < kBlendKSteps * 4) {
       const int wl = lane - 8;
       const int kstep = wl >> 2, h = (wl >> 1) & 1, hl = wl & 1;
+      // eight consecutive blend coefficients k0 .. k0 + 7: pose feature vec(R_j - I) (k < 207), then beta, then the
+      // template's two slots.  Branch-free: all sixteen LDS reads are issued together from clamped indices and the value is
+      // selected (written as if / else-if the eight values cost eight dependent LDS round trips)
+      const int k0 = kstep * 16 + 8 * h;
+      const int nfeat = 9 * (nJ - 1);
+      double vr[8], vb[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        vr[u] = sR[9 + min(k0 + u, nfeat - 1)];
+        vb[u] = sbeta[min(max(k0 + u - kPoseFeat, 0), max(nS, 1) - 1)];
+      }
       uint32_t pk[4];
 #pragma unroll
       for (int jj = 0; jj < 4; ++jj) {
         uint16_t b[2];
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-          const int k = kstep * 16 + 8 * h + 2 * jj + u;     // blend coefficient: pose feature vec(R_j - I), then beta
-          float x = 0.0f;
-          if (k < kPoseFeat) x = (Pb.pose_blend && k < 9 * (nJ - 1)) ? (float)(sR[9 + k] - (((k % 9) % 4 == 0) ? 1.0 : 0.0)) : 0.0f;
-          else if (k - kPoseFeat < nS) x = (float)sbeta[k - kPoseFeat];
-          else if (k == kPoseFeat + kMaxShape || k == kPoseFeat + kMaxShape + 1) x = 1.0f;   // the template's two slots
+          const int k = k0 + 2 * jj + u;
+          const float xr = (Pb.pose_blend && k < nfeat) ? (float)(vr[2 * jj + u] - (((k % 9) % 4 == 0) ? 1.0 : 0.0)) : 0.0f;
+          const float xb = (k - kPoseFeat < nS) ? (float)vb[2 * jj + u]
+                                                : ((k == kPoseFeat + kMaxShape || k == kPoseFeat + kMaxShape + 1) ? 1.0f : 0.0f);
+          const float x = (k < kPoseFeat) ? xr : xb;
           const uint16_t hi = f32_to_bf16(x);
           b[u] = hl == 0 ? hi : f32_to_bf16(x - bf16_to_f32(hi));
         }

@@ -37,6 +37,7 @@
 namespace bodyfit {
 namespace {
 
+[[maybe_unused]] constexpr int kPollWave = 7;
 [[maybe_unused]] constexpr unsigned long long kRoleTimeoutTicks = 5000000;   // 50 ms of s_memrealtime (100 MHz): give up
 
 __global__ __launch_bounds__(kThreads, 4) void k_frame_resjac(DevModel M, DevProblem Pb, const double* __restrict__ params,
@@ -156,7 +157,9 @@ __global__ __launch_bounds__(kThreads, 4) void k_sweep_roles(RoleArgs by_value) 
   unsigned* const error_word = A->sy.error;
   if (role == 2) grp = (idx * kPriorTileF) / kRoleGroup;
   auto wait_flags = [&]() -> bool {
-    // wave 0 polls the counters of the group's eight 32-frame units (each on a line of its own: lane u reads counter u with an sc1
+    // Wave 7 polls the counters of the group's eight 32-frame units.  Wave 7, because it has no operand stream of its own in
+    // flight (waves 0-5 carry the mesh role's LDS-DMA pieces): loads return in issue order, and a poll issued behind a wave's
+    // DMA pieces came back 3 us late.  Counters (each on a line of its own: lane u reads counter u with an sc1
     // load).  Every launch adds exactly the unit's frame count, so after launch `epoch` a complete unit reads epoch x count.
     // Polling is kept sparse: a few hundred waiting workgroups that hammer one line delay the very stores they wait for
     // (with 1 KB of per-frame flags polled every 128 cycles the hand-off took 3 us to arrive and the producers' store drain
@@ -164,14 +167,22 @@ __global__ __launch_bounds__(kThreads, 4) void k_sweep_roles(RoleArgs by_value) 
     // entry (no frame workgroup is faster), then one look every ~0.25 us.
     volatile unsigned* ctrl = reinterpret_cast<volatile unsigned*>(lds + kRoleCtrlOff);
     const int tid = threadIdx.x, lane = tid & 63;
-    if ((tid >> 6) == 0) {
+    if ((tid >> 6) == kPollWave) {
       const int fbeg = grp * kRoleGroup, nf = min(kRoleGroup, F - fbeg);
       const int nu = (nf + kFTile - 1) / kFTile;
       const unsigned want = epoch * (unsigned)min(kFTile, nf - min(lane, 7) * kFTile);
       const unsigned* ctr = flag_base + (size_t)(grp * (kRoleGroup / kFTile) + min(lane, 7)) * kUnitCounterStride;
       unsigned action = 0;
       const unsigned long long t_enter = __builtin_amdgcn_s_memrealtime();
-      for (int n = 0;; ++n) {
+#ifdef BODYFIT_STAMPS
+      unsigned long long t_issue = 0;
+      int n_polls = 0;
+#endif
+      for (;;) {
+#ifdef BODYFIT_STAMPS
+        t_issue = __builtin_amdgcn_s_memrealtime();
+        ++n_polls;
+#endif
         const unsigned got = __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (__all(lane >= nu || got == want)) break;
         const unsigned long long el = __builtin_amdgcn_s_memrealtime() - t_enter;
@@ -183,6 +194,20 @@ __global__ __launch_bounds__(kThreads, 4) void k_sweep_roles(RoleArgs by_value) 
         }
       }
       if (lane == 0) ctrl[0] = action;
+#if BODYFIT_ROLE_ACQUIRE
+      // agent-scope acquire (buffer_inv sc1) by the polling wave, waited for in front of the barrier below: the operand loads
+      // behind it are plain
+      if (role == 1) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+#endif
+#ifdef BODYFIT_STAMPS
+      if (A->Pb.dbg && lane == 0 && role == 1) {
+        unsigned long long* d = A->Pb.dbg + kStampBase + ((size_t)(grp * nVT + idx) * 8 + kPollWave) * 16;
+        d[5] = t_enter; d[6] = t_issue; d[7] = (unsigned long long)n_polls;
+      }
+#endif
     }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     const unsigned action = ctrl[0];

@@ -1066,22 +1066,13 @@ __global__ __launch_bounds__(256) void k_win_tail(WinProblem P, WinBuf W, const 
 }
 
 // ---- accept / reject the candidate (Ceres' step quality and radius rules, host_solver.cpp) ------------------------------
-// mode 0: all; 1: this shard's cost at the candidate -> W.fin[0] only; 2: decide with W.fin[0] (summed over the shards)
-__global__ __launch_bounds__(1024) void k_win_accept(WinProblem P, WinBuf W, const double* __restrict__ r_new,
-                                                     double* __restrict__ x, double* __restrict__ beta,
-                                                     const double* __restrict__ x_new, const double* __restrict__ beta_new,
-                                                     int mode) {
-  __shared__ double red[16];
+// the decision itself, for a candidate that exists (status HasCand), given the candidate's cost; thread 0 decides, every
+// thread then copies the accepted point.  Returns (to every thread) whether the candidate was accepted.
+__device__ __forceinline__ bool accept_core(const WinProblem& P, const WinBuf& W, double* __restrict__ x, double* __restrict__ beta,
+                                            const double* __restrict__ x_new, const double* __restrict__ beta_new, double new_cost,
+                                            int tid, int nthreads) {
   __shared__ int acc_flag;
-  const int tid = threadIdx.x;
   double* st = W.status;
-  if (mode == 1) {
-    const double c = window_cost(P, r_new, red, tid, 1024);
-    if (tid == 0) W.fin[0] = c;
-    return;
-  }
-  if (st[kWsHasCand] == 0.0) return;
-  const double new_cost = (mode == 2) ? W.fin[0] : window_cost(P, r_new, red, tid, 1024);
   if (tid == 0) {
     const double cost = st[kWsCost], model = st[kWsModel];
     const double change = cost - new_cost, rho = change / model;
@@ -1106,8 +1097,137 @@ __global__ __launch_bounds__(1024) void k_win_accept(WinProblem P, WinBuf W, con
   }
   __syncthreads();
   if (acc_flag) {
-    copy_batched(x, x_new, P.F * NP, tid, 1024);
+    copy_batched(x, x_new, P.F * NP, tid, nthreads);
     if (tid < P.nb) beta[tid] = beta_new[tid];
+  }
+  return acc_flag != 0;
+}
+// mode 0: all; 1: this shard's cost at the candidate -> W.fin[0] only; 2: decide with W.fin[0] (summed over the shards);
+// 3: this shard's cost at the candidate -> W.fin[5] only (sharded solves: the decision is k_win_decide's)
+__global__ __launch_bounds__(1024) void k_win_accept(WinProblem P, WinBuf W, const double* __restrict__ r_new,
+                                                     double* __restrict__ x, double* __restrict__ beta,
+                                                     const double* __restrict__ x_new, const double* __restrict__ beta_new,
+                                                     int mode) {
+  __shared__ double red[16];
+  const int tid = threadIdx.x;
+  double* st = W.status;
+  if (mode == 1 || mode == 3) {
+    const double c = window_cost(P, r_new, red, tid, 1024);
+    if (tid == 0) W.fin[mode == 1 ? 0 : 5] = c;
+    return;
+  }
+  if (st[kWsHasCand] == 0.0) return;
+  const double new_cost = (mode == 2) ? W.fin[0] : window_cost(P, r_new, red, tid, 1024);
+  (void)accept_core(P, W, x, beta, x_new, beta_new, new_cost, tid, 1024);
+}
+
+// ---- sharded solves (bodyfit_solve_sharded*): what the exchanges need ----------------------------------------------------
+// sum of the shards' partials in rank order: out[i] = sum_r gathered[r][i] (every rank computes bit-identical totals)
+__global__ __launch_bounds__(256) void k_sum_ranks(const double* __restrict__ g, int N, int stride, int n, double* __restrict__ out) {
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    double s = 0.0;
+    for (int r = 0; r < N; ++r) s += g[(size_t)r * stride + i];
+    out[i] = s;
+  }
+}
+// this shard's contribution to the interface system: [D_first, D_last, U_first, U_last | Rt_first, Rt_last | extra], one
+// contiguous buffer for ONE all-gather
+__global__ __launch_bounds__(256) void k_iface_pack(WinBuf W, int F, const double* __restrict__ extra, int n_extra,
+                                                    double* __restrict__ send) {
+  constexpr int blk = WB * WB, rhs = WR * WB;
+  const int fl = F - 1, total = 4 * blk + 2 * rhs + n_extra;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    double v;
+    if (i < blk) v = W.D[i];
+    else if (i < 2 * blk) v = W.D[(size_t)fl * blk + (i - blk)];
+    else if (i < 3 * blk) v = W.U[i - 2 * blk];
+    else if (i < 4 * blk) v = W.U[(size_t)fl * blk + (i - 3 * blk)];
+    else if (i < 4 * blk + rhs) v = W.Rt[i - 4 * blk];
+    else if (i < 4 * blk + 2 * rhs) v = W.Rt[(size_t)fl * rhs + (i - 4 * blk - rhs)];
+    else v = extra[i - 4 * blk - 2 * rhs];
+    send[i] = v;
+  }
+}
+// the gathered contributions -> the interface chain of 2 N frames (every rank builds the same), the extras summed in rank order
+__global__ __launch_bounds__(256) void k_iface_unpack(WinBuf Wi, const double* __restrict__ g, int N, int n_extra,
+                                                      double* __restrict__ extra_sum) {
+  constexpr int blk = WB * WB, rhs = WR * WB;
+  const int per = 4 * blk + 2 * rhs + n_extra;
+  const int total = N * (4 * blk + 2 * rhs) + n_extra;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    if (i < N * (4 * blk + 2 * rhs)) {
+      const int r = i / (4 * blk + 2 * rhs), j = i - r * (4 * blk + 2 * rhs);
+      const double v = g[(size_t)r * per + j];
+      if (j < 2 * blk) Wi.D[(size_t)(2 * r) * blk + j] = v;
+      else if (j < 4 * blk) Wi.U[(size_t)(2 * r) * blk + (j - 2 * blk)] = v;
+      else Wi.Rt[(size_t)(2 * r) * rhs + (j - 4 * blk)] = v;
+    } else {
+      const int e = i - N * (4 * blk + 2 * rhs);
+      double s = 0.0;
+      for (int r = 0; r < N; ++r) s += g[(size_t)r * per + 4 * blk + 2 * rhs + e];
+      extra_sum[e] = s;
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) *Wi.fail = 0;
+}
+// The steps of the neighbouring shards' boundary frames, computed HERE from the interface solution every rank holds (node
+// 2 r = first frame of shard r, 2 r + 1 = its last): the same arithmetic as k_win_step on the same numbers, so the row this
+// rank keeps of its neighbour's frame is bit-identical to the neighbour's own.  block 0: the next shard's first frame (the
+// halo row of the temporal pair this shard owns), block 1: the previous shard's last frame.
+__global__ __launch_bounds__(128) void k_win_halo_step(WinProblem P, const double* __restrict__ Xi, const double* __restrict__ dsb,
+                                                       int node_right, const double* __restrict__ scale_right,
+                                                       const double* __restrict__ x_right, double* __restrict__ d_right,
+                                                       double* __restrict__ xn_right, int node_left,
+                                                       const double* __restrict__ scale_left, const double* __restrict__ x_left,
+                                                       double* __restrict__ xn_left) {
+  const int tid = threadIdx.x;
+  if (tid >= NP) return;
+  const bool right = blockIdx.x == 0;
+  const int node = right ? node_right : node_left;
+  if (node < 0) return;
+  const double* X = Xi + (size_t)node * WR * WB;
+  double ds = X[NBETA * WB + tid];
+#pragma unroll
+  for (int c = 0; c < NBETA; ++c) ds -= (c < P.nb) ? X[c * WB + tid] * dsb[c] : 0.0;
+  const double sc = (right ? scale_right : scale_left)[tid];
+  const double xi = (right ? x_right : x_left)[tid];
+  double di = ds * sc;
+  if (tid == 0) {
+    const double s_new = fmin(fmax(xi + di, P.scale_lo), P.scale_hi);
+    di = s_new - xi;
+  }
+  if (right) { d_right[tid] = di; xn_right[tid] = xi + di; }
+  else xn_left[tid] = xi + di;
+}
+// a failed interface factorisation (every rank factors the same chain) is this shard's failure too
+__global__ void k_win_fold_fail(WinBuf W, WinBuf Wi) {
+  if (threadIdx.x == 0 && *Wi.fail) *W.fail = 1;
+}
+// The whole decision of a sharded iteration in one launch, from every shard's partials [model, |d|^2, |x|^2, max |g|, fail,
+// cost at the candidate] (gathered, [N][8]): k_win_finish's tests, then — if there is a candidate — k_win_accept's.  Every
+// rank runs it on the same numbers.  On acceptance the rows this rank keeps of its neighbours' boundary frames move too.
+__global__ __launch_bounds__(256) void k_win_decide(WinProblem P, WinBuf W, double* __restrict__ x, double* __restrict__ beta,
+                                                    double* __restrict__ x_new, double* __restrict__ beta_new,
+                                                    const double* __restrict__ g, int N, double* __restrict__ x_halo,
+                                                    const double* __restrict__ xn_halo, double* __restrict__ x_left,
+                                                    const double* __restrict__ xn_left) {
+  const int tid = threadIdx.x;
+  double pm = 0.0, dn = 0.0, xn = 0.0, gm = 0.0, fl = 0.0, cost = 0.0;
+  for (int r = 0; r < N; ++r) {
+    const double* o = g + (size_t)r * 8;
+    pm += o[0]; dn += o[1]; xn += o[2];
+    gm = fmax(gm, o[3]); fl = fmax(fl, o[4]);
+    cost += o[5];
+  }
+  if (tid == 0 && fl != 0.0) *W.fail = 1;
+  __syncthreads();
+  finish_core(P, W, x, beta, x_new, beta_new, pm, dn, xn, gm, tid);
+  __syncthreads();
+  if (W.status[kWsHasCand] == 0.0) return;
+  const bool accepted = accept_core(P, W, x, beta, x_new, beta_new, cost, tid, 256);
+  if (accepted && tid < NP) {
+    if (x_halo) x_halo[tid] = xn_halo[tid];
+    if (x_left) x_left[tid] = xn_left[tid];
   }
 }
 
@@ -1176,4 +1296,30 @@ void launch_win_accept(const WinProblem& P, const WinBuf& W, const double* d_r_n
   hipLaunchKernelGGL(k_win_accept, dim3(1), dim3(1024), 0, s, P, W, d_r_new, d_x, d_beta, d_x_new, d_beta_new, mode);
 }
 
+}  // namespace bodyfit
+
+namespace bodyfit {
+void launch_sum_ranks(const double* d_g, int N, int stride, int n, double* d_out, hipStream_t s) {
+  hipLaunchKernelGGL(k_sum_ranks, dim3((n + 255) / 256), dim3(256), 0, s, d_g, N, stride, n, d_out);
+}
+int iface_doubles(int n_extra) { return 4 * WB * WB + 2 * WR * WB + n_extra; }
+void launch_iface_pack(const WinBuf& W, int F, const double* d_extra, int n_extra, double* d_send, hipStream_t s) {
+  hipLaunchKernelGGL(k_iface_pack, dim3(64), dim3(256), 0, s, W, F, d_extra, n_extra, d_send);
+}
+void launch_iface_unpack(const WinBuf& Wi, const double* d_g, int N, int n_extra, double* d_extra_sum, hipStream_t s) {
+  hipLaunchKernelGGL(k_iface_unpack, dim3(64), dim3(256), 0, s, Wi, d_g, N, n_extra, d_extra_sum);
+}
+void launch_win_halo_step(const WinProblem& P, const double* d_Xi, const double* d_dsb, int node_right, const double* d_scale_right,
+                          const double* d_x_right, double* d_d_right, double* d_xn_right, int node_left,
+                          const double* d_scale_left, const double* d_x_left, double* d_xn_left, hipStream_t s) {
+  hipLaunchKernelGGL(k_win_halo_step, dim3(2), dim3(128), 0, s, P, d_Xi, d_dsb, node_right, d_scale_right, d_x_right, d_d_right,
+                     d_xn_right, node_left, d_scale_left, d_x_left, d_xn_left);
+}
+void launch_win_fold_fail(const WinBuf& W, const WinBuf& Wi, hipStream_t s) { hipLaunchKernelGGL(k_win_fold_fail, dim3(1), dim3(64), 0, s, W, Wi); }
+void launch_win_decide(const WinProblem& P, const WinBuf& W, double* d_x, double* d_beta, double* d_x_new, double* d_beta_new,
+                       const double* d_g, int N, double* d_x_halo, const double* d_xn_halo, double* d_x_left,
+                       const double* d_xn_left, hipStream_t s) {
+  hipLaunchKernelGGL(k_win_decide, dim3(1), dim3(256), 0, s, P, W, d_x, d_beta, d_x_new, d_beta_new, d_g, N, d_x_halo, d_xn_halo,
+                     d_x_left, d_xn_left);
+}
 }  // namespace bodyfit

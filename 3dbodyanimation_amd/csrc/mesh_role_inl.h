@@ -7,19 +7,21 @@
 // Per wave: one unit of 32 frames (MFMA M) x the tile's 32 vertices (MFMA N).
 //   blend     D[frame][vertex] per coordinate = [pose feature | beta | 1] . [posedirs | shapedirs - S_root | template],
 //             14 k-steps of v_mfma_f32_32x32x16_bf16, operands split hi + lo in bf16, three products per k-step.
-//             The tile's B operands are NOT resident: one k-step (6 KiB) at a time streams HBM/L3 -> LDS by LDS-DMA through a
-//             ring of four slabs shared by the eight waves (every wave issues one 1-KiB piece per slab), three slabs
-//             ahead of the one being multiplied; ONE workgroup barrier per k-step publishes slab s + 1 and frees slab s.
-//             The first four slabs are requested before the wait for the frame workgroups' hand-off, so the operand stream is
-//             already flowing when the blend coefficients arrive.
+//             Thirteen of the tile's fourteen operand slabs (6 KiB per k-step) are RESIDENT in LDS: they are requested by
+//             LDS-DMA at the very start, before the wait for the frame workgroups' hand-off (the operands do not depend on
+//             the pose), so the whole 78 KiB stream hides under that wait; the fourteenth slab goes L2 -> registers one
+//             k-step ahead of its use.  The blend itself has no barrier and no operand traffic per k-step.
 //   skinning  per accumulator row (two consecutive frames x 32 vertices): gather the vertex's <= 4 joint transforms from
-//             the wave's own ring of three rows in LDS (2,304 bytes per row, filled by LDS-DMA straight from the frame
-//             workgroups' hand-off buffer: no staging registers), blend, apply, one 12-byte write-through store per lane.
-// Every vector-memory operation of the two phases is issued in fixed per-step sets, so each "has my DMA landed" wait is
+//             the wave's own ring of four rows in LDS (2,304 bytes per row, filled by LDS-DMA straight from the frame
+//             workgroups' hand-off buffer: no staging registers), blend, apply, one 12-byte write-through store per lane;
+//   LDS       78 KiB, used twice: the slabs of k-steps 0-8 (region T) are dead after k-step 8, one workgroup barrier
+//             later the same bytes are the eight waves' transform rings; the slabs of k-steps 9-12 (region A) give the
+//             rings their fourth slot after the blend.  Two workgroup barriers in all.
+// Every vector-memory operation of the skinning phase is issued in fixed per-row sets, so each "has my DMA landed" wait is
 // a counted s_waitcnt vmcnt(N) with N known at compile time (vmcnt retires in order).
 // Hand-off (cdna guide, Guideline 16 R1): the frame workgroups store blend coefficients and transforms write-through
-// (sc1) and publish a per-frame flag; here wave 0 polls the group's flags, a workgroup barrier follows, and every
-// load of the handed-off bytes is an sc1 load (global_load ... sc1 to registers, global_load_lds ... sc1 to LDS).
+// (sc1) and publish per 32-frame unit; here wave 0 polls the group's counters, a workgroup barrier follows, and every
+// load of the handed-off bytes is an sc1 load (buffer_load ... sc1 to registers, buffer_load ... lds sc1 to LDS).
 #pragma once
 #include <hip/hip_ext.h>
 
@@ -30,16 +32,30 @@ namespace bodyfit {
 namespace {
 
 constexpr int kRoleGroup = 256;                                   // frames per mesh workgroup (8 waves x 32)
-constexpr int kRingSlabs = 4;
 constexpr int kSlabBytes = 3 * 2 * 1024;                          // one k-step of B: [coord][hi/lo][64 lanes x 16 B]
-constexpr int kBRingBytes = kRingSlabs * kSlabBytes;              // 24,576
+constexpr int kResident = 13;                                     // k-steps of B resident in LDS (the 14th goes through registers)
+constexpr int kRegionASlabs = 4;                                  // region A: slabs 9..12; after the blend: ring slot 3 of every wave
+constexpr int kRegionABytes = kRegionASlabs * kSlabBytes;         // 24,576
+constexpr int kRegionTSlabs = kResident - kRegionASlabs;          // region T: slabs 0..8; from k-step 9 on: the waves' transform rings
 constexpr int kTRowBytes = 2 * kRowBytes;                         // two frames' transforms: 2,304
-constexpr int kTRing = 3;
-constexpr int kTWaveBytes = kTRing * kTRowBytes;                  // 6,912
-constexpr int kRoleCtrlOff = kBRingBytes + kWaves * kTWaveBytes;  // 79,872: control words of the flag wait
+constexpr int kTRing = 4;                                         // rows per wave: slots 0-2 in region T, slot 3 in region A
+constexpr int kTWaveBytes = 3 * kTRowBytes;                       // 6,912 of region T per wave
+constexpr int kTSlot3Bytes = kRegionABytes / kWaves;              // 3,072 of region A per wave
+constexpr int kRoleCtrlOff = kRegionABytes + kWaves * kTWaveBytes;   // 79,872: control words of the flag wait
 constexpr int kRoleLdsBytes = kRoleCtrlOff + 16;
-constexpr int kLoadSc1 = 16;                                      // cache policy bit sc1 of loads / LDS-DMA
+#ifndef BODYFIT_ROLE_ACQUIRE
+#define BODYFIT_ROLE_ACQUIRE 0
+#endif
+// How the mesh role reads the operands handed over inside the launch: BODYFIT_ROLE_ACQUIRE = 1: one agent-scope acquire
+// behind the poll, then plain loads (L2-served); 0: no acquire, every load sc1.
+constexpr int kLoadSc1 = BODYFIT_ROLE_ACQUIRE ? 0 : 16;           // cache policy bit sc1 of loads / LDS-DMA
+static_assert(kRegionTSlabs * kSlabBytes == kWaves * kTWaveBytes, "the transform rings take over region T exactly");
+static_assert(kTSlot3Bytes >= kTRowBytes, "ring slot 3");
 static_assert(kRoleLdsBytes <= 80 * 1024, "two workgroups per CU");
+// LDS byte offset of resident slab s
+__host__ __device__ constexpr int role_slab_off(int s) {
+  return s < kRegionTSlabs ? kRegionABytes + s * kSlabBytes : (s - kRegionTSlabs) * kSlabBytes;
+}
 
 typedef __attribute__((address_space(3))) unsigned char lds_u8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
@@ -56,28 +72,36 @@ typedef const __attribute__((address_space(3))) f32x4 lds_f32x4;
       Pb.dbg[kStampBase + ((size_t)(group * M.nVTiles + vtile) * 8 + C.wave) * 16 + (i)] = t_;                 \
     }                                                                                                          \
   } while (0)
+// shader-cycle stamps of the blend's k-steps (slots 0-14) and the skinning rows (16-32), one 40-slot record per wave
+#define RCYC(i)                                                                                                \
+  do {                                                                                                         \
+    if (Pb.dbg && C.lane == 0) {                                                                               \
+      unsigned long long t_;                                                                                   \
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                              \
+      Pb.dbg[kStampBase + ((size_t)1 << 19) + ((size_t)(group * M.nVTiles + vtile) * 8 + C.wave) * 40 + (i)] = t_; \
+    }                                                                                                          \
+  } while (0)
 #else
 #define RSTAMP(i)
+#define RCYC(i)
 #endif
 
 #define ROLE_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 
-// vector-memory operations a wave issues in blend step t: its piece of slab t + 4, the A fragments (hi, lo) of k-step t + 3
-__host__ __device__ constexpr int role_blend_ops(int t, bool active) {
-  return (t < 0 || t >= kBlendKSteps) ? 0 : ((t + 4 < kBlendKSteps ? 1 : 0) + ((active && t + 3 < kBlendKSteps) ? 2 : 0));
-}
-// ... and in skinning row t: the row's store, the three DMA pieces of row t + 3
-__host__ __device__ constexpr int role_skin_ops(int t) { return (t < 0 || t >= 16) ? 0 : (1 + (t + 3 < 16 ? 3 : 0)); }
+// vector-memory operations a wave issues in skinning row t: the row's store, the three DMA pieces of row t + 4
+__host__ __device__ constexpr int role_skin_ops(int t) { return (t < 0 || t >= 16) ? 0 : (1 + (t + kTRing < 16 ? 3 : 0)); }
 
 struct RoleLane {                // per-lane constants of the skinning rows
   float w0, w1, w2, w3;          // skinning weights (scalars, not an array: hipcc kept an array member in scratch)
   unsigned tj0, tj1, tj2, tj3;   // LDS byte address of joint i's transform in ring slot 0, frame h
+  unsigned slot3;                // what to add for ring slot 3 (region A; wave-uniform)
   unsigned out_off;              // byte offset of (frame h, vertex v) in the cloud
 };
 
 struct RoleCtx {
-  lds_u8* ring;                  // B ring
-  lds_u8* trow;                  // this wave's transform ring
+  lds_u8* ring;                  // LDS base (region A, then region T)
+  lds_u8* trow;                  // this wave's transform ring slots 0-2 (region T)
+  lds_u8* trow3;                 // ... and slot 3 (region A)
   __amdgpu_buffer_rsrc_t dirs_rsrc, skin_rsrc;   // the model's operand blocks; the hand-off buffer of transforms
   unsigned dirs_soff, skin_soff;                 // byte offsets of this tile's block / of the unit's first frame
   int piece, slab_voff;                          // this wave's piece of every slab; piece * 1024 + lane * 16
@@ -87,18 +111,18 @@ struct RoleCtx {
 // LDS-DMA in its MUBUF form (buffer_load ... lds).  The FLAT-encoded global_load_lds makes hipcc treat every later
 // dependency wait as "a flat operation is pending": it then emits s_waitcnt vmcnt(0) lgkmcnt(0) in front of the first use of
 // ANY loaded register, which would drain the operand stream once per k-step (seen in the .s).
-// this wave's 1 KiB piece of slab s.  A slab is six pieces and the workgroup has eight waves: waves 6 and 7 request pieces 0
-// and 1 a second time (same bytes to the same place; an L2 hit), so that EVERY wave issues exactly one operation per slab
-// and the counted waits are the same code for all of them.  (A 12-byte-per-lane DMA would split a slab evenly, but the
-// hardware places lane l's 12 bytes at 16 l: tools/ubench/dma_layout.hip.)
+// this wave's 1 KiB piece of resident slab s.  A slab is six pieces and the workgroup has eight waves: waves 6 and 7 request
+// pieces 0 and 1 a second time (same bytes to the same place; an L2 hit), so that every wave issues the same operations.
+// (A 12-byte-per-lane DMA would split a slab evenly, but the hardware places lane l's 12 bytes at 16 l:
+// tools/ubench/dma_layout.hip.)
 __device__ __forceinline__ void role_dma_slab(const RoleCtx& C, int s) {
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(C.dirs_rsrc, (__attribute__((address_space(3))) void*)(C.ring + (s % kRingSlabs) * kSlabBytes + C.piece * 1024),
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(C.dirs_rsrc, (__attribute__((address_space(3))) void*)(C.ring + role_slab_off(s) + C.piece * 1024),
                                        16, C.slab_voff, C.dirs_soff + (unsigned)s * kSlabBytes, 0, 0);
 }
-// the transforms of accumulator row r (two consecutive frames, 2,304 bytes) into ring slot r % 3
+// the transforms of accumulator row r (two consecutive frames, 2,304 bytes) into ring slot r % 4
 __device__ __forceinline__ void role_dma_row(const RoleCtx& C, int r) {
   const unsigned so = C.skin_soff + (unsigned)r * kTRowBytes;
-  lds_u8* l = C.trow + (r % kTRing) * kTRowBytes;
+  lds_u8* l = (r % kTRing) == 3 ? C.trow3 : C.trow + (r % kTRing) * kTRowBytes;
   // (the instruction's immediate offset would be added to the LDS address as well as to the memory address: keep it 0)
   __builtin_amdgcn_raw_ptr_buffer_load_lds(C.skin_rsrc, (__attribute__((address_space(3))) void*)l, 16, C.lane * 16, so, 0, kLoadSc1);
   __builtin_amdgcn_raw_ptr_buffer_load_lds(C.skin_rsrc, (__attribute__((address_space(3))) void*)(l + 1024), 16, C.lane * 16, so + 1024, 0, kLoadSc1);
@@ -106,70 +130,63 @@ __device__ __forceinline__ void role_dma_row(const RoleCtx& C, int r) {
 }
 
 // ---- blend: k-step S ------------------------------------------------------------------------------------------------
-template <int S, bool kActive>
+// No barrier and no operand traffic per k-step: slabs 0-12 are resident (requested before the wait for the hand-off), the
+// waves run at their own pace and the two waves of a SIMD drift into opposite phases (one multiplies while the other reads).
+template <int S>
 __device__ __forceinline__ void role_blend_step(const RoleCtx& C, const __amdgpu_buffer_rsrc_t& feat_rsrc, unsigned feat_off,
                                                 f32x16 (&acc)[3], u32x4 (&a)[3][2], u32x4 (&bq)[3][2]) {
-  // own piece of slab S + 1 landed (with it, in order, the A fragments of this k-step): everything but the sets of the last
-  // two steps (for the first three steps: everything the prologue issued, which ended with vmcnt(0))
-  constexpr int kYoung = (S >= 3) ? role_blend_ops(S - 2, kActive) + role_blend_ops(S - 1, kActive)
-                                  : ((S >= 1 ? role_blend_ops(0, kActive) : 0) + (S >= 2 ? role_blend_ops(1, kActive) : 0));
-  __builtin_amdgcn_sched_barrier(0);   // (MFMAs are not memory operations: without this they drift across the barrier)
-  if constexpr (S >= 1) ROLE_WAIT_VM(kYoung);
-  // every wave has read slab S into registers (the reads were issued in step S - 1) and waited for its piece of slab S + 1
-  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-  __builtin_amdgcn_sched_barrier(0);
-  if constexpr (S + 4 < kBlendKSteps) role_dma_slab(C, S + 4);   // into the slot slab S has just left
-  if constexpr (kActive) {
-    const bf16x8 a_hi = __builtin_bit_cast(bf16x8, a[S % 3][0]);
-    const bf16x8 a_lo = __builtin_bit_cast(bf16x8, a[S % 3][1]);
+  const bf16x8 a_hi = __builtin_bit_cast(bf16x8, a[S % 3][0]);
+  const bf16x8 a_lo = __builtin_bit_cast(bf16x8, a[S % 3][1]);
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      const bf16x8 bhi = __builtin_bit_cast(bf16x8, bq[c][0]);
-      const bf16x8 blo = __builtin_bit_cast(bf16x8, bq[c][1]);
-      if constexpr (S == 0) {
-        f32x16 z;
+  for (int c = 0; c < 3; ++c) {
+    const bf16x8 bhi = __builtin_bit_cast(bf16x8, bq[c][0]);
+    const bf16x8 blo = __builtin_bit_cast(bf16x8, bq[c][1]);
+    if constexpr (S == 0) {
+      f32x16 z;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) z[r] = 0.0f;
-        acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, bhi, z, 0, 0, 0);
-      } else {
-        acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, bhi, acc[c], 0, 0, 0);
-      }
-      acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, blo, acc[c], 0, 0, 0);
-      acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo, bhi, acc[c], 0, 0, 0);
-      if constexpr (S + 1 < kBlendKSteps) {   // the next k-step's fragments of this coordinate, under the other coordinates' products
-        const lds_u8* sl = C.ring + ((S + 1) % kRingSlabs) * kSlabBytes + (c * 2) * 1024 + C.lane * 16;
-        bq[c][0] = *reinterpret_cast<lds_u32x4*>(sl);
-        bq[c][1] = *reinterpret_cast<lds_u32x4*>(sl + 1024);
-      }
+      for (int r = 0; r < 16; ++r) z[r] = 0.0f;
+      acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, bhi, z, 0, 0, 0);
+    } else {
+      acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, bhi, acc[c], 0, 0, 0);
     }
-    if constexpr (S + 3 < kBlendKSteps) {     // A fragments three k-steps ahead (L2; handed over in this launch: sc1)
-      const unsigned soff = feat_off + (unsigned)((S + 3) * 2 * 1024);
-      a[S % 3][0] = __builtin_amdgcn_raw_buffer_load_b128(feat_rsrc, (unsigned)(C.lane * 16), soff, kLoadSc1);
-      a[S % 3][1] = __builtin_amdgcn_raw_buffer_load_b128(feat_rsrc, (unsigned)(C.lane * 16 + 1024), soff, kLoadSc1);
+    acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, blo, acc[c], 0, 0, 0);
+    acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo, bhi, acc[c], 0, 0, 0);
+    if constexpr (S + 1 < kResident) {   // the next k-step's fragments of this coordinate, under the other coordinates' products
+      const lds_u8* sl = C.ring + role_slab_off(S + 1) + (c * 2) * 1024 + C.lane * 16;
+      bq[c][0] = *reinterpret_cast<lds_u32x4*>(sl);
+      bq[c][1] = *reinterpret_cast<lds_u32x4*>(sl + 1024);
+    } else if constexpr (S + 1 < kBlendKSteps) {   // the 14th k-step is not resident: L2 -> registers, a k-step of matrix work ahead
+      const unsigned so = C.dirs_soff + (unsigned)((S + 1) * kSlabBytes + (c * 2) * 1024);
+      bq[c][0] = __builtin_amdgcn_raw_buffer_load_b128(C.dirs_rsrc, (unsigned)(C.lane * 16), so, 0);
+      bq[c][1] = __builtin_amdgcn_raw_buffer_load_b128(C.dirs_rsrc, (unsigned)(C.lane * 16), so + 1024, 0);
     }
   }
-  if constexpr (kActive) {
-    // issue order of the step: each coordinate's three products, then the next k-step's two fragment reads of that
-    // coordinate (a whole k-step of matrix work ahead of their use), the A fragments last
-    if constexpr (S + 4 < kBlendKSteps) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // VMEM read (the slab piece)
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);                                     // MFMA
-      if constexpr (S + 1 < kBlendKSteps) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0); // DS read
-    }
-    if constexpr (S + 3 < kBlendKSteps) __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);   // VMEM read
+  if constexpr (S + 3 < kBlendKSteps) {     // A fragments three k-steps ahead (L2; handed over in this launch: sc1)
+    const unsigned soff = feat_off + (unsigned)((S + 3) * 2 * 1024);
+    a[S % 3][0] = __builtin_amdgcn_raw_buffer_load_b128(feat_rsrc, (unsigned)(C.lane * 16), soff, kLoadSc1);
+    a[S % 3][1] = __builtin_amdgcn_raw_buffer_load_b128(feat_rsrc, (unsigned)(C.lane * 16 + 1024), soff, kLoadSc1);
   }
+  // issue order of the step: each coordinate's three products, then the next k-step's two fragment reads of that
+  // coordinate (a whole k-step of matrix work ahead of their use), the A fragments last
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);                                        // MFMA
+    if constexpr (S + 1 < kResident) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);       // DS read
+    else if constexpr (S + 1 < kBlendKSteps) __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);   // VMEM read
+  }
+  if constexpr (S + 3 < kBlendKSteps) __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);     // VMEM read
   __builtin_amdgcn_sched_barrier(0);
-  asm volatile("" ::: "memory");   // the step's vector-memory set ends here (the counted waits rely on it)
 }
 
 // ---- skinning: accumulator row R (frames 2 R + h of the unit) ---------------------------------------------------------
+// The ring has four rows: row R + 4 is requested when row R has been read, three rows of work ahead of its use.
 template <int R>
 __device__ __forceinline__ void role_skin_row(const RoleCtx& C, const RoleLane& L, const f32x16 (&acc)[3],
                                               __amdgpu_buffer_rsrc_t cloud, unsigned row_off) {
-  // the row's transforms have landed: everything but the sets of the last two rows (rows 0-2 were requested before the blend)
-  if constexpr (R >= 3) ROLE_WAIT_VM(role_skin_ops(R - 2) + role_skin_ops(R - 1));
-  constexpr unsigned slot = (R % kTRing) * kTRowBytes;
+  // the row's transforms have landed: everything but the sets of the last three rows (rows 0-2 were requested at k-step 9,
+  // row 3 at the end of the blend, in front of row 0's set)
+  if constexpr (R >= 3) ROLE_WAIT_VM(role_skin_ops(R - 3) + role_skin_ops(R - 2) + role_skin_ops(R - 1));
+  const unsigned slot = (R % kTRing) == 3 ? L.slot3 : (unsigned)(R % kTRing) * kTRowBytes;
   f32x4 t[12];
   const unsigned tj[4] = {L.tj0, L.tj1, L.tj2, L.tj3};
   const float wgt[4] = {L.w0, L.w1, L.w2, L.w3};
@@ -205,7 +222,7 @@ __device__ __forceinline__ void role_skin_row(const RoleCtx& C, const RoleLane& 
     pk[k] = __float_as_uint(m.x + m.y);
   }
   __builtin_amdgcn_raw_buffer_store_b96(pk, cloud, L.out_off, row_off, kStoreAux);
-  if constexpr (R + 3 < 16) role_dma_row(C, R + 3);   // into the slot this row has just been read from
+  if constexpr (R + kTRing < 16) role_dma_row(C, R + kTRing);   // into the slot this row has been read from
   asm volatile("" ::: "memory");
 }
 
@@ -219,7 +236,8 @@ __device__ __forceinline__ void mesh_role(const DevModel& M, const DevProblem& P
   C.lane = threadIdx.x & 63;
   lds_u8* lds = (lds_u8*)lds_generic;
   C.ring = lds;
-  C.trow = lds + kBRingBytes + C.wave * kTWaveBytes;
+  C.trow = lds + kRegionABytes + C.wave * kTWaveBytes;
+  C.trow3 = lds + C.wave * kTSlot3Bytes;
   C.dirs_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(M.dirsB), 0, M.nVTiles * kBBytes, 0x00020000);
   C.dirs_soff = (unsigned)vtile * kBBytes;
   const int nFT = Pb.nFTiles;
@@ -234,11 +252,23 @@ __device__ __forceinline__ void mesh_role(const DevModel& M, const DevProblem& P
   const int v = vtile * kVTile + col;
 
   RSTAMP(0);
-  // ---- independent of the frame workgroups: the first four slabs of the operand stream, the lane's skinning weights -----
-#pragma unroll
-  for (int s = 0; s < kRingSlabs; ++s) role_dma_slab(C, s);
+  // ---- independent of the frame workgroups: thirteen of the tile's fourteen operand slabs (78 KiB), the lane's skinning
+  //      weights.  They land under the wait for the hand-off. -----------------------------------------------------------
   const uint32_t widx = M.wIdx[(size_t)vtile * 32 + col];
   const float4 wv = reinterpret_cast<const float4*>(M.wVal)[(size_t)vtile * 32 + col];
+  // The stream is a trickle, not a burst: requested all at once at the start of the launch (17 MB chip-wide) it stretched
+  // the frame workgroups' table loads by 900 cycles and their hand-off by 2 us, which every mesh workgroup then waits for.
+  // Nothing needs it before the hand-off: one slab per ~0.25 us from 1.2 us on (past the frame workgroups' table loads).
+  if (C.wave < 6) {   // six pieces per slab: waves 6 and 7 have none
+    const unsigned long long t_in = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t_in < 120) __builtin_amdgcn_s_sleep(8);
+#pragma unroll 1
+    for (int s = 0; s < kResident; ++s) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(C.dirs_rsrc, (__attribute__((address_space(3))) void*)(C.ring + role_slab_off(s) + C.piece * 1024),
+                                               16, C.slab_voff, C.dirs_soff + (unsigned)s * kSlabBytes, 0, 0);
+      __builtin_amdgcn_s_sleep(7);
+    }
+  }
   RoleLane L;
   L.w0 = wv.x; L.w1 = wv.y; L.w2 = wv.z; L.w3 = wv.w;
   const unsigned trow_addr = (unsigned)(size_t)C.trow + (unsigned)h * kRowBytes;   // LDS byte address
@@ -246,6 +276,7 @@ __device__ __forceinline__ void mesh_role(const DevModel& M, const DevProblem& P
   L.tj1 = trow_addr + ((widx >> 8) & 0xffu) * 48u;
   L.tj2 = trow_addr + ((widx >> 16) & 0xffu) * 48u;
   L.tj3 = trow_addr + (widx >> 24) * 48u;
+  L.slot3 = (unsigned)(size_t)C.trow3 - (unsigned)(size_t)C.trow;    // (mod 2^32: slot 3 lies below the ring)
   const unsigned stride = (unsigned)M.nVTiles * kVTile * 12;          // bytes per frame of the cloud
   L.out_off = (unsigned)h * stride + (unsigned)v * 12;
   const __amdgpu_buffer_rsrc_t cloud =
@@ -257,12 +288,12 @@ __device__ __forceinline__ void mesh_role(const DevModel& M, const DevProblem& P
   // ---- the group's frames have been handed over -----------------------------------------------------------------------
   if (!wait_flags()) return;   // (workgroup-uniform; includes the barrier that orders the poll before every operand load)
   RSTAMP(1);
+  // from here on the mesh role is the launch's critical path: the frame workgroup beside it is past its hand-off
+  __builtin_amdgcn_s_setprio(3);
 
   f32x16 acc[3];
   u32x4 a[3][2], bq[3][2];
   if (active) {
-#pragma unroll
-    for (int r = 0; r < kTRing; ++r) role_dma_row(C, r);
 #pragma unroll
     for (int ks = 0; ks < 3; ++ks) {
       const unsigned soff = feat_off + (unsigned)(ks * 2 * 1024);
@@ -270,32 +301,45 @@ __device__ __forceinline__ void mesh_role(const DevModel& M, const DevProblem& P
       a[ks][1] = __builtin_amdgcn_raw_buffer_load_b128(feat_rsrc, (unsigned)(C.lane * 16 + 1024), soff, kLoadSc1);
     }
   }
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // slabs 0-3, rows 0-2, A fragments 0-2
+  // every wave's pieces of the resident slabs have landed (they were requested microseconds ago; the A fragments just now)
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
   RSTAMP(2);
   if (active) {
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-      const lds_u8* sl = C.ring + (c * 2) * 1024 + C.lane * 16;
+      const lds_u8* sl = C.ring + role_slab_off(0) + (c * 2) * 1024 + C.lane * 16;
       bq[c][0] = *reinterpret_cast<lds_u32x4*>(sl);
       bq[c][1] = *reinterpret_cast<lds_u32x4*>(sl + 1024);
     }
-#define RB(S) role_blend_step<S, true>(C, feat_rsrc, feat_off, acc, a, bq)
-    RB(0); RB(1); RB(2); RB(3); RB(4); RB(5); RB(6); RB(7); RB(8); RB(9); RB(10); RB(11); RB(12); RB(13);
-#undef RB
-    // (the last steps issued nothing: every DMA of the blend has been waited for, rows 0-2 landed long ago)
-    RSTAMP(3);
-    const unsigned row0 = (unsigned)f0 * stride;
-#define RS(R) role_skin_row<R>(C, L, acc, cloud, row0 + (unsigned)(2 * (R)) * stride)
-    RS(0); RS(1); RS(2); RS(3); RS(4); RS(5); RS(6); RS(7); RS(8); RS(9); RS(10); RS(11); RS(12); RS(13); RS(14); RS(15);
-#undef RS
-    RSTAMP(4);
-  } else {
-    // a wave without frames (last group of a frame count that is not a multiple of 256) keeps the operand stream and the
-    // barriers of the others going
-#define RB(S) role_blend_step<S, false>(C, feat_rsrc, feat_off, acc, a, bq)
-    RB(0); RB(1); RB(2); RB(3); RB(4); RB(5); RB(6); RB(7); RB(8); RB(9); RB(10); RB(11); RB(12); RB(13);
-#undef RB
   }
+#define RB(S) RCYC(S); role_blend_step<S>(C, feat_rsrc, feat_off, acc, a, bq)
+  if (active) { RB(0); RB(1); RB(2); RB(3); RB(4); RB(5); RB(6); RB(7); RB(8); }
+  // k-step 9: every wave has read slabs 0-8 (region T) into registers, and slab 9 too (its reads were issued in k-step 8):
+  // region T becomes the waves' transform rings, rows 0-2 are requested now and land under the last five k-steps
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  if (active) {
+    role_dma_row(C, 0); role_dma_row(C, 1); role_dma_row(C, 2);
+    asm volatile("" ::: "memory");
+    RB(9); RB(10); RB(11); RB(12); RB(13);
+  }
+#undef RB
+  RCYC(14);
+  // every wave has read slabs 9-12 (region A): it becomes ring slot 3
+  __builtin_amdgcn_sched_barrier(0);   // (MFMAs are not memory operations: without this the last ones drift into the skinning rows)
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+  if (!active) return;
+  RSTAMP(3);
+  role_dma_row(C, 3);
+  asm volatile("" ::: "memory");
+  // rows 0-2 have landed: everything but row 3's three pieces (the blend's own loads were waited for where they were used)
+  ROLE_WAIT_VM(3);
+  const unsigned row0 = (unsigned)f0 * stride;
+#define RS(R) RCYC(16 + (R)); role_skin_row<R>(C, L, acc, cloud, row0 + (unsigned)(2 * (R)) * stride)
+  RS(0); RS(1); RS(2); RS(3); RS(4); RS(5); RS(6); RS(7); RS(8); RS(9); RS(10); RS(11); RS(12); RS(13); RS(14); RS(15);
+#undef RS
+  RCYC(32);
+  RSTAMP(4);
 }
 
 }  // namespace

@@ -218,8 +218,10 @@ def run_single(gpu_model, seq: KeypointSequence, intr, max_iters=100, beta_pose=
 
 def run_multi(gpu_model, seq: KeypointSequence, intr, max_iters_s1=1000, skip=10, wsize=20, overlap=5, beta_pose=5.0,
               beta_shape=25.0, lambda_t=3.0, out_dir: str | None = None, stage2_iters=60, faces=None, image_size=None,
-              frames_bgr=None):
-    """3dba_multi: stage 1 on the anchors (shared beta), stage 2 on sliding windows with the beta 'lock'."""
+              frames_bgr=None, trace: list | None = None):
+    """3dba_multi: stage 1 on the anchors (shared beta), stage 2 on sliding windows with the beta 'lock'.
+    trace (a list): receives a snapshot of the whole state (poses, r0, t, joint_aa, w) after every stage, for stage-by-stage
+    comparisons (tests/staged_oracle.py)."""
     F = seq.n_frames
     r0 = np.tile(synth.R0_DEFAULT.reshape(1, 3, 3), (F, 1, 1))      # avatars[i]->r[0]
     t = np.tile(np.array([0.0, 0.0, 3.0]), (F, 1))                  # avatars[i]->p
@@ -250,6 +252,12 @@ def run_multi(gpu_model, seq: KeypointSequence, intr, max_iters_s1=1000, skip=10
     for k, f in enumerate(anchors):                                 # each avatar's own w (:141-147)
         rows.append((f, float(px[k]), ms_anchor / len(anchors)))
     w[:] = w[0]                                                     # share the shape among all avatars (:154)
+
+    def snap(ids):
+        if trace is not None:
+            trace.append(dict(ids=list(ids), poses=poses.copy(), r0=r0.copy(), t=t.copy(), joint_aa=jaa.copy(), w=w.copy()))
+
+    snap(anchors)
     # ---- stage 2: sliding windows -----------------------------------------------------------------------------
     stride = wsize - overlap
     for s in range(0, F, stride):
@@ -259,6 +267,7 @@ def run_multi(gpu_model, seq: KeypointSequence, intr, max_iters_s1=1000, skip=10
         x, bw, _ = solve(ids, poses[ids].copy(), w[s].copy(), 1e5, stage2_iters)     # beta lock (Q9)
         w[s] = bw
         poses[ids] = x
+        snap(ids)
         ms_win = (time.perf_counter() - t0) * 1e3
         _, px = _updated(gpu_model, _subsequence(seq, ids), intr, r0[ids], t[ids], jaa[ids], w[ids])
         for k, f in enumerate(ids):

@@ -168,14 +168,28 @@ class TorchComm:
 
 
 def solve_window_sharded(api, gpu_model, seq, n_frames, dist, rank, world, init_params, beta0, beta_pose=5.0, beta_shape=25.0,
-                         lambda_temporal=3.0, max_iters=100, device=None, constant=None):
+                         lambda_temporal=3.0, max_iters=100, device=None, constant=None, rccl=None):
     """One window of `n_frames` frames fitted by `world` ranks (one process per GPU): every rank builds the problem of its
-    shard and calls bodyfit_solve_sharded.  Returns (x_local [f0:f1], beta, summary, shard)."""
+    shard and calls bodyfit_solve_sharded (host callbacks over torch.distributed) or, with rccl = an api.Rccl communicator,
+    bodyfit_solve_sharded_rccl.  Returns (x_local [f0:f1], beta, summary, shard)."""
     shard = make_shard(n_frames, world, rank)
     sl = slice_sequence(seq, shard)
     prob = api.Problem(gpu_model, sl["kp_offset"], sl["kp_id"], sl["kp_uv"], sl["intr"], sl["R0"], n_cols=86, use_shape=True,
                        beta_pose=beta_pose, beta_shape=beta_shape if shard.owns_shape_prior else 0.0,
                        lambda_temporal=lambda_temporal, temporal_halo=shard.halo)
-    comm = TorchComm(api, dist, rank, world, device=device)
-    x, b, summ = prob.solve_sharded(local_params(init_params, shard), beta0, comm.c, constant=constant, max_iters=max_iters)
+    if rccl is not None:      # RCCL on the solve's device buffers and stream: nothing is staged through the host
+        x, b, summ = prob.solve_sharded_rccl(local_params(init_params, shard), beta0, rccl, constant=constant, max_iters=max_iters)
+    else:
+        comm = TorchComm(api, dist, rank, world, device=device)
+        x, b, summ = prob.solve_sharded(local_params(init_params, shard), beta0, comm.c, constant=constant, max_iters=max_iters)
+    summ.exchanges = prob.last_exchange_count()     # all-gathers this solve issued (3 per LM iteration + 4 at the start)
     return x, b, summ, shard
+
+
+def make_rccl(api, dist, rank: int, world: int, device: int):
+    """An api.Rccl communicator for the ranks of a torch.distributed group: rank 0 draws the id (ncclGetUniqueId), the group's
+    own host channel ships it, every rank joins (ncclCommInitRank)."""
+    box = [api.Rccl.unique_id() if rank == 0 else None]
+    if world > 1:
+        dist.broadcast_object_list(box, src=0)
+    return api.Rccl.create(box[0], rank, world, device)

@@ -252,18 +252,39 @@ int bodyfit_solve(bodyfit_problem* p, double* frame_params, double* beta, const 
  * takes the same decisions from the same reduced scalars); the linear solve is substructured: cyclic reduction of the
  * local chain down to its two end frames, an all-gather of those 2 N interface blocks, the interface system solved by
  * every rank, local back-substitution.  The shared-shape terms [H_bb, g_beta] cross the ranks ONCE per LM iteration.
- * The communicator works on HOST buffers (the payloads are small: <= 225 KB per rank and iteration); with
- * torch.distributed that is gloo on CPU tensors or RCCL ("nccl") through a device staging tensor
- * (3dbodyanimation_amd/sharded.py: TorchComm).  Both callbacks return 0 on success.
+ * Per LM iteration the ranks exchange THREE all-gathers (the 2 N interface blocks with the beta terms riding on them, 225 KB
+ * per rank; the beta Schur partials, 110 doubles; six scalars) and every rank sums the gathered partials in rank order, so the
+ * decisions are identical everywhere without a broadcast.  Two transports:
+ *   bodyfit_solve_sharded        the caller's callback on HOST buffers (device -> host -> callback -> device; torch.distributed
+ *                                "gloo" in the tests, MPI in a C++ host).  Only `allgather` is called; `allreduce` may be NULL.
+ *   bodyfit_solve_sharded_rccl   RCCL on the solve's device buffers and stream (ncclAllGather over xGMI): no host staging and no
+ *                                stream synchronisation between the host's status reads (every fourth iteration).
+ * Both callbacks / RCCL calls must be entered by every rank of the communicator the same number of times; a rank that fails
+ * (HIP error, failed transport) returns an error while its peers wait in the next exchange, so give the process group / RCCL a
+ * timeout.
  *   frame_params [F_local (+1 halo row)][76] in/out: the halo row is refreshed from the neighbour by the solve. */
 typedef struct bodyfit_comm {
   int rank, size;
   void* ctx;
-  int (*allreduce)(void* ctx, double* buf, int n, int op /* 0 sum, 1 max */);            /* in place, every rank gets the result */
+  int (*allreduce)(void* ctx, double* buf, int n, int op /* 0 sum, 1 max */);            /* unused since round 3; may be NULL */
   int (*allgather)(void* ctx, const double* send, double* recv /* [size][n] */, int n);
 } bodyfit_comm;
 int bodyfit_solve_sharded(bodyfit_problem* p, double* frame_params, double* beta, const unsigned char* param_constant,
                           const bodyfit_comm* comm, const bodyfit_fit_options* options, bodyfit_fit_summary* summary);
+
+/* RCCL communicator of the sharded solve.  librccl is bound at run time (dlopen), so libbodyfit.so has no link-time dependency
+ * on it.  Either let the library create the communicator — rank 0 obtains the 128-byte id (ncclGetUniqueId) and ships it to the
+ * other ranks by any host channel, every rank then calls bodyfit_rccl_create (ncclCommInitRank, collective) — or hand in an
+ * ncclComm_t the application already has (bodyfit_rccl_wrap; not destroyed by bodyfit_rccl_destroy).                       */
+typedef struct bodyfit_rccl bodyfit_rccl;
+int bodyfit_rccl_unique_id(unsigned char* id128);
+int bodyfit_rccl_create(const unsigned char* id128, int rank, int size, int device, bodyfit_rccl** out);
+int bodyfit_rccl_wrap(void* nccl_comm, int rank, int size, bodyfit_rccl** out);
+void bodyfit_rccl_destroy(bodyfit_rccl* c);
+int bodyfit_solve_sharded_rccl(bodyfit_problem* p, double* frame_params, double* beta, const unsigned char* param_constant,
+                               bodyfit_rccl* comm, const bodyfit_fit_options* options, bodyfit_fit_summary* summary);
+/* all-gathers issued by the problem's last sharded solve (tests assert the number of exchanges per iteration) */
+long bodyfit_last_exchange_count(const bodyfit_problem* p);
 
 /* Normal equations of the reprojection blocks, built on the device (window solvers: bodyfit_solve's host loop,
  * 3dbodyanimation_amd/sharded_lm.py): evaluate at (frame_params, beta) and return the residual vector [total_rows], the

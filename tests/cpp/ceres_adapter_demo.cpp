@@ -1,12 +1,15 @@
 // Drives include/bodyfit_ceres.h the way ceres::Problem::Evaluate would (tests/cpp/ceres_double is an interface double, not
 // Ceres): every residual block of a shared-beta window is added to a Problem, the evaluation callback runs one device sweep,
 // every block is evaluated with Ceres' pointer conventions, and the assembled residual vector / Jacobian is compared with
-// bodyfit_evaluate_batch's.  Input blob: the format of tests/test_gpu_cpp_api.py.
+// bodyfit_evaluate_batch's.  The parameters live where the reference keeps them: one FramePoseParams per frame (scale, rootAA,
+// rootT as members, the joints in a std::vector<std::array<double,3>> whose slot 0 is unused: include/MultiFrameBA.h:9-14), so
+// nothing is contiguous.  Input blob: the format of tests/test_gpu_cpp_api.py.
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
 
+#include "bodyfit.hpp"
 #include "bodyfit_ceres.h"
 
 void ceres::HuberLoss::Evaluate(double s, double rho[3]) const {
@@ -48,19 +51,47 @@ int main(int argc, char** argv) {
   bodyfit_layout L;
   bodyfit_problem_layout(bp, &L);
 
-  // the parameters Ceres would own: FramePoseParams per frame, one shared beta
-  std::vector<double> x((size_t)F * 76, 0.0), beta(10, 0.0);
+  // the parameters Ceres would own: the reference's FramePoseParams per frame (NOT contiguous), one shared beta
+  std::vector<bodyfit::FramePoseParams> poses(F);
+  std::vector<double> beta(10, 0.0);
+  auto packed = [&](std::vector<double>& x) {     // the same point as a packed [F][76] array, for the reference evaluation
+    x.assign((size_t)F * 76, 0.0);
+    for (int i = 0; i < F; ++i) {
+      double* xi = x.data() + (size_t)i * 76;
+      xi[0] = poses[i].scale;
+      for (int c = 0; c < 3; ++c) { xi[1 + c] = poses[i].rootAA[c]; xi[4 + c] = poses[i].rootT[c]; }
+      for (int j = 1; j < 24; ++j)
+        for (int c = 0; c < 3; ++c) xi[7 + 3 * (j - 1) + c] = poses[i].jointAA[j][c];
+    }
+  };
   for (int i = 0; i < F; ++i) {
-    x[(size_t)i * 76] = 1.0 + 0.01 * i; x[(size_t)i * 76 + 6] = 3.0;
+    bodyfit::FramePoseParams& P = poses[i];
+    P.jointAA.assign(24, {0.0, 0.0, 0.0});
+    std::vector<double> xi(76, 0.0);
+    xi[0] = 1.0 + 0.01 * i; xi[6] = 3.0;
     for (int c = 1; c < 76; ++c)
-      if (c != 6) x[(size_t)i * 76 + c] += 0.05 * std::sin(0.37 * c + 1.3 * i);
+      if (c != 6) xi[c] += 0.05 * std::sin(0.37 * c + 1.3 * i);
+    P.scale = xi[0];
+    for (int c = 0; c < 3; ++c) { P.rootAA[c] = xi[1 + c]; P.rootT[c] = xi[4 + c]; }
+    for (int j = 1; j < 24; ++j)
+      for (int c = 0; c < 3; ++c) P.jointAA[j][c] = xi[7 + 3 * (j - 1) + c];
+    P.jointAA[0] = {123.0, 456.0, 789.0};   // the unused slot must not matter
   }
   for (int k = 0; k < 10; ++k) beta[k] = 0.3 * std::cos(1.1 * k);
 
   ceres::Problem problem;
-  const int n_blocks = bodyfit_ceres::AddResidualBlocks(&problem, bp, F, koff.data(), x.data(), beta.data());
+  const bodyfit_ceres::BlockTable table = bodyfit_ceres::BlocksOf(poses);
+  const int n_blocks = bodyfit_ceres::AddResidualBlocks(&problem, bp, koff.data(), table, beta.data());
   const int expect_blocks = K + F + 1 + 25 * (F - 1);
-  bodyfit_ceres::SweepCallback cb(bp, x.data(), beta.data());
+  bodyfit_ceres::SweepCallback cb(bp, table, beta.data());
+  // column of a parameter block in the dense [F x 76 | beta] layout used for the comparison
+  auto column_of = [&](const double* base) -> size_t {
+    if (base >= beta.data() && base < beta.data() + 10) return (size_t)F * 76 + (base - beta.data());
+    for (int f2 = 0; f2 < F; ++f2)
+      for (int b2 = 0; b2 < bodyfit_ceres::kFrameBlocks; ++b2)
+        if (table.frame[f2][b2] == base) return (size_t)f2 * 76 + (b2 == 0 ? 0 : b2 == 1 ? 1 : b2 == 2 ? 4 : 7 + 3 * (b2 - 3));
+    return (size_t)-1;
+  };
 
   // what ceres::Problem::Evaluate does: callback, then every block with its parameter pointers and Jacobian buffers
   cb.PrepareForEvaluation(true, true);
@@ -83,14 +114,15 @@ int main(int argc, char** argv) {
     J_all.resize((row0 + nr) * (size_t)ncol, 0.0);
     for (size_t b = 0; b < sizes.size(); ++b) {
       if (!jp[b]) continue;
-      const double* base = rec->blocks[b];
-      const size_t col = (base >= beta.data() && base < beta.data() + 10) ? (size_t)F * 76 + (base - beta.data()) : (size_t)(base - x.data());
+      const size_t col = column_of(rec->blocks[b]);
+      if (col == (size_t)-1) { ++bad; continue; }
       for (int i = 0; i < nr; ++i)
         for (int c = 0; c < sizes[b]; ++c) J_all[(row0 + i) * ncol + col + c] = jb[b][(size_t)i * sizes[b] + c];
     }
   }
   // reference: the batched evaluation of the same point
-  std::vector<double> r_ref(L.total_rows), J_ref((size_t)L.reproj_rows * 86);
+  std::vector<double> r_ref(L.total_rows), J_ref((size_t)L.reproj_rows * 86), x;
+  packed(x);
   if (bodyfit_evaluate_batch(bp, x.data(), beta.data(), r_ref.data(), J_ref.data(), nullptr, 1) != BODYFIT_OK) return 1;
   double dr = 0.0, dj = 0.0;
   if ((int)r_all.size() != L.total_rows) ++bad;
@@ -105,7 +137,8 @@ int main(int argc, char** argv) {
         }
   // a second call at the same point costs no sweep and gives the same numbers; a moved point is re-evaluated
   cb.PrepareForEvaluation(false, false);
-  x[4] += 0.01;
+  poses[0].rootT[0] += 0.01;
+  packed(x);
   cb.PrepareForEvaluation(false, true);
   std::vector<double> r2(2);
   const auto& rec0 = *problem.records()[0];

@@ -1,7 +1,9 @@
 // INTERFACE DOUBLE, test infrastructure — NOT Ceres.  Declares, with the signatures of Ceres 1.14's public headers
 // (include/ceres/cost_function.h, evaluation_callback.h, loss_function.h, problem.h), exactly the members that
 // include/bodyfit_ceres.h uses, so that the adapter can be compiled and its blocks driven the way
-// ceres::Problem::Evaluate drives them.  Ceres itself is not in this repository's image.  No solver here.
+// ceres::Problem::Evaluate drives them, plus the three names INTEGRATION.md's snippet mentions (Solver::Options with its
+// evaluation_callback member, Solver::Summary, Solve: DECLARED only, so the snippet can be syntax-checked).  Ceres itself is
+// not in this repository's image.  No solver here.
 #pragma once
 #include <memory>
 #include <vector>
@@ -62,5 +64,12 @@ class Problem {
  private:
   std::vector<std::unique_ptr<ResidualBlockRecord>> records_;
 };
+
+class Solver {
+ public:
+  struct Options { EvaluationCallback* evaluation_callback = nullptr; int max_num_iterations = 50; };
+  struct Summary {};
+};
+void Solve(const Solver::Options& options, Problem* problem, Solver::Summary* summary);   // declared, never defined
 
 }  // namespace ceres

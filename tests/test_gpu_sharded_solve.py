@@ -27,6 +27,11 @@ def _worker(rank, world, port, F, iters, out_path):
     gm = api.Model(model, device=0)
     x, b, summ, shard = sharded.solve_window_sharded(api, gm, seq, F, dist, rank, world, seq.init_params, np.zeros(10),
                                                      max_iters=iters)
+    # three all-gathers per launched iteration (interface blocks + beta terms, Schur partials, scalars) and four at the start
+    # (boundary rows, initial cost, the first iteration's beta terms and scaling rows); the host looks at the status every
+    # fourth iteration, so up to three iterations are launched beyond the last counted one
+    n_loop, rem = divmod(summ.exchanges - 4, 3)
+    assert rem == 0 and summ.iterations <= n_loop <= min(iters, summ.iterations + 3), (summ.exchanges, summ.iterations)
     parts = [None] * world
     dist.all_gather_object(parts, (shard.f0, shard.f1, x, b, summ.iterations, summ.n_successful, summ.final_cost,
                                    summ.initial_cost))
@@ -55,3 +60,32 @@ def test_sharded_solve_equals_unsharded(tmp_path, world, F, iters):
     assert abs(float(g["c0"]) - float(g["c02"])) <= 1e-12 * float(g["c02"])
     assert abs(float(g["cost"]) - float(g["cost2"])) <= 1e-9 * float(g["cost2"])
     assert np.abs(g["x"][:, 1:] - g["x2"][:, 1:]).max() < 1e-7 and np.abs(g["b"] - g["b2"]).max() < 1e-7
+
+
+def test_rccl_transport_single_rank(monkeypatch):
+    """bodyfit_solve_sharded_rccl with the exchanges as real RCCL all-gathers on the device buffers and the solve's stream.
+    A test box has ONE GPU, so the communicator has one rank; BODYFIT_FORCE_SHARDED=1 makes that rank still take the sharded
+    code path (its two end frames as the interface system, every exchange issued through ncclAllGather).  The result must be
+    the unsharded device window LM's."""
+    import torch  # noqa: F401  (one HIP runtime / one librccl in the process)
+    sys.path.insert(0, ROOT)
+    api = importlib.import_module("3dbodyanimation_amd.api")
+    synth = importlib.import_module("3dbodyanimation_amd.synth")
+    sharded = importlib.import_module("3dbodyanimation_amd.sharded")
+    model = synth.make_model(0)
+    F, iters = 24, 10
+    seq = synth.make_sequence(model, F, seed=6)
+    gm = api.Model(model, device=0)
+    comm = api.Rccl.create(api.Rccl.unique_id(), 0, 1, 0)
+    monkeypatch.setenv("BODYFIT_FORCE_SHARDED", "1")
+    x, b, summ, shard = sharded.solve_window_sharded(api, gm, seq, F, None, 0, 1, seq.init_params, np.zeros(10), max_iters=iters,
+                                                     rccl=comm)
+    monkeypatch.delenv("BODYFIT_FORCE_SHARDED")
+    comm.close()
+    n_loop, rem = divmod(summ.exchanges - 4, 3)
+    assert rem == 0 and summ.iterations <= n_loop <= iters
+    prob = api.Problem.from_sequence(gm, seq, n_cols=86, use_shape=True, beta_pose=5.0, beta_shape=25.0, lambda_temporal=3.0)
+    x2, b2, s2 = prob.solve(seq.init_params, np.zeros(10), independent=False, max_iters=iters, scale_bounds=(-1e300, 1e300), solver=3)
+    assert (summ.iterations, summ.n_successful) == (s2[0].iterations, s2[0].n_successful)
+    assert abs(summ.final_cost - s2[0].final_cost) <= 1e-9 * s2[0].final_cost
+    assert np.abs(x[:, 1:] - x2[:, 1:]).max() < 1e-7 and np.abs(b - b2).max() < 1e-7

@@ -22,7 +22,8 @@ lib = api.load_library()
 nvt = (6890 + 31) // 32
 nG = (F + 255) // 256
 BASE = 1 << 20
-buf = torch.zeros(BASE + nG * nvt * 8 * 16 + 64, dtype=torch.int64, device="cuda")
+CYC = BASE + (1 << 19)
+buf = torch.zeros(CYC + nG * nvt * 8 * 40 + 64, dtype=torch.int64, device="cuda")
 lib.bodyfit_debug_set_stamp_buffer.argtypes = [C.c_void_p, C.c_void_p]
 lib.bodyfit_debug_set_stamp_buffer(prob.h, buf.data_ptr())
 x = torch.from_numpy(seq.gt_params + 0.01).cuda()
@@ -36,7 +37,7 @@ ms = raw[BASE:BASE + nG * nvt * 8 * 16].reshape(nG * nvt, 8, 16).astype(np.float
 t0 = min(fr[:, 0, 10].min(), ms[:, :, 0].min())
 us = lambda a: (a - t0) / 100.0
 def q(a):
-    a = np.asarray(a).ravel()
+    a = np.asarray(a, dtype=np.float64).ravel()
     return f"min {a.min():6.2f}  med {np.median(a):6.2f}  max {a.max():6.2f}"
 print(f"F = {F}; all times in us after the first workgroup's entry")
 print("frame role: entry              ", q(us(fr[:, 0, 10])))
@@ -48,9 +49,13 @@ pub = us(fr[:, 7, 12])
 late = np.argsort(pub)[-24:]
 print("frame role: latest 24 hand-offs (frame: us):", " ".join(f"{int(i)}:{pub[i]:.1f}" for i in late))
 print("frame role: hand-off percentiles 50/90/95/99/100:", np.percentile(pub, [50, 90, 95, 99, 100]).round(2))
+xcc = fr[:, 0, 9].astype(int)
+print("frame role: median hand-off by XCD:", " ".join(f"{x}:{np.median(pub[xcc == x]):.2f}/{pub[xcc == x].max():.2f}(n={int((xcc == x).sum())})" for x in sorted(set(xcc))))
+print("frame role: XCD of block b (first 16 blocks):", xcc[:16])
 print("frame role: end                ", q(us(fr[:, :, 11].max(1))))
 print("mesh role: entry               ", q(us(ms[:, :, 0])))
 print("mesh role: flags seen          ", q(us(ms[:, :, 1])))
+print("mesh role wave 7: polling from ", q(us(ms[:, 7, 5])), "| last poll issued", q(us(ms[:, 7, 6])), "| polls", q(ms[:, 7, 7] * 100.0 + t0 - t0) if False else q(ms[:, 7, 7]))
 print("mesh role: blend starts        ", q(us(ms[:, :, 2])))
 print("mesh role: blend done          ", q(us(ms[:, :, 3])))
 print("mesh role: skinning done       ", q(us(ms[:, :, 4])))
@@ -61,4 +66,17 @@ names = ["A tables", "B rodrigues/offsets", "C chain walks / landmark items", "C
 print("frame role phases, shader cycles (median over frames of the slowest wave | per wave 0..7):")
 for i, n in enumerate(names):
     print(f"  {n:32s} {int(np.median(cyc[:, :, i].max(1))):6d} |", np.median(cyc[:, :, i], axis=0).astype(int))
+is_late = pub > np.percentile(pub, 85)
+print("late frames (top 15 % hand-off) vs the rest, slowest-wave cycles per phase:")
+for i, n in enumerate(names):
+    print(f"  {n:32s} late {int(np.median(cyc[is_late][:, :, i].max(1))):6d}   rest {int(np.median(cyc[~is_late][:, :, i].max(1))):6d}")
 print("frame role total cycles (median):", int(np.median(fr[:, :, 8].max(1) - fr[:, :, 0].min(1))))
+
+cy = raw[CYC:CYC + nG * nvt * 8 * 40].reshape(nG * nvt, 8, 40).astype(np.float64)
+steps = np.diff(cy[:, :, 0:15], axis=2)
+rows = np.diff(cy[:, :, 16:33], axis=2)
+print("mesh role blend k-steps, shader cycles (median over tiles; waves 0-3 | waves 4-7):")
+print("   ", np.median(steps[:, :4], axis=(0, 1)).astype(int), "|", np.median(steps[:, 4:], axis=(0, 1)).astype(int))
+print("mesh role skinning rows, shader cycles (median over tiles and waves):")
+print("   ", np.median(rows, axis=(0, 1)).astype(int))
+print("blend total cycles (median)", int(np.median(cy[:, :, 14] - cy[:, :, 0])), " skin total", int(np.median(cy[:, :, 32] - cy[:, :, 16])))
