@@ -60,6 +60,30 @@ struct Allocs {
   }
 };
 
+// a page-locked host buffer (hipHostMalloc): the host side of every copy of the Ceres-kept path.  From pageable memory the
+// runtime stages a copy through its own bounce buffers in chunks, synchronously: 9 MB of Jacobian per 256-frame sweep came
+// back at ~17 GB/s and the sweep's parameters went up behind a stall; page-locked, both are single DMA transfers that are
+// asynchronous on the problem's copy stream.
+template <typename T>
+struct Pinned {
+  T* p = nullptr;
+  size_t n = 0;
+  ~Pinned() { if (p) (void)hipHostFree(p); }
+  hipError_t ensure(size_t want) {
+    if (want <= n) return hipSuccess;
+    if (p) (void)hipHostFree(p);
+    p = nullptr; n = 0;
+    void* q = nullptr;
+    const hipError_t e = hipHostMalloc(&q, std::max<size_t>(want, 1) * sizeof(T), hipHostMallocDefault);
+    if (e == hipSuccess) { p = static_cast<T*>(q); n = want; }
+    return e;
+  }
+  T* data() { return p; }
+  const T* data() const { return p; }
+  T& operator[](size_t i) { return p[i]; }
+  const T& operator[](size_t i) const { return p[i]; }
+};
+
 }  // namespace
 
 struct bodyfit_model {
@@ -123,8 +147,11 @@ struct bodyfit_problem {
   // host cache of the last batched evaluation (serves bodyfit_evaluate_block)
   std::mutex mu;
   bool cache_valid = false, cache_has_jac = false;
-  std::vector<double> c_params, c_beta, c_r, c_J;
-  std::vector<int> c_comp;
+  // (page-locked mirrors: the sweep's parameters go up from them, its residuals / Jacobian / components come back into them)
+  Pinned<double> c_params, c_beta, c_r, c_J;
+  Pinned<int> c_comp;
+  size_t c_npar = 0, c_nbeta = 0;       // valid entries of c_params / c_beta
+  hipStream_t copy_stream = nullptr;   // the Ceres-kept path's own stream (H2D, sweep, D2H)
   Allocs mem;
 };
 
@@ -737,6 +764,7 @@ void bodyfit_problem_destroy(bodyfit_problem* p) {
   if (!p) return;
   (void)hipSetDevice(p->m->device);
   if (p->lm_stream) (void)hipStreamDestroy(p->lm_stream);
+  if (p->copy_stream) (void)hipStreamDestroy(p->copy_stream);
   delete p;
 }
 
@@ -778,28 +806,32 @@ int bodyfit_evaluate_batch(bodyfit_problem* p, const double* frame_params, const
   std::lock_guard<std::mutex> lock(p->mu);
   const size_t npar = (size_t)p->n_param_rows * npose;
   const size_t nbeta = has_beta ? (size_t)(p->desc.beta_per_frame ? p->d.F * m->nS : m->nS) : 0;
-  HIP_TRY(hipMemcpyAsync(p->d_params, frame_params, npar * sizeof(double), hipMemcpyHostToDevice, nullptr));
-  if (nbeta) HIP_TRY(hipMemcpyAsync(p->d_beta, beta, nbeta * sizeof(double), hipMemcpyHostToDevice, nullptr));
   const int wj = (want_jacobian && p->lay.reproj_rows > 0) ? 1 : 0;
-  int rc = sweep(p, p->d_params, has_beta ? p->d_beta : nullptr, wj, p->desc.want_mesh != 0, nullptr);
+  const size_t nr = (size_t)p->lay.total_rows, nJ = (size_t)p->lay.reproj_rows * p->lay.n_cols;
+  // everything crosses PCIe from / into page-locked mirrors, on the problem's own stream
+  HIP_TRY(p->c_params.ensure(npar)); HIP_TRY(p->c_beta.ensure(nbeta)); HIP_TRY(p->c_r.ensure(nr));
+  HIP_TRY(p->c_comp.ensure((size_t)p->d.F));
+  if (wj) HIP_TRY(p->c_J.ensure(nJ));
+  if (!p->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&p->copy_stream, hipStreamNonBlocking));
+  hipStream_t st = p->copy_stream;
+  p->cache_valid = false;
+  std::memcpy(p->c_params.data(), frame_params, npar * sizeof(double));
+  if (nbeta) std::memcpy(p->c_beta.data(), beta, nbeta * sizeof(double));
+  p->c_npar = npar; p->c_nbeta = nbeta;
+  HIP_TRY(hipMemcpyAsync(p->d_params, p->c_params.data(), npar * sizeof(double), hipMemcpyHostToDevice, st));
+  if (nbeta) HIP_TRY(hipMemcpyAsync(p->d_beta, p->c_beta.data(), nbeta * sizeof(double), hipMemcpyHostToDevice, st));
+  int rc = sweep(p, p->d_params, has_beta ? p->d_beta : nullptr, wj, p->desc.want_mesh != 0, st);
   if (rc) return rc;
-  p->c_params.assign(frame_params, frame_params + npar);
-  p->c_beta.assign(beta ? beta : frame_params, (beta ? beta : frame_params) + nbeta);
-  p->c_r.resize((size_t)p->lay.total_rows);
-  p->c_comp.resize((size_t)p->d.F);
-  HIP_TRY(hipMemcpyAsync(p->c_r.data(), p->d_r, p->c_r.size() * sizeof(double), hipMemcpyDeviceToHost, nullptr));
-  HIP_TRY(hipMemcpyAsync(p->c_comp.data(), p->d_comp, p->c_comp.size() * sizeof(int), hipMemcpyDeviceToHost, nullptr));
-  if (wj) {
-    p->c_J.resize((size_t)p->lay.reproj_rows * p->lay.n_cols);
-    HIP_TRY(hipMemcpyAsync(p->c_J.data(), p->d_J, p->c_J.size() * sizeof(double), hipMemcpyDeviceToHost, nullptr));
-  }
-  HIP_TRY(hipStreamSynchronize(nullptr));
+  HIP_TRY(hipMemcpyAsync(p->c_r.data(), p->d_r, nr * sizeof(double), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(p->c_comp.data(), p->d_comp, (size_t)p->d.F * sizeof(int), hipMemcpyDeviceToHost, st));
+  if (wj) HIP_TRY(hipMemcpyAsync(p->c_J.data(), p->d_J, nJ * sizeof(double), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
   if (int fc = fused_check(p)) return fc;
   p->cache_valid = true;
   p->cache_has_jac = wj != 0;
-  if (residuals) std::memcpy(residuals, p->c_r.data(), p->c_r.size() * sizeof(double));
-  if (jacobian && wj) std::memcpy(jacobian, p->c_J.data(), p->c_J.size() * sizeof(double));
-  if (gmm_comp) std::memcpy(gmm_comp, p->c_comp.data(), p->c_comp.size() * sizeof(int));
+  if (residuals) std::memcpy(residuals, p->c_r.data(), nr * sizeof(double));
+  if (jacobian && wj) std::memcpy(jacobian, p->c_J.data(), nJ * sizeof(double));
+  if (gmm_comp) std::memcpy(gmm_comp, p->c_comp.data(), (size_t)p->d.F * sizeof(int));
   return BODYFIT_OK;
 }
 
@@ -1596,8 +1628,9 @@ int bodyfit_evaluate_block(bodyfit_problem* p, int kind, int index, const double
   } else {
     frame = index;
   }
-  // gather the caller's parameter blocks into the packed frame row
-  std::vector<double> x(npose), b(nS, 0.0);
+  // gather the caller's parameter blocks into the packed frame row (stack arrays: this function runs once per residual
+  // block and Ceres thread, nothing on its hit path allocates)
+  double x[kFrameParams] = {0.0}, b[kMaxShape] = {0.0};
   if (kind == 0) {
     x[0] = parameters[0][0];
     for (int i = 0; i < 3; ++i) { x[1 + i] = parameters[1][i]; x[4 + i] = parameters[2][i]; }
@@ -1615,15 +1648,15 @@ int bodyfit_evaluate_block(bodyfit_problem* p, int kind, int index, const double
     if (hit) {
       const double* cx = p->c_params.data() + (size_t)frame * npose;
       const int i0 = (kind == 0) ? 0 : 7;
-      hit = std::memcmp(cx + i0, x.data() + i0, (size_t)(npose - i0) * sizeof(double)) == 0;
+      hit = p->c_npar == (size_t)p->n_param_rows * npose && std::memcmp(cx + i0, x + i0, (size_t)(npose - i0) * sizeof(double)) == 0;
       if (hit && kind == 0 && has_beta) {
         const double* cb = p->c_beta.data() + (p->desc.beta_per_frame ? (size_t)frame * nS : 0);
-        hit = std::memcmp(cb, b.data(), (size_t)nS * sizeof(double)) == 0;
+        hit = std::memcmp(cb, b, (size_t)nS * sizeof(double)) == 0;
       }
     }
     if (!hit) {
       // refresh the cached parameter set with this frame's values and sweep again
-      std::vector<double> par = p->c_params, be = p->c_beta;
+      std::vector<double> par(p->c_params.data(), p->c_params.data() + p->c_npar), be(p->c_beta.data(), p->c_beta.data() + p->c_nbeta);
       if (par.size() != (size_t)p->n_param_rows * npose) {
         par.assign((size_t)p->n_param_rows * npose, 0.0);
         for (int f = 0; f < p->n_param_rows; ++f) { par[(size_t)f * npose] = 1.0; par[(size_t)f * npose + 6] = 3.0; }
@@ -1631,9 +1664,9 @@ int bodyfit_evaluate_block(bodyfit_problem* p, int kind, int index, const double
       const size_t nb = has_beta ? (size_t)(p->desc.beta_per_frame ? p->d.F * nS : nS) : 0;
       if (be.size() != nb) be.assign(nb, 0.0);
       const int i0 = (kind == 0) ? 0 : 7;
-      std::memcpy(par.data() + (size_t)frame * npose + i0, x.data() + i0, (size_t)(npose - i0) * sizeof(double));
+      std::memcpy(par.data() + (size_t)frame * npose + i0, x + i0, (size_t)(npose - i0) * sizeof(double));
       if (kind == 0 && has_beta)
-        std::memcpy(be.data() + (p->desc.beta_per_frame ? (size_t)frame * nS : 0), b.data(), (size_t)nS * sizeof(double));
+        std::memcpy(be.data() + (p->desc.beta_per_frame ? (size_t)frame * nS : 0), b, (size_t)nS * sizeof(double));
       lock.unlock();
       int rc = bodyfit_evaluate_batch(p, par.data(), nb ? be.data() : nullptr, nullptr, nullptr, nullptr, 1);
       if (rc) return rc;

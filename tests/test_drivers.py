@@ -207,13 +207,10 @@ def test_staging_against_the_checkers_staged_run(gpu_model, model):
     # the root orientations incl. the twice-solved overlap frames (Q8), translations and joint angles of the write-back
     for st_got, st_want in zip(trace, want["stages"]):
         assert st_got["ids"] == st_want["ids"]
-        d, _ = gauge_free_diff(st_got["poses"], st_want["poses"])
-        assert d < 1e-6, (st_got["ids"][0], d)
-        assert np.abs(st_got["w"] - st_want["w"]).max() < 1e-6
-        assert np.abs(st_got["r0"] - st_want["r0"]).max() < 1e-6
-        assert np.abs(st_got["joint_aa"] - st_want["joint_aa"]).max() < 1e-6
-        s_ = np.abs(st_got["poses"][:, :1])
-        assert np.abs(st_got["t"] / s_ - st_want["t"] / s_).max() < 1e-5
+        # (raw parameters: from equal starting states the two LMs walk the same path, so no gauge has to be factored out —
+        #  and it could not be: OptimizeMultiFrame sets no bounds on the scale, which passes through 0 in this sequence)
+        for key in ("poses", "w", "r0", "t", "joint_aa"):
+            assert np.abs(st_got[key] - st_want[key]).max() < 1e-6, (st_got["ids"][0], key)
     # the overlap frames were solved twice: their root orientation is NOT what a single solve leaves (Q8)
     assert np.abs(trace[2]["r0"][15:20] - trace[1]["r0"][15:20]).max() > 1e-3
     assert np.abs(got["w"][[0, 15, 30]]).max() < 1e-3 and np.abs(got["w"][1]).max() > 1e-3      # Q9
@@ -229,4 +226,6 @@ def test_staging_against_the_checkers_staged_run(gpu_model, model):
         d, ok = gauge_free_diff(single["params"][k], ws[f]["x"])
         assert d < 1e-4 and ok, (f, d)
         assert np.abs(single["r0"][k].reshape(3, 3) - ws[f]["r0"]).max() < 1e-4
-        assert abs(single["log"][k][1] - ws[f]["px"]) < 1e-3 * max(1.0, ws[f]["px"])
+        # (the log's pixel error is NOT compared here: it is taken without the Sim3 scale (Q5) and so depends on where along the
+        #  exact null direction (s, t) -> (c s, c t) a converged single-frame fit happens to stop — two correct solvers differ
+        #  there (tests/test_gpu_fit.py::gauge_free_diff); the multi-frame stages above walk identical paths and do compare it)

@@ -202,3 +202,29 @@ def test_c5_stage1_103_anchors_against_oracle_evaluator(api, synth, model, gpu_m
         assert np.abs(J[k0:k1] - Jo[k0:k1]).max() <= 1e-9 * max(1.0, np.abs(Jo[k0:k1]).max())
     K = prob.layout.n_keypoints
     assert np.sqrt((r[:K2].reshape(K, 2) ** 2).sum(1)).mean() < 2.5
+
+
+def test_c5_stage1_103_anchors_against_the_checkers_lm(api, synth, model, gpu_model, oracle_mod, omodel):
+    """BASELINE configs[4], stage 1 at its real size (103 anchors, 7,838 unknowns, src/main_multi_frame.cpp:109-134; solver
+    configuration include/MultiFrameBA.h:144-151): the FIT of the device window LM against the checker's LM — the oracle
+    evaluator under oracle/lm_dense.py in its scipy.sparse form (same rows and rules as the dense form: tests/test_oracle.py) —
+    iterate for iterate over 30 iterations from the reference's initial state."""
+    seq = synth.make_sequence(model, 1024, seed=3)
+    ids = list(range(0, 1024, 10))
+    class S: pass
+    s = S(); offs = [0]; kid = []; uv = []
+    for f in ids:
+        k0, k1 = seq.kp_offset[f], seq.kp_offset[f + 1]
+        kid.append(seq.kp_id[k0:k1]); uv.append(seq.kp_uv[k0:k1]); offs.append(offs[-1] + k1 - k0)
+    s.kp_offset = np.array(offs, np.int32); s.kp_id = np.concatenate(kid); s.kp_uv = np.concatenate(uv)
+    s.intr = seq.intr; s.R0 = seq.R0[ids]
+    assert len(ids) == 103
+    prob = api.Problem.from_sequence(gpu_model, s, n_cols=86, use_shape=True, beta_pose=5.0, beta_shape=25.0, lambda_temporal=3.0)
+    for iters in (8, 30):
+        x, b, summ = prob.solve(seq.init_params[ids], np.zeros(10), independent=False, max_iters=iters, scale_bounds=(-1e300, 1e300),
+                                solver=3)
+        xo, bo, info = _lm(oracle_mod).solve(omodel, s, seq.init_params[ids], np.zeros(10), n_cols=86, use_shape=True, beta_pose=5.0,
+                                            beta_shape=25.0, lam=3.0, max_iters=iters, scale_bounds=(-1e300, 1e300), sparse=True)
+        assert (summ[0].iterations, summ[0].n_successful) == (info["iterations"], info["n_ok"])
+        assert abs(summ[0].final_cost - info["final_cost"]) < 1e-8 * info["final_cost"]
+        assert np.abs(x - xo).max() < 1e-6 and np.abs(b - bo).max() < 1e-6

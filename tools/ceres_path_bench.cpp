@@ -1,0 +1,118 @@
+// Throughput of the Ceres-kept path (north_star: "the Ceres outer loop is kept"): what a ceres::Solve over
+// include/bodyfit_ceres.h pays per evaluation point — the EvaluationCallback's device sweep with its PCIe copies
+// (parameters up, residuals and Jacobian down, page-locked mirrors) and every residual block's Evaluate slicing that sweep
+// with Ceres' pointer conventions.  Ceres itself is not in this image: the blocks are driven through the interface double
+// tests/cpp/ceres_double exactly the way ceres::Problem::Evaluate drives them (include/Sim3BA.h:263-264,420,476-479).
+// usage: ceres_path_bench <blob> <mode: c3 | c4> <seconds>      (blob: the format of tests/test_gpu_cpp_api.py)
+// prints one JSON object.
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "bodyfit.hpp"
+#include "bodyfit_ceres.h"
+
+void ceres::HuberLoss::Evaluate(double s, double rho[3]) const {
+  if (s > b_) { const double r = std::sqrt(s); rho[0] = 2 * a_ * r - b_; rho[1] = a_ / r; rho[2] = -rho[1] / (2 * s); }
+  else { rho[0] = s; rho[1] = 1; rho[2] = 0; }
+}
+
+template <typename T>
+static std::vector<T> rd(FILE* f, size_t n) {
+  std::vector<T> v(n);
+  if (n && fread(v.data(), sizeof(T), n, f) != n) { std::fprintf(stderr, "short read\n"); std::exit(2); }
+  return v;
+}
+
+int main(int argc, char** argv) {
+  if (argc < 4) return 2;
+  FILE* f = std::fopen(argv[1], "rb");
+  if (!f) return 2;
+  const std::string mode = argv[2];
+  const double seconds = std::atof(argv[3]);
+  auto hdr = rd<int>(f, 7);
+  const int V = hdr[0], nJ = hdr[1], nS = hdr[2], P = hdr[3], nL = hdr[4], F = hdr[5], K = hdr[6];
+  auto vt = rd<double>(f, (size_t)V * 3), sd = rd<double>(f, (size_t)V * 3 * nS), pd = rd<double>(f, (size_t)V * 3 * P),
+       jr = rd<double>(f, (size_t)nJ * V), w = rd<double>(f, (size_t)V * nJ);
+  auto parent = rd<int>(f, nJ), lvid = rd<int>(f, nL), koff = rd<int>(f, F + 1), kid = rd<int>(f, K);
+  auto uv = rd<double>(f, (size_t)2 * K), intr = rd<double>(f, 4);
+  std::fclose(f);
+  const bool c3 = mode == "c3";   // c3: independent frames, own beta each, mesh on; c4: one shared-beta window
+
+  bodyfit_model_desc md{V, nJ, nS, P, vt.data(), sd.data(), pd.data(), jr.data(), w.data(), parent.data(), nL, lvid.data()};
+  bodyfit_model* model = nullptr;
+  if (bodyfit_model_create(&md, 0, &model) != BODYFIT_OK) { std::fprintf(stderr, "%s\n", bodyfit_last_error()); return 1; }
+  std::vector<double> R0((size_t)F * 9, 0.0);
+  for (int i = 0; i < F; ++i) R0[i * 9] = R0[i * 9 + 4] = R0[i * 9 + 8] = -1.0;
+  bodyfit_problem_desc pdsc{};
+  pdsc.n_frames = F; pdsc.kp_offset = koff.data(); pdsc.kp_id = kid.data(); pdsc.kp_uv = uv.data();
+  pdsc.fx = intr[0]; pdsc.fy = intr[1]; pdsc.cx = intr[2]; pdsc.cy = intr[3];
+  pdsc.R0 = R0.data(); pdsc.n_cols = 86; pdsc.use_shape = 1; pdsc.pose_blend = 1; pdsc.huber_delta = 3.0;
+  if (c3) { pdsc.beta_per_frame = 1; pdsc.beta_pose = 20.0; pdsc.beta_shape = 30.0; pdsc.want_mesh = 1; }
+  else { pdsc.beta_pose = 5.0; pdsc.beta_shape = 25.0; pdsc.lambda_temporal = 3.0; }
+  bodyfit_problem* bp = nullptr;
+  if (bodyfit_problem_create(model, &pdsc, &bp) != BODYFIT_OK) { std::fprintf(stderr, "%s\n", bodyfit_last_error()); return 1; }
+
+  // the reference's own parameter memory: FramePoseParams per frame (not contiguous), beta
+  std::vector<bodyfit::FramePoseParams> poses(F);
+  for (int i = 0; i < F; ++i) {
+    poses[i].scale = 1.0; poses[i].jointAA.assign(24, {0.0, 0.0, 0.0});
+    for (int c = 0; c < 3; ++c) { poses[i].rootAA[c] = 0.01 * (c + 1); poses[i].rootT[c] = c == 2 ? 3.0 : 0.0; }
+    for (int j = 1; j < 24; ++j)
+      for (int c = 0; c < 3; ++c) poses[i].jointAA[j][c] = 0.05 * std::sin(0.37 * (3 * j + c) + 1.3 * i);
+  }
+  std::vector<double> beta((size_t)(c3 ? F : 1) * 10, 0.1);
+  ceres::Problem problem;
+  const bodyfit_ceres::BlockTable table = bodyfit_ceres::BlocksOf(poses);
+  bodyfit_ceres::AddOptions ao;
+  ao.beta_per_frame = c3;
+  const int n_blocks = bodyfit_ceres::AddResidualBlocks(&problem, bp, koff.data(), table, beta.data(), ao);
+  bodyfit_ceres::SweepCallback cb(bp, table, beta.data());
+
+  // Jacobian buffers of the largest block, reused (Ceres owns such scratch per thread)
+  size_t max_res = 0, max_blocks = 0;
+  for (const auto& rec : problem.records()) {
+    max_res = std::max<size_t>(max_res, rec->cost->num_residuals());
+    max_blocks = std::max(max_blocks, rec->cost->parameter_block_sizes().size());
+  }
+  std::vector<double> r(max_res);
+  std::vector<std::vector<double>> jb(max_blocks, std::vector<double>(max_res * 10));
+  std::vector<double*> jp(max_blocks);
+  for (size_t b = 0; b < max_blocks; ++b) jp[b] = jb[b].data();
+
+  auto one_point = [&](int it) -> bool {
+    poses[it % F].rootT[0] += 1e-6;                       // a new evaluation point
+    cb.PrepareForEvaluation(true, true);                  // ONE device sweep, copies included
+    if (!cb.ok()) return false;
+    for (const auto& rec : problem.records())             // what ceres::Problem::Evaluate does with every block
+      if (!rec->cost->Evaluate(rec->blocks.data(), r.data(), jp.data())) return false;
+    return true;
+  };
+  for (int it = 0; it < 3; ++it)
+    if (!one_point(it)) { std::fprintf(stderr, "evaluation failed: %s\n", bodyfit_last_error()); return 1; }
+  int n = 0;
+  double t_sweep = 0.0;
+  const auto t0 = std::chrono::steady_clock::now();
+  double el = 0.0;
+  while (el < seconds) {
+    const auto a = std::chrono::steady_clock::now();
+    poses[n % F].rootT[0] += 1e-6;
+    cb.PrepareForEvaluation(true, true);
+    const auto b = std::chrono::steady_clock::now();
+    t_sweep += std::chrono::duration<double>(b - a).count();
+    for (const auto& rec : problem.records())
+      if (!rec->cost->Evaluate(rec->blocks.data(), r.data(), jp.data())) return 1;
+    ++n;
+    el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  }
+  std::printf("{\"mode\": \"%s\", \"frames\": %d, \"blocks\": %d, \"points\": %d, \"points_per_s\": %.1f, \"evals_per_s\": %.1f, "
+              "\"blocks_per_s\": %.1f, \"sweep_with_copies_us\": %.1f, \"blocks_us_per_point\": %.1f}\n",
+              mode.c_str(), F, n_blocks, n, n / el, n / el * F, n / el * n_blocks, t_sweep / n * 1e6, (el - t_sweep) / n * 1e6);
+  bodyfit_problem_destroy(bp);
+  bodyfit_model_destroy(model);
+  return 0;
+}
