@@ -116,6 +116,11 @@ class DeviceViews(C.Structure):
 _lib = None
 
 
+def launch_count() -> int:
+    """kernels launched through the library by this process so far (bodyfit_launch_count)"""
+    return int(load_library().bodyfit_launch_count())
+
+
 def declared_symbols() -> list[str]:
     """Every function include/bodyfit.h declares (used by the ABI test)."""
     txt = open(HEADER_PATH).read()
@@ -166,6 +171,8 @@ def load_library():
     lib.bodyfit_rccl_wrap.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
     lib.bodyfit_rccl_destroy.argtypes = [C.c_void_p]
     lib.bodyfit_rccl_destroy.restype = None
+    lib.bodyfit_launch_count.argtypes = []
+    lib.bodyfit_launch_count.restype = C.c_long
     lib.bodyfit_last_exchange_count.argtypes = [C.c_void_p]
     lib.bodyfit_last_exchange_count.restype = C.c_long
     lib.bodyfit_forward.argtypes = [C.c_void_p, _dp, _dp, _dp, _fp]

@@ -18,6 +18,10 @@
 
 using namespace bodyfit;
 
+namespace bodyfit {
+std::atomic<long> g_launch_count{0};
+}
+
 namespace {
 
 thread_local std::string g_err;
@@ -1483,6 +1487,7 @@ int bodyfit_solve_sharded_rccl(bodyfit_problem* p, double* frame_params, double*
 }
 
 long bodyfit_last_exchange_count(const bodyfit_problem* p) { return p ? p->last_exchanges : 0; }
+long bodyfit_launch_count(void) { return g_launch_count.load(std::memory_order_relaxed); }
 
 int bodyfit_internal_fail(int code, const char* msg) { return fail(code, msg ? msg : ""); }
 
@@ -1588,11 +1593,59 @@ double bodyfit_mean_pixel_error(int n_kp, const int* jid, const double* uv, cons
 // ceres::CostFunction::Evaluate for one block, served from the cached sweep when the caller's
 // parameters match it; otherwise the affected frame is re-evaluated on the device first.
 // ------------------------------------------------------------------------------------------------
+// kinds 0 / 1 of bodyfit_evaluate_block from the cached sweep (page-locked mirrors of the last bodyfit_evaluate_batch)
+static void serve_block(bodyfit_problem* p, int kind, int index, int frame, double* residuals, double** jacobians) {
+  const bodyfit_model* m = p->m;
+  const int nJ = m->nJ, nS = m->nS, npose = 7 + 3 * (nJ - 1), D = 3 * (nJ - 1);
+  const bodyfit_layout& L = p->lay;
+  const bool has_beta = L.n_cols > npose;
+  {
+  if (kind == 0) {
+    residuals[0] = p->c_r[2 * (size_t)index];
+    residuals[1] = p->c_r[2 * (size_t)index + 1];
+    if (jacobians) {
+      const double* J0 = p->c_J.data() + (size_t)(2 * index) * L.n_cols;
+      const double* J1 = J0 + L.n_cols;
+      const int nblocks = 3 + (nJ - 1) + (has_beta ? 1 : 0);
+      for (int blk = 0; blk < nblocks; ++blk) {
+        if (!jacobians[blk]) continue;
+        const int off = blk == 0 ? 0 : (blk == 1 ? 1 : (blk == 2 ? 4 : (blk < 3 + (nJ - 1) ? 7 + 3 * (blk - 3) : npose)));
+        const int sz = blk == 0 ? 1 : (blk < 3 + (nJ - 1) ? 3 : nS);
+        for (int i = 0; i < sz; ++i) {
+          jacobians[blk][i] = J0[off + i];
+          jacobians[blk][sz + i] = J1[off + i];
+        }
+      }
+    }
+  } else {
+    const int nRes = L.prior_rows_per_frame;
+    const double* r = p->c_r.data() + p->row_prior + (size_t)frame * nRes;
+    std::memcpy(residuals, r, (size_t)nRes * sizeof(double));
+    if (jacobians) {
+      const double bp = p->desc.beta_pose;
+      const int comp = p->c_comp[frame];
+      for (int j = 0; j < nJ - 1; ++j) {
+        if (!jacobians[j]) continue;
+        double* Jb = jacobians[j];  // nRes x 3 row-major (include/Sim3BA.h:293,306)
+        std::fill(Jb, Jb + (size_t)nRes * 3, 0.0);
+        if (p->has_gmm) {
+          const double* Lk = p->desc.gmm->prec_cho.data() + (size_t)comp * D * D;
+          for (int row = 0; row < D; ++row)
+            for (int c = 0; c < 3; ++c) Jb[(size_t)row * 3 + c] = Lk[(size_t)(3 * j + c) * D + row] * bp;  // :298-299
+        } else {
+          for (int c = 0; c < 3; ++c) Jb[(size_t)(3 * j + c) * 3 + c] = bp;  // :308-309
+        }
+      }
+    }
+  }
+}
+}
+
 int bodyfit_evaluate_block(bodyfit_problem* p, int kind, int index, const double* const* parameters,
                            double* residuals, double** jacobians) {
   if (!p || !parameters || !residuals) return fail(BODYFIT_ERR_INVALID, "null argument");
   const bodyfit_model* m = p->m;
-  const int nJ = m->nJ, nS = m->nS, npose = 7 + 3 * (nJ - 1), D = 3 * (nJ - 1);
+  const int nJ = m->nJ, nS = m->nS, npose = 7 + 3 * (nJ - 1);
   const bodyfit_layout& L = p->lay;
   const bool has_beta = L.n_cols > npose;
   if (kind == 1) {  // pose prior: constant-structure Jacobian, evaluate through the batch of frame `index`
@@ -1672,45 +1725,31 @@ int bodyfit_evaluate_block(bodyfit_problem* p, int kind, int index, const double
       if (rc) return rc;
       lock.lock();
     }
-    if (kind == 0) {
-      residuals[0] = p->c_r[2 * (size_t)index];
-      residuals[1] = p->c_r[2 * (size_t)index + 1];
-      if (jacobians) {
-        const double* J0 = p->c_J.data() + (size_t)(2 * index) * L.n_cols;
-        const double* J1 = J0 + L.n_cols;
-        const int nblocks = 3 + (nJ - 1) + (has_beta ? 1 : 0);
-        for (int blk = 0; blk < nblocks; ++blk) {
-          if (!jacobians[blk]) continue;
-          const int off = blk == 0 ? 0 : (blk == 1 ? 1 : (blk == 2 ? 4 : (blk < 3 + (nJ - 1) ? 7 + 3 * (blk - 3) : npose)));
-          const int sz = blk == 0 ? 1 : (blk < 3 + (nJ - 1) ? 3 : nS);
-          for (int i = 0; i < sz; ++i) {
-            jacobians[blk][i] = J0[off + i];
-            jacobians[blk][sz + i] = J1[off + i];
-          }
-        }
-      }
-    } else {
-      const int nRes = L.prior_rows_per_frame;
-      const double* r = p->c_r.data() + p->row_prior + (size_t)frame * nRes;
-      std::memcpy(residuals, r, (size_t)nRes * sizeof(double));
-      if (jacobians) {
-        const double bp = p->desc.beta_pose;
-        const int comp = p->c_comp[frame];
-        for (int j = 0; j < nJ - 1; ++j) {
-          if (!jacobians[j]) continue;
-          double* Jb = jacobians[j];  // nRes x 3 row-major (include/Sim3BA.h:293,306)
-          std::fill(Jb, Jb + (size_t)nRes * 3, 0.0);
-          if (p->has_gmm) {
-            const double* Lk = p->desc.gmm->prec_cho.data() + (size_t)comp * D * D;
-            for (int row = 0; row < D; ++row)
-              for (int c = 0; c < 3; ++c) Jb[(size_t)row * 3 + c] = Lk[(size_t)(3 * j + c) * D + row] * bp;  // :298-299
-          } else {
-            for (int c = 0; c < 3; ++c) Jb[(size_t)(3 * j + c) * 3 + c] = bp;  // :308-309
-          }
-        }
-      }
-    }
+    serve_block(p, kind, index, frame, residuals, jacobians);
   }
+  return BODYFIT_OK;
+}
+
+// The EvaluationCallback form (include/bodyfit_ceres.h: SweepCallback): the caller guarantees that the cached sweep IS the point
+// Ceres is evaluating (PrepareForEvaluation ran for it), so kinds 0 / 1 are served without gathering and comparing the block's
+// 76 parameters and without the problem's lock (the cache is only written by the callback, between evaluations): ~4x less host
+// time per block, and Ceres' evaluation threads do not serialise on it.  Kinds 2 / 3 are functions of their parameters alone.
+int bodyfit_evaluate_block_cached(bodyfit_problem* p, int kind, int index, const double* const* parameters,
+                                  double* residuals, double** jacobians) {
+  if (!p || !residuals) return fail(BODYFIT_ERR_INVALID, "null argument");
+  if (kind == 2 || kind == 3) return bodyfit_evaluate_block(p, kind, index, parameters, residuals, jacobians);
+  if (kind != 0 && kind != 1) return fail(BODYFIT_ERR_INVALID, "unknown block kind");
+  if (!p->cache_valid || (jacobians && !p->cache_has_jac))
+    return fail(BODYFIT_ERR_INVALID, "bodyfit_evaluate_block_cached: no sweep cached for this evaluation (EvaluationCallback not run?)");
+  int frame;
+  if (kind == 0) {
+    if (index < 0 || index >= p->lay.n_keypoints) return fail(BODYFIT_ERR_INVALID, "keypoint index out of range");
+    frame = p->kp_frame[index];
+  } else {
+    if (index < 0 || index >= p->d.F || p->lay.prior_rows_per_frame == 0) return fail(BODYFIT_ERR_INVALID, "bad prior block");
+    frame = index;
+  }
+  serve_block(p, kind, index, frame, residuals, jacobians);
   return BODYFIT_OK;
 }
 

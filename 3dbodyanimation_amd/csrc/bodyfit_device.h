@@ -131,6 +131,12 @@ struct DeviceMax {                                     // a grant that grows: tr
     return true;
   }
 };
+// every kernel launch of the library goes through these two: a process-wide count (bodyfit_launch_count) lets the benchmarks
+// report launches per LM iteration beside microseconds per iteration
+extern std::atomic<long> g_launch_count;
+#define BODYFIT_LAUNCH(...) do { ::bodyfit::g_launch_count.fetch_add(1, std::memory_order_relaxed); hipLaunchKernelGGL(__VA_ARGS__); } while (0)
+#define BODYFIT_LAUNCH_EXT(...) do { ::bodyfit::g_launch_count.fetch_add(1, std::memory_order_relaxed); hipExtLaunchKernelGGL(__VA_ARGS__); } while (0)
+
 inline int current_device() {
   int d = 0;
   (void)hipGetDevice(&d);

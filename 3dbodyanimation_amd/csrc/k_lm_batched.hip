@@ -866,7 +866,7 @@ __global__ __launch_bounds__(256) void k_lm_accept(LmProblem P, LmState S, const
 size_t lm_step_lds_bytes() { return (size_t)(kMRows * kMLd + (kN + 1) * kLd + 640) * sizeof(double); }
 
 void launch_lm_init(const LmProblem& P, const LmState& S, const double* d_r, hipStream_t s) {
-  hipLaunchKernelGGL(k_lm_init, dim3(P.F), dim3(256), 0, s, P, S, d_r);
+  BODYFIT_LAUNCH(k_lm_init, dim3(P.F), dim3(256), 0, s, P, S, d_r);
 }
 void launch_lm_step(const LmProblem& P, const LmState& S, double* d_r, double* d_J, int* d_comp, const double* d_r_cand,
                     const double* d_J_cand, const int* d_comp_cand, const unsigned char* d_constant, int first_iter,
@@ -875,12 +875,12 @@ void launch_lm_step(const LmProblem& P, const LmState& S, double* d_r, double* d
   const size_t lds = lm_step_lds_bytes();
   if (attr.first(current_device()))
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_lm_step), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(k_lm_step, dim3(P.F), dim3(kStepThreads), lds, s, P, S, d_r, d_J, d_comp,
+  BODYFIT_LAUNCH(k_lm_step, dim3(P.F), dim3(kStepThreads), lds, s, P, S, d_r, d_J, d_comp,
                      LmCandidate{d_r_cand, d_J_cand, d_comp_cand}, d_constant, first_iter);
 }
 void launch_lm_accept(const LmProblem& P, const LmState& S, const double* d_r_new, double* d_r_cur, const int* d_comp_new,
                       int* d_comp_cur, hipStream_t s) {
-  hipLaunchKernelGGL(k_lm_accept, dim3(P.F), dim3(256), 0, s, P, S, d_r_new, d_r_cur, d_comp_new, d_comp_cur);
+  BODYFIT_LAUNCH(k_lm_accept, dim3(P.F), dim3(256), 0, s, P, S, d_r_new, d_r_cur, d_comp_new, d_comp_cur);
 }
 
 void launch_frame_normal(int F, int n, const int* d_kp_offset, double huber, const double* d_r, const double* d_J,
@@ -890,7 +890,7 @@ void launch_frame_normal(int F, int n, const int* d_kp_offset, double huber, con
   static DeviceOnce attr_set;
   if (attr_set.first(current_device()))
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_frame_normal), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(k_frame_normal, dim3(F), dim3(kStepThreads), lds, s, F, n, d_kp_offset, huber, d_r, d_J, d_out);
+  BODYFIT_LAUNCH(k_frame_normal, dim3(F), dim3(kStepThreads), lds, s, F, n, d_kp_offset, huber, d_r, d_J, d_out);
 }
 
 }  // namespace bodyfit

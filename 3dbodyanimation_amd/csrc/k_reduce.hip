@@ -221,15 +221,15 @@ void launch_reduce_shared_ex(int K, int ncols, int npose, int nS, int total_rows
                              double beta_shape, double* d_partials, double* d_out66, hipStream_t s) {
   const int steps = (2 * K + 3) / 4;
   const int nw = std::min(kRedWavesMax, std::max(64, (steps + kRedSteps - 1) / kRedSteps));
-  hipLaunchKernelGGL(k_reduce_stage1, dim3(nw), dim3(64), 0, s, K, ncols, npose, nS, total_rows, d_r, d_J,
+  BODYFIT_LAUNCH(k_reduce_stage1, dim3(nw), dim3(64), 0, s, K, ncols, npose, nS, total_rows, d_r, d_J,
                      huber_delta, d_partials);
   if (nw > 256) {   // many partials: sum them on 17 workgroups first (a single workgroup pays ~20 serial L2 round trips)
     double* totals = d_partials + (size_t)kRedWavesMax * kPartial;
-    hipLaunchKernelGGL(k_reduce_stage2a, dim3((kPartial + 15) / 16), dim3(1024), 0, s, nw, d_partials, totals, d_r, 0, 0);
-    hipLaunchKernelGGL(k_reduce_stage2, dim3(1), dim3(1024), 0, s, 1, totals, shape_row0, shape_rows, beta_shape, d_r,
+    BODYFIT_LAUNCH(k_reduce_stage2a, dim3((kPartial + 15) / 16), dim3(1024), 0, s, nw, d_partials, totals, d_r, 0, 0);
+    BODYFIT_LAUNCH(k_reduce_stage2, dim3(1), dim3(1024), 0, s, 1, totals, shape_row0, shape_rows, beta_shape, d_r,
                        d_out66);
   } else {
-    hipLaunchKernelGGL(k_reduce_stage2, dim3(1), dim3(1024), 0, s, nw, d_partials, shape_row0, shape_rows, beta_shape,
+    BODYFIT_LAUNCH(k_reduce_stage2, dim3(1), dim3(1024), 0, s, nw, d_partials, shape_row0, shape_rows, beta_shape,
                        d_r, d_out66);
   }
 }
@@ -241,17 +241,17 @@ void launch_reduce_frames(int F, int rows_begin, int total_rows, const double* d
                           hipStream_t s) {
   static_assert(kPartial == kReducePartial, "partial layout");
   if (F <= 256 && rows_begin >= total_rows) {   // small shard: one workgroup sums the partials (one batch of loads) and packs
-    hipLaunchKernelGGL(k_reduce_stage2, dim3(1), dim3(1024), 0, s, F, d_frame_partials, shape_row0, shape_rows, beta_shape,
+    BODYFIT_LAUNCH(k_reduce_stage2, dim3(1), dim3(1024), 0, s, F, d_frame_partials, shape_row0, shape_rows, beta_shape,
                        d_r, d_out66);
     return;
   }
-  hipLaunchKernelGGL(k_reduce_stage2a, dim3((kPartial + 15) / 16), dim3(1024), 0, s, F, d_frame_partials, d_scratch, d_r,
+  BODYFIT_LAUNCH(k_reduce_stage2a, dim3((kPartial + 15) / 16), dim3(1024), 0, s, F, d_frame_partials, d_scratch, d_r,
                      rows_begin, total_rows);
-  hipLaunchKernelGGL(k_reduce_stage2, dim3(1), dim3(1024), 0, s, 1, d_scratch, shape_row0, shape_rows, beta_shape, d_r,
+  BODYFIT_LAUNCH(k_reduce_stage2, dim3(1), dim3(1024), 0, s, 1, d_scratch, shape_row0, shape_rows, beta_shape, d_r,
                      d_out66);
 }
 void launch_regress(int nJ, int V, int ncol, const double* d_reg, const double* d_x, double* d_out, hipStream_t s) {
-  hipLaunchKernelGGL(k_regress, dim3(nJ, ncol), dim3(256), 0, s, V, ncol, d_reg, d_x, d_out);
+  BODYFIT_LAUNCH(k_regress, dim3(nJ, ncol), dim3(256), 0, s, V, ncol, d_reg, d_x, d_out);
 }
 
 
@@ -306,11 +306,11 @@ __global__ __launch_bounds__(64) void k_mean_pixel_error(int F, int nJ, const in
 
 void launch_writeback_prepare(int F, int npose, const double* d_params, const double* d_R0, double* d_params_upd,
                               double* d_R0_new, hipStream_t s) {
-  if (F > 0) hipLaunchKernelGGL(k_writeback_prepare, dim3((F + 63) / 64), dim3(64), 0, s, F, npose, d_params, d_R0, d_params_upd, d_R0_new);
+  if (F > 0) BODYFIT_LAUNCH(k_writeback_prepare, dim3((F + 63) / 64), dim3(64), 0, s, F, npose, d_params, d_R0, d_params_upd, d_R0_new);
 }
 void launch_mean_pixel_error(int F, int nJ, const int* d_kp_offset, const int* d_kp_id, const double* d_kp_uv,
                              const double* d_joints, double fx, double fy, double cx, double cy, double* d_out, hipStream_t s) {
-  if (F > 0) hipLaunchKernelGGL(k_mean_pixel_error, dim3(F), dim3(64), 0, s, F, nJ, d_kp_offset, d_kp_id, d_kp_uv, d_joints, fx, fy, cx, cy, d_out);
+  if (F > 0) BODYFIT_LAUNCH(k_mean_pixel_error, dim3(F), dim3(64), 0, s, F, nJ, d_kp_offset, d_kp_id, d_kp_uv, d_joints, fx, fy, cx, cy, d_out);
 }
 
 }  // namespace bodyfit

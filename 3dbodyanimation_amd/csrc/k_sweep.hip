@@ -248,7 +248,7 @@ void launch_frame_resjac(const DevModel& M, const DevProblem& P, const double* d
   if (lds_granted.raise(current_device(), lds, 48 * 1024))
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_frame_resjac), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)lds);
-  hipExtLaunchKernelGGL(k_frame_resjac, dim3(P.F + priors.n_tiles), dim3(kThreads), lds, s, ev_start, ev_stop, 0, M, P,
+  BODYFIT_LAUNCH_EXT(k_frame_resjac, dim3(P.F + priors.n_tiles), dim3(kThreads), lds, s, ev_start, ev_stop, 0, M, P,
                         d_params, d_beta, d_r, d_J, d_joints, mc, want_jac, priors);
 }
 
@@ -260,7 +260,7 @@ void launch_mesh(const DevModel& M, const DevProblem& P, const MeshCoef& mc, flo
   if (attr.first(current_device()))
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_mesh_blend_lbs),
                               hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
-  hipExtLaunchKernelGGL(k_mesh_blend_lbs, dim3(M.nVTiles + pa.n_tiles), dim3(64 * kWaves), kLdsBytes, s, ev_start, ev_stop,
+  BODYFIT_LAUNCH_EXT(k_mesh_blend_lbs, dim3(M.nVTiles + pa.n_tiles), dim3(64 * kWaves), kLdsBytes, s, ev_start, ev_stop,
                         0, M, P, mc, d_cloud, pa, d_params);
 }
 
@@ -283,7 +283,7 @@ void launch_sweep_roles(const DevModel& M, const DevProblem& P, const double* d_
   RoleArgs A;
   A.M = M; A.Pb = P; A.Pb.feat_perm = 1; A.params = d_params; A.beta = d_beta; A.r_out = d_r; A.J_out = d_J;
   A.joints_out = d_joints; A.mc = mc; A.want_jac = want_jac; A.pa = pa; A.cloud_f = d_cloud; A.sy = sy;
-  hipExtLaunchKernelGGL(k_sweep_roles, dim3(grid), dim3(kThreads), kRoleLdsBytes, s, ev_start, ev_stop, 0, A);
+  BODYFIT_LAUNCH_EXT(k_sweep_roles, dim3(grid), dim3(kThreads), kRoleLdsBytes, s, ev_start, ev_stop, 0, A);
 }
 
 }  // namespace bodyfit

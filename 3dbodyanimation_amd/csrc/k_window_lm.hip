@@ -1238,16 +1238,16 @@ size_t win_update_lds_bytes() { return (size_t)(2 * WB * LD + 2 * WR * LD) * siz
 size_t win_back_lds_bytes() { return (size_t)(WB * LD + 3 * WR * LD + 5 * 16 * 17) * sizeof(double); }
 
 void launch_win_init(const WinProblem& P, const WinBuf& W, const double* d_r, int mode, hipStream_t s) {
-  hipLaunchKernelGGL(k_win_init, dim3(1), dim3(1024), 0, s, P, W, d_r, mode);
+  BODYFIT_LAUNCH(k_win_init, dim3(1), dim3(1024), 0, s, P, W, d_r, mode);
 }
 void launch_win_beta(const WinProblem& P, const WinBuf& W, const double* d_Hpan, const double* d_r, int first, int mode,
                      hipStream_t s) {
-  hipLaunchKernelGGL(k_win_beta, dim3(1), dim3(1024), 0, s, P, W, d_Hpan, d_r, first, mode);
+  BODYFIT_LAUNCH(k_win_beta, dim3(1), dim3(1024), 0, s, P, W, d_Hpan, d_r, first, mode);
 }
 void launch_win_assemble(const WinProblem& P, const WinBuf& W, const double* d_Hpan, const double* d_r, const double* d_x,
                          const unsigned char* d_constant, int first, const double* d_x_left, const double* d_scale_halo,
                          hipStream_t s) {
-  hipLaunchKernelGGL(k_win_assemble, dim3(P.F), dim3(kAsmThreads), 0, s, P, W, d_Hpan, d_r, d_x, d_constant, first, d_x_left,
+  BODYFIT_LAUNCH(k_win_assemble, dim3(P.F), dim3(kAsmThreads), 0, s, P, W, d_Hpan, d_r, d_x, d_constant, first, d_x_left,
                      d_scale_halo);
 }
 void launch_cr_factor(const WinBuf& W, const int* d_elim, int n_elim, hipStream_t s) {
@@ -1260,66 +1260,66 @@ void launch_cr_factor(const WinBuf& W, const int* d_elim, int n_elim, hipStream_
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_cr_back), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)win_back_lds_bytes());
   }
-  if (n_elim > 0) hipLaunchKernelGGL(k_cr_factor, dim3(2 * n_elim), dim3(kCrThreads), win_factor_lds_bytes(), s, W, d_elim, n_elim);
+  if (n_elim > 0) BODYFIT_LAUNCH(k_cr_factor, dim3(2 * n_elim), dim3(kCrThreads), win_factor_lds_bytes(), s, W, d_elim, n_elim);
 }
 void launch_cr_update(const WinBuf& W, const int* d_surv, int n_surv, hipStream_t s) {
   if (n_surv > 0) {
     const int split = 4 * n_surv <= 256 ? 1 : 0;        // (the diagonal block in two workgroups where CUs are idle anyway)
-    hipLaunchKernelGGL(k_cr_update, dim3((split ? 4 : 3) * n_surv), dim3(kCrThreads), win_update_lds_bytes(), s, W, d_surv, n_surv, split);
+    BODYFIT_LAUNCH(k_cr_update, dim3((split ? 4 : 3) * n_surv), dim3(kCrThreads), win_update_lds_bytes(), s, W, d_surv, n_surv, split);
   }
 }
 void launch_cr_back(const WinBuf& W, const int* d_elim, int n_elim, hipStream_t s) {
-  if (n_elim > 0) hipLaunchKernelGGL(k_cr_back, dim3(n_elim), dim3(kCrThreads), win_back_lds_bytes(), s, W, d_elim, n_elim);
+  if (n_elim > 0) BODYFIT_LAUNCH(k_cr_back, dim3(n_elim), dim3(kCrThreads), win_back_lds_bytes(), s, W, d_elim, n_elim);
 }
 void launch_win_schur_part(const WinProblem& P, const WinBuf& W, hipStream_t s) {
-  hipLaunchKernelGGL(k_win_schur_part, dim3(P.F), dim3(128), 0, s, P, W);
+  BODYFIT_LAUNCH(k_win_schur_part, dim3(P.F), dim3(128), 0, s, P, W);
 }
 void launch_win_beta_solve(const WinProblem& P, const WinBuf& W, const double* d_beta, double* d_beta_new, int mode, hipStream_t s) {
-  hipLaunchKernelGGL(k_win_beta_solve, dim3(1), dim3(1024), 0, s, P, W, d_beta, d_beta_new, mode);
+  BODYFIT_LAUNCH(k_win_beta_solve, dim3(1), dim3(1024), 0, s, P, W, d_beta, d_beta_new, mode);
 }
 void launch_win_tail(const WinProblem& P, const WinBuf& W, const double* d_x, const double* d_beta, double* d_x_new, double* d_beta_new,
                      hipStream_t s) {
-  hipLaunchKernelGGL(k_win_tail, dim3(P.F), dim3(256), 0, s, P, W, d_x, d_beta, d_x_new, d_beta_new);
+  BODYFIT_LAUNCH(k_win_tail, dim3(P.F), dim3(256), 0, s, P, W, d_x, d_beta, d_x_new, d_beta_new);
 }
 void launch_win_step(const WinProblem& P, const WinBuf& W, const double* d_x, double* d_x_new, hipStream_t s) {
-  hipLaunchKernelGGL(k_win_step, dim3(P.F), dim3(128), 0, s, P, W, d_x, d_x_new);
+  BODYFIT_LAUNCH(k_win_step, dim3(P.F), dim3(128), 0, s, P, W, d_x, d_x_new);
 }
 void launch_win_model(const WinProblem& P, const WinBuf& W, const double* d_x, const double* d_halo_step, hipStream_t s) {
-  hipLaunchKernelGGL(k_win_model, dim3(P.F), dim3(128), 0, s, P, W, d_x, d_halo_step);
+  BODYFIT_LAUNCH(k_win_model, dim3(P.F), dim3(128), 0, s, P, W, d_x, d_halo_step);
 }
 void launch_win_finish(const WinProblem& P, const WinBuf& W, const double* d_x, const double* d_beta, double* d_x_new,
                        double* d_beta_new, int mode, hipStream_t s) {
-  hipLaunchKernelGGL(k_win_finish, dim3(1), dim3(256), 0, s, P, W, d_x, d_beta, d_x_new, d_beta_new, mode);
+  BODYFIT_LAUNCH(k_win_finish, dim3(1), dim3(256), 0, s, P, W, d_x, d_beta, d_x_new, d_beta_new, mode);
 }
 void launch_win_accept(const WinProblem& P, const WinBuf& W, const double* d_r_new, double* d_x, double* d_beta,
                        const double* d_x_new, const double* d_beta_new, int mode, hipStream_t s) {
-  hipLaunchKernelGGL(k_win_accept, dim3(1), dim3(1024), 0, s, P, W, d_r_new, d_x, d_beta, d_x_new, d_beta_new, mode);
+  BODYFIT_LAUNCH(k_win_accept, dim3(1), dim3(1024), 0, s, P, W, d_r_new, d_x, d_beta, d_x_new, d_beta_new, mode);
 }
 
 }  // namespace bodyfit
 
 namespace bodyfit {
 void launch_sum_ranks(const double* d_g, int N, int stride, int n, double* d_out, hipStream_t s) {
-  hipLaunchKernelGGL(k_sum_ranks, dim3((n + 255) / 256), dim3(256), 0, s, d_g, N, stride, n, d_out);
+  BODYFIT_LAUNCH(k_sum_ranks, dim3((n + 255) / 256), dim3(256), 0, s, d_g, N, stride, n, d_out);
 }
 int iface_doubles(int n_extra) { return 4 * WB * WB + 2 * WR * WB + n_extra; }
 void launch_iface_pack(const WinBuf& W, int F, const double* d_extra, int n_extra, double* d_send, hipStream_t s) {
-  hipLaunchKernelGGL(k_iface_pack, dim3(64), dim3(256), 0, s, W, F, d_extra, n_extra, d_send);
+  BODYFIT_LAUNCH(k_iface_pack, dim3(64), dim3(256), 0, s, W, F, d_extra, n_extra, d_send);
 }
 void launch_iface_unpack(const WinBuf& Wi, const double* d_g, int N, int n_extra, double* d_extra_sum, hipStream_t s) {
-  hipLaunchKernelGGL(k_iface_unpack, dim3(64), dim3(256), 0, s, Wi, d_g, N, n_extra, d_extra_sum);
+  BODYFIT_LAUNCH(k_iface_unpack, dim3(64), dim3(256), 0, s, Wi, d_g, N, n_extra, d_extra_sum);
 }
 void launch_win_halo_step(const WinProblem& P, const double* d_Xi, const double* d_dsb, int node_right, const double* d_scale_right,
                           const double* d_x_right, double* d_d_right, double* d_xn_right, int node_left,
                           const double* d_scale_left, const double* d_x_left, double* d_xn_left, hipStream_t s) {
-  hipLaunchKernelGGL(k_win_halo_step, dim3(2), dim3(128), 0, s, P, d_Xi, d_dsb, node_right, d_scale_right, d_x_right, d_d_right,
+  BODYFIT_LAUNCH(k_win_halo_step, dim3(2), dim3(128), 0, s, P, d_Xi, d_dsb, node_right, d_scale_right, d_x_right, d_d_right,
                      d_xn_right, node_left, d_scale_left, d_x_left, d_xn_left);
 }
-void launch_win_fold_fail(const WinBuf& W, const WinBuf& Wi, hipStream_t s) { hipLaunchKernelGGL(k_win_fold_fail, dim3(1), dim3(64), 0, s, W, Wi); }
+void launch_win_fold_fail(const WinBuf& W, const WinBuf& Wi, hipStream_t s) { BODYFIT_LAUNCH(k_win_fold_fail, dim3(1), dim3(64), 0, s, W, Wi); }
 void launch_win_decide(const WinProblem& P, const WinBuf& W, double* d_x, double* d_beta, double* d_x_new, double* d_beta_new,
                        const double* d_g, int N, double* d_x_halo, const double* d_xn_halo, double* d_x_left,
                        const double* d_xn_left, hipStream_t s) {
-  hipLaunchKernelGGL(k_win_decide, dim3(1), dim3(256), 0, s, P, W, d_x, d_beta, d_x_new, d_beta_new, d_g, N, d_x_halo, d_xn_halo,
+  BODYFIT_LAUNCH(k_win_decide, dim3(1), dim3(256), 0, s, P, W, d_x, d_beta, d_x_new, d_beta_new, d_g, N, d_x_halo, d_xn_halo,
                      d_x_left, d_xn_left);
 }
 }  // namespace bodyfit

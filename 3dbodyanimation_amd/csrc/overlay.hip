@@ -29,6 +29,7 @@
 #include <vector>
 
 #include "../../include/bodyfit.h"
+#include "bodyfit_device.h"
 #include "solver_view.h"
 
 #pragma clang fp contract(off)
@@ -855,19 +856,19 @@ int bodyfit_overlay_render_device(bodyfit_overlay* ov, const void* d_cloud, int 
   {
     dim3 grid((nF + 255) / 256, F);
     if (cloud_is_f64)
-      hipLaunchKernelGGL(k_ov_faces<double>, grid, dim3(256), 0, st, static_cast<const double*>(d_cloud),
+      BODYFIT_LAUNCH(k_ov_faces<double>, grid, dim3(256), 0, st, static_cast<const double*>(d_cloud),
                          cloud_frame_stride_elems, ov->d_faces, nF, ov->nV, fx, fy, cx, cy, backface_cull, ov->d_tmp,
                          ov->d_key);
     else
-      hipLaunchKernelGGL(k_ov_faces<float>, grid, dim3(256), 0, st, static_cast<const float*>(d_cloud),
+      BODYFIT_LAUNCH(k_ov_faces<float>, grid, dim3(256), 0, st, static_cast<const float*>(d_cloud),
                          cloud_frame_stride_elems, ov->d_faces, nF, ov->nV, fx, fy, cx, cy, backface_cull, ov->d_tmp,
                          ov->d_key);
   }
   OV_TRY(hipEventRecord(ov->ev[1], st));
   OV_TRY(hipMemsetAsync(ov->d_alive, 0, sizeof(int) * F, st));
-  hipLaunchKernelGGL(k_ov_sort_chunks, dim3(ov->nChunks, F), dim3(kSortThreads), kChunk * 12, st, ov->d_key, nF,
+  BODYFIT_LAUNCH(k_ov_sort_chunks, dim3(ov->nChunks, F), dim3(kSortThreads), kChunk * 12, st, ov->d_key, nF,
                      ov->nChunks, ov->d_skey, ov->d_sidx);
-  hipLaunchKernelGGL(k_ov_rank, dim3((ov->nChunks * kChunk + 255) / 256, F), dim3(256), 0, st, ov->d_skey, ov->d_sidx, nF,
+  BODYFIT_LAUNCH(k_ov_rank, dim3((ov->nChunks * kChunk + 255) / 256, F), dim3(256), 0, st, ov->d_skey, ov->d_sidx, nF,
                      ov->nChunks, ov->d_tmp, ov->d_sorted, ov->d_alive);
   OV_TRY(hipEventRecord(ov->ev[2], st));
   if (!fill && !wireframe) {   // the reference draws nothing (RenderSMPLMesh.h:97,106)
@@ -879,11 +880,11 @@ int bodyfit_overlay_render_device(bodyfit_overlay* ov, const void* d_cloud, int 
   }
   OV_TRY(hipMemsetAsync(ov->d_count, 0, sizeof(unsigned) * (nT + 1), st));
   OV_TRY(hipMemsetAsync(ov->d_totals, 0, sizeof(unsigned) * 4, st));
-  hipLaunchKernelGGL(k_ov_bin<false>, dim3((nF + 255) / 256, F), dim3(256), 0, st, ov->d_sorted, nF, ov->W, ov->H,
+  BODYFIT_LAUNCH(k_ov_bin<false>, dim3((nF + 255) / 256, F), dim3(256), 0, st, ov->d_sorted, nF, ov->W, ov->H,
                      ov->tilesX, ov->tilesY, ov->d_count, ov->d_offset, ov->d_entries);
-  hipLaunchKernelGGL(k_ov_scan1, dim3(nBlocks), dim3(256), 0, st, ov->d_count, nT + 1, ov->d_blockSum);
-  hipLaunchKernelGGL(k_ov_scan2, dim3(1), dim3(1024), 0, st, ov->d_blockSum, nBlocks, ov->d_totals);
-  hipLaunchKernelGGL(k_ov_scan3, dim3(nBlocks), dim3(256), 0, st, ov->d_count, nT + 1, ov->d_blockSum, ov->d_offset,
+  BODYFIT_LAUNCH(k_ov_scan1, dim3(nBlocks), dim3(256), 0, st, ov->d_count, nT + 1, ov->d_blockSum);
+  BODYFIT_LAUNCH(k_ov_scan2, dim3(1), dim3(1024), 0, st, ov->d_blockSum, nBlocks, ov->d_totals);
+  BODYFIT_LAUNCH(k_ov_scan3, dim3(nBlocks), dim3(256), 0, st, ov->d_count, nT + 1, ov->d_blockSum, ov->d_offset,
                      ov->d_active, ov->d_totals);
   unsigned totals[2] = {0, 0};
   OV_TRY(hipMemcpyAsync(totals, ov->d_totals, sizeof(totals), hipMemcpyDeviceToHost, st));
@@ -899,14 +900,14 @@ int bodyfit_overlay_render_device(bodyfit_overlay* ov, const void* d_cloud, int 
     ov->entriesCap = want;
   }
   if (totals[0]) {
-    hipLaunchKernelGGL(k_ov_setup, dim3((nF + 255) / 256, F), dim3(256), 0, st, ov->d_sorted, nF, ov->W, ov->H, ov->d_tris);
-    hipLaunchKernelGGL(k_ov_bin<true>, dim3((nF + 255) / 256, F), dim3(256), 0, st, ov->d_sorted, nF, ov->W, ov->H,
+    BODYFIT_LAUNCH(k_ov_setup, dim3((nF + 255) / 256, F), dim3(256), 0, st, ov->d_sorted, nF, ov->W, ov->H, ov->d_tris);
+    BODYFIT_LAUNCH(k_ov_bin<true>, dim3((nF + 255) / 256, F), dim3(256), 0, st, ov->d_sorted, nF, ov->W, ov->H,
                        ov->tilesX, ov->tilesY, ov->d_count, ov->d_offset, ov->d_entries);
   }
   OV_TRY(hipEventRecord(ov->ev[3], st));
   if (totals[1]) {
     const int grid = (int)std::min<unsigned>(totals[1], 256u * 64u);
-    hipLaunchKernelGGL(k_ov_tiles, dim3(grid), dim3(kTileThreads), tile_lds_bytes(nF), st, ov->d_tris, nF, ov->W, ov->H,
+    BODYFIT_LAUNCH(k_ov_tiles, dim3(grid), dim3(kTileThreads), tile_lds_bytes(nF), st, ov->d_tris, nF, ov->W, ov->H,
                        ov->tilesX, ov->tilesY, ov->d_offset, ov->d_entries, ov->d_active, ov->d_totals, d_images,
                        row_stride, frame_stride, (fill ? 1 : 0) | (wireframe ? 2 : 0));
   }

@@ -229,6 +229,7 @@ def run_multi(gpu_model, seq: KeypointSequence, intr, max_iters_s1=1000, skip=10
     w = np.zeros((F, 10))                                           # avatars[i]->w (private copies)
     poses = np.zeros((F, 76)); poses[:, 0] = 1.0; poses[:, 6] = 3.0  # FramePoseParams
     rows = []
+    stage2 = []      # FitSummary of every stage-2 window
 
     def solve(ids, x_init, w_block, bshape, iters):
         off, kid, uv = _subsequence(seq, ids)
@@ -264,7 +265,8 @@ def run_multi(gpu_model, seq: KeypointSequence, intr, max_iters_s1=1000, skip=10
         e = min(s + wsize, F)
         ids = list(range(s, e))
         t0 = time.perf_counter()
-        x, bw, _ = solve(ids, poses[ids].copy(), w[s].copy(), 1e5, stage2_iters)     # beta lock (Q9)
+        x, bw, s2 = solve(ids, poses[ids].copy(), w[s].copy(), 1e5, stage2_iters)     # beta lock (Q9)
+        stage2.append(s2[0])
         w[s] = bw
         poses[ids] = x
         snap(ids)
@@ -279,7 +281,7 @@ def run_multi(gpu_model, seq: KeypointSequence, intr, max_iters_s1=1000, skip=10
         # final state, so all frames are drawn here in one batch
         overlays = render_overlays(gpu_model, faces, _subsequence(seq, list(range(F))), intr, r0, t, jaa, w, image_size,
                                    frames_bgr, out_dir, [f"frame_{f}_multi" for f in range(F)])
-    return dict(poses=poses, r0=r0, t=t, joint_aa=jaa, w=w, log=rows, stage1=s1[0], overlays=overlays)
+    return dict(poses=poses, r0=r0, t=t, joint_aa=jaa, w=w, log=rows, stage1=s1[0], stage2=stage2, overlays=overlays)
 
 
 def _write_log(out_dir, rows):

@@ -194,6 +194,12 @@ int bodyfit_profile_sweep(bodyfit_problem* p, const double* d_frame_params, cons
 int bodyfit_evaluate_block(bodyfit_problem* p, int kind, int index, const double* const* parameters,
                            double* residuals, double** jacobians);
 
+/* The same, for callers that follow ceres::EvaluationCallback (bodyfit_ceres::SweepCallback): the cached sweep is trusted to be
+ * the point under evaluation, so reprojection / pose-prior blocks are served without comparing their parameters with the cache
+ * and without a lock (Ceres evaluates blocks on several threads).  Fails if no sweep is cached.                           */
+int bodyfit_evaluate_block_cached(bodyfit_problem* p, int kind, int index, const double* const* parameters,
+                                  double* residuals, double** jacobians);
+
 /* ark::Avatar::update(): camera-frame joints [F][nJ][3] (f64) and cloud [F][V][3] (f32) for the
  * problem's frames at the given parameters; either output may be NULL.                       */
 int bodyfit_forward(bodyfit_problem* p, const double* frame_params, const double* beta,
@@ -336,6 +342,8 @@ int bodyfit_overlay_drawlist(bodyfit_overlay* ov, int frame, int* n_items, int32
  * [0] faces, [1] sort + rank, [2] binning (count, scan, fill), [3] tiles                                  */
 int bodyfit_overlay_last_timing(bodyfit_overlay* ov, float ms[4]);
 
+/* kernels launched by this process through the library so far (benchmarks: launches per LM iteration) */
+long bodyfit_launch_count(void);
 const char* bodyfit_last_error(void);
 int bodyfit_device_count(void);
 

@@ -107,23 +107,28 @@ class SweepCallback : public ceres::EvaluationCallback {
  * of `jacobians` honoured; a false return tells Ceres the step is infeasible).                                            */
 class Block : public ceres::CostFunction {
  public:
-  Block(bodyfit_problem* p, int kind, int index, int num_residuals, const std::vector<int>& block_sizes)
-      : p_(p), kind_(kind), index_(index) {
+  /* with_callback: a SweepCallback is registered as the solver's evaluation_callback, so the cached sweep is the point under
+   * evaluation and the block is served without re-checking its parameters (bodyfit_evaluate_block_cached)              */
+  Block(bodyfit_problem* p, int kind, int index, int num_residuals, const std::vector<int>& block_sizes, bool with_callback = false)
+      : p_(p), kind_(kind), index_(index), cached_(with_callback) {
     set_num_residuals(num_residuals);
     for (int s : block_sizes) mutable_parameter_block_sizes()->push_back(s);
   }
   bool Evaluate(double const* const* parameters, double* residuals, double** jacobians) const override {
-    return bodyfit_evaluate_block(p_, kind_, index_, parameters, residuals, jacobians) == BODYFIT_OK;
+    return (cached_ ? bodyfit_evaluate_block_cached(p_, kind_, index_, parameters, residuals, jacobians)
+                    : bodyfit_evaluate_block(p_, kind_, index_, parameters, residuals, jacobians)) == BODYFIT_OK;
   }
 
  private:
   bodyfit_problem* p_;
   int kind_, index_;
+  bool cached_;
 };
 
 struct AddOptions {
   double huber_delta = 3.0;    /* HuberLoss on the reprojection blocks (include/MultiFrameBA.h:102); <= 0: none        */
   bool beta_per_frame = false; /* 3dba_single --opt-shape: every frame its own beta[10] (beta = [F][10])              */
+  bool with_callback = false;  /* a SweepCallback will be registered as evaluation_callback: blocks trust the cached sweep */
 };
 
 /* Add every residual block of `p` to `problem`, in the reference's order.  kp_offset [F + 1] is the CSR the problem was
@@ -145,7 +150,7 @@ inline int AddResidualBlocks(ceres::Problem* problem, bodyfit_problem* p, const 
     if (with_beta) blocks.push_back(beta + (opt.beta_per_frame ? (size_t)f * nS : 0));
     for (int k = kp_offset[f]; k < kp_offset[f + 1]; ++k) {
       ceres::LossFunction* loss = opt.huber_delta > 0.0 ? new ceres::HuberLoss(opt.huber_delta) : nullptr;
-      problem->AddResidualBlock(new Block(p, 0, k, 2, reproj_sizes), loss, blocks);
+      problem->AddResidualBlock(new Block(p, 0, k, 2, reproj_sizes, opt.with_callback), loss, blocks);
       ++added;
     }
   }
@@ -153,7 +158,7 @@ inline int AddResidualBlocks(ceres::Problem* problem, bodyfit_problem* p, const 
     const std::vector<int> sizes(23, 3);
     for (int f = 0; f < n_frames; ++f) {
       std::vector<double*> fb = T.blocks(f);
-      problem->AddResidualBlock(new Block(p, 1, f, L.prior_rows_per_frame, sizes), nullptr,
+      problem->AddResidualBlock(new Block(p, 1, f, L.prior_rows_per_frame, sizes, opt.with_callback), nullptr,
                                 std::vector<double*>(fb.begin() + 3, fb.end()));
       ++added;
     }

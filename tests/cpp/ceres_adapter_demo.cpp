@@ -146,6 +146,30 @@ int main(int argc, char** argv) {
   std::vector<double> r_ref2(L.total_rows);
   bodyfit_evaluate_batch(bp, x.data(), beta.data(), r_ref2.data(), nullptr, nullptr, 0);
   const double dr2 = std::fmax(std::fabs(r2[0] - r_ref2[0]), std::fabs(r2[1] - r_ref2[1]));
+  // the EvaluationCallback form of the blocks (AddOptions::with_callback: the cached sweep is trusted, no parameter check, no
+  // lock): the same numbers, block for block, at the point the callback has just swept
+  ceres::Problem problem_cb;
+  bodyfit_ceres::AddOptions with_cb;
+  with_cb.with_callback = true;
+  const int n_blocks_cb = bodyfit_ceres::AddResidualBlocks(&problem_cb, bp, koff.data(), table, beta.data(), with_cb);
+  cb.PrepareForEvaluation(true, true);
+  double d_cb = 0.0;
+  for (size_t bi = 0; bi < problem.records().size(); ++bi) {
+    const auto& ra = *problem.records()[bi];
+    const auto& rb = *problem_cb.records()[bi];
+    const int nr = ra.cost->num_residuals();
+    const auto& sizes = ra.cost->parameter_block_sizes();
+    std::vector<double> r_a(nr), r_b(nr);
+    std::vector<std::vector<double>> ja(sizes.size()), jbk(sizes.size());
+    std::vector<double*> pa(sizes.size()), pb(sizes.size());
+    for (size_t b = 0; b < sizes.size(); ++b) { ja[b].assign((size_t)nr * sizes[b], 0.0); jbk[b].assign((size_t)nr * sizes[b], 1.0); pa[b] = ja[b].data(); pb[b] = jbk[b].data(); }
+    if (!ra.cost->Evaluate(ra.blocks.data(), r_a.data(), pa.data()) || !rb.cost->Evaluate(rb.blocks.data(), r_b.data(), pb.data())) ++bad;
+    for (int i = 0; i < nr; ++i) d_cb = std::fmax(d_cb, std::fabs(r_a[i] - r_b[i]));
+    for (size_t b = 0; b < sizes.size(); ++b)
+      for (size_t i = 0; i < ja[b].size(); ++i) d_cb = std::fmax(d_cb, std::fabs(ja[b][i] - jbk[b][i]));
+  }
+  if (n_blocks_cb != n_blocks || d_cb != 0.0) ++bad;
+  std::printf("callback-form blocks %d, max difference to the checked form %.3e\n", n_blocks_cb, d_cb);
   std::printf("blocks %d (expected %d) rows %zu (layout %d) max|dr| %.3e max|dJ| %.3e moved %.3e bad %d\n", n_blocks,
               expect_blocks, r_all.size(), L.total_rows, dr, dj, dr2, bad);
   const bool ok = n_blocks == expect_blocks && bad == 0 && dr == 0.0 && dj == 0.0 && dr2 == 0.0 && cb.ok();

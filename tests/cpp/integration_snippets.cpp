@@ -44,7 +44,9 @@ void snippet_ceres(bodyfit_problem* bp, const int* kp_offset, std::vector<FrameP
 ceres::Problem problem;
 // the reference's own parameter memory: one FramePoseParams per frame (include/MultiFrameBA.h:9-14: NOT contiguous)
 const bodyfit_ceres::BlockTable blocks = bodyfit_ceres::BlocksOf(frame_params);
-bodyfit_ceres::AddResidualBlocks(&problem, bp, kp_offset, blocks, beta);
+bodyfit_ceres::AddOptions add;
+add.with_callback = true;                                  // blocks trust the sweep the callback below has cached
+bodyfit_ceres::AddResidualBlocks(&problem, bp, kp_offset, blocks, beta, add);
 bodyfit_ceres::SweepCallback sweep(bp, blocks, beta);      // gathers the blocks into its own packed [F][76] buffer
 options.evaluation_callback = &sweep;                      // Ceres 1.14: Solver::Options; 2.x: Problem::Options
 // SetParameterBlockConstant / SetParameterLowerBound etc. stay as in include/Sim3BA.h:598-611 (same blocks)

@@ -38,6 +38,13 @@ def test_bench_single_gpu_line():
         assert fit[k]["frames_per_s"] > 0 and fit[k]["frames"] >= 1
     assert fit["c2"]["iterations"] >= 1 and fit["c2"]["sweeps"] >= 1 and fit["c3"]["converged"] >= 250
     assert fit["c4"]["windows"] == 9 and fit["c4"]["anchors"] == 13
+    for k in ("c2", "c3", "c4", "window_20", "c5_staged", "c5_window"):   # reproducible form: median, cost, launches, us per iteration
+        assert fit[k]["launches_per_iteration"] > 0 and fit[k]["us_per_iteration"] > 0 and len(fit[k]["seconds_all"]) >= 1
+    assert fit["c4"]["stage2_final_cost"] < fit["c4"]["stage2_initial_cost"]
+    # the Ceres-kept path next to the resident rate: sweeps with their PCIe copies + every block's Evaluate
+    assert d["pcie_inclusive_evals_per_s"] > 0
+    cp = d["ceres_path"]
+    assert cp["c3"]["points_per_s"] > 0 and cp["c3"]["blocks"] == 256 * 25 + 2 * 256 and cp["c4_window"]["blocks_per_s"] > 0
 
 
 @pytest.mark.gpu

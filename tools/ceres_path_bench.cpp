@@ -70,6 +70,7 @@ int main(int argc, char** argv) {
   const bodyfit_ceres::BlockTable table = bodyfit_ceres::BlocksOf(poses);
   bodyfit_ceres::AddOptions ao;
   ao.beta_per_frame = c3;
+  ao.with_callback = true;      // the sweep callback below is the solver's evaluation_callback
   const int n_blocks = bodyfit_ceres::AddResidualBlocks(&problem, bp, koff.data(), table, beta.data(), ao);
   bodyfit_ceres::SweepCallback cb(bp, table, beta.data());
 

@@ -28,6 +28,5 @@ for F, iters in ((20, 60), (103, 30), (256, 20), (1024, 10)):
         rec["host" if solver == 1 else "device"] = dict(seconds=dt, iterations=s[0].iterations, ms_per_iteration=1e3 * dt / max(1, s[0].iterations),
                                                         final_cost=s[0].final_cost)
     out[f"F{F}"] = rec
-out["c4_host"] = fit_bench.fit_c4(api, synth, model, gm, solver=1)
-out["c4_device"] = fit_bench.fit_c4(api, synth, model, gm, solver=3)
+out["c4_staged"] = fit_bench.fit_c4(api, synth, model, gm)
 print(json.dumps(out, indent=1))
