@@ -244,6 +244,7 @@ int sweep(bodyfit_problem* p, const double* d_params, const double* d_beta, int 
       p->fused_epoch = 0;
     }
     sy.epoch = ++p->fused_epoch;
+    sy.resident_blocks = 2 * m->n_cus;
     p->fused_unchecked = true;
     launch_sweep_roles(m->d, dp, d_params, d_beta, d_r, want_jac ? d_J : nullptr, p->d_joints, mc, want_jac, pa,
                        p->d_cloud, sy, st, ev ? ev[4] : nullptr, ev ? ev[5] : nullptr);
@@ -372,6 +373,13 @@ int bodyfit_model_create(const bodyfit_model_desc* desc, int device, bodyfit_mod
   HIP_TRY(m->mem.upload(&d.level_off, level_off));
   HIP_TRY(m->mem.upload(&d.level_joint, level_joint));
   HIP_TRY(m->mem.upload(&d.anc_mask, anc));
+  // the same ancestors as a packed walk list: nearest first, 5 bits each, 0-terminated (joint ids 1..23; depth <= 12)
+  std::vector<unsigned long long> chain(nJ, 0ull);
+  for (int j = 1; j < nJ; ++j) {
+    int lvl = 0;
+    for (int k = m->parent[j]; k > 0 && lvl < 12; k = m->parent[k], ++lvl) chain[j] |= (unsigned long long)k << (5 * lvl);
+  }
+  HIP_TRY(m->mem.upload(&d.anc_chain, chain));
   HIP_TRY(m->mem.upload(&d.offset, m->offset));
   HIP_TRY(m->mem.upload(&d.dS, dS));
   HIP_TRY(m->mem.upload(&d.Jc0, Jc0));

@@ -27,6 +27,7 @@ struct DevModel {
   const int* level_off;        // [nLevels+1]  joints of depth d+1
   const int* level_joint;      // [nJ-1]
   const unsigned* anc_mask;    // [nJ] bit k: k is a proper ancestor of j, k != root
+  const unsigned long long* anc_chain;   // [nJ] the same ancestors as a walk list: nearest first, 5 bits each, 0-terminated
   const double* offset;        // [nJ][3]       include/Sim3BA.h:372-392
   const double* dS;            // [nJ][3][nS]   S_j - S_par(j)   (j = 0: S_0)
   const double* Jc0;           // [nJ][3]       rest joints, root at origin, beta = 0
@@ -64,9 +65,16 @@ struct DevProblem {
   double huber;
 };
 
+// Byte offset of one MFMA A fragment (row = lane & 31, k-half = lane >> 5; hl: 0 = bf16 hi part, 1 = lo part) inside the
+// 2 KiB block of a k-step: [hi | lo][2 k-halves][32 rows][8 bf16], i.e. a wave's 64 fragments of one part are 1 KiB of
+// contiguous memory (eight lines per load).  Measured and rejected: [32 rows][hi | lo][k-half] (a frame publishes 64
+// contiguous bytes per k-step instead of four 16-byte pieces) — the hand-off was no earlier and every fragment load then
+// touches sixteen lines (mesh role prologue 0.7 -> 1.1 us, step 24.1 -> 24.8 us).
+__host__ __device__ inline unsigned feat_frag_off(int lane, int hl) { return (unsigned)(hl * 1024 + lane * 16); }
+
 // operands the per-frame kernel prepares for the mesh kernel
 struct MeshCoef {
-  uint16_t* featA;   // [nFTiles][kBlendKSteps][2 hi/lo][64][8] bf16: pose features, then beta
+  uint16_t* featA;   // [nFTiles][kBlendKSteps][2 hi/lo][64][8] bf16 (feat_frag_off): pose features, then beta
   float* skinT;      // [F][nJ][12] f32: rows of [s R_root R0 A_j | s R_root R0 (P_j - A_j Jc_j) + t]
 };
 
@@ -107,6 +115,7 @@ struct FusedSync {
   unsigned* flag;              // [frames / 32, rounded up to whole groups of 8][kUnitCounterStride]
   unsigned* error;             // set when a workgroup's bounded wait ran out
   unsigned epoch;              // launch number, >= 1
+  int resident_blocks;         // blocks resident from the start of the launch (2 per CU)
 };
 constexpr int kRoleMaxFrames = 16384;
 

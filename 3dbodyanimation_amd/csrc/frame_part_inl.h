@@ -164,7 +164,8 @@ constexpr int OFF_DS = OFF_KPUV + 2 * KC;      // 24*3*10  S_j - S_par(j)
 constexpr int OFF_SC = OFF_DS + 720;           // 24*3*10  S_j - S_0
 constexpr int OFF_PART = OFF_SC + 720;         // landmark rest vertices [<= 96], root keypoint offset [100..102]
 constexpr int OFF_T = OFF_PART + 128;          // 24*3*10  T_j = B_j - A_j Sc_j (landmark shape columns)
-constexpr int OFF_LM = OFF_T + 720;            // landmarks: nL * LM_STRIDE, then their shapedirs rows nL * 3 * 10
+constexpr int OFF_CHAIN = OFF_T + 720;         // 24 ancestor walk lists (64-bit words)
+constexpr int OFF_LM = OFF_CHAIN + 24;         // landmarks: nL * LM_STRIDE, then their shapedirs rows nL * 3 * 10
 constexpr int LM_VP = 0;                       // 3
 constexpr int LM_Q = 3;                        // 3
 constexpr int LM_A = 6;                        // 9  blended rotation
@@ -244,6 +245,7 @@ __device__ __forceinline__ void frame_part(const DevModel& M, const DevProblem& 
   unsigned* sAnc = reinterpret_cast<unsigned*>(sTab + TAB_ANC);
   int* sKpId = sTab + TAB_KPID;
   unsigned* sKpAnc = reinterpret_cast<unsigned*>(sTab + 48);   // [KC] ancestor mask of each staged keypoint's joint
+  unsigned long long* sChain = reinterpret_cast<unsigned long long*>(sm + OFF_CHAIN);   // [24] ancestor walk lists
 
   STAMP_REAL(10);
   STAMP(0);
@@ -265,6 +267,7 @@ __device__ __forceinline__ void frame_part(const DevModel& M, const DevProblem& 
   const int tj_c = min(tid, nJ - 1);
   const int par_in = M.parent[tj_c];
   const unsigned anc_in = M.anc_mask[tj_c];
+  const unsigned long long chain_in = M.anc_chain[tj_c];
   const int nlw = nL * kMaxLmNnz, lw_i = min(tid, max(nlw, 1) - 1);          // <= 256 items: one pass
   const double lww_in = M.lm_ww[lw_i];
   const int lwj_in = M.lm_wj[lw_i];
@@ -312,7 +315,7 @@ __device__ __forceinline__ void frame_part(const DevModel& M, const DevProblem& 
     kp_u0 = Pb.kp_uv[2 * (size_t)(k_begin0 + (tid & (KC - 1)))];
     kp_v0 = Pb.kp_uv[2 * (size_t)(k_begin0 + (tid & (KC - 1))) + 1];
   }
-  if (tid < nJ) { sParent[tid] = par_in; sAnc[tid] = anc_in; }
+  if (tid < nJ) { sParent[tid] = par_in; sAnc[tid] = anc_in; sChain[tid] = chain_in; }
   volatile int* sWalkDone = reinterpret_cast<volatile int*>(sPart + 104);   // phase C: wave 6's chain quantities are in LDS
   if (tid == 0) *sWalkDone = 0;
   if (tid < nlw) {   // landmark skinning weights, fixed stride (padded with weight 0)
@@ -379,6 +382,12 @@ __device__ __forceinline__ void frame_part(const DevModel& M, const DevProblem& 
     if (i < 3) sPart[100 + i] = o;     // the root keypoint's own q = offset_0 + S_0 beta (include/Sim3BA.h:142-170)
     sJc[i] = jc;
   }
+  // Everything phase A requested has been consumed by now (or, R0 on wave 6, landed microseconds ago), but each of those
+  // loads and its use sit under the same lane predicate in DIFFERENT blocks, so hipcc's wait-count pass still carries their
+  // destination registers as "maybe pending" and puts s_waitcnt vmcnt(0) in front of every later reuse of such a register
+  // — in phase C that is right behind the 27 landmark loads (wave 0: in front of the root entries the hand-off waits for).
+  // An explicit vmcnt(0) the pass can see (the builtin, not asm text) costs nothing here and clears that state.
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), expcnt / lgkmcnt untouched
   frame_sync<kFused>();
 
   STAMP(2);
@@ -398,18 +407,21 @@ __device__ __forceinline__ void frame_part(const DevModel& M, const DevProblem& 
   auto lm_load = [&](int l, double (&pdv)[27]) {
     // UNCONDITIONAL loads from a clamped (always valid) row, masked by a factor: written as `on ? load : 0` hipcc branches
     // around every pair of loads and waits vmcnt(0) inside each branch, i.e. 14 dependent L2 round trips (seen in the .s)
-    const double onf = (lm_blend && l < nL && lm_k < nJ - 1) ? 1.0 : 0.0;
+    // The mask is NOT applied here: a product right behind the loads makes hipcc wait for all 27 of them on the spot
+    // (s_waitcnt vmcnt(0) in the .s), i.e. the wave sits out an L2 round trip before the work that was meant to run under it
+    // (on wave 0: the blend-coefficient stores and the root entries wave 7's hand-off waits for).  lm_terms masks the factors.
     const double* row = M.lm_pd + (size_t)min(l, max(nL, 1) - 1) * 27 * 32 + lm_k;
 #pragma unroll
-    for (int ae = 0; ae < 27; ++ae) pdv[ae] = row[ae * 32] * onf;
+    for (int ae = 0; ae < 27; ++ae) pdv[ae] = row[ae * 32];
   };
   auto lm_terms = [&](int l, const double (&pdv)[27]) {
     const int k = min(lm_k + 1, nJ - 1);
     const bool on = l < nL && lm_k < nJ - 1;
+    const double onf = (lm_blend && on) ? 1.0 : 0.0;      // (masked lanes loaded a clamped, valid row)
     double part[3] = {0.0, 0.0, 0.0};
 #pragma unroll
     for (int e = 0; e < 9; ++e) {
-      const double fe = sR[k * 9 + e] - ((e % 4 == 0) ? 1.0 : 0.0);
+      const double fe = (sR[k * 9 + e] - ((e % 4 == 0) ? 1.0 : 0.0)) * onf;
 #pragma unroll
       for (int a = 0; a < 3; ++a) part[a] += pdv[a * 9 + e] * fe;
     }
@@ -420,7 +432,7 @@ __device__ __forceinline__ void frame_part(const DevModel& M, const DevProblem& 
         double h[3] = {0.0, 0.0, 0.0};
 #pragma unroll
         for (int e = 0; e < 9; ++e) {
-          const double de = d[e];
+          const double de = d[e] * onf;
 #pragma unroll
           for (int a = 0; a < 3; ++a) h[a] += pdv[a * 9 + e] * de;
         }
@@ -443,6 +455,14 @@ __device__ __forceinline__ void frame_part(const DevModel& M, const DevProblem& 
   // (waves whose two landmark slots are both beyond nL skip the loads and the 108 products per lane altogether: with 11
   //  landmarks that is waves 6-7, which carry the chain walks, this phase's longest items)
   const bool lm_wave0 = 2 * wave < nL, lm_wave1 = 2 * wave + 16 < nL;
+  // root entries A_0 = I, P_0 = 0, B_0 = 0 (wave 0), first thing: wave 7's mesh operands wait for them (counter below)
+  if (tid < 9) sA[tid] = (tid % 4 == 0) ? 1.0 : 0.0;
+  if (tid >= 16 && tid < 19) sP[tid - 16] = 0.0;
+  if (tid >= 32 && tid - 32 < 3 * nS) { sB[tid - 32] = 0.0; sT[tid - 32] = 0.0; }
+  if (wave == 0) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (lane == 0) __hip_atomic_fetch_add(const_cast<int*>(sWalkDone), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
   double pdv0[27];
   if (lm_wave0) lm_load(lm_l, pdv0);
   for (int i = tid; i < 208; i += kThreads) {
@@ -450,25 +470,46 @@ __device__ __forceinline__ void frame_part(const DevModel& M, const DevProblem& 
     if (i < 9 * (nJ - 1)) v = sR[9 + i] - (((i % 9) % 4 == 0) ? 1.0 : 0.0);
     sFeat[i] = v;
   }
-  // chain walk of one item up the kinematic chain (kind 0: column sel of A_j, 1: P_j, 2: column sel of B_j)
-  auto walk = [&](int kind, int j, int sel) {
-    double v0, v1, v2;
-    if (kind == 0) { v0 = sR[j * 9 + sel]; v1 = sR[j * 9 + 3 + sel]; v2 = sR[j * 9 + 6 + sel]; }
-    else if (kind == 1) { v0 = sO[j * 3]; v1 = sO[j * 3 + 1]; v2 = sO[j * 3 + 2]; }
-    else {
-      v0 = sDS[(j * 3 + 0) * nS + sel]; v1 = sDS[(j * 3 + 1) * nS + sel]; v2 = sDS[(j * 3 + 2) * nS + sel];
-    }
-    for (int k = sParent[j]; k > 0; k = sParent[k]) {
-      const double* R = sR + k * 9;
-      double t0 = R[0] * v0 + R[1] * v1 + R[2] * v2;
-      double t1 = R[3] * v0 + R[4] * v1 + R[5] * v2;
-      double t2 = R[6] * v0 + R[7] * v1 + R[8] * v2;
-      if (kind == 1) { t0 += sO[k * 3]; t1 += sO[k * 3 + 1]; t2 += sO[k * 3 + 2]; }
-      else if (kind == 2) {
-        t0 += sDS[(k * 3 + 0) * nS + sel]; t1 += sDS[(k * 3 + 1) * nS + sel]; t2 += sDS[(k * 3 + 2) * nS + sel];
-      }
+  // chain walk of one item up the kinematic chain (kind 0: column sel of A_j, 1: P_j, 2: column sel of B_j).
+  // The ancestors come from the joint's packed walk list (ONE LDS read), not from parent[parent[...]] (a dependent LDS round
+  // trip per level), and the next level's rotation and offset are requested before this level's products: a level costs
+  // its nine dependent f64 products, not three LDS round trips (walks: 6.4 k -> ~2.5 k cycles on the hand-off's critical path).
+  // `kind` may differ from lane to lane (phase C walks A columns and P vectors in the same pass): the loop body is the same
+  // for every kind — v <- R_k v + m T[(3 k + a) stride + sel] with per-lane (table, stride, sel, m) — so lanes of different
+  // kinds walk TOGETHER; written as one branch per kind, the kinds of a wave ran one after the other (twice the chain depth).
+  auto walk = [&](int kind, int j, int sel, bool on) {
+    j = on ? j : 1;
+    const double* tab = (kind == 2) ? sDS : sO;            // the per-level addend: o_k (kind 1), dS_k[:, sel] (kind 2), none (0)
+    const int stride = (kind == 2) ? nS : 1, off = (kind == 2) ? sel : 0;
+    const double m = (kind == 0) ? 0.0 : 1.0;
+    const double* ini = (kind == 0) ? (sR + j * 9 + sel) : (tab + (j * 3) * stride + off);
+    const int istride = (kind == 0) ? 3 : stride;
+    double v0 = ini[0], v1 = ini[istride], v2 = ini[2 * istride];
+    unsigned long long ch = on ? sChain[j] : 0ull;
+    int k = (int)(ch & 31ull);
+    double Rc[9], oc[3];
+    auto fetch = [&](int kk, double (&Rn)[9], double (&on_)[3]) {   // (kk = 0 past the end: the root's entries, not used)
+#pragma unroll
+      for (int e = 0; e < 9; ++e) Rn[e] = sR[kk * 9 + e];
+#pragma unroll
+      for (int a3 = 0; a3 < 3; ++a3) on_[a3] = tab[(kk * 3 + a3) * stride + off];
+    };
+    fetch(k, Rc, oc);
+    while (k > 0) {
+      ch >>= 5;
+      const int kn = (int)(ch & 31ull);
+      double Rn[9], on_[3];
+      fetch(kn, Rn, on_);
+      const double t0 = Rc[0] * v0 + Rc[1] * v1 + Rc[2] * v2 + m * oc[0];
+      const double t1 = Rc[3] * v0 + Rc[4] * v1 + Rc[5] * v2 + m * oc[1];
+      const double t2 = Rc[6] * v0 + Rc[7] * v1 + Rc[8] * v2 + m * oc[2];
       v0 = t0; v1 = t1; v2 = t2;
+#pragma unroll
+      for (int e = 0; e < 9; ++e) Rc[e] = Rn[e];
+      oc[0] = on_[0]; oc[1] = on_[1]; oc[2] = on_[2];
+      k = kn;
     }
+    if (!on) return;
     if (kind == 0) { sA[j * 9 + sel] = v0; sA[j * 9 + 3 + sel] = v1; sA[j * 9 + 6 + sel] = v2; }
     else if (kind == 1) { sP[j * 3] = v0; sP[j * 3 + 1] = v1; sP[j * 3 + 2] = v2; }
     else {
@@ -479,9 +520,9 @@ __device__ __forceinline__ void frame_part(const DevModel& M, const DevProblem& 
       sT[(j * 3 + 0) * nS + sel] = v0 - c[0]; sT[(j * 3 + 1) * nS + sel] = v1 - c[1]; sT[(j * 3 + 2) * nS + sel] = v2 - c[2];
     }
   };
-  // blend-coefficient fragments of the mesh kernel: they need R_j (phase B) and beta only, so wave 6 stores them first
-  // thing (it has the least to do in this phase) and they have long left when it signals
-  if (wave == 6 && mc.featA) {
+  // blend-coefficient fragments of the mesh kernel: they need R_j (phase B) and beta only, so wave 0 stores them first
+  // thing, in the shadow of its landmark posedirs loads, and they have long left when it says so (below)
+  if (wave == 0 && mc.featA) {
     // MFMA row of this frame inside its 32-frame tile.  feat_perm (k_sweep_roles' mesh role): accumulator register i of the
     // half-wave h holds frame 2 i + h, so that one register row covers two CONSECUTIVE frames (2,304 contiguous bytes of
     // transforms); otherwise (k_mesh_blend_lbs) the natural order, register i <-> frames 8 (i >> 2) + (i & 3) + 4 h.
@@ -517,7 +558,8 @@ __device__ __forceinline__ void frame_part(const DevModel& M, const DevProblem& 
         }
         pk[jj] = (uint32_t)b[0] | ((uint32_t)b[1] << 16);
       }
-      uint4* dst = reinterpret_cast<uint4*>(mc.featA + ((((size_t)ftile * kBlendKSteps + kstep) * 2 + hl) * 64 + (h * 32 + row)) * 8);
+      uint4* dst = reinterpret_cast<uint4*>(reinterpret_cast<unsigned char*>(mc.featA) + ((size_t)ftile * kBlendKSteps + kstep) * 2048 +
+                                            feat_frag_off(h * 32 + row, hl));
       store_operand16<kFused>(dst, make_uint4(pk[0], pk[1], pk[2], pk[3]));
     }
   }
@@ -534,16 +576,13 @@ __device__ __forceinline__ void frame_part(const DevModel& M, const DevProblem& 
     // before phase E are walked in phase D, where most threads are idle
     const int nA = 3 * (nJ - 1), nP = nJ - 1;
     const int nA6 = (nA + 1) / 2, nP6 = (nP + 1) / 2;
-    if (wave == 6) {
-      if (lane < nA6) walk(0, 1 + lane / 3, lane % 3);
-      else if (lane - nA6 < nP6) walk(1, 1 + (lane - nA6), 0);
-    } else if (wave == 7) {
-      if (lane < nA - nA6) walk(0, 1 + (nA6 + lane) / 3, (nA6 + lane) % 3);
-      else if (lane - (nA - nA6) < nP - nP6) walk(1, 1 + nP6 + (lane - (nA - nA6)), 0);
+    if (wave == 6 || wave == 7) {   // ONE walk call per wave: its A lanes and its P lanes go up their chains together
+      const int a0 = wave == 6 ? 0 : nA6, na = wave == 6 ? nA6 : nA - nA6;
+      const int p0 = wave == 6 ? 0 : nP6, np = wave == 6 ? nP6 : nP - nP6;
+      const bool isA = lane < na, isP = !isA && lane - na < np;
+      const int item = isA ? a0 + lane : p0 + (lane - na);
+      walk(isA ? 0 : 1, isA ? 1 + item / 3 : 1 + item, isA ? item % 3 : 0, isA || isP);
     }
-    if (tid < 9) sA[tid] = (tid % 4 == 0) ? 1.0 : 0.0;       // root: A_0 = I, P_0 = 0, B_0 = 0
-    if (tid >= 16 && tid < 19) sP[tid - 16] = 0.0;
-    if (tid >= 32 && tid - 32 < 3 * nS) { sB[tid - 32] = 0.0; sT[tid - 32] = 0.0; }
   }
   // ---- mesh operands (blend-coefficient fragments, skinning transforms) and posed joints: wave 7, still in phase C ----
   // They need R_j (phase B), the chain quantities A_j, P_j (waves 6 and 7, just above), the root entries (waves 0, above)
@@ -551,43 +590,65 @@ __device__ __forceinline__ void frame_part(const DevModel& M, const DevProblem& 
   // everything is stored by this ONE wave, so the in-launch hand-off needs no workgroup barrier (cdna guide, Guideline 16 R1:
   // one lane signals for all the stores of its workgroup after every STORING wave's vmcnt(0)); the drain and the signal
   // are wave 7's only work in phase D.
-  if (wave == 6 || wave == 0) {
-    // (LDS serves a wave in order; the wait also keeps hipcc from sinking the writes.)  Wave 6 also waits for its blend-
-    // coefficient stores (requested a chain walk ago) to have left: wave 7, which sees both adds before it signals, then
-    // signals for wave 6's stores too (cdna guide, Guideline 16: "each wave adds to a counter in LDS after its wait and the
-    // wave whose add is last signals")
-    if (kFused && wave == 6) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // Who tells wave 7 what, through one LDS counter (every add program-ordered behind the adder's LDS writes; LDS serves a wave
+  // in order, and the lgkmcnt wait keeps hipcc from sinking the writes):
+  //   wave 0: the root entries are in LDS (first thing in this phase)       (+1)
+  //   wave 6: its chain quantities and Rr0 are in LDS                      (+256)  -> count >= 257: wave 7 builds the transforms
+  //   wave 0: its blend-coefficient stores have LEFT (vmcnt(0))            (+1)    -> count 258: wave 7 may signal for them too
+  // (wave 6 counts in its own byte: wave 0's second add may come before wave 6's)
+  // (cdna guide, Guideline 16: "each wave adds to a counter in LDS after its wait and the wave whose add is last signals")
+  if (wave == 6) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (lane == 0) __hip_atomic_fetch_add(const_cast<int*>(sWalkDone), 256, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
+  if (kFused && wave == 0) {
+    STAMP_REAL(13);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    STAMP_REAL(14);
     if (lane == 0) __hip_atomic_fetch_add(const_cast<int*>(sWalkDone), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   }
   if (wave == 7) {
-    STAMP_REAL(13);
-    for (int spin = 0; spin < (1 << 20) && *sWalkDone < 2; ++spin) __builtin_amdgcn_s_sleep(1);
+    STAMP(13);
+    for (int spin = 0; spin < (1 << 20) && *sWalkDone < 257; ++spin) __builtin_amdgcn_s_sleep(1);
     asm volatile("" ::: "memory");
-    STAMP_REAL(14);
+    STAMP(14);
     const double s_ = sx[0];
     const double* Rr0_ = sCam;
-    if (lane < nJ) {
-      const int jj = lane;
-      double RA[9], t[3], q[3];
-      mul33(Rr0_, sA + jj * 9, RA);
-      mv3(sA + jj * 9, sJc[jj * 3], sJc[jj * 3 + 1], sJc[jj * 3 + 2], q);
-      mv3(Rr0_, sP[jj * 3] - q[0], sP[jj * 3 + 1] - q[1], sP[jj * 3 + 2] - q[2], t);
+    // item = (joint jj, row r) of the 3 x 4 transform  s Rr0 [A_jj | P_jj - A_jj Jc_jj] + [0 | t]: item it of frame f is the
+    // 16-byte chunk 3 nJ f + it of skinT (and double 3 nJ f + it of joints_out), so a wave's stores are CONTIGUOUS (nine full
+    // 128-byte lines per frame; one lane per joint wrote 16-byte pieces 48 bytes apart, three partial writes to every line:
+    // the write-through acknowledgements the hand-off waits for had a tail of 1-2 us)
+    for (int it = lane; it < 3 * nJ; it += 64) {
+      const int jj = it / 3, r = it - 3 * jj;
+      const double* Aj = sA + jj * 9;
+      const double a0 = Rr0_[r * 3], a1 = Rr0_[r * 3 + 1], a2 = Rr0_[r * 3 + 2];
+      double q[3];
+      mv3(Aj, sJc[jj * 3], sJc[jj * 3 + 1], sJc[jj * 3 + 2], q);
+      const double p0 = sP[jj * 3], p1 = sP[jj * 3 + 1], p2 = sP[jj * 3 + 2];
       if (mc.skinT) {
-        float4* T = reinterpret_cast<float4*>(mc.skinT + ((size_t)f * nJ + jj) * 12);
-#pragma unroll
-        for (int r = 0; r < 3; ++r)
-          store_operand16<kFused>(T + r, make_uint4(__float_as_uint((float)(s_ * RA[r * 3 + 0])), __float_as_uint((float)(s_ * RA[r * 3 + 1])),
-                                                    __float_as_uint((float)(s_ * RA[r * 3 + 2])),
-                                                    __float_as_uint((float)(s_ * t[r] + sx[4 + r]))));
+        const double ra0 = a0 * Aj[0] + a1 * Aj[3] + a2 * Aj[6];      // row r of Rr0 A_jj (mul33's order of products)
+        const double ra1 = a0 * Aj[1] + a1 * Aj[4] + a2 * Aj[7];
+        const double ra2 = a0 * Aj[2] + a1 * Aj[5] + a2 * Aj[8];
+        const double tr = a0 * (p0 - q[0]) + a1 * (p1 - q[1]) + a2 * (p2 - q[2]);
+        float4* T = reinterpret_cast<float4*>(mc.skinT + (size_t)f * nJ * 12) + it;
+        store_operand16<kFused>(T, make_uint4(__float_as_uint((float)(s_ * ra0)), __float_as_uint((float)(s_ * ra1)),
+                                              __float_as_uint((float)(s_ * ra2)), __float_as_uint((float)(s_ * tr + sx[4 + r]))));
       }
-      if (joints_out) {
-        mv3(Rr0_, sP[jj * 3], sP[jj * 3 + 1], sP[jj * 3 + 2], t);
-#pragma unroll
-        for (int r = 0; r < 3; ++r) joints_out[((size_t)f * nJ + jj) * 3 + r] = s_ * t[r] + sx[4 + r];
-      }
+      if (joints_out) joints_out[(size_t)f * nJ * 3 + it] = s_ * (a0 * p0 + a1 * p1 + a2 * p2) + sx[4 + r];
     }
-    STAMP_REAL(15);
+    STAMP(15);
+    if constexpr (kFused) {
+      // hand-off, still inside phase C (wave 7 has ~2 k cycles of slack before the landmark waves reach the phase's barrier):
+      // this wave's operand stores have left, wave 0's too (count 258), then one agent-scope add to the counter of the frame's
+      // 32-frame unit
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      STAMP_REAL(9);
+      for (int spin = 0; spin < (1 << 20) && *sWalkDone < 258; ++spin) __builtin_amdgcn_s_sleep(1);
+      asm volatile("" ::: "memory");
+      if (lane == 0)
+        (void)__hip_atomic_fetch_add(fu.flag + (size_t)(f / kFTile) * kUnitCounterStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      STAMP_REAL(12);
+    }
   }
   if (lm_wave0) lm_terms(lm_l, pdv0);
   if (lm_wave1) {   // landmarks 16..31: second pass
@@ -600,20 +661,9 @@ __device__ __forceinline__ void frame_part(const DevModel& M, const DevProblem& 
 
   STAMP(4);
   // ---- D. wave 0-1: W_{k,c} = A_p (dR_{k,c} R_k^T) A_p^T ; wave 2: landmark LBS ; waves 3-6: B_j columns (d P_j / d beta) ;
-  //         wave 7: the hand-off of the mesh operands it stored in phase C ----
+  //         (wave 7 stored and handed over the mesh operands in phase C) ----
   if (use_shape && want_jac) {
-    for (int it = tid - 192; it >= 0 && tid < 448 && it < nS * (nJ - 1); it += 256) walk(2, 1 + it / nS, it % nS);
-  }
-  if constexpr (kFused) {
-    if (wave == 7) {
-      // hand-off: this wave's operand stores of phase C (the only ones of the workgroup; nothing else of this wave is in
-      // flight) have left, then one agent-scope add to the counter of the frame's 32-frame unit.  The write-through stores
-      // take 1-3 us to be acknowledged; wave 7 has nothing else to do in this phase.
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (lane == 0)
-        (void)__hip_atomic_fetch_add(fu.flag + (size_t)(f / kFTile) * kUnitCounterStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      STAMP_REAL(12);
-    }
+    for (int it = tid - 192; it >= 0 && tid < 448 && it < nS * (nJ - 1); it += 256) walk(2, 1 + it / nS, it % nS, true);
   }
   if (want_jac && tid < 3 * (nJ - 1)) {
     const int k = 1 + tid / 3, c = tid % 3, p = sParent[k];

@@ -164,7 +164,10 @@ __global__ __launch_bounds__(kThreads, 4) void k_sweep_roles(RoleArgs by_value) 
     // Polling is kept sparse: a few hundred waiting workgroups that hammer one line delay the very stores they wait for
     // (with 1 KB of per-frame flags polled every 128 cycles the hand-off took 3 us to arrive and the producers' store drain
     // 3 us instead of 1).  One immediate look (later groups: their frames are long done), then nothing before 3 us after
-    // entry (no frame workgroup is faster), then one look every ~0.25 us.
+    // entry (no frame workgroup is faster), then one look at a time: a round trip to the memory side, where agent-scope
+    // counters live, plus a short sleep, ~1.1 us per look.  Measured and rejected: three looks in flight ~0.27 us apart by the
+    // lanes whose unit is still incomplete — the step was no shorter (24.1-24.5 against 23.9-24.5 us, same box) and the
+    // hand-off itself came later (the producers' adds queue behind the looks on the same eight lines).
     volatile unsigned* ctrl = reinterpret_cast<volatile unsigned*>(lds + kRoleCtrlOff);
     const int tid = threadIdx.x, lane = tid & 63;
     if ((tid >> 6) == kPollWave) {
@@ -233,7 +236,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_sweep_roles(RoleArgs by_value) 
   const DevModel M = A->M;
   const DevProblem Pb = A->Pb;
   const MeshCoef mc = A->mc;
-  mesh_role(M, Pb, mc, A->cloud_f, idx, grp, lds, wait_flags);
+  mesh_role(M, Pb, mc, A->cloud_f, idx, grp, lds, (int)blockIdx.x < A->sy.resident_blocks, wait_flags);
 #endif
 }
 

@@ -79,7 +79,7 @@ struct Lane {                    // per-lane constants of the skinning rows
 // sc1 load (served by L2, never by this CU's L1, which may hold the previous launch's lines).
 struct OperandSrc {
   const unsigned char* skinT;
-  const uint4* feat;                       // featA + lane
+  const uint4* feat;                       // featA
   __amdgpu_buffer_rsrc_t skinT_rsrc;       // fused only
   __amdgpu_buffer_rsrc_t feat_rsrc;        // fused only
 };
@@ -101,14 +101,14 @@ template <bool kFused>
 __device__ __forceinline__ void feat_load(const OperandSrc& src, int ftile, int ks, int lane, uint4& hi, uint4& lo) {
   if constexpr (kFused) {
     const unsigned soff = (unsigned)((ftile * kBlendKSteps + ks) * 2 * 1024);
-    const u32x4 h = __builtin_amdgcn_raw_buffer_load_b128(src.feat_rsrc, (unsigned)(lane * 16), soff, 16);
-    const u32x4 l = __builtin_amdgcn_raw_buffer_load_b128(src.feat_rsrc, (unsigned)(lane * 16 + 1024), soff, 16);
+    const u32x4 h = __builtin_amdgcn_raw_buffer_load_b128(src.feat_rsrc, feat_frag_off(lane, 0), soff, 16);
+    const u32x4 l = __builtin_amdgcn_raw_buffer_load_b128(src.feat_rsrc, feat_frag_off(lane, 1), soff, 16);
     hi = make_uint4(h.x, h.y, h.z, h.w);
     lo = make_uint4(l.x, l.y, l.z, l.w);
   } else {
-    const uint4* fa = src.feat + (size_t)ftile * kBlendKSteps * 2 * 64;
-    hi = fa[(size_t)ks * 128];
-    lo = fa[(size_t)ks * 128 + 64];
+    const unsigned char* fa = reinterpret_cast<const unsigned char*>(src.feat) + ((size_t)ftile * kBlendKSteps + ks) * 2048;
+    hi = *reinterpret_cast<const uint4*>(fa + feat_frag_off(lane, 0));
+    lo = *reinterpret_cast<const uint4*>(fa + feat_frag_off(lane, 1));
   }
 }
 __device__ __forceinline__ void skin_store(unsigned char* l, int lane, const u32x4 (&reg)[kSkinVec]) {
@@ -275,7 +275,7 @@ __device__ __forceinline__ void mesh_part(const DevModel& M, const DevProblem& P
   // this wave's units: frame tiles wave, wave + 8, ...
   OperandSrc src;
   src.skinT = reinterpret_cast<const unsigned char*>(mc.skinT);
-  src.feat = reinterpret_cast<const uint4*>(mc.featA) + lane;
+  src.feat = reinterpret_cast<const uint4*>(mc.featA);
   if constexpr (kFused) {
     src.skinT_rsrc = __builtin_amdgcn_make_buffer_rsrc(mc.skinT, 0, nFT * kFTile * kRowBytes, 0x00020000);
     src.feat_rsrc = __builtin_amdgcn_make_buffer_rsrc(mc.featA, 0, nFT * kBlendKSteps * 2 * 1024, 0x00020000);

@@ -163,8 +163,8 @@ __device__ __forceinline__ void role_blend_step(const RoleCtx& C, const __amdgpu
   }
   if constexpr (S + 3 < kBlendKSteps) {     // A fragments three k-steps ahead (L2; handed over in this launch: sc1)
     const unsigned soff = feat_off + (unsigned)((S + 3) * 2 * 1024);
-    a[S % 3][0] = __builtin_amdgcn_raw_buffer_load_b128(feat_rsrc, (unsigned)(C.lane * 16), soff, kLoadSc1);
-    a[S % 3][1] = __builtin_amdgcn_raw_buffer_load_b128(feat_rsrc, (unsigned)(C.lane * 16 + 1024), soff, kLoadSc1);
+    a[S % 3][0] = __builtin_amdgcn_raw_buffer_load_b128(feat_rsrc, feat_frag_off(C.lane, 0), soff, kLoadSc1);
+    a[S % 3][1] = __builtin_amdgcn_raw_buffer_load_b128(feat_rsrc, feat_frag_off(C.lane, 1), soff, kLoadSc1);
   }
   // issue order of the step: each coordinate's three products, then the next k-step's two fragment reads of that
   // coordinate (a whole k-step of matrix work ahead of their use), the A fragments last
@@ -230,7 +230,8 @@ __device__ __forceinline__ void role_skin_row(const RoleCtx& C, const RoleLane& 
 // group's hand-off flags (or the operands are from an earlier launch).  `lds`: kRoleLdsBytes.
 template <typename WaitFlags>
 __device__ __forceinline__ void mesh_role(const DevModel& M, const DevProblem& Pb, const MeshCoef& mc, float* __restrict__ cloud_f,
-                                          int vtile, int group, unsigned char* lds_generic, WaitFlags wait_flags) {
+                                          int vtile, int group, unsigned char* lds_generic, bool beside_its_frames,
+                                          WaitFlags wait_flags) {
   RoleCtx C;
   C.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   C.lane = threadIdx.x & 63;
@@ -256,17 +257,21 @@ __device__ __forceinline__ void mesh_role(const DevModel& M, const DevProblem& P
   //      weights.  They land under the wait for the hand-off. -----------------------------------------------------------
   const uint32_t widx = M.wIdx[(size_t)vtile * 32 + col];
   const float4 wv = reinterpret_cast<const float4*>(M.wVal)[(size_t)vtile * 32 + col];
-  // The stream is a trickle, not a burst: requested all at once at the start of the launch (17 MB chip-wide) it stretched
-  // the frame workgroups' table loads by 900 cycles and their hand-off by 2 us, which every mesh workgroup then waits for.
-  // Nothing needs it before the hand-off: one slab per ~0.25 us from 1.2 us on (past the frame workgroups' table loads).
+  // A workgroup that is resident from the start of the launch runs BESIDE the frame workgroups it waits for: its stream is a
+  // trickle, not a burst — requested all at once (17 MB chip-wide) it stretched the frame workgroups' table loads by 900
+  // cycles and their hand-off by 2 us, which every mesh workgroup then waits for; nothing needs it before the hand-off:
+  // one slab per ~0.25 us from 1.2 us on (past the frame workgroups' table loads).  A workgroup dispatched later (more
+  // frames than one group: its frames were handed over long ago) requests everything at once.
   if (C.wave < 6) {   // six pieces per slab: waves 6 and 7 have none
-    const unsigned long long t_in = __builtin_amdgcn_s_memrealtime();
-    while (__builtin_amdgcn_s_memrealtime() - t_in < 120) __builtin_amdgcn_s_sleep(8);
+    if (beside_its_frames) {
+      const unsigned long long t_in = __builtin_amdgcn_s_memrealtime();
+      while (__builtin_amdgcn_s_memrealtime() - t_in < 120) __builtin_amdgcn_s_sleep(8);
+    }
 #pragma unroll 1
     for (int s = 0; s < kResident; ++s) {
       __builtin_amdgcn_raw_ptr_buffer_load_lds(C.dirs_rsrc, (__attribute__((address_space(3))) void*)(C.ring + role_slab_off(s) + C.piece * 1024),
                                                16, C.slab_voff, C.dirs_soff + (unsigned)s * kSlabBytes, 0, 0);
-      __builtin_amdgcn_s_sleep(7);
+      if (beside_its_frames) __builtin_amdgcn_s_sleep(7);
     }
   }
   RoleLane L;
@@ -297,8 +302,8 @@ __device__ __forceinline__ void mesh_role(const DevModel& M, const DevProblem& P
 #pragma unroll
     for (int ks = 0; ks < 3; ++ks) {
       const unsigned soff = feat_off + (unsigned)(ks * 2 * 1024);
-      a[ks][0] = __builtin_amdgcn_raw_buffer_load_b128(feat_rsrc, (unsigned)(C.lane * 16), soff, kLoadSc1);
-      a[ks][1] = __builtin_amdgcn_raw_buffer_load_b128(feat_rsrc, (unsigned)(C.lane * 16 + 1024), soff, kLoadSc1);
+      a[ks][0] = __builtin_amdgcn_raw_buffer_load_b128(feat_rsrc, feat_frag_off(C.lane, 0), soff, kLoadSc1);
+      a[ks][1] = __builtin_amdgcn_raw_buffer_load_b128(feat_rsrc, feat_frag_off(C.lane, 1), soff, kLoadSc1);
     }
   }
   // every wave's pieces of the resident slabs have landed (they were requested microseconds ago; the A fragments just now)

@@ -43,11 +43,25 @@ print(f"F = {F}; all times in us after the first workgroup's entry")
 print("frame role: entry              ", q(us(fr[:, 0, 10])))
 print("frame role: hand-off published ", q(us(fr[:, 7, 12])))
 w7 = fr[:, 7, :]
-print("frame role wave 7: walks done", q(us(w7[:, 13])), "| wave 6 + 0 seen", q(us(w7[:, 14])))
-print("                   operands stored", q(us(w7[:, 15])), "| drained + signalled", q(us(w7[:, 12])))
+c0 = w7[:, 2]   # start of phase C (shader cycles)
+print("frame role wave 7, shader cycles into phase C: walks done", q(w7[:, 13] - c0), "| wave 6 + 0 seen", q(w7[:, 14] - c0),
+      "| operands stored", q(w7[:, 15] - c0), "| end of C", q(w7[:, 3] - c0))
+print("                   own stores drained (us)", q(us(w7[:, 9])), "| signalled (us)", q(us(w7[:, 12])), "| waiting for wave 0's drain", q((w7[:, 12] - w7[:, 9]) / 100))
+print("frame role wave 0: blend coefficients issued (us)", q(us(fr[:, 0, 13])), "| drained", q(us(fr[:, 0, 14])), "| drain time", q((fr[:, 0, 14] - fr[:, 0, 13]) / 100))
 pub = us(fr[:, 7, 12])
 late = np.argsort(pub)[-24:]
 print("frame role: latest 24 hand-offs (frame: us):", " ".join(f"{int(i)}:{pub[i]:.1f}" for i in late))
+print("frame role: latest 8 hand-offs: frame (XCD) entry us | wave 7 cycles entry->C, C->walks, ->seen, ->stored | hand-off us | us per 1000 cycles")
+for i in late[-8:]:
+    cyc_all = w7[i, 15] - w7[i, 0]
+    print(f"    {int(i):4d} ({int(fr[i, 0, 9])})  {us(fr[i, 0, 10]):5.2f} | {int(w7[i, 2] - w7[i, 0]):6d} {int(w7[i, 13] - w7[i, 2]):6d} {int(w7[i, 14] - w7[i, 13]):6d} {int(w7[i, 15] - w7[i, 14]):6d}"
+          f" | {pub[i]:5.2f} | {(pub[i] - us(fr[i, 0, 10])) / cyc_all * 1000:.3f}")
+med = np.argsort(pub)[F // 2 - 4:F // 2 + 4]
+print("frame role: 8 median hand-offs, same columns")
+for i in med:
+    cyc_all = w7[i, 15] - w7[i, 0]
+    print(f"    {int(i):4d} ({int(fr[i, 0, 9])})  {us(fr[i, 0, 10]):5.2f} | {int(w7[i, 2] - w7[i, 0]):6d} {int(w7[i, 13] - w7[i, 2]):6d} {int(w7[i, 14] - w7[i, 13]):6d} {int(w7[i, 15] - w7[i, 14]):6d}"
+          f" | {pub[i]:5.2f} | {(pub[i] - us(fr[i, 0, 10])) / cyc_all * 1000:.3f}")
 print("frame role: hand-off percentiles 50/90/95/99/100:", np.percentile(pub, [50, 90, 95, 99, 100]).round(2))
 xcc = fr[:, 0, 9].astype(int)
 print("frame role: median hand-off by XCD:", " ".join(f"{x}:{np.median(pub[xcc == x]):.2f}/{pub[xcc == x].max():.2f}(n={int((xcc == x).sum())})" for x in sorted(set(xcc))))
