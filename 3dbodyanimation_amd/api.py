@@ -159,6 +159,7 @@ def load_library():
     lib.bodyfit_evaluate_batch.argtypes = [C.c_void_p, _dp, _dp, _dp, _dp, _ip, C.c_int]
     lib.bodyfit_evaluate_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
     lib.bodyfit_reduce_shared_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.bodyfit_arm_shared_reduction.argtypes = [C.c_void_p, C.c_void_p]
     lib.bodyfit_profile_sweep.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, _dp]
     lib.bodyfit_solve.argtypes = [C.c_void_p, _dp, _dp, C.POINTER(C.c_ubyte), C.c_int, C.POINTER(FitOptions),
                                   C.POINTER(FitSummary), C.c_int]
@@ -375,6 +376,11 @@ class Problem:
 
     def reduce_shared_device(self, d_out_ptr: int | None = None, stream: int | None = None):
         _check(load_library().bodyfit_reduce_shared_device(self.h, d_out_ptr, stream))
+
+    def arm_shared_reduction(self, d_out_ptr: int | None):
+        """Following Jacobian sweeps deposit [cost | g_beta | H_bb] in d_out_ptr at their own tail when they can (one-launch
+        sweep, shared beta, <= 256 frames + prior tiles); reduce_shared_device(d_out_ptr) then launches nothing.  None disarms."""
+        _check(load_library().bodyfit_arm_shared_reduction(self.h, d_out_ptr))
 
     def profile_sweep(self, d_params_ptr, d_beta_ptr, want_jacobian=True, with_reduce=False, iters=50, stream=None):
         ms = np.zeros(5)

@@ -144,6 +144,9 @@ struct bodyfit_problem {
   bool fused_enabled = true, fused_unchecked = false;
   double* d_frame_partials = nullptr; // [F][258] per-frame beta partials written by k_frame_resjac (shared-beta problems)
   int partials_tiles = 0;             // prior tiles that added their plain-cost rows behind the frame rows
+  double* armed_out66 = nullptr;      // bodyfit_arm_shared_reduction: where a folding sweep deposits [cost | g_beta | H_bb]
+  unsigned fold_count = 0;            // tickets taken by the folding sweeps since the sync buffer was zeroed
+  bool fold_fresh = false;            // the last sweep folded into armed_out66
   bool partials_fresh = false;        // the last sweep produced them (want_jac)      // [F][76] update parameters + [F][9] R0' + [F] mean pixel error, on first use   // [F][87][88] per-frame normal-equation panels (window solver), on first use
   // host copies
   std::vector<int> kp_offset, kp_id, kp_frame;
@@ -209,6 +212,7 @@ int sweep(bodyfit_problem* p, const double* d_params, const double* d_beta, int 
   dp.beta_partials = (want_jac && !frame_flags) ? p->d_frame_partials : nullptr;
   dp.huber = p->desc.huber_delta;
   p->partials_fresh = dp.beta_partials != nullptr;
+  p->fold_fresh = false;
   dp.frame_flags = frame_flags;
   dp.frame_mask = frame_mask;
   double* d_r = r_base ? r_base : p->d_r;
@@ -239,15 +243,31 @@ int sweep(bodyfit_problem* p, const double* d_params, const double* d_beta, int 
     FusedSync sy{};
     sy.error = reinterpret_cast<unsigned*>(p->d_fused);
     sy.flag = reinterpret_cast<unsigned*>(p->d_fused + kFusedSyncHeader);
-    if (p->fused_epoch >= (1u << 26)) {   // epoch x 32 is about to wrap the 32-bit unit counters: start over (stream-ordered)
+    if (p->fused_epoch >= (1u << 26) || p->fold_count >= (1u << 31)) {
+      // epoch x 32 is about to wrap the 32-bit unit counters (or the fold ticket): start over (stream-ordered)
       (void)hipMemsetAsync(p->d_fused, 0, p->fused_bytes, st);
       p->fused_epoch = 0;
+      p->fold_count = 0;
     }
     sy.epoch = ++p->fused_epoch;
     sy.resident_blocks = 2 * m->n_cus;
     p->fused_unchecked = true;
+    FoldTail fold{};
+    const int n_partials = p->d.F + pa.n_tiles;
+    if (p->armed_out66 && dp.beta_partials && !p->desc.beta_per_frame && d_beta && n_partials <= kFoldMaxPartials) {
+      // the shared-shape reduction rides on this launch's tail (bodyfit_arm_shared_reduction)
+      fold.ticket = reinterpret_cast<unsigned*>(p->d_fused + kFoldTicketOffset);
+      fold.want = (p->fold_count += (unsigned)n_partials);
+      fold.n_partials = n_partials;
+      fold.partials = dp.beta_partials;
+      fold.beta = d_beta;
+      fold.shape_rows = p->lay.shape_rows;
+      fold.beta_shape = D.beta_shape;
+      fold.out66 = p->armed_out66;
+      p->fold_fresh = true;
+    }
     launch_sweep_roles(m->d, dp, d_params, d_beta, d_r, want_jac ? d_J : nullptr, p->d_joints, mc, want_jac, pa,
-                       p->d_cloud, sy, st, ev ? ev[4] : nullptr, ev ? ev[5] : nullptr);
+                       p->d_cloud, sy, fold, st, ev ? ev[4] : nullptr, ev ? ev[5] : nullptr);
   } else {
     launch_frame_resjac(m->d, dp, d_params, d_beta, d_r, want_jac ? d_J : nullptr, p->d_joints, mc, want_jac,
                         mesh ? none : pa, st, ev ? ev[0] : nullptr, ev ? ev[1] : nullptr);
@@ -883,15 +903,26 @@ int bodyfit_frame_normals(bodyfit_problem* p, const double* frame_params, const 
   return bodyfit_internal_frame_normals(p, frame_params, beta, residuals, gmm_comp, normals);
 }
 
+int bodyfit_arm_shared_reduction(bodyfit_problem* p, double* d_out66) {
+  if (!p) return fail(BODYFIT_ERR_INVALID, "null argument");
+  if (d_out66 && (p->desc.beta_per_frame || p->m->nS != kMaxShape || p->lay.n_cols <= 7 + 3 * (p->m->nJ - 1)))
+    return fail(BODYFIT_ERR_INVALID, "bodyfit_arm_shared_reduction: needs a problem with a shared 10-coefficient shape block");
+  std::lock_guard<std::mutex> lock(p->mu);
+  p->armed_out66 = d_out66;
+  p->fold_fresh = false;
+  return BODYFIT_OK;
+}
+
 int bodyfit_reduce_shared_device(bodyfit_problem* p, double* d_out66, void* stream) {
   if (!p) return fail(BODYFIT_ERR_INVALID, "null argument");
   HIP_TRY(hipSetDevice(p->m->device));
   const int npose = 7 + 3 * (p->m->nJ - 1);
   const int shared_shape_rows = (!p->desc.beta_per_frame) ? p->lay.shape_rows : 0;
+  if (p->fold_fresh && d_out66 && d_out66 == p->armed_out66) return BODYFIT_OK;   // the sweep's own tail has written it
   if (p->d_frame_partials && p->partials_fresh) {
     // the sweep's k_frame_resjac already reduced every frame's reprojection rows: sum the per-frame partials and the
     // prior / temporal rows, pack
-    launch_reduce_frames(p->d.F + p->partials_tiles, 0, 0, p->d_r, p->row_shape, shared_shape_rows,
+    launch_reduce_frames(p->d.F + p->partials_tiles, p->d_r, p->row_shape, shared_shape_rows,
                          p->desc.beta_shape, p->d_frame_partials, p->d_partials, d_out66 ? d_out66 : p->d_normal,
                          static_cast<hipStream_t>(stream));
   } else {
@@ -923,7 +954,7 @@ int bodyfit_profile_sweep(bodyfit_problem* p, const double* d_frame_params, cons
     rc = sweep(p, d_frame_params, d_beta, want_jacobian, mesh, st, e);
     if (rc == BODYFIT_OK && with_reduce) {
       (void)hipEventRecord(e[6], st);
-      rc = bodyfit_reduce_shared_device(p, nullptr, stream);
+      rc = bodyfit_reduce_shared_device(p, p->armed_out66, stream);   // (armed: the sweep's own tail did it, nothing is launched)
       (void)hipEventRecord(e[7], st);
     }
   }

@@ -90,6 +90,12 @@ struct DevGmm {
 
 // prior residuals computed by extra workgroups of the k_frame_resjac launch (priors_inl.h)
 constexpr int kReducePartial = 258;   // entries per reduction partial: 16 x 16 Gram tile (H_bb upper + g_beta in column 10), huber cost, plain cost
+// The per-frame partials of the sweep (k_frame_resjac / k_sweep_roles, priors_inl.h) use the first kFoldEntries slots of such a
+// row, COMPACT: [huber cost | plain cost | Gram entries (i, j), i < 10, i <= j <= 10, row after row] — the 67 numbers the
+// reduction needs, 5 lines instead of 17 for the workgroup that sums them inside the launch (one CU pulls every partial).
+constexpr int kFoldEntries = 67;
+__host__ __device__ inline int fold_slot_cost(int which) { return which; }                                  // 0: huber, 1: plain
+__host__ __device__ inline int fold_slot_gram(int i, int j) { return 2 + 11 * i - (i * (i - 1)) / 2 + (j - i); }   // j >= i
 
 struct PriorArgs {
   int F, nS, beta_stride, has_gmm, n_pairs, n_tiles;   // n_tiles = 0: no prior workgroups
@@ -118,6 +124,28 @@ struct FusedSync {
   int resident_blocks;         // blocks resident from the start of the launch (2 per CU)
 };
 constexpr int kRoleMaxFrames = 16384;
+
+// 8-byte write-through store (sc1): the payload form of a hand-off to a workgroup on another XCD inside the launch
+__device__ __forceinline__ void store_f64_through(double* p, double v) {
+  asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+}
+
+// Tail of a one-launch Jacobian sweep of a shared-shape problem (bodyfit_arm_shared_reduction): every frame / prior workgroup
+// takes a ticket behind its partial ([258] doubles, k_reduce.hip's layout); the LAST one sums the partials in k_reduce_stage2's
+// order and packs [cost | g_beta (10) | upper H_bb (55)] into out66, while the mesh workgroups are still running: the sharded
+// evaluation needs no reduction launch behind the sweep.
+struct FoldTail {
+  unsigned* ticket;          // null: no fold.  Counts up over the launches that fold (never reset between them)
+  unsigned want;             // ticket value after this launch's last workgroup
+  int n_partials;            // frames + prior tiles, <= kFoldMaxPartials
+  const double* partials;    // [n_partials][kReducePartial]
+  const double* beta;        // shared shape coefficients (shape-prior terms of the gradient)
+  int shape_rows;
+  double beta_shape;
+  double* out66;
+};
+constexpr int kFoldMaxPartials = 256;
+constexpr int kFoldTicketOffset = 128;   // byte offset of the ticket inside the sync header (a line of its own)
 
 // A kernel's dynamic-LDS grant (hipFuncSetAttribute) is an attribute of the kernel ON ONE DEVICE: a process that creates
 // models on several devices needs it on each of them.  Bookkeeping per device, not per process.
@@ -274,13 +302,13 @@ void launch_mesh(const DevModel& M, const DevProblem& P, const MeshCoef& mc, flo
 bool role_sweep_fits(const DevModel& M, const DevProblem& P);
 void launch_sweep_roles(const DevModel& M, const DevProblem& P, const double* d_params, const double* d_beta, double* d_r,
                         double* d_J, double* d_joints, const MeshCoef& mc, int want_jac, const PriorArgs& pa, float* d_cloud,
-                        const FusedSync& sy, hipStream_t s, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
+                        const FusedSync& sy, const FoldTail& fold, hipStream_t s, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 // (ev_start / ev_stop: optional events that take the dispatch's own begin / end timestamps, hipExtLaunchKernelGGL)
 void launch_reduce_shared_ex(int K, int ncols, int npose, int nS, int total_rows, const double* d_r,
                              const double* d_J, double huber_delta, int shape_row0, int shape_rows,
                              double beta_shape, double* d_partials, double* d_out66, hipStream_t s);
 int reduce_partials_doubles();
-void launch_reduce_frames(int F, int rows_begin, int total_rows, const double* d_r, int shape_row0, int shape_rows,
+void launch_reduce_frames(int F, const double* d_r, int shape_row0, int shape_rows,
                           double beta_shape, const double* d_frame_partials, double* d_scratch, double* d_out66,
                           hipStream_t s);
 void launch_writeback_prepare(int F, int npose, const double* d_params, const double* d_R0, double* d_params_upd,

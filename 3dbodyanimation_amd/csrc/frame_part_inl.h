@@ -974,11 +974,18 @@ __device__ __forceinline__ void frame_part(const DevModel& M, const DevProblem& 
   }
   if (fold) {
     double* out = Pb.beta_partials + (size_t)f * kReducePartial;
-    if (wave == 0) {     // D layout (f64 16x16): column = lane & 15, row = (lane >> 4) + 4 q
+    // (one-launch sweep: write-through, the launch's last frame / prior workgroup may sum the partials, k_sweep.hip fold_tail)
+    if (wave == 0) {     // D layout (f64 16x16): column = lane & 15, row = (lane >> 4) + 4 q; kept: (i, j), i < 10, i <= j <= 10
 #pragma unroll
-      for (int q = 0; q < 4; ++q) out[((lane >> 4) + 4 * q) * 16 + (lane & 15)] = fold_gram[q];
+      for (int q = 0; q < 4; ++q) {
+        const int gi = (lane >> 4) + 4 * q, gj = lane & 15;
+        if (gi < 10 && gj >= gi && gj <= 10) {
+          double* o = out + fold_slot_gram(gi, gj);
+          if constexpr (kFused) store_f64_through(o, fold_gram[q]); else *o = fold_gram[q];
+        }
+      }
     } else if (tid == 64) {
-      out[256] = fold_acc;
+      if constexpr (kFused) store_f64_through(out + fold_slot_cost(0), fold_acc); else out[fold_slot_cost(0)] = fold_acc;
     }
   }
   STAMP(8);

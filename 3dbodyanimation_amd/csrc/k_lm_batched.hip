@@ -288,7 +288,7 @@ __global__ __launch_bounds__(kStepThreads) void k_lm_step(LmProblem P, LmState S
   for (int u = 0; u < 11; ++u) {
     const int i = tid + u * kStepThreads, row = i / 88, c = i % 88;
     const bool on = row < nrows && c < n;
-    jv[u] = J[on ? (size_t)(2 * k0 + row) * n + c : (size_t)2 * k0 * n];
+    jv[u] = J[on ? (size_t)(2 * k0 + row) * n + c : (size_t)0];
     if (!on) jv[u] = 0.0;
   }
   double r_own, r_other;     // this row's residual and the other coordinate of its keypoint
@@ -792,7 +792,7 @@ __global__ __launch_bounds__(kStepThreads) void k_frame_normal(int F, int n, con
   for (int u = 0; u < 11; ++u) {
     const int i = tid + u * kStepThreads, row = i / 88, c = i % 88;
     const bool on = row < nrows && c < n;
-    jv[u] = J[on ? (size_t)(2 * k0 + row) * n + c : (size_t)2 * k0 * n];
+    jv[u] = J[on ? (size_t)(2 * k0 + row) * n + c : (size_t)0];
     if (!on) jv[u] = 0.0;
   }
   double r_own, r_other;

@@ -107,9 +107,10 @@ __global__ __launch_bounds__(64) void k_reduce_stage1(int K, int ncols, int npos
 // 16 slices per entry; a slice's partials are requested in fixed-trip batches of 16 (all in flight), because a
 // runtime-bounded loop of loads pays one L2 round trip per iteration.
 constexpr int kSlices = 16;
+// compact: the partials are the sweep's per-frame rows (bodyfit_device.h kFoldEntries: 67 leading slots), not Gram tiles
 __global__ __launch_bounds__(1024) void k_reduce_stage2(int nw, const double* __restrict__ partials, int shape_row0,
                                                          int shape_rows, double beta_shape,
-                                                         const double* __restrict__ r, double* __restrict__ out) {
+                                                         const double* __restrict__ r, double* __restrict__ out, int compact) {
   __shared__ double sred[kSlices][kPartial];
   const int tid = threadIdx.x;
   for (int idx = tid; idx < kSlices * kPartial; idx += 1024) {
@@ -135,10 +136,10 @@ __global__ __launch_bounds__(1024) void k_reduce_stage2(int nw, const double* __
       for (int sl = 0; sl < kSlices; ++sl) v += sred[sl][e];
       return v;
     };
-    auto G = [&](int i, int j) { return T(i * 16 + j); };
+    auto G = [&](int i, int j) { return T(compact ? fold_slot_gram(i, j) : i * 16 + j); };
     double v;
     if (tid == 0) {
-      v = T(256) + T(257);
+      v = compact ? T(fold_slot_cost(0)) + T(fold_slot_cost(1)) : T(256) + T(257);
     } else if (tid < 11) {
       v = G(tid - 1, 10);
       if (tid - 1 < shape_rows) v += beta_shape * r[shape_row0 + tid - 1];     // shared shape prior, J = beta_s I
@@ -227,28 +228,27 @@ void launch_reduce_shared_ex(int K, int ncols, int npose, int nS, int total_rows
     double* totals = d_partials + (size_t)kRedWavesMax * kPartial;
     BODYFIT_LAUNCH(k_reduce_stage2a, dim3((kPartial + 15) / 16), dim3(1024), 0, s, nw, d_partials, totals, d_r, 0, 0);
     BODYFIT_LAUNCH(k_reduce_stage2, dim3(1), dim3(1024), 0, s, 1, totals, shape_row0, shape_rows, beta_shape, d_r,
-                       d_out66);
+                       d_out66, 0);
   } else {
     BODYFIT_LAUNCH(k_reduce_stage2, dim3(1), dim3(1024), 0, s, nw, d_partials, shape_row0, shape_rows, beta_shape,
-                       d_r, d_out66);
+                       d_r, d_out66, 0);
   }
 }
 
-// Folded path: k_frame_resjac already left one partial per frame (d_frame_partials, [F][258], entries it does not own
-// stay zero from allocation); sum them and the plain rows on 17 workgroups, then pack.
-void launch_reduce_frames(int F, int rows_begin, int total_rows, const double* d_r, int shape_row0, int shape_rows,
+// Folded path: the sweep already left one partial per frame and per prior tile (d_frame_partials, [F][258], compact: the
+// first kFoldEntries slots; the rest stay zero from allocation); sum them on 17 workgroups, then pack.
+void launch_reduce_frames(int F, const double* d_r, int shape_row0, int shape_rows,
                           double beta_shape, const double* d_frame_partials, double* d_scratch, double* d_out66,
                           hipStream_t s) {
   static_assert(kPartial == kReducePartial, "partial layout");
-  if (F <= 256 && rows_begin >= total_rows) {   // small shard: one workgroup sums the partials (one batch of loads) and packs
+  if (F <= 256) {   // small shard: one workgroup sums the partials (one batch of loads) and packs
     BODYFIT_LAUNCH(k_reduce_stage2, dim3(1), dim3(1024), 0, s, F, d_frame_partials, shape_row0, shape_rows, beta_shape,
-                       d_r, d_out66);
+                       d_r, d_out66, 1);
     return;
   }
-  BODYFIT_LAUNCH(k_reduce_stage2a, dim3((kPartial + 15) / 16), dim3(1024), 0, s, F, d_frame_partials, d_scratch, d_r,
-                     rows_begin, total_rows);
+  BODYFIT_LAUNCH(k_reduce_stage2a, dim3((kPartial + 15) / 16), dim3(1024), 0, s, F, d_frame_partials, d_scratch, d_r, 0, 0);
   BODYFIT_LAUNCH(k_reduce_stage2, dim3(1), dim3(1024), 0, s, 1, d_scratch, shape_row0, shape_rows, beta_shape, d_r,
-                     d_out66);
+                     d_out66, 1);
 }
 void launch_regress(int nJ, int V, int ncol, const double* d_reg, const double* d_x, double* d_out, hipStream_t s) {
   BODYFIT_LAUNCH(k_regress, dim3(nJ, ncol), dim3(256), 0, s, V, ncol, d_reg, d_x, d_out);

@@ -91,6 +91,82 @@ __global__ __launch_bounds__(64 * kWaves) void k_mesh_blend_lbs(DevModel M, DevP
 // All arguments of the one-launch sweep, passed BY VALUE as one struct and read through the kernel-argument segment pointer
 // where they are used.  (As separate by-value arguments hipcc loads all ~110 argument SGPRs at kernel entry and carries them
 // across the roles as spills.)
+// Last frame / prior workgroup of a folding launch: [cost | g_beta | upper H_bb] from the per-workgroup partials, in
+// k_reduce_stage2's order of additions (16 slices of partials summed as a tree of 16, then the slices in order), so the
+// folded and the separately launched reduction agree to the last bit.  Called by every wave of a frame / prior workgroup once
+// its own partial is stored (write-through).  lds: >= 16 * 67 * 8 + 16 bytes, free at this point.
+__device__ __forceinline__ void fold_tail(unsigned* ticket, unsigned want, int n_partials, const double* partials,
+                                          const double* beta, int shape_rows, double beta_shape, double* out66,
+                                          unsigned char* lds) {
+  constexpr int kEntries = kFoldEntries;             // 2 cost entries + the 65 entries (i, j), i < 10, i <= j <= 10 of the Gram tile
+  const int tid = threadIdx.x;
+  volatile unsigned* last = reinterpret_cast<volatile unsigned*>(lds);
+  double* sred = reinterpret_cast<double*>(lds + 16);   // [16][kEntries]
+  // every storing wave's partial has left (cdna guide, Guideline 16 R1), then ONE ticket per workgroup
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  if (tid == 0) {
+    const unsigned old = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    last[0] = (old + 1u == want) ? 1u : 0u;
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  if (last[0] == 0u) return;
+  auto entry_of = [](int t) { return t; };          // (the sweep's partial rows are compact: bodyfit_device.h kFoldEntries)
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(partials), 0,
+                                                                      n_partials * kReducePartial * 8, 0x00020000);
+  typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_;
+  constexpr int kItems = 16 * kEntries, kPasses = (kItems + kThreads - 1) / kThreads;
+  // every load of the workgroup in ONE batch (the tail is a chain of round trips to the memory side: ticket, partials):
+  // two items per thread and a third for the first kItems - 2 kThreads threads
+  static_assert(kPasses == 3 && kItems - 2 * kThreads <= 64, "fold_tail: item split");
+  u32x2_ a0[16], a1[16], a2[16];
+  {
+    const int s0 = tid / kEntries, e0 = entry_of(tid % kEntries);
+    const int i1 = tid + kThreads, s1 = i1 / kEntries, e1 = entry_of(i1 % kEntries);
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {   // sc1: written by workgroups of other XCDs in this launch; rows past n_partials read 0
+      a0[u] = __builtin_amdgcn_raw_buffer_load_b64(rs, (unsigned)(((s0 + 16 * u) * kReducePartial + e0) * 8), 0, 16);
+      a1[u] = __builtin_amdgcn_raw_buffer_load_b64(rs, (unsigned)(((s1 + 16 * u) * kReducePartial + e1) * 8), 0, 16);
+    }
+    if (tid < kItems - 2 * kThreads) {   // (wave 0 only)
+      const int i2 = tid + 2 * kThreads, s2 = i2 / kEntries, e2 = entry_of(i2 % kEntries);
+#pragma unroll
+      for (int u = 0; u < 16; ++u)
+        a2[u] = __builtin_amdgcn_raw_buffer_load_b64(rs, (unsigned)(((s2 + 16 * u) * kReducePartial + e2) * 8), 0, 16);
+    }
+  }
+  auto tree = [](const u32x2_ (&a)[16]) {
+    auto d = [&](int u) { return __longlong_as_double((long long)(((unsigned long long)a[u].y << 32) | (unsigned long long)a[u].x)); };
+    return (((d(0) + d(1)) + (d(2) + d(3))) + ((d(4) + d(5)) + (d(6) + d(7)))) +
+           (((d(8) + d(9)) + (d(10) + d(11))) + ((d(12) + d(13)) + (d(14) + d(15))));
+  };
+  sred[tid] = tree(a0);
+  sred[tid + kThreads] = tree(a1);
+  if (tid < kItems - 2 * kThreads) sred[tid + 2 * kThreads] = tree(a2);
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  if (tid < 66) {
+    auto T = [&](int t) {
+      double v = 0.0;
+#pragma unroll
+      for (int sl = 0; sl < 16; ++sl) v += sred[sl * kEntries + t];
+      return v;
+    };
+    auto G = [&](int i, int j) { return T(fold_slot_gram(i, j)); };
+    double v;
+    if (tid == 0) {
+      v = T(0) + T(1);
+    } else if (tid < 11) {
+      v = G(tid - 1, 10);
+      if (tid - 1 < shape_rows) v += beta_shape * (beta_shape * beta[tid - 1]);   // shared shape prior: r = beta_s beta, J = beta_s I
+    } else {
+      int row = 0, rem = tid - 11;
+      while (rem >= 10 - row) { rem -= 10 - row; ++row; }
+      v = G(row, row + rem);
+      if (rem == 0 && row < shape_rows) v += beta_shape * beta_shape;
+    }
+    out66[tid] = v;
+  }
+}
+
 struct RoleArgs {
   DevModel M;
   DevProblem Pb;
@@ -104,6 +180,7 @@ struct RoleArgs {
   PriorArgs pa;
   float* cloud_f;
   FusedSync sy;
+  FoldTail fold;
 };
 typedef const __attribute__((address_space(4))) RoleArgs* RoleArgP;
 
@@ -149,6 +226,9 @@ __global__ __launch_bounds__(kThreads, 4) void k_sweep_roles(RoleArgs by_value) 
     __builtin_amdgcn_s_setprio(2);
     frame_part<true>(M, Pb, A->params, A->beta, A->r_out, A->J_out, A->joints_out, mc, A->want_jac,
                      reinterpret_cast<double*>(lds), idx, fu);
+    if (A->fold.ticket)
+      fold_tail(A->fold.ticket, A->fold.want, A->fold.n_partials, A->fold.partials, A->fold.beta, A->fold.shape_rows,
+                A->fold.beta_shape, A->fold.out66, lds);
     return;
   }
   // ---- mesh and prior roles: both start their real work once the group's frames have been handed over ----------------------
@@ -231,6 +311,9 @@ __global__ __launch_bounds__(kThreads, 4) void k_sweep_roles(RoleArgs by_value) 
     if (!wait_flags()) return;
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // the control word has been read by every wave
     prior_block(pa, idx, A->params, reinterpret_cast<double*>(lds));
+    if (A->fold.ticket)
+      fold_tail(A->fold.ticket, A->fold.want, A->fold.n_partials, A->fold.partials, A->fold.beta, A->fold.shape_rows,
+                A->fold.beta_shape, A->fold.out66, lds);
     return;
   }
   const DevModel M = A->M;
@@ -276,7 +359,7 @@ bool role_sweep_fits(const DevModel& M, const DevProblem& P) {
 
 void launch_sweep_roles(const DevModel& M, const DevProblem& P, const double* d_params, const double* d_beta, double* d_r,
                         double* d_J, double* d_joints, const MeshCoef& mc, int want_jac, const PriorArgs& pa, float* d_cloud,
-                        const FusedSync& sy, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop) {
+                        const FusedSync& sy, const FoldTail& fold, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop) {
   static DeviceOnce attr;
   if (attr.first(current_device()))
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_sweep_roles), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -285,7 +368,7 @@ void launch_sweep_roles(const DevModel& M, const DevProblem& P, const double* d_
   const int grid = P.F + nG * M.nVTiles + pa.n_tiles;
   RoleArgs A;
   A.M = M; A.Pb = P; A.Pb.feat_perm = 1; A.params = d_params; A.beta = d_beta; A.r_out = d_r; A.J_out = d_J;
-  A.joints_out = d_joints; A.mc = mc; A.want_jac = want_jac; A.pa = pa; A.cloud_f = d_cloud; A.sy = sy;
+  A.joints_out = d_joints; A.mc = mc; A.want_jac = want_jac; A.pa = pa; A.cloud_f = d_cloud; A.sy = sy; A.fold = fold;
   BODYFIT_LAUNCH_EXT(k_sweep_roles, dim3(grid), dim3(kThreads), kRoleLdsBytes, s, ev_start, ev_stop, 0, A);
 }
 

@@ -406,6 +406,19 @@ __device__ __forceinline__ void block_from_lds(double* __restrict__ dst, const d
 //   side 0:  rows of U_a (-> Pt_j)  and the 16 rows of Rt_j (-> Yt_j);  writes L_j
 //   side 1:  rows of U_j^T (-> Qt_j)
 constexpr int kCrRowsMax = WB + WB + WR;   // 176
+#ifdef BODYFIT_CR_STAMPS   // diagnostic build only (tools/ubench/cr_factor_phases.hip): s_memtime of wave 0 per phase
+__device__ unsigned long long g_cr_stamps[64];
+#define CR_STAMP(i)                                                                   \
+  do {                                                                                \
+    if (blockIdx.x == 0 && threadIdx.x == 0) {                                        \
+      unsigned long long t_;                                                          \
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");     \
+      g_cr_stamps[i] = t_;                                                            \
+    }                                                                                 \
+  } while (0)
+#else
+#define CR_STAMP(i)
+#endif
 __global__ __launch_bounds__(kCrThreads) void k_cr_factor(WinBuf W, const int* __restrict__ elim, int n_elim) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   double* M = sm;                          // [kCrRowsMax][LD]
@@ -415,6 +428,7 @@ __global__ __launch_bounds__(kCrThreads) void k_cr_factor(WinBuf W, const int* _
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int j = elim[3 * e], a = elim[3 * e + 1], b = elim[3 * e + 2];
   if (side == 1 && b < 0) return;
+  CR_STAMP(0);
   const int nU = (side == 0) ? (a >= 0 ? WB : 0) : WB;       // appended coupling rows
   const int nApp = nU + (side == 0 ? WR : 0);
   const int nRows = WB + nApp;
@@ -434,6 +448,7 @@ __global__ __launch_bounds__(kCrThreads) void k_cr_factor(WinBuf W, const int* _
   }
   if (tid == 0) stat[0] = 1.0;
   __syncthreads();
+  CR_STAMP(1);
   constexpr int NPAN = WB / 16;   // 5
   double* Linv = stat + 8;        // [16][17]: L_pp^-T of the current panel
   // (a) diagonal block p + identity below it, in the registers of wave 0: lanes 0-15 rows of the block, lanes 16-31 rows of I
@@ -463,6 +478,7 @@ __global__ __launch_bounds__(kCrThreads) void k_cr_factor(WinBuf W, const int* _
   };
   if (wave == 0) diag_block(0);
   __syncthreads();
+  CR_STAMP(2);
   const int nRowTiles = nRows / 16;
   for (int p = 0; p < NPAN; ++p) {
     const int c0 = 16 * p;
@@ -481,6 +497,7 @@ __global__ __launch_bounds__(kCrThreads) void k_cr_factor(WinBuf W, const int* _
       }
     }
     __syncthreads();
+    CR_STAMP(3 + 4 * p);
     // (c) trailing update on the matrix cores: rows of tile I, columns of panel Kc > p:  M[I][Kc] -= X_I X_Kc^T.
     //     Look-ahead: wave 0 updates the next diagonal tile first and factors it at once (the serial part of a panel)
     //     while the other seven waves update the rest.
@@ -501,7 +518,9 @@ __global__ __launch_bounds__(kCrThreads) void k_cr_factor(WinBuf W, const int* _
       };
       if (wave == 0) {
         tile_update(p + 1, p + 1);
+        CR_STAMP(4 + 4 * p);
         diag_block(p + 1);
+        CR_STAMP(5 + 4 * p);
       } else {
         int t = 0;
         for (int I = p + 1; I < nRowTiles; ++I) {
@@ -515,6 +534,7 @@ __global__ __launch_bounds__(kCrThreads) void k_cr_factor(WinBuf W, const int* _
       }
     }
     __syncthreads();
+    CR_STAMP(6 + 4 * p);
   }
   if (tid == 0 && stat[0] == 0.0) *W.fail = 1;
   if (side == 0) {
@@ -524,6 +544,7 @@ __global__ __launch_bounds__(kCrThreads) void k_cr_factor(WinBuf W, const int* _
   } else {
     block_from_lds<WB>(W.Qt + (size_t)j * WB * WB, M + WB * LD, tid);
   }
+  CR_STAMP(24);
 }
 
 // C[ti][tj] (16 x 16 tile, accumulator layout: row = (lane >> 4) + 4 q, column = lane & 15) += sign * sum_k X[i][k] Y[i'][k]

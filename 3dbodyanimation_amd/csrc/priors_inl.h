@@ -164,7 +164,7 @@ __device__ inline void prior_block(const PriorArgs& A, int tile, const double* _
     if (tid == 0) {
       double v = 0.0;
       for (int w = 0; w < NT / 64; ++w) v += sval[w];
-      A.plain_cost[(size_t)tile * kReducePartial + 257] = v;
+      store_f64_through(A.plain_cost + (size_t)tile * kReducePartial + fold_slot_cost(1), v);   // (may be summed inside the launch: fold_tail)
     }
   }
 }

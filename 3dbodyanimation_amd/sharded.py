@@ -107,6 +107,7 @@ class HipLocal:
         self.prob = api.Problem(gpu_model, seq_slice["kp_offset"], seq_slice["kp_id"], seq_slice["kp_uv"],
                                 seq_slice["intr"], seq_slice["R0"], n_cols=86, use_shape=True, **prior_kw)
         self.buf = torch.zeros(N_SHARED, dtype=torch.float64, device=device)
+        self.prob.arm_shared_reduction(self.buf.data_ptr())   # (one-launch sweeps reduce at their own tail)
 
     def evaluate_shared(self, local_params, beta):
         torch = self.torch

@@ -315,6 +315,9 @@ def main():
     torch.cuda.set_stream(work_stream)
     stream = work_stream.cuda_stream
 
+    if with_reduce:
+        prob.arm_shared_reduction(d_red.data_ptr())   # shards of <= 256 frames: the reduction rides on the sweep's tail
+
     def step():
         prob.evaluate_device(d_params.data_ptr(), d_beta.data_ptr(), True, stream)
         if with_reduce:

@@ -176,6 +176,13 @@ int bodyfit_problem_views(bodyfit_problem* p, bodyfit_device_views* out);
  *         out[1..10] = g_beta = sum J_beta^T (rho' r),  out[11..65] = upper(H_bb) = sum rho' J_beta^T J_beta.
  * d_out66 (device, 66 doubles) is what the caller all-reduces across ranks (RCCL).            */
 int bodyfit_reduce_shared_device(bodyfit_problem* p, double* d_out66, void* stream);
+/* Arm the reduction: every following Jacobian sweep of this problem (want_jacobian, want_mesh, shared beta, at most
+ * 256 frames + prior tiles: a shard of a sharded window) deposits the 66 doubles in d_out66 at ITS OWN TAIL — the last
+ * frame workgroup to finish sums the per-frame partials while the mesh workgroups are still running — and
+ * bodyfit_reduce_shared_device(p, d_out66, stream) on the same stream then launches nothing.  Sweeps that cannot fold
+ * (two-launch sweep, longer shards) leave the work to bodyfit_reduce_shared_device as before; the numbers are
+ * bit-identical either way.  d_out66 = NULL disarms.                                                             */
+int bodyfit_arm_shared_reduction(bodyfit_problem* p, double* d_out66);
 
 /* Measurement aid: `iters` sweeps with HIP events around every kernel on `stream`;
  * avg_ms[5] = average launch duration (ms) of {frame_resjac, 0 (the prior workgroups ride on the mesh launch,
@@ -293,7 +300,7 @@ int bodyfit_solve_sharded_rccl(bodyfit_problem* p, double* frame_params, double*
 long bodyfit_last_exchange_count(const bodyfit_problem* p);
 
 /* Normal equations of the reprojection blocks, built on the device (window solvers: bodyfit_solve's host loop,
- * 3dbodyanimation_amd/sharded_lm.py): evaluate at (frame_params, beta) and return the residual vector [total_rows], the
+ * the numpy cross-check tests/sharded_lm_check.py): evaluate at (frame_params, beta) and return the residual vector [total_rows], the
  * GMM components [F] (may be NULL) and, per frame, the lower triangle of J^T rho' J over its n_cols columns with the
  * gradient J^T rho' r in row n_cols, as a [F][87][88] row-major panel (HuberLoss weights rho' applied per keypoint,
  * include/MultiFrameBA.h:64,102).  Prior and temporal blocks have constant Jacobians and are left to the caller.

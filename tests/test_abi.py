@@ -51,20 +51,19 @@ def test_ceres_adapter_header_compiles_against_the_interface_double():
                            os.path.join(root, "tests", "cpp", "ceres_adapter_demo.cpp")])
 
 
-def test_inline_asm_dpp_hazards_are_kept(tmp_path):
+def test_inline_asm_dpp_hazards_are_kept():
     """dense_inl.h issues its 64-bit DPP instructions as inline asm, which hipcc's hazard recogniser does not look into: the
-    generated ISA of both users is scanned for a VGPR read through DPP within two instructions of its VALU write, and for a
-    transcendental's result read by the next instruction (tools/check_dpp_hazards.py)."""
+    generated ISA of both users — built by the Makefile with the flags of the shipped library (`make hazards`, also part of
+    `make all`) — is scanned for a VGPR read through DPP within two instructions of its VALU write (a branch target inside
+    that window counts as a violation), and for a transcendental's result read by the next instruction
+    (tools/check_dpp_hazards.py)."""
+    import re
+    import shutil
     import subprocess
-    import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    outs = []
-    for name in ("k_lm_batched", "k_window_lm"):
-        out = tmp_path / (name + ".s")
-        subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-S", "--cuda-device-only",
-                               os.path.join(root, "3dbodyanimation_amd", "csrc", name + ".hip"), "-o", str(out)],
-                              stderr=subprocess.DEVNULL)
-        outs.append(str(out))
-    res = subprocess.run([sys.executable, os.path.join(root, "tools", "check_dpp_hazards.py")] + outs, capture_output=True, text=True)
-    assert res.returncode == 0, res.stdout
-    assert "512 DPP instructions checked, 0 violations" in res.stdout
+    if not (os.path.exists("/opt/rocm/bin/hipcc") or shutil.which("hipcc")):
+        pytest.skip("hipcc not available")
+    res = subprocess.run(["make", "-C", os.path.join(root, "3dbodyanimation_amd", "csrc"), "hazards"], capture_output=True, text=True)
+    assert res.returncode == 0, res.stdout + res.stderr
+    counts = re.findall(r"(\d+) DPP instructions checked, (\d+) violations", res.stdout)
+    assert len(counts) == 2 and all(int(n) > 0 and int(b) == 0 for n, b in counts), res.stdout

@@ -170,3 +170,45 @@ def test_one_launch_against_oracle(model):
     for f in (0, 7, 15):
         _, co = om.forward(x[f], seq.gt_beta, seq.R0[f])
         assert np.abs(cloud[f] - co).max() < 5e-6
+
+
+@pytest.mark.parametrize("F", [2, 17, 40, 128, 240])
+def test_reduction_at_the_sweeps_own_tail(model, F):
+    """bodyfit_arm_shared_reduction: the last frame / prior workgroup of a one-launch Jacobian sweep sums the per-frame partials
+    and packs [cost | g_beta | H_bb] inside the launch.  Against the separately launched reduction of the same sweep (bit for
+    bit: same order of additions), over many launches back to back with changing parameters (a stale partial, a ticket that
+    lets a workgroup through early or a missed write-through would show as a difference), with evaluations that do not fold
+    (no Jacobian) in between, and after disarming."""
+    import torch
+    m, gm = model
+    seq = synth.make_sequence(m, F, seed=31 + F, noise_px=4.0)
+    prob = _problem(gm, seq, True, shared=True)
+    rng = np.random.default_rng(F)
+    armed = torch.full((66,), -1.0, dtype=torch.float64, device="cuda")
+    plain = torch.zeros(66, dtype=torch.float64, device="cuda")
+    prob.arm_shared_reduction(armed.data_ptr())
+    n0 = api.launch_count()
+    for it in range(24):
+        x = torch.from_numpy(seq.gt_params + rng.normal(scale=0.02, size=seq.gt_params.shape)).cuda()
+        b = torch.from_numpy(seq.gt_beta + 0.05 * rng.normal(size=10)).cuda()
+        if it % 5 == 3:
+            prob.evaluate_device(x.data_ptr(), b.data_ptr(), False, None)   # a residual-only sweep: takes no ticket
+        prob.evaluate_device(x.data_ptr(), b.data_ptr(), True, None)
+        before = api.launch_count()
+        prob.reduce_shared_device(armed.data_ptr(), None)                   # nothing to launch
+        assert api.launch_count() == before
+        prob.reduce_shared_device(plain.data_ptr(), None)                   # another target: the launched reduction
+        assert api.launch_count() > before
+        torch.cuda.synchronize()
+        a, p = armed.cpu().numpy(), plain.cpu().numpy()
+        assert np.array_equal(a, p), (it, np.abs(a - p).max())
+        assert a[0] > 0.0
+    assert api.launch_count() > n0
+    prob.arm_shared_reduction(None)
+    armed.fill_(-1.0)
+    prob.evaluate_device(x.data_ptr(), b.data_ptr(), True, None)
+    before = api.launch_count()
+    prob.reduce_shared_device(armed.data_ptr(), None)
+    assert api.launch_count() > before
+    torch.cuda.synchronize()
+    assert np.array_equal(armed.cpu().numpy(), p)
