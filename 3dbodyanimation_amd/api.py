@@ -462,6 +462,13 @@ class Problem:
         """all-gathers issued by the last sharded solve of this problem"""
         return int(load_library().bodyfit_last_exchange_count(self.h))
 
+    def cache_sweep(self, params, beta=None):
+        """One sweep kept in the problem's host cache for evaluate_block (what bodyfit_ceres::SweepCallback does): no caller
+        buffers, so only the structurally non-zero Jacobian column blocks cross PCIe."""
+        x = _c64(params)
+        b = _c64(beta) if beta is not None else None
+        _check(load_library().bodyfit_evaluate_batch(self.h, _d(x), _d(b) if b is not None else None, None, None, None, 1))
+
     def evaluate_block(self, kind: int, index: int, blocks: list[np.ndarray], n_res: int, want=None):
         """ceres::CostFunction::Evaluate on one block.  `want[b]` False -> jacobians[b] = NULL."""
         blocks = [_c64(b) for b in blocks]

@@ -156,6 +156,14 @@ struct bodyfit_problem {
   bool cache_valid = false, cache_has_jac = false;
   // (page-locked mirrors: the sweep's parameters go up from them, its residuals / Jacobian / components come back into them)
   Pinned<double> c_params, c_beta, c_r, c_J;
+  // packed form of the cached Jacobian (bodyfit_evaluate_batch without a caller's Jacobian buffer): only the column blocks a
+  // probe sweep found non-zero cross PCIe, k_pack_jacobian's layout
+  Pinned<double> c_Jp;
+  std::vector<unsigned> pk_mask, pk_off;   // [K] block masks, [K + 1] offsets (doubles) into the packed buffer
+  unsigned* d_pk_mask = nullptr;
+  unsigned* d_pk_off = nullptr;
+  double* d_Jp = nullptr;
+  bool pk_ready = false, cache_packed = false;
   Pinned<int> c_comp;
   size_t c_npar = 0, c_nbeta = 0;       // valid entries of c_params / c_beta
   hipStream_t copy_stream = nullptr;   // the Ceres-kept path's own stream (H2D, sweep, D2H)
@@ -827,6 +835,67 @@ int bodyfit_evaluate_device(bodyfit_problem* p, const double* d_frame_params, co
   return sweep(p, d_frame_params, d_beta, want_jacobian, p->desc.want_mesh != 0, static_cast<hipStream_t>(stream));
 }
 
+// Which column blocks of each reprojection block's Jacobian are STRUCTURALLY non-zero: found once per problem by a probe
+// sweep at a generic (pseudo-random) point — a block that is zero there is zero everywhere (the chain walk of
+// include/Sim3BA.h:173-207 reaches a keypoint's kinematic ancestors only; landmark / regressor keypoints come out dense).
+// No model-specific reasoning on the host: the kernel's own output decides.  Called under the problem's lock.
+static int build_pack_tables(bodyfit_problem* p, hipStream_t st) {
+  const bodyfit_model* m = p->m;
+  const int nJ = m->nJ, nS = m->nS, npose = 7 + 3 * (nJ - 1), n = p->lay.n_cols, K = p->lay.n_keypoints;
+  const bool has_beta = n > npose;
+  const size_t npar = (size_t)p->n_param_rows * npose;
+  const size_t nbeta = has_beta ? (size_t)(p->desc.beta_per_frame ? p->d.F * nS : nS) : 0;
+  const size_t nJd = (size_t)p->lay.reproj_rows * n;
+  HIP_TRY(p->c_J.ensure(nJd));
+  std::vector<double> x(npar), b(nbeta);
+  unsigned long long sd = 0x9e3779b97f4a7c15ull;
+  auto u = [&]() { sd = sd * 6364136223846793005ull + 1442695040888963407ull; return (double)(sd >> 11) / 9007199254740992.0 - 0.5; };
+  for (int f = 0; f < p->n_param_rows; ++f) {
+    double* q = x.data() + (size_t)f * npose;
+    q[0] = 1.0 + 0.2 * u();
+    for (int i = 1; i < 4; ++i) q[i] = 0.6 * u();
+    q[4] = 0.2 * u(); q[5] = 0.2 * u(); q[6] = 3.0 + 0.4 * u();
+    for (int i = 7; i < npose; ++i) q[i] = 0.6 * u();
+  }
+  for (auto& v : b) v = u();
+  HIP_TRY(hipMemcpyAsync(p->d_params, x.data(), npar * sizeof(double), hipMemcpyHostToDevice, st));
+  if (nbeta) HIP_TRY(hipMemcpyAsync(p->d_beta, b.data(), nbeta * sizeof(double), hipMemcpyHostToDevice, st));
+  HIP_TRY(hipStreamSynchronize(st));   // (x, b are pageable: the copies above have left them)
+  if (int rc = sweep(p, p->d_params, has_beta ? p->d_beta : nullptr, 1, false, st)) return rc;
+  HIP_TRY(hipMemcpyAsync(p->c_J.data(), p->d_J, nJd * sizeof(double), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  const int nblocks = 3 + (nJ - 1) + (has_beta ? 1 : 0);
+  p->pk_mask.assign((size_t)K, 0u);
+  p->pk_off.assign((size_t)K + 1, 0u);
+  size_t total = 0;
+  for (int k = 0; k < K; ++k) {
+    const double* J0 = p->c_J.data() + (size_t)(2 * k) * n;
+    const double* J1 = J0 + n;
+    unsigned mask = 0;
+    int ncol = 0;
+    for (int blk = 0; blk < nblocks; ++blk) {
+      const int off = blk == 0 ? 0 : (blk < 3 + (nJ - 1) ? 1 + 3 * (blk - 1) : npose);
+      const int sz = blk == 0 ? 1 : (blk < 3 + (nJ - 1) ? 3 : n - npose);
+      bool any = false;
+      for (int i = 0; i < sz; ++i) any = any || J0[off + i] != 0.0 || J1[off + i] != 0.0;
+      if (any) { mask |= 1u << blk; ncol += sz; }
+    }
+    p->pk_mask[k] = mask;
+    p->pk_off[k] = (unsigned)total;
+    total += 2 * (size_t)ncol;
+  }
+  if (total >= ((size_t)1 << 32)) return fail(BODYFIT_ERR_INVALID, "packed Jacobian exceeds 2^32 doubles");
+  p->pk_off[K] = (unsigned)total;
+  HIP_TRY(p->mem.alloc(&p->d_pk_mask, (size_t)std::max(K, 1)));
+  HIP_TRY(p->mem.alloc(&p->d_pk_off, (size_t)K + 1));
+  HIP_TRY(p->mem.alloc(&p->d_Jp, std::max<size_t>(total, 1)));
+  HIP_TRY(p->c_Jp.ensure(std::max<size_t>(total, 1)));
+  HIP_TRY(hipMemcpy(p->d_pk_mask, p->pk_mask.data(), (size_t)K * sizeof(unsigned), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(p->d_pk_off, p->pk_off.data(), ((size_t)K + 1) * sizeof(unsigned), hipMemcpyHostToDevice));
+  p->pk_ready = true;
+  return BODYFIT_OK;
+}
+
 int bodyfit_evaluate_batch(bodyfit_problem* p, const double* frame_params, const double* beta, double* residuals,
                            double* jacobian, int* gmm_comp, int want_jacobian) {
   if (!p || !frame_params) return fail(BODYFIT_ERR_INVALID, "null argument");
@@ -843,10 +912,16 @@ int bodyfit_evaluate_batch(bodyfit_problem* p, const double* frame_params, const
   // everything crosses PCIe from / into page-locked mirrors, on the problem's own stream
   HIP_TRY(p->c_params.ensure(npar)); HIP_TRY(p->c_beta.ensure(nbeta)); HIP_TRY(p->c_r.ensure(nr));
   HIP_TRY(p->c_comp.ensure((size_t)p->d.F));
-  if (wj) HIP_TRY(p->c_J.ensure(nJ));
   if (!p->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&p->copy_stream, hipStreamNonBlocking));
   hipStream_t st = p->copy_stream;
   p->cache_valid = false;
+  // No caller's Jacobian buffer: the sweep is cached for bodyfit_evaluate_block (Ceres' EvaluationCallback pattern), and only
+  // the structurally non-zero column blocks cross PCIe (BODYFIT_PACKED_J=0: the dense panel, as with a caller's buffer)
+  static const bool packed_enabled = [] { const char* e = std::getenv("BODYFIT_PACKED_J"); return !(e && e[0] == '0'); }();
+  const bool packed = wj && !jacobian && packed_enabled && p->lay.n_cols <= 128;
+  if (packed && !p->pk_ready)
+    if (int rcp = build_pack_tables(p, st)) return rcp;
+  if (wj && !packed) HIP_TRY(p->c_J.ensure(nJ));
   std::memcpy(p->c_params.data(), frame_params, npar * sizeof(double));
   if (nbeta) std::memcpy(p->c_beta.data(), beta, nbeta * sizeof(double));
   p->c_npar = npar; p->c_nbeta = nbeta;
@@ -854,13 +929,34 @@ int bodyfit_evaluate_batch(bodyfit_problem* p, const double* frame_params, const
   if (nbeta) HIP_TRY(hipMemcpyAsync(p->d_beta, p->c_beta.data(), nbeta * sizeof(double), hipMemcpyHostToDevice, st));
   int rc = sweep(p, p->d_params, has_beta ? p->d_beta : nullptr, wj, p->desc.want_mesh != 0, st);
   if (rc) return rc;
-  HIP_TRY(hipMemcpyAsync(p->c_r.data(), p->d_r, nr * sizeof(double), hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipMemcpyAsync(p->c_comp.data(), p->d_comp, (size_t)p->d.F * sizeof(int), hipMemcpyDeviceToHost, st));
-  if (wj) HIP_TRY(hipMemcpyAsync(p->c_J.data(), p->d_J, nJ * sizeof(double), hipMemcpyDeviceToHost, st));
+  static const bool pack_direct = [] { const char* e = std::getenv("BODYFIT_PACK_DIRECT"); return !(e && e[0] == '0'); }();
+  const bool one_kernel_down = wj && packed && pack_direct;   // residuals and components ride on the packing kernel
+  if (!one_kernel_down) {
+    HIP_TRY(hipMemcpyAsync(p->c_r.data(), p->d_r, nr * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(p->c_comp.data(), p->d_comp, (size_t)p->d.F * sizeof(int), hipMemcpyDeviceToHost, st));
+  }
+  size_t n_down = 0;
+  const double* src_down = nullptr;
+  double* dst_down = nullptr;
+  // (measured and rejected: the Jacobian's two halves on two streams / copy engines — 234 against 221 us per sweep)
+  if (one_kernel_down) {
+    // the packing kernel stores straight into the page-locked host cache (it is device-addressable), residuals and GMM
+    // components with it: ONE kernel behind the sweep instead of a kernel and three copy commands (219 -> 207 -> see DESIGN 6)
+    launch_pack_jacobian(p->lay.n_keypoints, p->lay.n_cols, m->nJ - 1, p->d_J, p->d_pk_mask, p->d_pk_off, p->c_Jp.data(), p->d_r,
+                         (int)nr, p->c_r.data(), p->d_comp, p->d.F, p->c_comp.data(), st);
+  } else if (wj && packed) {
+    launch_pack_jacobian(p->lay.n_keypoints, p->lay.n_cols, m->nJ - 1, p->d_J, p->d_pk_mask, p->d_pk_off, p->d_Jp, nullptr, 0,
+                         nullptr, nullptr, 0, nullptr, st);
+    n_down = (size_t)p->pk_off[p->lay.n_keypoints]; src_down = p->d_Jp; dst_down = p->c_Jp.data();
+  } else if (wj) {
+    n_down = nJ; src_down = p->d_J; dst_down = p->c_J.data();
+  }
+  if (n_down) HIP_TRY(hipMemcpyAsync(dst_down, src_down, n_down * sizeof(double), hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
   if (int fc = fused_check(p)) return fc;
   p->cache_valid = true;
   p->cache_has_jac = wj != 0;
+  p->cache_packed = packed;
   if (residuals) std::memcpy(residuals, p->c_r.data(), nr * sizeof(double));
   if (jacobian && wj) std::memcpy(jacobian, p->c_J.data(), nJ * sizeof(double));
   if (gmm_comp) std::memcpy(gmm_comp, p->c_comp.data(), (size_t)p->d.F * sizeof(int));
@@ -1422,7 +1518,12 @@ static int solve_window_device(bodyfit_problem* p, double* frame_params, double*
     summary->termination = status[kWsActive] != 0.0 ? 1 : (int)status[kWsTermination];
     summary->usable = summary->termination != 2;
     summary->n_successful = (int)status[kWsOk]; summary->n_unsuccessful = (int)status[kWsBad];
-    summary->n_sweeps = n_sweeps;
+    // the evaluations the solve NEEDED, from the device's own record (one at the start, one per iteration at the candidate, one
+    // with the Jacobian per accepted step: what the host loop issues).  The loop above issues more: between two status reads it
+    // runs ahead of the decisions (a Jacobian sweep after a rejected step, up to three iterations past the termination; those
+    // kernels find the solve inactive and leave the state alone): n_sweeps - issued = that slack, (void)n_sweeps below.
+    summary->n_sweeps = 1 + (int)status[kWsIters] + (int)status[kWsOk];
+    (void)n_sweeps;
     summary->initial_cost = status[kWsInitialCost]; summary->final_cost = status[kWsCost];
   }
   return BODYFIT_OK;
@@ -1642,7 +1743,25 @@ static void serve_block(bodyfit_problem* p, int kind, int index, int frame, doub
   if (kind == 0) {
     residuals[0] = p->c_r[2 * (size_t)index];
     residuals[1] = p->c_r[2 * (size_t)index + 1];
-    if (jacobians) {
+    if (jacobians && p->cache_packed) {
+      // packed cache: [present columns of row 0 | of row 1] of this keypoint, blocks in order; the others are zero
+      const unsigned mask = p->pk_mask[index], o0 = p->pk_off[index], nc = (p->pk_off[index + 1] - o0) >> 1;
+      const double* P0 = p->c_Jp.data() + o0;
+      const double* P1 = P0 + nc;
+      const int nblocks = 3 + (nJ - 1) + (has_beta ? 1 : 0);
+      int at = 0;
+      for (int blk = 0; blk < nblocks; ++blk) {
+        const int sz = blk == 0 ? 1 : (blk < 3 + (nJ - 1) ? 3 : nS);
+        const bool present = (mask >> blk) & 1u;
+        if (jacobians[blk]) {
+          for (int i = 0; i < sz; ++i) {
+            jacobians[blk][i] = present ? P0[at + i] : 0.0;
+            jacobians[blk][sz + i] = present ? P1[at + i] : 0.0;
+          }
+        }
+        if (present) at += sz;
+      }
+    } else if (jacobians) {
       const double* J0 = p->c_J.data() + (size_t)(2 * index) * L.n_cols;
       const double* J1 = J0 + L.n_cols;
       const int nblocks = 3 + (nJ - 1) + (has_beta ? 1 : 0);

@@ -4,6 +4,7 @@
 #include <stdint.h>
 
 #include <atomic>
+#include "device_once.h"   // DeviceOnce / DeviceMax: per-device bookkeeping of kernel attributes
 
 namespace bodyfit {
 
@@ -147,27 +148,6 @@ struct FoldTail {
 constexpr int kFoldMaxPartials = 256;
 constexpr int kFoldTicketOffset = 128;   // byte offset of the ticket inside the sync header (a line of its own)
 
-// A kernel's dynamic-LDS grant (hipFuncSetAttribute) is an attribute of the kernel ON ONE DEVICE: a process that creates
-// models on several devices needs it on each of them.  Bookkeeping per device, not per process.
-struct DeviceOnce {
-  std::atomic<unsigned long long> done[4] = {};       // bit d of word d / 64: granted on device d (d < 256)
-  bool first(int device) {                             // true exactly once per device
-    const unsigned d = (unsigned)device & 255u;
-    const unsigned long long bit = 1ull << (d & 63u);
-    return (done[d >> 6].fetch_or(bit, std::memory_order_acq_rel) & bit) == 0;
-  }
-};
-struct DeviceMax {                                     // a grant that grows: true when `want` exceeds what device d has
-  std::atomic<size_t> granted[256] = {};
-  bool raise(int device, size_t want, size_t initial) {
-    std::atomic<size_t>& g = granted[(unsigned)device & 255u];
-    size_t cur = g.load(std::memory_order_acquire);
-    if (cur == 0) cur = initial;
-    if (want <= cur) return false;
-    g.store(want, std::memory_order_release);
-    return true;
-  }
-};
 // every kernel launch of the library goes through these two: a process-wide count (bodyfit_launch_count) lets the benchmarks
 // report launches per LM iteration beside microseconds per iteration
 extern std::atomic<long> g_launch_count;
@@ -308,6 +288,10 @@ void launch_reduce_shared_ex(int K, int ncols, int npose, int nS, int total_rows
                              const double* d_J, double huber_delta, int shape_row0, int shape_rows,
                              double beta_shape, double* d_partials, double* d_out66, hipStream_t s);
 int reduce_partials_doubles();
+// the non-zero column blocks of every reprojection block's Jacobian, contiguous (bodyfit_api.hip: packed cache of the host path)
+void launch_pack_jacobian(int K, int ncols, int n_joint_blocks, const double* d_J, const unsigned* d_mask, const unsigned* d_off,
+                          double* d_out, const double* d_r, int nr, double* r_out, const int* d_comp, int ncomp, int* comp_out,
+                          hipStream_t s);
 void launch_reduce_frames(int F, const double* d_r, int shape_row0, int shape_rows,
                           double beta_shape, const double* d_frame_partials, double* d_scratch, double* d_out66,
                           hipStream_t s);

@@ -250,6 +250,61 @@ void launch_reduce_frames(int F, const double* d_r, int shape_row0, int shape_ro
   BODYFIT_LAUNCH(k_reduce_stage2, dim3(1), dim3(1024), 0, s, 1, d_scratch, shape_row0, shape_rows, beta_shape, d_r,
                      d_out66, 1);
 }
+// ---- Jacobian packing for the host-pointer path (bodyfit_evaluate_batch without a caller's Jacobian buffer: the cached sweep
+//      that bodyfit_evaluate_block serves ceres::CostFunction::Evaluate calls from).  A reprojection block's Jacobian is dense
+//      in its 86 columns only on paper: a keypoint moves with its kinematic ancestors, so most of the 23 joint blocks are
+//      structurally zero (include/Sim3BA.h:173-207: the chain walk touches the ancestors only).  What crosses PCIe is the
+//      column blocks a probe sweep found non-zero: per keypoint [present columns of row 0 | of row 1]. ---------------------
+namespace {
+// Blocks beyond the K keypoints copy the residual vector and the GMM components (r_out / comp_out may be null): with the
+// outputs in device-addressable page-locked host memory this ONE kernel is the whole way down of a cached sweep.
+__global__ __launch_bounds__(128) void k_pack_jacobian(int K, int ncols, int njb, const double* __restrict__ J,
+                                                        const unsigned* __restrict__ mask, const unsigned* __restrict__ off,
+                                                        double* __restrict__ out, const double* __restrict__ r, int nr,
+                                                        double* __restrict__ r_out, const int* __restrict__ comp, int ncomp,
+                                                        int* __restrict__ comp_out) {
+  const int k = blockIdx.x, c = threadIdx.x;
+  if (k >= K) {
+    const int nrb = r_out ? (nr + 1023) / 1024 : 0;
+    const int b = k - K;
+    if (b < nrb) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = b * 1024 + u * 128 + c;
+        if (i < nr) r_out[i] = r[i];
+      }
+    } else if (comp_out) {
+      for (int i = (b - nrb) * 1024 + c; i < min(ncomp, (b - nrb + 1) * 1024); i += 128) comp_out[i] = comp[i];
+    }
+    return;
+  }
+  if (c >= ncols) return;
+  const unsigned m = mask[k];
+  // block of column c and the block's first column: [scale 1][rootAA 3][rootT 3][joint AA 3 each ...][beta: the rest]
+  // (njb: joint blocks = joints - 1)
+  int blk, first;
+  if (c == 0) { blk = 0; first = 0; }
+  else if (c < 7 + 3 * njb) { blk = 1 + (c - 1) / 3; first = 1 + 3 * (blk - 1); }
+  else { blk = 3 + njb; first = 7 + 3 * njb; }
+  if (!((m >> blk) & 1u)) return;
+  int before = 0;                                     // present columns in front of this block
+  for (int b = 0; b < blk; ++b)
+    if ((m >> b) & 1u) before += (b == 0) ? 1 : 3;
+  const unsigned o0 = off[k], nc = (off[k + 1] - o0) >> 1;
+  const int idx = before + (c - first);
+  out[o0 + idx] = J[(size_t)(2 * k) * ncols + c];
+  out[o0 + nc + idx] = J[(size_t)(2 * k + 1) * ncols + c];
+}
+}  // namespace
+void launch_pack_jacobian(int K, int ncols, int n_joint_blocks, const double* d_J, const unsigned* d_mask, const unsigned* d_off,
+                          double* d_out, const double* d_r, int nr, double* r_out, const int* d_comp, int ncomp, int* comp_out,
+                          hipStream_t s) {
+  const int extra = (r_out ? (nr + 1023) / 1024 : 0) + (comp_out ? (ncomp + 1023) / 1024 : 0);
+  if (K + extra > 0)
+    BODYFIT_LAUNCH(k_pack_jacobian, dim3(K + extra), dim3(128), 0, s, K, ncols, n_joint_blocks, d_J, d_mask, d_off, d_out, d_r, nr,
+                   r_out, d_comp, ncomp, comp_out);
+}
+
 void launch_regress(int nJ, int V, int ncol, const double* d_reg, const double* d_x, double* d_out, hipStream_t s) {
   BODYFIT_LAUNCH(k_regress, dim3(nJ, ncol), dim3(256), 0, s, V, ncol, d_reg, d_x, d_out);
 }

@@ -251,7 +251,8 @@ typedef struct bodyfit_fit_summary {
   int termination;          /* 0 convergence, 1 iteration limit, 2 failure */
   int usable;               /* Summary::IsSolutionUsable() */
   int n_successful, n_unsuccessful;
-  int n_sweeps;             /* device evaluations issued by the whole solve */
+  int n_sweeps;             /* device evaluations the solve needed: 1 + one per iteration + one per accepted step (the
+                               device window LM issues a few more speculatively between two status reads) */
   double initial_cost, final_cost;
 } bodyfit_fit_summary;
 int bodyfit_solve(bodyfit_problem* p, double* frame_params, double* beta, const unsigned char* param_constant,

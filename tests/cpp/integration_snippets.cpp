@@ -70,6 +70,21 @@ int fit_window_sharded(bodyfit_problem* problem, int rank, int size, double* my_
 }                                                          // every rank returns the same summary and the same beta
 // [/snippet]
 
+// ---- multi-GPU: the same solve with RCCL as the transport (device buffers, the solve's stream) -------------------------------
+// [snippet:sharded_rccl]
+int fit_window_sharded_rccl(bodyfit_problem* problem, int rank, int size, int device, double* my_frame_params, double* beta,
+                            const bodyfit_fit_options* opt, bodyfit_fit_summary* sum) {
+  unsigned char id[128];                                   // ncclUniqueId: made on rank 0, carried by any host channel
+  if (rank == 0 && bodyfit_rccl_unique_id(id)) return 1;
+  MPI_Bcast(id, 128, MPI_BYTE, 0, MPI_COMM_WORLD);
+  bodyfit_rccl* rc = nullptr;                              // (an application that already has an ncclComm_t: bodyfit_rccl_wrap)
+  if (bodyfit_rccl_create(id, rank, size, device, &rc)) return 1;   // ncclCommInitRank: collective
+  const int status = bodyfit_solve_sharded_rccl(problem, my_frame_params, beta, nullptr, rc, opt, sum);
+  bodyfit_rccl_destroy(rc);                                // (keep it for the next window instead)
+  return status;
+}
+// [/snippet]
+
 // ---- D. overlay ---------------------------------------------------------------------------------------------------------
 struct MatLike { unsigned char* data; int rows, cols; size_t step; };   // cv::Mat's members the snippet touches
 void snippet_overlay(MatLike vis, const std::vector<double>& cloud_in, const std::vector<std::array<int, 3>>& faces, double fx, double fy, double cx,

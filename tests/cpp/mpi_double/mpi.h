@@ -8,8 +8,10 @@ typedef int MPI_Op;
 #define MPI_DOUBLE 1
 #define MPI_SUM 2
 #define MPI_MAX 3
+#define MPI_BYTE 4
 #define MPI_SUCCESS 0
 #define MPI_IN_PLACE ((void*)1)
 extern "C" int MPI_Allreduce(const void* sendbuf, void* recvbuf, int count, MPI_Datatype type, MPI_Op op, MPI_Comm comm);
 extern "C" int MPI_Allgather(const void* sendbuf, int sendcount, MPI_Datatype sendtype, void* recvbuf, int recvcount,
                              MPI_Datatype recvtype, MPI_Comm comm);
+extern "C" int MPI_Bcast(void* buf, int count, MPI_Datatype type, int root, MPI_Comm comm);

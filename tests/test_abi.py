@@ -67,3 +67,17 @@ def test_inline_asm_dpp_hazards_are_kept():
     assert res.returncode == 0, res.stdout + res.stderr
     counts = re.findall(r"(\d+) DPP instructions checked, (\d+) violations", res.stdout)
     assert len(counts) == 2 and all(int(n) > 0 and int(b) == 0 for n, b in counts), res.stdout
+
+
+def test_per_device_attribute_bookkeeping(tmp_path):
+    """hipFuncSetAttribute grants are per device: the bookkeeping (csrc/device_once.h) is exercised on the CPU, including
+    concurrent first use (tests/cpp/device_once_test.cpp)."""
+    import shutil
+    import subprocess
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "device_once_test")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-pthread", os.path.join(root, "tests", "cpp", "device_once_test.cpp"), "-o", exe])
+    res = subprocess.run([exe], capture_output=True, text=True)
+    assert res.returncode == 0 and "ok" in res.stdout, res.stdout

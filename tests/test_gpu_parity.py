@@ -442,3 +442,52 @@ def test_sweeps_are_deterministic(api, synth, model, gpu_model):
         cur = snapshot()
         for a, b in zip(ref, cur):
             assert np.array_equal(a, b)
+
+
+@pytest.mark.gpu
+def test_model_on_a_second_device(api, synth, model, oracle_mod):
+    """A model created on a device other than the first one used: every kernel's dynamic-LDS grant is per device
+    (csrc/device_once.h).  Needs two GPUs (skipped on a one-GPU box; the bookkeeping itself is tested on the CPU in test_abi)."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one GPU")
+    gm1 = api.Model(model, device=1)
+    seq = synth.make_sequence(model, 5, seed=77)
+    w, mu, cov = synth.make_gmm(0)
+    prob = api.Problem.from_sequence(gm1, seq, n_cols=86, use_shape=True, beta_per_frame=True, beta_pose=20.0,
+                                     gmm=api.Gmm(w, mu, cov, device=1), beta_shape=30.0, want_mesh=True)
+    x = seq.gt_params + 0.01
+    b = np.tile(seq.gt_beta, (5, 1))
+    r, J, _ = prob.evaluate(x, b, True)
+    om = oracle_mod.OracleModel(model)
+    ro, Jo = om.evaluate_batch(seq, x, b[0], 86, True, True)
+    K = len(ro)
+    assert np.abs(r[:K] - ro).max() < 1e-9
+    xs, bs, ss = prob.solve(seq.init_params, np.zeros((5, 10)), independent=True, max_iters=20)   # the LM kernels' grants too
+    assert all(s.final_cost <= s.initial_cost for s in ss)
+
+
+@pytest.mark.gpu
+def test_packed_cache_serves_every_block_of_the_dense_panel(api, synth, model, gpu_model):
+    """bodyfit_evaluate_batch without a caller's Jacobian buffer ships only the column blocks a probe sweep found non-zero
+    (k_pack_jacobian); bodyfit_evaluate_block must hand out, for EVERY keypoint (FK joints of every chain depth, vertex
+    landmarks) and every parameter block, exactly the numbers of the dense panel, zeros included."""
+    F = 6
+    seq = synth.make_sequence(model, F, seed=16)
+    assert (seq.kp_id >= 24).any() and (seq.kp_id < 24).any()
+    rng = np.random.default_rng(5)
+    x = random_params(rng, F); beta = rng.normal(size=10)
+    prob = api.Problem.from_sequence(gpu_model, seq, n_cols=86, use_shape=True, beta_pose=5.0, beta_shape=25.0,
+                                     lambda_temporal=3.0)
+    r, J, _ = prob.evaluate(x, beta, True)              # the dense panel
+    prob.cache_sweep(x, beta)                           # the packed cache
+    zero_blocks = 0
+    for f in range(F):
+        blocks = [x[f, 0:1], x[f, 1:4], x[f, 4:7]] + [x[f, 7 + 3 * j:10 + 3 * j] for j in range(23)] + [beta]
+        for k in range(int(seq.kp_offset[f]), int(seq.kp_offset[f + 1])):
+            rb, jacs = prob.evaluate_block(0, k, blocks, 2)
+            assert np.array_equal(rb, r[2 * k:2 * k + 2])
+            Jcat = np.concatenate(jacs, axis=1)
+            assert np.array_equal(Jcat, J[2 * k:2 * k + 2]), (f, k, int(seq.kp_id[k]))
+            zero_blocks += sum(1 for j in jacs if not j.any())
+    assert zero_blocks > 0   # (the packing has something to leave out: non-ancestor joints of the FK keypoints)

@@ -11,6 +11,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <atomic>
+#include <thread>
 #include <vector>
 
 #include "bodyfit.hpp"
@@ -74,24 +76,59 @@ int main(int argc, char** argv) {
   const int n_blocks = bodyfit_ceres::AddResidualBlocks(&problem, bp, koff.data(), table, beta.data(), ao);
   bodyfit_ceres::SweepCallback cb(bp, table, beta.data());
 
-  // Jacobian buffers of the largest block, reused (Ceres owns such scratch per thread)
+  // Jacobian buffers of the largest block, one set per evaluation thread (Ceres owns such scratch per thread)
   size_t max_res = 0, max_blocks = 0;
   for (const auto& rec : problem.records()) {
     max_res = std::max<size_t>(max_res, rec->cost->num_residuals());
     max_blocks = std::max(max_blocks, rec->cost->parameter_block_sizes().size());
   }
-  std::vector<double> r(max_res);
-  std::vector<std::vector<double>> jb(max_blocks, std::vector<double>(max_res * 10));
-  std::vector<double*> jp(max_blocks);
-  for (size_t b = 0; b < max_blocks; ++b) jp[b] = jb[b].data();
+  // ceres::Problem::Evaluate walks the residual blocks with options.num_threads threads; the reference sets 8
+  // (include/Sim3BA.h:476-479, include/MultiFrameBA.h:148).  The same here: a pool of `threads` workers, each with its own
+  // scratch, over contiguous ranges of the blocks (argv[4], default 8; 1 = the calling thread alone).
+  const int threads = argc > 4 ? std::max(1, std::atoi(argv[4])) : 8;
+  struct Scratch { std::vector<double> r; std::vector<std::vector<double>> jb; std::vector<double*> jp; };
+  std::vector<Scratch> scratch(threads);
+  for (auto& sc : scratch) {
+    sc.r.resize(max_res);
+    sc.jb.assign(max_blocks, std::vector<double>(max_res * 10));
+    sc.jp.resize(max_blocks);
+    for (size_t b = 0; b < max_blocks; ++b) sc.jp[b] = sc.jb[b].data();
+  }
+  const auto& recs = problem.records();
+  const size_t nrec = recs.size();
+  std::atomic<long> generation{0}, done{0};
+  std::atomic<bool> failed{false}, quit{false};
+  auto run_range = [&](int t) {
+    const size_t b0 = nrec * t / threads, b1 = nrec * (t + 1) / threads;
+    Scratch& sc = scratch[t];
+    for (size_t i = b0; i < b1; ++i)
+      if (!recs[i]->cost->Evaluate(recs[i]->blocks.data(), sc.r.data(), sc.jp.data())) failed.store(true);
+  };
+  std::vector<std::thread> pool;
+  for (int t = 1; t < threads; ++t)
+    pool.emplace_back([&, t] {
+      long seen = 0;
+      for (;;) {
+        while (generation.load(std::memory_order_acquire) == seen && !quit.load()) std::this_thread::yield();
+        if (quit.load()) return;
+        ++seen;
+        run_range(t);
+        done.fetch_add(1, std::memory_order_release);
+      }
+    });
+  auto evaluate_blocks = [&]() -> bool {                   // what ceres::Problem::Evaluate does with every block
+    done.store(0);
+    generation.fetch_add(1, std::memory_order_release);
+    run_range(0);
+    while (done.load(std::memory_order_acquire) < threads - 1) std::this_thread::yield();
+    return !failed.load();
+  };
 
   auto one_point = [&](int it) -> bool {
     poses[it % F].rootT[0] += 1e-6;                       // a new evaluation point
     cb.PrepareForEvaluation(true, true);                  // ONE device sweep, copies included
     if (!cb.ok()) return false;
-    for (const auto& rec : problem.records())             // what ceres::Problem::Evaluate does with every block
-      if (!rec->cost->Evaluate(rec->blocks.data(), r.data(), jp.data())) return false;
-    return true;
+    return evaluate_blocks();
   };
   for (int it = 0; it < 3; ++it)
     if (!one_point(it)) { std::fprintf(stderr, "evaluation failed: %s\n", bodyfit_last_error()); return 1; }
@@ -105,14 +142,15 @@ int main(int argc, char** argv) {
     cb.PrepareForEvaluation(true, true);
     const auto b = std::chrono::steady_clock::now();
     t_sweep += std::chrono::duration<double>(b - a).count();
-    for (const auto& rec : problem.records())
-      if (!rec->cost->Evaluate(rec->blocks.data(), r.data(), jp.data())) return 1;
+    if (!evaluate_blocks()) return 1;
     ++n;
     el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   }
-  std::printf("{\"mode\": \"%s\", \"frames\": %d, \"blocks\": %d, \"points\": %d, \"points_per_s\": %.1f, \"evals_per_s\": %.1f, "
-              "\"blocks_per_s\": %.1f, \"sweep_with_copies_us\": %.1f, \"blocks_us_per_point\": %.1f}\n",
-              mode.c_str(), F, n_blocks, n, n / el, n / el * F, n / el * n_blocks, t_sweep / n * 1e6, (el - t_sweep) / n * 1e6);
+  quit.store(true);
+  for (auto& th : pool) th.join();
+  std::printf("{\"mode\": \"%s\", \"frames\": %d, \"blocks\": %d, \"block_threads\": %d, \"points\": %d, \"points_per_s\": %.1f, "
+              "\"evals_per_s\": %.1f, \"blocks_per_s\": %.1f, \"sweep_with_copies_us\": %.1f, \"blocks_us_per_point\": %.1f}\n",
+              mode.c_str(), F, n_blocks, threads, n, n / el, n / el * F, n / el * n_blocks, t_sweep / n * 1e6, (el - t_sweep) / n * 1e6);
   bodyfit_problem_destroy(bp);
   bodyfit_model_destroy(model);
   return 0;
