@@ -11,7 +11,7 @@ for spec in "c3" "c4" "window 20" "window 545"; do
   timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $out -o f --output-format csv -- python3 tools/fit_prof.py $spec > $out.log 2>&1
   f=$(find $out -name "*kernel_stats.csv" | head -1)
   [ -n "$f" ] && cp $f gpurun_out/profiles_$tag/${tag}_fit_${name}_kernel_stats.csv
-  tail -1 $out.log > gpurun_out/profiles_$tag/${tag}_fit_${name}.txt
+  grep "^{'frames" $out.log | tail -1 > gpurun_out/profiles_$tag/${tag}_fit_${name}.txt
   find $out -name "*.csv" -size +1M -delete
 done
 ls gpurun_out/profiles_$tag
