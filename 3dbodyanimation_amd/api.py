@@ -386,8 +386,8 @@ class Problem:
         ms = np.zeros(5)
         _check(load_library().bodyfit_profile_sweep(self.h, d_params_ptr, d_beta_ptr, int(want_jacobian),
                                                     int(with_reduce), int(iters), stream, _d(ms)))
-        # (the prior workgroups ride on one of the launches; sweep_fused != 0: the sweep was ONE launch)
-        return dict(frame_resjac=ms[0], mesh_blend_lbs=ms[2], reduce_shared=ms[3], sweep_fused=ms[4])
+        # (the prior workgroups ride on one of the launches; sweep_roles != 0: the sweep was ONE launch)
+        return dict(frame_resjac=ms[0], mesh_blend_lbs=ms[2], reduce_shared=ms[3], sweep_roles=ms[4])
 
     def views(self) -> DeviceViews:
         v = DeviceViews()

@@ -1031,7 +1031,7 @@ int bodyfit_reduce_shared_device(bodyfit_problem* p, double* d_out66, void* stre
 }
 
 // Per-kernel timing with HIP events on `stream`: `iters` sweeps, avg_ms[0..4] = {frame_resjac, priors,
-// mesh_blend_lbs, reduce_shared, sweep_fused} average launch durations in milliseconds.
+// mesh_blend_lbs, reduce_shared, sweep_roles} average launch durations in milliseconds.
 int bodyfit_profile_sweep(bodyfit_problem* p, const double* d_frame_params, const double* d_beta,
                           int want_jacobian, int with_reduce, int iters, void* stream, double* avg_ms) {
   if (!p || !d_frame_params || !avg_ms || iters <= 0) return fail(BODYFIT_ERR_INVALID, "bad argument");

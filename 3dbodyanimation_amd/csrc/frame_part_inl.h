@@ -1,6 +1,7 @@
 // frame_part_inl.h — per-frame keypoint residuals + analytic Jacobian, f64, one 8-wave workgroup per frame: the body
-// shared by k_frame_resjac (its own launch) and k_sweep_fused (one launch for the whole sweep: frame part, then the
-// workgroup's mesh tile), both in k_sweep.hip.
+// shared by k_frame_resjac (its own launch) and the frame role of k_sweep_roles (one launch for the whole sweep: frame, mesh
+// and prior workgroups side by side; kFused = true: the mesh operands and the reduction partial are handed over inside the
+// launch, write-through), both in k_sweep.hip.
 //
 // Replaces, for every reprojection block of a frame at once, what the reference evaluates through
 // ceres::DynamicAutoDiffCostFunction<ReprojCost[Shape]> (include/Sim3BA.h:34-88,126-227,420,581;
@@ -17,15 +18,15 @@
 //   A  model tables, landmark weights, the frame's parameters -> LDS
 //   B  wave 0: Rodrigues R_j, dR_j/da (both branches of Ceres' AngleAxisRotatePoint) | waves 1-3: chain offsets
 //      o_j(beta), centred rest joints | wave 4: landmark rest vertices
-//   C  waves 6-7: A_j columns and P_j as independent 3-vector walks up the kinematic chain | waves 0-5: landmark
-//      items (landmark l, joint k) on lane k - 1 of half-wave l: the landmark's 27 posedirs values are read ONCE
-//      (joint-minor table, coalesced) and give the blend row (half-wave shuffle reduction) and the Jacobian inner
-//      products pd . vec(dR_{k,c})
-//   D  W_{k,c} = A_par(k) dR_{k,c} R_k^T A_par(k)^T (d x / d a_{k,c} = W (x - P_k)) | landmark LBS | camera matrices and
-//      the mesh kernel's blend-coefficient fragments (wave 3) | waves 4-7: B_j columns (d P_j / d beta) and
-//      T_j = B_j - A_j Sc_j
-//   E  skinning transforms and posed joints (wave 7) | complete landmark terms d q_l / d theta_{k,c} per (landmark,
-//      joint) and d q_l / d beta = Ablend sd_l + sum_i w_i T_{j_i}
+//   C  waves 6-7: A_j columns and P_j as independent 3-vector walks up the kinematic chain (one branch-free pass over packed
+//      ancestor lists), wave 6 also the camera matrices | wave 0 first: root entries, the mesh's blend-coefficient fragments |
+//      waves 0-5: landmark items (landmark l, joint k) on lane k - 1 of half-wave l: the landmark's 27 posedirs values are
+//      read ONCE (joint-minor table, coalesced) and give the blend row (half-wave shuffle reduction) and the Jacobian inner
+//      products pd . vec(dR_{k,c}) | wave 7, behind an LDS counter (not a barrier): skinning transforms and posed joints as
+//      (joint, row) items, and — one-launch sweep — the hand-off: drain, one agent-scope add to its 32-frame unit's counter
+//   D  W_{k,c} = A_par(k) dR_{k,c} R_k^T A_par(k)^T (d x / d a_{k,c} = W (x - P_k)) | landmark LBS | waves 3-6: B_j columns
+//      (d P_j / d beta) and T_j = B_j - A_j Sc_j
+//   E  complete landmark terms d q_l / d theta_{k,c} per (landmark, joint) and d q_l / d beta = Ablend sd_l + sum_i w_i T_{j_i}
 //   F  per chunk of 32 keypoints: keypoint stage (projection, residuals, d pi), then the Jacobian sweep with
 //      thread = column (W_{k,c} and P_k in registers), consecutive threads on consecutive columns of the dense
 //      row-major [2K][ncols] panel, written through L2; then (shared beta only) the frame's Gram partial on wave 0

@@ -85,7 +85,7 @@ __global__ __launch_bounds__(64 * kWaves) void k_mesh_blend_lbs(DevModel M, DevP
     prior_block(pa, (int)blockIdx.x - M.nVTiles, params, reinterpret_cast<double*>(lds));
     return;
   }
-  mesh_part<false>(M, Pb, mc, cloud_f, (int)blockIdx.x, lds, lds + kBBytes);
+  mesh_part(M, Pb, mc, cloud_f, (int)blockIdx.x, lds, lds + kBBytes);
 }
 
 // All arguments of the one-launch sweep, passed BY VALUE as one struct and read through the kernel-argument segment pointer

@@ -1,5 +1,5 @@
-// mesh_part_inl.h — batched SMPL forward of all 6890 vertices, the body shared by k_mesh_blend_lbs (its own launch) and
-// k_sweep_fused (the mesh part of the one-launch sweep), both in k_sweep.hip: blendshapes (MFMA) fused with
+// mesh_part_inl.h — batched SMPL forward of all 6890 vertices, the body of k_mesh_blend_lbs (k_sweep.hip: the second launch of
+// the two-launch sweep; the one-launch sweep's mesh role is mesh_role_inl.h): blendshapes (MFMA) fused with
 // 24-joint linear-blend skinning, f32 out.  Replaces ark::Avatar::update()'s cloud
 // (call sites include/Sim3BA.h:371,538; include/MultiFrameBA.h:53,173; src/main_single_frame.cpp:254).
 //
@@ -75,41 +75,20 @@ struct Lane {                    // per-lane constants of the skinning rows
 // one quarter of a unit: 8 frames x 24 transforms, contiguous in HBM.  skinT is allocated (and zeroed) for whole
 // frame tiles, so the loads need no predicate (a predicated load is a branch, and a branch ends the slot's
 // scheduling region).
-// Fused sweep: the operands were handed over inside the launch by write-through stores, so EVERY load of them is an
-// sc1 load (served by L2, never by this CU's L1, which may hold the previous launch's lines).
 struct OperandSrc {
   const unsigned char* skinT;
   const uint4* feat;                       // featA
-  __amdgpu_buffer_rsrc_t skinT_rsrc;       // fused only
-  __amdgpu_buffer_rsrc_t feat_rsrc;        // fused only
 };
-template <bool kFused>
 __device__ __forceinline__ void skin_load(const OperandSrc& src, int ftile, int q, int lane, u32x4 (&reg)[kSkinVec]) {
-  if constexpr (kFused) {
-    const unsigned soff = (unsigned)((ftile * kFTile + q * 8) * kRowBytes);
+  const unsigned char* g = src.skinT + ((size_t)ftile * kFTile + q * 8) * kRowBytes + lane * 16;
 #pragma unroll
-    for (int i = 0; i < kSkinVec; ++i)
-      reg[i] = __builtin_amdgcn_raw_buffer_load_b128(src.skinT_rsrc, (unsigned)(lane * 16 + i * 1024), soff, 16);
-  } else {
-    const unsigned char* g = src.skinT + ((size_t)ftile * kFTile + q * 8) * kRowBytes + lane * 16;
-#pragma unroll
-    for (int i = 0; i < kSkinVec; ++i) reg[i] = *reinterpret_cast<const u32x4*>(g + i * 1024);
-  }
+  for (int i = 0; i < kSkinVec; ++i) reg[i] = *reinterpret_cast<const u32x4*>(g + i * 1024);
 }
 // A fragments of k-step ks of frame tile ftile (hi, lo)
-template <bool kFused>
 __device__ __forceinline__ void feat_load(const OperandSrc& src, int ftile, int ks, int lane, uint4& hi, uint4& lo) {
-  if constexpr (kFused) {
-    const unsigned soff = (unsigned)((ftile * kBlendKSteps + ks) * 2 * 1024);
-    const u32x4 h = __builtin_amdgcn_raw_buffer_load_b128(src.feat_rsrc, feat_frag_off(lane, 0), soff, 16);
-    const u32x4 l = __builtin_amdgcn_raw_buffer_load_b128(src.feat_rsrc, feat_frag_off(lane, 1), soff, 16);
-    hi = make_uint4(h.x, h.y, h.z, h.w);
-    lo = make_uint4(l.x, l.y, l.z, l.w);
-  } else {
-    const unsigned char* fa = reinterpret_cast<const unsigned char*>(src.feat) + ((size_t)ftile * kBlendKSteps + ks) * 2048;
-    hi = *reinterpret_cast<const uint4*>(fa + feat_frag_off(lane, 0));
-    lo = *reinterpret_cast<const uint4*>(fa + feat_frag_off(lane, 1));
-  }
+  const unsigned char* fa = reinterpret_cast<const unsigned char*>(src.feat) + ((size_t)ftile * kBlendKSteps + ks) * 2048;
+  hi = *reinterpret_cast<const uint4*>(fa + feat_frag_off(lane, 0));
+  lo = *reinterpret_cast<const uint4*>(fa + feat_frag_off(lane, 1));
 }
 __device__ __forceinline__ void skin_store(unsigned char* l, int lane, const u32x4 (&reg)[kSkinVec]) {
 #pragma unroll
@@ -163,10 +142,10 @@ __device__ __forceinline__ void row_apply(const Lane& L, const float4 (&t)[12], 
 }
 
 // ---- blend phase: k-step S of the unit whose A fragments start at fa --------------------------------------------
-template <int S, bool kFused>
+template <int S>
 __device__ __forceinline__ void blend_step(const unsigned char* sB, int lane, const OperandSrc& src, int ftile, f32x16 (&acc)[3],
                                            uint4 (&a)[kBlendKSteps][2], uint4 (&bq)[2][3][2]) {
-  if constexpr (S + kAhead < kBlendKSteps) feat_load<kFused>(src, ftile, S + kAhead, lane, a[S + kAhead][0], a[S + kAhead][1]);
+  if constexpr (S + kAhead < kBlendKSteps) feat_load(src, ftile, S + kAhead, lane, a[S + kAhead][0], a[S + kAhead][1]);
   if constexpr (S + 1 < kBlendKSteps) {
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
@@ -205,7 +184,7 @@ __device__ __forceinline__ void blend_step(const unsigned char* sB, int lane, co
 }
 
 // ---- skinning phase: row S of the unit at frame tile ftile ----------------------------------------------------------
-template <int S, bool kFused>
+template <int S>
 __device__ __forceinline__ void skin_step(const Lane& L, unsigned char* sSkin, int lane, unsigned stride, const OperandSrc& src,
                                           __amdgpu_buffer_rsrc_t cloud, int ftile, const f32x16 (&acc)[3], float4 (&tq)[2][12],
                                           u32x4 (&treg)[kSkinVec]) {
@@ -214,7 +193,7 @@ __device__ __forceinline__ void skin_step(const Lane& L, unsigned char* sSkin, i
     // quarter boundary: every read of the previous quarter has been issued (LDS serves a wave in order), so the slice
     // is overwritten with this quarter (in registers since the previous boundary) and the next one goes in flight
     skin_store(sSkin, lane, treg);
-    if constexpr (q < 3) skin_load<kFused>(src, ftile, q + 1, lane, treg);
+    if constexpr (q < 3) skin_load(src, ftile, q + 1, lane, treg);
     row_fetch<S>(L, tq[S & 1]);
   }
   if constexpr ((S & 3) != 3) row_fetch<S + 1>(L, tq[(S + 1) & 1]);
@@ -231,12 +210,8 @@ __device__ __forceinline__ void skin_step(const Lane& L, unsigned char* sSkin, i
 }
 
 // One vertex tile x all frames.  sB: the tile's operand image in LDS (84 KiB); sSkinBase: 8 x 9 KiB of transform slices.
-// kFused (k_sweep_fused): the operand image was staged during the frame part and the per-frame operands were handed over
-// inside the launch; the caller has waited for both (counter poll, workgroup barrier) before this is entered.
-template <bool kFused>
 __device__ __forceinline__ void mesh_part(const DevModel& M, const DevProblem& Pb, const MeshCoef& mc, float* __restrict__ cloud_f,
-                                          int vtile, unsigned char* sB, unsigned char* sSkinBase, uint32_t widx_pre = 0,
-                                          float4 wv_pre = float4{0.f, 0.f, 0.f, 0.f}) {
+                                          int vtile, unsigned char* sB, unsigned char* sSkinBase) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int col = lane & 31, h = lane >> 5;
   const int v = vtile * kVTile + col;
@@ -246,7 +221,7 @@ __device__ __forceinline__ void mesh_part(const DevModel& M, const DevProblem& P
   unsigned char* sSkin = sSkinBase + wave * kQuarterBytes;             // this wave's transform slice
 
   // ---- stage this vertex tile's B operands: HBM -> LDS, 1 KiB per wave-instruction -------------------
-  if constexpr (!kFused) {
+  {
     const unsigned char* gp = reinterpret_cast<const unsigned char*>(M.dirsB) + (size_t)vtile * kBBytes;
 #pragma unroll
     for (int i = 0; i < (kPieces + kWaves - 1) / kWaves; ++i) {
@@ -256,9 +231,8 @@ __device__ __forceinline__ void mesh_part(const DevModel& M, const DevProblem& P
   }
   Lane L;
   {
-    // (fused sweep: the caller requested the lane's skinning weights before its wait for the hand-off)
-    const uint32_t widx = kFused ? widx_pre : M.wIdx[(size_t)vtile * 32 + col];
-    const float4 wv = kFused ? wv_pre : reinterpret_cast<const float4*>(M.wVal)[(size_t)vtile * 32 + col];
+    const uint32_t widx = M.wIdx[(size_t)vtile * 32 + col];
+    const float4 wv = reinterpret_cast<const float4*>(M.wVal)[(size_t)vtile * 32 + col];
     const float wgt[4] = {wv.x, wv.y, wv.z, wv.w};
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -276,22 +250,16 @@ __device__ __forceinline__ void mesh_part(const DevModel& M, const DevProblem& P
   OperandSrc src;
   src.skinT = reinterpret_cast<const unsigned char*>(mc.skinT);
   src.feat = reinterpret_cast<const uint4*>(mc.featA);
-  if constexpr (kFused) {
-    src.skinT_rsrc = __builtin_amdgcn_make_buffer_rsrc(mc.skinT, 0, nFT * kFTile * kRowBytes, 0x00020000);
-    src.feat_rsrc = __builtin_amdgcn_make_buffer_rsrc(mc.featA, 0, nFT * kBlendKSteps * 2 * 1024, 0x00020000);
-  }
   f32x16 acc[3];
   uint4 a[kBlendKSteps][2], bq[2][3][2];
   u32x4 treg[kSkinVec];
   float4 tq[2][12];
   if (wave < nFT) {
 #pragma unroll
-    for (int ks = 0; ks < kAhead; ++ks) feat_load<kFused>(src, wave, ks, lane, a[ks][0], a[ks][1]);
+    for (int ks = 0; ks < kAhead; ++ks) feat_load(src, wave, ks, lane, a[ks][0], a[ks][1]);
   }
-  if constexpr (!kFused) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
   MSTAMP(1);
   // Waves w and w + 4 share a SIMD.  Left alone they run their phases in lock-step (both blending at half the matrix
   // rate, then both skinning against each other for LDS bandwidth); with the second wave at a higher issue priority
@@ -299,23 +267,23 @@ __device__ __forceinline__ void mesh_part(const DevModel& M, const DevProblem& P
   if (wave >= 4) __builtin_amdgcn_s_setprio(2);
 
   for (int ftile = wave; ftile < nFT; ftile += kWaves) {
-    skin_load<kFused>(src, ftile, 0, lane, treg);                      // quarter 0: in flight across the blend phase
+    skin_load(src, ftile, 0, lane, treg);                      // quarter 0: in flight across the blend phase
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       const uint4* bp = reinterpret_cast<const uint4*>(sB + (size_t)(c * 2) * 1024) + lane;
       bq[0][c][0] = bp[0]; bq[0][c][1] = bp[64];
     }
-#define BSTEP(S) blend_step<S, kFused>(sB, lane, src, ftile, acc, a, bq)
+#define BSTEP(S) blend_step<S>(sB, lane, src, ftile, acc, a, bq)
     BSTEP(0); BSTEP(1); BSTEP(2); BSTEP(3); BSTEP(4); BSTEP(5); BSTEP(6);
     BSTEP(7); BSTEP(8); BSTEP(9); BSTEP(10); BSTEP(11); BSTEP(12); BSTEP(13);
 #undef BSTEP
     MSTAMP(2);
-#define SSTEP(S) skin_step<S, kFused>(L, sSkin, lane, stride, src, cloud, ftile, acc, tq, treg)
+#define SSTEP(S) skin_step<S>(L, sSkin, lane, stride, src, cloud, ftile, acc, tq, treg)
     SSTEP(0); SSTEP(1); SSTEP(2); SSTEP(3); SSTEP(4); SSTEP(5); SSTEP(6); SSTEP(7);
     SSTEP(8); SSTEP(9); SSTEP(10); SSTEP(11); SSTEP(12);
     if (ftile + kWaves < nFT) {      // next unit's first A fragments (the transform staging registers are free now)
 #pragma unroll
-      for (int ks = 0; ks < kAhead; ++ks) feat_load<kFused>(src, ftile + kWaves, ks, lane, a[ks][0], a[ks][1]);
+      for (int ks = 0; ks < kAhead; ++ks) feat_load(src, ftile + kWaves, ks, lane, a[ks][0], a[ks][1]);
     }
     SSTEP(13); SSTEP(14); SSTEP(15);
 #undef SSTEP

@@ -355,10 +355,9 @@ def main():
         alg = {"mesh_blend_lbs": B_MODEL_MESH + F * B_FRAME_MESH,
                "frame_resjac": F * (608 + 80 + 500 + 400 + 34_400 + 24 * 12 * 4 + 217 * 4)}
         pmc_name = {"mesh_blend_lbs": "k_mesh_blend_lbs", "frame_resjac": "k_frame_resjac", "sweep_roles": "k_sweep_roles"}
-        fused = prof.get("sweep_fused", 0.0) > 0.0
+        fused = prof.get("sweep_roles", 0.0) > 0.0
         if fused:   # the sweep was ONE launch (frame, mesh and prior roles side by side): its bytes are the two parts' bytes
             alg = {"sweep_roles": alg["mesh_blend_lbs"] + alg["frame_resjac"]}
-            prof = dict(prof, sweep_roles=prof["sweep_fused"])
         # HBM bytes per launch: rocprofv3 cannot run inside this process, so `traffic` is what the committed --pmc passes
         # of THIS command measured (tools/profile_round.sh writes profiles/rN_xx_pmc_traffic.json: FETCH_SIZE doubled per the
         # gfx950 note + WRITE_SIZE); `traffic_source` names that file.  Null when no committed pass matches the workload

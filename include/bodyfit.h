@@ -185,10 +185,10 @@ int bodyfit_reduce_shared_device(bodyfit_problem* p, double* d_out66, void* stre
 int bodyfit_arm_shared_reduction(bodyfit_problem* p, double* d_out66);
 
 /* Measurement aid: `iters` sweeps with HIP events around every kernel on `stream`;
- * avg_ms[5] = average launch duration (ms) of {frame_resjac, 0 (the prior workgroups ride on the mesh launch,
- * or on frame_resjac when the mesh is off), mesh_blend_lbs, reduce_shared, sweep_fused}.  A sweep with the mesh on and at
- * most 256 frames is ONE launch (sweep_fused: frame part + mesh part per workgroup); then entries 0 and 2 are 0, and
- * otherwise entry 4 is 0. */
+ * avg_ms[5] = average launch duration (ms) of {frame_resjac, 0 (the prior workgroups ride on another launch),
+ * mesh_blend_lbs, reduce_shared, sweep_roles}.  A sweep with the mesh on is ONE launch (sweep_roles: frame, mesh and prior
+ * workgroups side by side); then entries 0 and 2 are 0.  Without the mesh, or with BODYFIT_ONE_LAUNCH=0, entry 4 is 0.
+ * Entry 3 is ~0 when the reduction rode on the sweep's own tail (bodyfit_arm_shared_reduction). */
 int bodyfit_profile_sweep(bodyfit_problem* p, const double* d_frame_params, const double* d_beta,
                           int want_jacobian, int with_reduce, int iters, void* stream, double* avg_ms);
 

@@ -116,8 +116,8 @@ def test_one_launch_reports_its_kernel(model):
     st = torch.cuda.current_stream().cuda_stream
     one = _problem(gm, seq, True).profile_sweep(dx.data_ptr(), db.data_ptr(), True, False, 3, st)
     two = _problem(gm, seq, False).profile_sweep(dx.data_ptr(), db.data_ptr(), True, False, 3, st)
-    assert one["sweep_fused"] > 0 and one["frame_resjac"] == 0 and one["mesh_blend_lbs"] == 0
-    assert two["sweep_fused"] == 0 and two["frame_resjac"] > 0 and two["mesh_blend_lbs"] > 0
+    assert one["sweep_roles"] > 0 and one["frame_resjac"] == 0 and one["mesh_blend_lbs"] == 0
+    assert two["sweep_roles"] == 0 and two["frame_resjac"] > 0 and two["mesh_blend_lbs"] > 0
 
 
 def test_one_launch_shared_beta_window(model):
