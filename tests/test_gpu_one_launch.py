@@ -212,3 +212,30 @@ def test_reduction_at_the_sweeps_own_tail(model, F):
     assert api.launch_count() > before
     torch.cuda.synchronize()
     assert np.array_equal(armed.cpu().numpy(), p)
+
+
+def test_reduction_at_the_tail_of_a_shard(model):
+    """The same fold for the problem a rank of a sharded window builds: a halo row behind the last frame (temporal_halo, so one
+    more parameter row than frames and one more temporal pair), no shape prior on this rank.  Against the launched reduction."""
+    import torch
+    m, gm = model
+    F = 33
+    seq = synth.make_sequence(m, F + 1, seed=77, noise_px=3.0)
+    o = int(seq.kp_offset[F])
+    with _Env(BODYFIT_ONE_LAUNCH="1"):
+        prob = api.Problem(gm, seq.kp_offset[:F + 1], seq.kp_id[:o], seq.kp_uv[:o], seq.intr, seq.R0[:F], n_cols=86, use_shape=True,
+                           beta_pose=5.0, beta_shape=0.0, lambda_temporal=3.0, temporal_halo=1, want_mesh=True)
+    rng = np.random.default_rng(9)
+    armed = torch.zeros(66, dtype=torch.float64, device="cuda")
+    plain = torch.zeros(66, dtype=torch.float64, device="cuda")
+    prob.arm_shared_reduction(armed.data_ptr())
+    for it in range(6):
+        x = torch.from_numpy(seq.gt_params + rng.normal(scale=0.02, size=seq.gt_params.shape)).cuda()   # F + 1 rows
+        b = torch.from_numpy(seq.gt_beta + 0.05 * rng.normal(size=10)).cuda()
+        prob.evaluate_device(x.data_ptr(), b.data_ptr(), True, None)
+        before = api.launch_count()
+        prob.reduce_shared_device(armed.data_ptr(), None)
+        assert api.launch_count() == before
+        prob.reduce_shared_device(plain.data_ptr(), None)
+        torch.cuda.synchronize()
+        assert np.array_equal(armed.cpu().numpy(), plain.cpu().numpy())
