@@ -236,18 +236,17 @@ __global__ __launch_bounds__(kThreads, 4) void k_sweep_roles(RoleArgs by_value) 
   unsigned* const flag_base = A->sy.flag;
   unsigned* const error_word = A->sy.error;
   if (role == 2) grp = (idx * kPriorTileF) / kRoleGroup;
-  auto wait_flags = [&]() -> bool {
-    // Wave 7 polls the counters of the group's eight 32-frame units.  Wave 7, because it has no operand stream of its own in
-    // flight (waves 0-5 carry the mesh role's LDS-DMA pieces): loads return in issue order, and a poll issued behind a wave's
-    // DMA pieces came back 3 us late.  Counters (each on a line of its own: lane u reads counter u with an sc1
-    // load).  Every launch adds exactly the unit's frame count, so after launch `epoch` a complete unit reads epoch x count.
-    // Polling is kept sparse: a few hundred waiting workgroups that hammer one line delay the very stores they wait for
-    // (with 1 KB of per-frame flags polled every 128 cycles the hand-off took 3 us to arrive and the producers' store drain
-    // 3 us instead of 1).  One immediate look (later groups: their frames are long done), then nothing before 3 us after
-    // entry (no frame workgroup is faster), then one look at a time: a round trip to the memory side, where agent-scope
-    // counters live, plus a short sleep, ~1.1 us per look.  Measured and rejected: three looks in flight ~0.27 us apart by the
-    // lanes whose unit is still incomplete — the step was no shorter (24.1-24.5 against 23.9-24.5 us, same box) and the
-    // hand-off itself came later (the producers' adds queue behind the looks on the same eight lines).
+  // How a waiting workgroup learns that frames have been handed over: counters, one per 32-frame unit, each on a line of its
+  // own; every launch adds exactly the unit's frame count (one agent-scope add per frame), so after launch `epoch` a complete
+  // unit reads epoch x count.  A look is an sc1 load: a round trip to the memory side, where agent-scope counters live
+  // (~0.8 us).  Polling is kept sparse: a few hundred waiting workgroups that hammer a line delay the very adds and stores they
+  // wait for (with 1 KB of per-frame flags polled every 128 cycles the hand-off took 3 us to arrive and the producers' store
+  // drain 3 us instead of 1): one immediate look (later groups: their frames are long done), then nothing before 3 us after
+  // entry (no frame workgroup is faster), then one look at a time with a short sleep, ~1.1 us per look.  Measured and
+  // rejected: three looks in flight ~0.27 us apart (the step was no shorter, the hand-off itself came later: the producers'
+  // adds queue behind the looks); other sleeps between looks (2, 20: no difference).  The polling wave must have no operand
+  // stream of its own in flight: loads return in issue order, and a look issued behind LDS-DMA pieces came back 3 us late.
+  auto wait_flags = [&]() -> bool {   // prior role: all eight units of the group, polled by wave 7 (lane u: counter u)
     volatile unsigned* ctrl = reinterpret_cast<volatile unsigned*>(lds + kRoleCtrlOff);
     const int tid = threadIdx.x, lane = tid & 63;
     if ((tid >> 6) == kPollWave) {
@@ -257,15 +256,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_sweep_roles(RoleArgs by_value) 
       const unsigned* ctr = flag_base + (size_t)(grp * (kRoleGroup / kFTile) + min(lane, 7)) * kUnitCounterStride;
       unsigned action = 0;
       const unsigned long long t_enter = __builtin_amdgcn_s_memrealtime();
-#ifdef BODYFIT_STAMPS
-      unsigned long long t_issue = 0;
-      int n_polls = 0;
-#endif
       for (;;) {
-#ifdef BODYFIT_STAMPS
-        t_issue = __builtin_amdgcn_s_memrealtime();
-        ++n_polls;
-#endif
         const unsigned got = __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (__all(lane >= nu || got == want)) break;
         const unsigned long long el = __builtin_amdgcn_s_memrealtime() - t_enter;
@@ -277,26 +268,10 @@ __global__ __launch_bounds__(kThreads, 4) void k_sweep_roles(RoleArgs by_value) 
         }
       }
       if (lane == 0) ctrl[0] = action;
-#if BODYFIT_ROLE_ACQUIRE
-      // agent-scope acquire (buffer_inv sc1) by the polling wave, waited for in front of the barrier below: the operand loads
-      // behind it are plain
-      if (role == 1) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
-#endif
-#ifdef BODYFIT_STAMPS
-      if (A->Pb.dbg && lane == 0 && role == 1) {
-        unsigned long long* d = A->Pb.dbg + kStampBase + ((size_t)(grp * nVT + idx) * 8 + kPollWave) * 16;
-        d[5] = t_enter; d[6] = t_issue; d[7] = (unsigned long long)n_polls;
-      }
-#endif
     }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     const unsigned action = ctrl[0];
     if (action != 0) {
-      // (the operand stream's first slabs are still in flight: drain before the LDS is given back)
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       if (tid == 0) __hip_atomic_store(error_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       return false;
     }
@@ -319,7 +294,29 @@ __global__ __launch_bounds__(kThreads, 4) void k_sweep_roles(RoleArgs by_value) 
   const DevModel M = A->M;
   const DevProblem Pb = A->Pb;
   const MeshCoef mc = A->mc;
-  mesh_role(M, Pb, mc, A->cloud_f, idx, grp, lds, (int)blockIdx.x < A->sy.resident_blocks, wait_flags);
+  // mesh role: one wave, one unit — the wave's lanes all look at its unit's counter (one address: a broadcast load) and the wave
+  // starts its blend as soon as ITS 32 frames are in (mesh_role_inl.h)
+  const unsigned long long t_role = __builtin_amdgcn_s_memrealtime();
+  const int my_unit = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const unsigned want = epoch * (unsigned)max(0, min(kFTile, F - (grp * kRoleGroup + my_unit * kFTile)));
+  const unsigned* ctr = flag_base + (size_t)(grp * (kRoleGroup / kFTile) + my_unit) * kUnitCounterStride;
+  auto wait_unit = [&]() -> bool {
+    for (;;) {
+      const unsigned got = __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (got == want) return true;
+      const unsigned long long el = __builtin_amdgcn_s_memrealtime() - t_role;
+      if (el > kRoleTimeoutTicks) return false;
+      if (el < 300) {
+        for (int i = 0; i < 6 && __builtin_amdgcn_s_memrealtime() - t_role < 300; ++i) __builtin_amdgcn_s_sleep(20);
+      } else {
+        __builtin_amdgcn_s_sleep(9);   // (2 and 20 measured: no difference)
+      }
+    }
+  };
+  auto fail = [&]() {
+    if (threadIdx.x == 0) __hip_atomic_store(error_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+  mesh_role(M, Pb, mc, A->cloud_f, idx, grp, lds, (int)blockIdx.x < A->sy.resident_blocks, ctr, want, wait_unit, fail);
 #endif
 }
 

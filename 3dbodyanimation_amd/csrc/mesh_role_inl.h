@@ -43,12 +43,10 @@ constexpr int kTWaveBytes = 3 * kTRowBytes;                       // 6,912 of re
 constexpr int kTSlot3Bytes = kRegionABytes / kWaves;              // 3,072 of region A per wave
 constexpr int kRoleCtrlOff = kRegionABytes + kWaves * kTWaveBytes;   // 79,872: control words of the flag wait
 constexpr int kRoleLdsBytes = kRoleCtrlOff + 16;
-#ifndef BODYFIT_ROLE_ACQUIRE
-#define BODYFIT_ROLE_ACQUIRE 0
-#endif
-// How the mesh role reads the operands handed over inside the launch: BODYFIT_ROLE_ACQUIRE = 1: one agent-scope acquire
-// behind the poll, then plain loads (L2-served); 0: no acquire, every load sc1.
-constexpr int kLoadSc1 = BODYFIT_ROLE_ACQUIRE ? 0 : 16;           // cache policy bit sc1 of loads / LDS-DMA
+// How the mesh role reads the operands handed over inside the launch: every load of them (buffer loads, LDS-DMA) carries the
+// cache policy bit sc1.  (Measured and rejected: one agent-scope acquire — buffer_inv sc1 — behind the poll and plain loads
+// after it: no difference.)
+constexpr int kLoadSc1 = 16;
 static_assert(kRegionTSlabs * kSlabBytes == kWaves * kTWaveBytes, "the transform rings take over region T exactly");
 static_assert(kTSlot3Bytes >= kTRowBytes, "ring slot 3");
 static_assert(kRoleLdsBytes <= 80 * 1024, "two workgroups per CU");
@@ -228,10 +226,12 @@ __device__ __forceinline__ void role_skin_row(const RoleCtx& C, const RoleLane& 
 
 // One workgroup: vertex tile `vtile`, frames [256 group, 256 group + 256).  flags_ready: the caller has waited for the
 // group's hand-off flags (or the operands are from an earlier launch).  `lds`: kRoleLdsBytes.
-template <typename WaitFlags>
+// unit_ctr / unit_want: this wave's unit counter (k_sweep.hip) and the value it shows once the unit's frames have all been
+// handed over; wait_unit polls it (bounded), fail() marks the launch as incomplete.
+template <typename WaitUnit, typename Fail>
 __device__ __forceinline__ void mesh_role(const DevModel& M, const DevProblem& Pb, const MeshCoef& mc, float* __restrict__ cloud_f,
                                           int vtile, int group, unsigned char* lds_generic, bool beside_its_frames,
-                                          WaitFlags wait_flags) {
+                                          const unsigned* unit_ctr, unsigned unit_want, WaitUnit wait_unit, Fail fail) {
   RoleCtx C;
   C.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   C.lane = threadIdx.x & 63;
@@ -253,6 +253,10 @@ __device__ __forceinline__ void mesh_role(const DevModel& M, const DevProblem& P
   const int v = vtile * kVTile + col;
 
   RSTAMP(0);
+  // one look at the unit's counter before anything else (loads return in order: it is back before the operand stream below):
+  // a workgroup dispatched late finds its frames long handed over and never polls
+  unsigned look0 = 0;
+  asm volatile("global_load_dword %0, %1, off sc1" : "=v"(look0) : "v"(unit_ctr) : "memory");
   // ---- independent of the frame workgroups: thirteen of the tile's fourteen operand slabs (78 KiB), the lane's skinning
   //      weights.  They land under the wait for the hand-off. -----------------------------------------------------------
   const uint32_t widx = M.wIdx[(size_t)vtile * 32 + col];
@@ -290,8 +294,15 @@ __device__ __forceinline__ void mesh_role(const DevModel& M, const DevProblem& P
       __builtin_amdgcn_make_buffer_rsrc(mc.featA, 0, nFT * kBlendKSteps * 2 * 1024, 0x00020000);
   const unsigned feat_off = (unsigned)((active ? ftile : 0) * kBlendKSteps * 2 * 1024);
 
-  // ---- the group's frames have been handed over -----------------------------------------------------------------------
-  if (!wait_flags()) return;   // (workgroup-uniform; includes the barrier that orders the poll before every operand load)
+  // every wave's pieces of the resident slabs have landed (requested microseconds ago), the control word is clear
+  volatile unsigned* ctrl = reinterpret_cast<volatile unsigned*>(lds_generic + kRoleCtrlOff);
+  if (threadIdx.x == 0) ctrl[0] = 0u;
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" : "+v"(look0)::"memory");
+  // ---- this wave's 32-frame unit has been handed over: each wave waits for ITS unit alone and starts its blend at once (the
+  //      units' slowest frames are 6.6-8.2 us after the launch's start: a wave that starts early has the SIMD to itself for the
+  //      first nine k-steps; the workgroup meets again at the barrier in front of k-step 9).  A wait that runs out leaves a mark
+  //      the whole workgroup acts on behind that barrier. ------------------------------------------------------------------
+  if (active && look0 != unit_want && !wait_unit()) ctrl[0] = 1u;
   RSTAMP(1);
   // from here on the mesh role is the launch's critical path: the frame workgroup beside it is past its hand-off
   __builtin_amdgcn_s_setprio(3);
@@ -306,8 +317,6 @@ __device__ __forceinline__ void mesh_role(const DevModel& M, const DevProblem& P
       a[ks][1] = __builtin_amdgcn_raw_buffer_load_b128(feat_rsrc, feat_frag_off(C.lane, 1), soff, kLoadSc1);
     }
   }
-  // every wave's pieces of the resident slabs have landed (they were requested microseconds ago; the A fragments just now)
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
   RSTAMP(2);
   if (active) {
 #pragma unroll
@@ -322,6 +331,11 @@ __device__ __forceinline__ void mesh_role(const DevModel& M, const DevProblem& P
   // k-step 9: every wave has read slabs 0-8 (region T) into registers, and slab 9 too (its reads were issued in k-step 8):
   // region T becomes the waves' transform rings, rows 0-2 are requested now and land under the last five k-steps
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  if (ctrl[0] != 0u) {   // (workgroup-uniform: written before the barrier) a unit never arrived: leave, the host falls back
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    fail();
+    return;
+  }
   if (active) {
     role_dma_row(C, 0); role_dma_row(C, 1); role_dma_row(C, 2);
     asm volatile("" ::: "memory");

@@ -68,8 +68,7 @@ print("frame role: median hand-off by XCD:", " ".join(f"{x}:{np.median(pub[xcc =
 print("frame role: XCD of block b (first 16 blocks):", xcc[:16])
 print("frame role: end                ", q(us(fr[:, :, 11].max(1))))
 print("mesh role: entry               ", q(us(ms[:, :, 0])))
-print("mesh role: flags seen          ", q(us(ms[:, :, 1])))
-print("mesh role wave 7: polling from ", q(us(ms[:, 7, 5])), "| last poll issued", q(us(ms[:, 7, 6])), "| polls", q(ms[:, 7, 7] * 100.0 + t0 - t0) if False else q(ms[:, 7, 7]))
+print("mesh role: own unit seen complete (per wave)", q(us(ms[:, :, 1])))
 print("mesh role: blend starts        ", q(us(ms[:, :, 2])))
 print("mesh role: blend done          ", q(us(ms[:, :, 3])))
 print("mesh role: skinning done       ", q(us(ms[:, :, 4])))
