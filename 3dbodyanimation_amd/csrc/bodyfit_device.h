@@ -118,8 +118,10 @@ constexpr size_t kFusedSyncHeader = 256;  // error word, pad (the counters start
 // and LINE (measured: 512 adds into one line took 6 us and held back every store queued behind them on that channel), so a
 // unit's 32 adds must not share a line, or a channel, with the other units'.
 constexpr int kUnitCounterStride = 64;    // dwords
+constexpr int kUnitCoefOffset = 32;   // unsigneds: the unit's SECOND counter (blend coefficients published), 128 bytes behind the first
 struct FusedSync {
-  unsigned* flag;              // [frames / 32, rounded up to whole groups of 8][kUnitCounterStride]
+  unsigned* flag;              // [frames / 32, rounded up to whole groups of 8][kUnitCounterStride]: word 0 counts the frames whose
+                               // skinning transforms are published, word kUnitCoefOffset those whose blend coefficients are
   unsigned* error;             // set when a workgroup's bounded wait ran out
   unsigned epoch;              // launch number, >= 1
   int resident_blocks;         // blocks resident from the start of the launch (2 per CU)

@@ -522,7 +522,9 @@ __device__ __forceinline__ void frame_part(const DevModel& M, const DevProblem& 
     }
   };
   // blend-coefficient fragments of the mesh kernel: they need R_j (phase B) and beta only, so wave 0 stores them first
-  // thing, in the shadow of its landmark posedirs loads, and they have long left when it says so (below)
+  // thing, in the shadow of its landmark posedirs loads, and they have long left when it says so (below).  (Measured and
+  // rejected: on wave 6, the phase's lightest wave, in front of its chain walk — wave 0 is this phase's longest wave by 1.8 k
+  // cycles — : wave 7 then waits for wave 6's later walk, the transforms go out 2 us later and the phase is no shorter.)
   if (wave == 0 && mc.featA) {
     // MFMA row of this frame inside its 32-frame tile.  feat_perm (k_sweep_roles' mesh role): accumulator register i of the
     // half-wave h holds frame 2 i + h, so that one register row covers two CONSECUTIVE frames (2,304 contiguous bytes of
@@ -594,9 +596,11 @@ __device__ __forceinline__ void frame_part(const DevModel& M, const DevProblem& 
   // Who tells wave 7 what, through one LDS counter (every add program-ordered behind the adder's LDS writes; LDS serves a wave
   // in order, and the lgkmcnt wait keeps hipcc from sinking the writes):
   //   wave 0: the root entries are in LDS (first thing in this phase)       (+1)
-  //   wave 6: its chain quantities and Rr0 are in LDS                      (+256)  -> count >= 257: wave 7 builds the transforms
-  //   wave 0: its blend-coefficient stores have LEFT (vmcnt(0))            (+1)    -> count 258: wave 7 may signal for them too
-  // (wave 6 counts in its own byte: wave 0's second add may come before wave 6's)
+  //   wave 6: its chain quantities and Rr0 are in LDS                      (+256)  -> count 257: wave 7 builds the transforms
+  // The hand-off itself is TWO signals per frame (one-launch sweep), each by the wave that stored the payload, after its own
+  // vmcnt(0): wave 0 for the blend coefficients (they need R_j only: out at ~4.8 us, the slowest of 256 frames at 5.8 us),
+  // wave 7 for the transforms (behind the chain walks: 5.9 us median, 7.7-8.3 us the slowest).  A mesh wave starts its blend on
+  // the first and needs the second only in front of its skinning rows, 3 us later.
   // (cdna guide, Guideline 16: "each wave adds to a counter in LDS after its wait and the wave whose add is last signals")
   if (wave == 6) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -606,7 +610,9 @@ __device__ __forceinline__ void frame_part(const DevModel& M, const DevProblem& 
     STAMP_REAL(13);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     STAMP_REAL(14);
-    if (lane == 0) __hip_atomic_fetch_add(const_cast<int*>(sWalkDone), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (lane == 0 && mc.featA)
+      (void)__hip_atomic_fetch_add(fu.flag + (size_t)(f / kFTile) * kUnitCounterStride + kUnitCoefOffset, 1u, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
   }
   if (wave == 7) {
     STAMP(13);
@@ -639,13 +645,10 @@ __device__ __forceinline__ void frame_part(const DevModel& M, const DevProblem& 
     }
     STAMP(15);
     if constexpr (kFused) {
-      // hand-off, still inside phase C (wave 7 has ~2 k cycles of slack before the landmark waves reach the phase's barrier):
-      // this wave's operand stores have left, wave 0's too (count 258), then one agent-scope add to the counter of the frame's
-      // 32-frame unit
+      // hand-off of the transforms, still inside phase C (wave 7 has ~1 k cycles of slack before wave 0 reaches the phase's
+      // barrier): this wave's stores have left, then one agent-scope add to the counter of the frame's 32-frame unit
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       STAMP_REAL(9);
-      for (int spin = 0; spin < (1 << 20) && *sWalkDone < 258; ++spin) __builtin_amdgcn_s_sleep(1);
-      asm volatile("" ::: "memory");
       if (lane == 0)
         (void)__hip_atomic_fetch_add(fu.flag + (size_t)(f / kFTile) * kUnitCounterStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       STAMP_REAL(12);

@@ -300,9 +300,9 @@ __global__ __launch_bounds__(kThreads, 4) void k_sweep_roles(RoleArgs by_value) 
   const int my_unit = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const unsigned want = epoch * (unsigned)max(0, min(kFTile, F - (grp * kRoleGroup + my_unit * kFTile)));
   const unsigned* ctr = flag_base + (size_t)(grp * (kRoleGroup / kFTile) + my_unit) * kUnitCounterStride;
-  auto wait_unit = [&]() -> bool {
+  auto wait_unit = [&](const unsigned* c) -> bool {
     for (;;) {
-      const unsigned got = __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned got = __hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (got == want) return true;
       const unsigned long long el = __builtin_amdgcn_s_memrealtime() - t_role;
       if (el > kRoleTimeoutTicks) return false;

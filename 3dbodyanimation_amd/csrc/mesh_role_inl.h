@@ -226,8 +226,9 @@ __device__ __forceinline__ void role_skin_row(const RoleCtx& C, const RoleLane& 
 
 // One workgroup: vertex tile `vtile`, frames [256 group, 256 group + 256).  flags_ready: the caller has waited for the
 // group's hand-off flags (or the operands are from an earlier launch).  `lds`: kRoleLdsBytes.
-// unit_ctr / unit_want: this wave's unit counter (k_sweep.hip) and the value it shows once the unit's frames have all been
-// handed over; wait_unit polls it (bounded), fail() marks the launch as incomplete.
+// unit_ctr / unit_want: this wave's unit counters (k_sweep.hip; word 0: transforms, word kUnitCoefOffset: blend coefficients) and
+// the value each shows once the unit's frames have all published; wait_unit(counter) polls one (bounded), fail() marks the launch
+// as incomplete.
 template <typename WaitUnit, typename Fail>
 __device__ __forceinline__ void mesh_role(const DevModel& M, const DevProblem& Pb, const MeshCoef& mc, float* __restrict__ cloud_f,
                                           int vtile, int group, unsigned char* lds_generic, bool beside_its_frames,
@@ -256,7 +257,7 @@ __device__ __forceinline__ void mesh_role(const DevModel& M, const DevProblem& P
   // one look at the unit's counter before anything else (loads return in order: it is back before the operand stream below):
   // a workgroup dispatched late finds its frames long handed over and never polls
   unsigned look0 = 0;
-  asm volatile("global_load_dword %0, %1, off sc1" : "=v"(look0) : "v"(unit_ctr) : "memory");
+  asm volatile("global_load_dword %0, %1, off sc1" : "=v"(look0) : "v"(unit_ctr + kUnitCoefOffset) : "memory");
   // ---- independent of the frame workgroups: thirteen of the tile's fourteen operand slabs (78 KiB), the lane's skinning
   //      weights.  They land under the wait for the hand-off. -----------------------------------------------------------
   const uint32_t widx = M.wIdx[(size_t)vtile * 32 + col];
@@ -298,11 +299,12 @@ __device__ __forceinline__ void mesh_role(const DevModel& M, const DevProblem& P
   volatile unsigned* ctrl = reinterpret_cast<volatile unsigned*>(lds_generic + kRoleCtrlOff);
   if (threadIdx.x == 0) ctrl[0] = 0u;
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" : "+v"(look0)::"memory");
-  // ---- this wave's 32-frame unit has been handed over: each wave waits for ITS unit alone and starts its blend at once (the
+  // ---- this wave's 32-frame unit has published its BLEND COEFFICIENTS (the transforms follow ~2 us later and are needed in
+  //      front of k-step 9 only): each wave waits for ITS unit alone and starts its blend at once (the
   //      units' slowest frames are 6.6-8.2 us after the launch's start: a wave that starts early has the SIMD to itself for the
   //      first nine k-steps; the workgroup meets again at the barrier in front of k-step 9).  A wait that runs out leaves a mark
   //      the whole workgroup acts on behind that barrier. ------------------------------------------------------------------
-  if (active && look0 != unit_want && !wait_unit()) ctrl[0] = 1u;
+  if (active && look0 != unit_want && !wait_unit(unit_ctr + kUnitCoefOffset)) ctrl[0] = 1u;
   RSTAMP(1);
   // from here on the mesh role is the launch's critical path: the frame workgroup beside it is past its hand-off
   __builtin_amdgcn_s_setprio(3);
@@ -327,7 +329,16 @@ __device__ __forceinline__ void mesh_role(const DevModel& M, const DevProblem& P
     }
   }
 #define RB(S) RCYC(S); role_blend_step<S>(C, feat_rsrc, feat_off, acc, a, bq)
-  if (active) { RB(0); RB(1); RB(2); RB(3); RB(4); RB(5); RB(6); RB(7); RB(8); }
+  // the unit's transforms: one look at their counter four k-steps (~1.5 us) ahead of the barrier behind which the first rows are
+  // requested; eight fragment loads are issued behind it, so it is back at vmcnt(8).  Normally complete; else poll (bounded).
+  unsigned look1 = unit_want;
+  if (active) {
+    RB(0); RB(1); RB(2); RB(3); RB(4);
+    asm volatile("global_load_dword %0, %1, off sc1" : "=v"(look1) : "v"(unit_ctr) : "memory");
+    RB(5); RB(6); RB(7); RB(8);
+    asm volatile("s_waitcnt vmcnt(8)" : "+v"(look1)::"memory");
+    if (look1 != unit_want && !wait_unit(unit_ctr)) ctrl[0] = 1u;
+  }
   // k-step 9: every wave has read slabs 0-8 (region T) into registers, and slab 9 too (its reads were issued in k-step 8):
   // region T becomes the waves' transform rings, rows 0-2 are requested now and land under the last five k-steps
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");

@@ -47,7 +47,9 @@ c0 = w7[:, 2]   # start of phase C (shader cycles)
 print("frame role wave 7, shader cycles into phase C: walks done", q(w7[:, 13] - c0), "| wave 6 + 0 seen", q(w7[:, 14] - c0),
       "| operands stored", q(w7[:, 15] - c0), "| end of C", q(w7[:, 3] - c0))
 print("                   own stores drained (us)", q(us(w7[:, 9])), "| signalled (us)", q(us(w7[:, 12])), "| waiting for wave 0's drain", q((w7[:, 12] - w7[:, 9]) / 100))
-print("frame role wave 0: blend coefficients issued (us)", q(us(fr[:, 0, 13])), "| drained", q(us(fr[:, 0, 14])), "| drain time", q((fr[:, 0, 14] - fr[:, 0, 13]) / 100))
+print("frame role: blend coefficients published (wave 0) ", q(us(fr[:, 0, 14])), "| slowest frame of each 32-frame unit:", np.round([us(fr[u * 32:(u + 1) * 32, 0, 14]).max() for u in range((F + 31) // 32)][:8], 2))
+print("frame role: transforms published (wave 7), slowest frame of each unit:", np.round([us(fr[u * 32:(u + 1) * 32, 7, 12]).max() for u in range((F + 31) // 32)][:8], 2))
+print("frame role wave 0: blend coefficients drain starts (us)", q(us(fr[:, 0, 13])), "| drained", q(us(fr[:, 0, 14])), "| drain time", q((fr[:, 0, 14] - fr[:, 0, 13]) / 100))
 pub = us(fr[:, 7, 12])
 late = np.argsort(pub)[-24:]
 print("frame role: latest 24 hand-offs (frame: us):", " ".join(f"{int(i)}:{pub[i]:.1f}" for i in late))
