@@ -45,11 +45,13 @@ namespace {
 __device__ __forceinline__ void store_through(double* p, double v) {
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
-// One-launch sweep (kFused): plain stores.  There the panel is written while other frame workgroups hand their mesh operands
-// over and the mesh workgroups poll for them: 1.1 M eight-byte write-through stores (one fabric write each) kept the
-// memory side busy enough to delay hand-off signals by up to 7 us (tools/stamp_roles.py).
+// One-launch sweep (kFused): the same.  (An earlier form of that kernel did better with plain stores: its Jacobian phases ran
+// while other frame workgroups were still handing their operands over to consumers that polled the producers' lines, and
+// 1.1 M eight-byte write-through stores delayed those signals by up to 7 us.  With two signals per frame on lines the consumers do
+// not poll, the hand-off is over before the first panel row is written; same box, 256 frames: 22.0 against 22.6 us per step.
+// BODYFIT_J_THROUGH=0 compiles the plain form for A/B runs.)
 #ifndef BODYFIT_J_THROUGH
-#define BODYFIT_J_THROUGH 0
+#define BODYFIT_J_THROUGH 1
 #endif
 template <bool kFused>
 __device__ __forceinline__ void store_J(double* p, double v) {
