@@ -63,3 +63,23 @@ for F in (13, 20, 103, 300):
         if ref is None: ref = cur
         assert np.array_equal(ref[0], cur[0]) and np.array_equal(ref[1], cur[1]) and ref[2:] == cur[2:], (F, rep)
     print("window F", F, "bit-stable over 12 fits,", ref[2], "iterations", flush=True)
+
+# shared-shape reduction at the sweep's own tail (ticket + write-through partials): 4,000 folding sweeps per size, the armed
+# target compared with the launched reduction every 500
+for F in (8, 96, 250):
+    seq = synth.make_sequence(model, F, seed=50 + F, noise_px=3.0)
+    prob = api.Problem.from_sequence(gm, seq, n_cols=86, use_shape=True, beta_pose=5.0, beta_shape=25.0, lambda_temporal=3.0, want_mesh=True)
+    armed = torch.zeros(66, dtype=torch.float64, device="cuda"); plain = torch.zeros(66, dtype=torch.float64, device="cuda")
+    prob.arm_shared_reduction(armed.data_ptr())
+    rng = np.random.default_rng(F)
+    for i in range(4000):
+        if i % 500 == 0:
+            x = torch.from_numpy(seq.gt_params + rng.normal(scale=0.02, size=seq.gt_params.shape)).cuda()
+            b = torch.from_numpy(seq.gt_beta + 0.05 * rng.normal(size=10)).cuda()
+        prob.evaluate_device(x.data_ptr(), b.data_ptr(), True, None)
+        prob.reduce_shared_device(armed.data_ptr(), None)
+        if i % 500 == 499:
+            prob.reduce_shared_device(plain.data_ptr(), None)
+            torch.cuda.synchronize()
+            assert np.array_equal(armed.cpu().numpy(), plain.cpu().numpy()), (F, i)
+    print("folded reduction F", F, "ok", round(time.time() - t0, 1), "s", flush=True)
