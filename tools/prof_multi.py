@@ -1,0 +1,18 @@
+import importlib, os, sys, time, cProfile, pstats
+import numpy as np
+sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tools"))
+api = importlib.import_module("3dbodyanimation_amd.api"); synth = importlib.import_module("3dbodyanimation_amd.synth")
+drivers = importlib.import_module("3dbodyanimation_amd.drivers")
+model = synth.make_model(0); gm = api.Model(model)
+seq = synth.make_sequence(model, 128, seed=2)
+ks = drivers.KeypointSequence(seq.kp_offset, seq.kp_id, seq.kp_uv, [f"{i:06d}.json" for i in range(128)])
+drivers.run_multi(gm, ks, seq.intr)
+t0 = time.perf_counter(); drivers.run_multi(gm, ks, seq.intr); print("run_multi", time.perf_counter() - t0)
+s20 = synth.make_sequence(model, 20, seed=5)
+t0 = time.perf_counter()
+for _ in range(10):
+    p = api.Problem.from_sequence(gm, s20, n_cols=86, use_shape=True, beta_pose=5.0, beta_shape=25.0, lambda_temporal=3.0)
+    p.close()
+print("problem create+destroy x10", time.perf_counter() - t0)
+pr = cProfile.Profile(); pr.enable(); drivers.run_multi(gm, ks, seq.intr); pr.disable()
+pstats.Stats(pr).sort_stats("tottime").print_stats(12)
