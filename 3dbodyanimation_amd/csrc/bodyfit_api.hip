@@ -144,6 +144,7 @@ struct bodyfit_problem {
   bool fused_enabled = true, fused_unchecked = false;
   double* d_frame_partials = nullptr; // [F][258] per-frame beta partials written by k_frame_resjac (shared-beta problems)
   int partials_tiles = 0;             // prior tiles that added their plain-cost rows behind the frame rows
+  unsigned long long role_timeout_ticks = kRoleTimeoutDefault;   // bound of the one-launch sweep's in-launch waits
   double* armed_out66 = nullptr;      // bodyfit_arm_shared_reduction: where a folding sweep deposits [cost | g_beta | H_bb]
   unsigned fold_count = 0;            // tickets taken by the folding sweeps since the sync buffer was zeroed
   bool fold_fresh = false;            // the last sweep folded into armed_out66
@@ -259,6 +260,7 @@ int sweep(bodyfit_problem* p, const double* d_params, const double* d_beta, int 
     }
     sy.epoch = ++p->fused_epoch;
     sy.resident_blocks = 2 * m->n_cus;
+    sy.timeout_ticks = p->role_timeout_ticks;
     p->fused_unchecked = true;
     FoldTail fold{};
     const int n_partials = p->d.F + pa.n_tiles;
@@ -1643,6 +1645,15 @@ int bodyfit_internal_solver_view(bodyfit_problem* p, bodyfit_solver_view* out) {
   for (int f = 0; f < p->d.F; ++f)
     out->max_kp_per_frame = std::max(out->max_kp_per_frame, p->kp_offset[f + 1] - p->kp_offset[f]);
   out->prec_cho = p->has_gmm ? p->desc.gmm->prec_cho.data() : nullptr;
+  return BODYFIT_OK;
+}
+
+// Test hook (not part of include/bodyfit.h): the bound of the one-launch sweep's in-launch waits, in 10 ns ticks.  A bound of
+// one tick makes every wait run out, which is how tests/test_gpu_one_launch.py exercises the error word and the fall-back to
+// the two-launch sweep.  0 restores the default.
+int bodyfit_internal_set_role_timeout(bodyfit_problem* p, unsigned long long ticks) {
+  if (!p) return fail(BODYFIT_ERR_INVALID, "null argument");
+  p->role_timeout_ticks = ticks ? ticks : kRoleTimeoutDefault;
   return BODYFIT_OK;
 }
 

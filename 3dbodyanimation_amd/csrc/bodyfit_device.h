@@ -125,7 +125,9 @@ struct FusedSync {
   unsigned* error;             // set when a workgroup's bounded wait ran out
   unsigned epoch;              // launch number, >= 1
   int resident_blocks;         // blocks resident from the start of the launch (2 per CU)
+  unsigned long long timeout_ticks;   // bound of every in-launch wait (s_memrealtime ticks, 100 MHz); kRoleTimeoutDefault
 };
+constexpr unsigned long long kRoleTimeoutDefault = 5000000;   // 50 ms: give up, set the error word, the host falls back
 constexpr int kRoleMaxFrames = 16384;
 
 // 8-byte write-through store (sc1): the payload form of a hand-off to a workgroup on another XCD inside the launch

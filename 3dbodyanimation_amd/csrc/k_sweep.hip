@@ -24,7 +24,7 @@
 //
 // Progress: a mesh workgroup waits only for frame workgroups, which wait for nothing; frame workgroups precede the mesh
 // workgroups that need them in block order, and the hardware dispatches blocks in order.  HIP does not promise that
-// order, so every wait is bounded: after kRoleTimeoutTicks the workgroup sets the problem's error word and leaves, the host
+// order, so every wait is bounded: after FusedSync::timeout_ticks (50 ms) the workgroup sets the problem's error word and leaves, the host
 // reports the sweep as failed and the problem falls back to the two-launch sweep.
 #include <hip/hip_ext.h>
 
@@ -38,7 +38,6 @@ namespace bodyfit {
 namespace {
 
 [[maybe_unused]] constexpr int kPollWave = 7;
-[[maybe_unused]] constexpr unsigned long long kRoleTimeoutTicks = 5000000;   // 50 ms of s_memrealtime (100 MHz): give up
 
 __global__ __launch_bounds__(kThreads, 4) void k_frame_resjac(DevModel M, DevProblem Pb, const double* __restrict__ params,
                                                       const double* __restrict__ beta, double* __restrict__ r_out,
@@ -233,6 +232,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_sweep_roles(RoleArgs by_value) 
   }
   // ---- mesh and prior roles: both start their real work once the group's frames have been handed over ----------------------
   const unsigned epoch = A->sy.epoch;
+  const unsigned long long kRoleTimeoutTicks = A->sy.timeout_ticks;
   unsigned* const flag_base = A->sy.flag;
   unsigned* const error_word = A->sy.error;
   if (role == 2) grp = (idx * kPriorTileF) / kRoleGroup;

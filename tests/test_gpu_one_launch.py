@@ -239,3 +239,34 @@ def test_reduction_at_the_tail_of_a_shard(model):
         prob.reduce_shared_device(plain.data_ptr(), None)
         torch.cuda.synchronize()
         assert np.array_equal(armed.cpu().numpy(), plain.cpu().numpy())
+
+
+def test_a_wait_that_runs_out_is_reported_and_the_problem_falls_back(model):
+    """Every in-launch wait is bounded.  With the bound set to one tick (test hook) the mesh and prior workgroups give up at
+    once: the sweep must come back (no hang), the next synchronous entry point must report the incomplete sweep, and from
+    then on the problem uses the two-launch sweep — whose results are the reference ones."""
+    import ctypes as C
+    m, gm = model
+    F = 40
+    seq = synth.make_sequence(m, F, seed=3)
+    rng = np.random.default_rng(2)
+    x = seq.gt_params + rng.normal(scale=0.02, size=seq.gt_params.shape)
+    w, mu, cov = synth.make_gmm(0)
+    gmm = api.Gmm(w, mu, cov)
+    beta = np.tile(seq.gt_beta, (F, 1))
+    good = _problem(gm, seq, False, gmm=gmm)
+    r_ref, J_ref, _ = good.evaluate(x, beta, True)
+    _, cloud_ref = good.forward(x, beta)
+    prob = _problem(gm, seq, True, gmm=gmm)
+    lib = api.load_library()
+    lib.bodyfit_internal_set_role_timeout.argtypes = [C.c_void_p, C.c_ulonglong]
+    assert lib.bodyfit_internal_set_role_timeout(prob.h, 1) == 0
+    with pytest.raises(api.BodyfitError, match="timed out"):
+        prob.evaluate(x, beta, True)
+    r, J, _ = prob.evaluate(x, beta, True)          # two launches from here on
+    assert np.array_equal(r, r_ref) and np.array_equal(J, J_ref)
+    _, cloud = prob.forward(x, beta)
+    assert np.array_equal(cloud, cloud_ref)
+    before = api.launch_count()
+    prob.evaluate(x, beta, True)
+    assert api.launch_count() - before >= 2
