@@ -1307,7 +1307,7 @@ static int solve_window_device(bodyfit_problem* p, double* frame_params, double*
   if (sharded) build_cr_schedule(NI, false, sched, ilevels);
   // ---- one pooled allocation, kept across solves ----
   WinBuf W{}, Wi{};
-  double *d_x, *d_b, *d_xn, *d_bn, *d_rn, *d_xl, *d_sh, *d_dh, *d_xln, *d_sl, *d_cg, *d_send, *d_gath;
+  double *d_x, *d_b, *d_xn, *d_bn, *d_rn, *d_xl, *d_sh, *d_dh, *d_xln, *d_sl, *d_cg, *d_send, *d_gath, *d_Jn;
   int *d_compn, *d_sched;
   unsigned char* d_const = nullptr;
   {
@@ -1323,6 +1323,7 @@ static int solve_window_device(bodyfit_problem* p, double* frame_params, double*
                  o_xn = take((size_t)(F + 1) * npose * 8), o_bn = take(nb * 8), o_rn = take((size_t)std::max(1, p->lay.total_rows) * 8),
                  o_cn = take((size_t)F * 4), o_sched = take(sched.size() * 4), o_const = take((size_t)npose),
                  o_xl = take(npose * 8), o_sh = take(npose * 8), o_dh = take(npose * 8), o_xln = take(npose * 8), o_sl = take(npose * 8),
+                 o_Jn = take(sharded ? 8 : (size_t)std::max(1, p->lay.reproj_rows) * p->lay.n_cols * 8),
                  o_cg = take(112 * 8), o_send = take(sharded ? (size_t)iface_doubles(112) * 8 : 8),
                  o_gath = take(sharded ? (size_t)N * iface_doubles(112) * 8 : 8);
     if (!p->win_pool || p->win_pool_bytes < off) {
@@ -1344,6 +1345,7 @@ static int solve_window_device(bodyfit_problem* p, double* frame_params, double*
     if (param_constant) d_const = Bp + o_const;
     d_xl = dp(o_xl); d_sh = dp(o_sh); d_dh = dp(o_dh); d_xln = dp(o_xln); d_sl = dp(o_sl);
     d_cg = dp(o_cg); d_send = dp(o_send); d_gath = dp(o_gath);
+    d_Jn = dp(o_Jn);
   }
   if (!p->d_frame_normal) HIP_TRY(p->mem.alloc(&p->d_frame_normal, (size_t)F * kNormalRows * kNormalLd));
   if (!p->lm_stream) HIP_TRY(hipStreamCreateWithFlags(&p->lm_stream, hipStreamNonBlocking));
@@ -1385,7 +1387,11 @@ static int solve_window_device(bodyfit_problem* p, double* frame_params, double*
     launch_frame_normal(F, n, p->d.kp_offset, p->desc.huber_delta, p->d_r, p->d_J, p->d_frame_normal, st);
     return BODYFIT_OK;
   };
-  int rc = jac_sweep();
+  // One GPU: the loop never sweeps twice at the same point.  The sweep at a candidate also leaves the candidate's Jacobian
+  // (second buffers); the next iteration's k_frame_normal takes the starting point's (r, J), the accepted candidate's, or
+  // nothing at all (rejected step: the panels are current), as the device's own record says (W.status[kWsJsel]).  (The
+  // sharded loop still re-sweeps: its decision is taken across ranks after the candidate sweep.)
+  int rc = sharded ? jac_sweep() : sweep(p, d_x, d_b, 1, false, st);
   if (rc) return rc;
   if (!sharded) {
     launch_win_init(P, W, p->d_r, 0, st);
@@ -1400,7 +1406,10 @@ static int solve_window_device(bodyfit_problem* p, double* frame_params, double*
   bool need_jac = false, first = true;
   const size_t rhs = (size_t)kWinRhs * kWinBlock;
   for (int it = 0; it < opt->max_iters; ++it) {
-    if (need_jac) {
+    if (!sharded) {
+      launch_frame_normal_sel(F, n, p->d.kp_offset, p->desc.huber_delta, p->d_r, p->d_J, d_rn, d_Jn, W.status + kWsJsel,
+                              p->lay.total_rows, p->d_frame_normal, st);
+    } else if (need_jac) {
       if ((rc = jac_sweep())) return rc;
       ++n_sweeps;
     }
@@ -1479,7 +1488,7 @@ static int solve_window_device(bodyfit_problem* p, double* frame_params, double*
       launch_win_finish(P, W, d_x, d_b, d_xn, d_bn, 1, st);              // this shard's scalars -> W.fin[0..4]
     }
     if (!sharded) {
-      rc = sweep(p, d_xn, d_bn, 0, false, st, nullptr, d_rn, d_compn);
+      rc = sweep(p, d_xn, d_bn, 1, false, st, nullptr, d_rn, d_compn, nullptr, 0, nullptr, false, d_Jn);
       if (rc) return rc;
       ++n_sweeps;
       launch_win_accept(P, W, d_rn, d_x, d_b, d_xn, d_bn, 0, st);
@@ -1495,10 +1504,10 @@ static int solve_window_device(bodyfit_problem* p, double* frame_params, double*
     }
     first = false;
     if (!opt->verbose && (it & 3) != 3 && it + 1 < opt->max_iters) {
-      // One GPU: the device takes every decision itself, so the host only looks at the status record every fourth
-      // iteration (a read-back drains the launch pipeline: ~30 us of a ~450 us iteration at 20 frames).  The Jacobian sweep
-      // is then issued unconditionally (after a rejected step it recomputes the same normals), and iterations launched
-      // after the solve has terminated leave the state untouched (every kernel checks the active / candidate flags).
+      // The device takes every decision itself, so the host only looks at the status record every fourth iteration (a
+      // read-back drains the launch pipeline: ~30 us of a ~250 us iteration at 20 frames).  Iterations launched after the
+      // solve has terminated leave the state untouched (every kernel checks the active / candidate flags); the sharded loop
+      // issues its Jacobian sweep unconditionally in between (after a rejected step it recomputes the same normals).
       need_jac = true;
       continue;
     }

@@ -199,6 +199,12 @@ void launch_lm_accept(const LmProblem& P, const LmState& S, const double* d_r_ne
 constexpr int kNormalRows = 87, kNormalLd = 88;   // per-frame normal-equation panel of k_frame_normal: (n + 1) x 88, lower
 void launch_frame_normal(int F, int n, const int* d_kp_offset, double huber, const double* d_r, const double* d_J,
                          double* d_out, hipStream_t s);
+// The window LM's form: `sel` (device, W.status + kWsJsel) says whether the panels are rebuilt from the starting point's (r, J)
+// (0), from the accepted candidate's (r_alt, J_alt) (1: the candidate's rows are also copied into r, which the assembly reads), or
+// left alone (2: the last step was rejected).
+void launch_frame_normal_sel(int F, int n, const int* d_kp_offset, double huber, double* d_r, const double* d_J,
+                             const double* d_r_alt, const double* d_J_alt, const double* d_sel, int total_rows, double* d_out,
+                             hipStream_t s);
 
 // ---- device-resident LM for one shared-beta window (k_window_lm.hip): block cyclic reduction over the frames ----------
 constexpr int kWinBlock = 80;     // 76 frame parameters padded to whole 16-column panels (identity on the padding)
@@ -206,7 +212,9 @@ constexpr int kWinRhs = 16;       // [B (10 columns) | rhs] transposed, padded t
 constexpr int kWinPart = 128;     // per-frame partials: Schur S_f (100) + rb_f (10) + pad + model / |d|^2 / |x|^2 at 112..114
 enum {   // status record of the window LM (doubles), read back by the host once per iteration
   kWsCost = 0, kWsRadius, kWsDec, kWsModel, kWsHasCand, kWsIters, kWsOk, kWsBad, kWsTermination, kWsActive,
-  kWsInitialCost, kWsAccepted, kWsGmax, kWsNewCost, kWsCount = 16
+  kWsInitialCost, kWsAccepted, kWsGmax, kWsNewCost,
+  kWsJsel,          // which Jacobian the next k_frame_normal reads: 0 the starting point's, 1 the accepted candidate's, 2 none (rejected)
+  kWsCount = 16
 };
 struct WinProblem {
   int F, K, total_rows, nb;

@@ -777,13 +777,32 @@ __global__ __launch_bounds__(kStepThreads) void k_lm_step(LmProblem P, LmState S
 // on the f64 matrix cores, lower triangle of an (n + 1) x kLd panel per frame.  The host adds the prior / temporal
 // blocks (constant Jacobians) and runs the block-tridiagonal factorisation; it no longer needs J itself
 // ("normal equations built on device").
+// sel != nullptr (window LM, launch_frame_normal_sel): *sel = 0: (r_io, J); 1: (r_alt, J_alt) — the accepted candidate, whose
+// residual rows this launch also copies into r_io (its own frame's reprojection rows and a slice of the remaining rows per
+// workgroup); 2: nothing to do.
 __global__ __launch_bounds__(kStepThreads) void k_frame_normal(int F, int n, const int* __restrict__ kp_offset, double huber,
-                                                       const double* __restrict__ r, const double* __restrict__ J,
+                                                       double* __restrict__ r_io, const double* __restrict__ J_in,
+                                                       const double* __restrict__ r_alt, const double* __restrict__ J_alt,
+                                                       const double* __restrict__ sel, int total_rows,
                                                        double* __restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   double* Jh = sm;                         // kRowsMax x kJLd : robustified [J | r]
   double* ds = sm + kRowsMax * kJLd;       // per-row sqrt(rho')
   const int f = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int which = sel ? (int)sel[0] : 0;   // (uniform)
+  if (which == 2) return;
+  const double* __restrict__ r = (which == 1) ? r_alt : r_io;
+  const double* __restrict__ J = (which == 1) ? J_alt : J_in;
+  if (which == 1) {
+    // the candidate's rows become the current ones: this frame's reprojection rows (read again below from r_alt, not from
+    // here) and the f-th slice of the prior / shape / temporal rows
+    const int kA = 2 * kp_offset[0], kB = 2 * kp_offset[F];          // reprojection rows [kA, kB)
+    const int a0 = 2 * kp_offset[f], a1 = 2 * kp_offset[f + 1];
+    for (int i = a0 + tid; i < a1; i += kStepThreads) r_io[i] = r_alt[i];
+    const int rest = total_rows - (kB - kA), chunk = (rest + F - 1) / F;
+    const int b0 = kB + f * chunk, b1 = min(total_rows, b0 + chunk);
+    for (int i = b0 + tid; i < b1; i += kStepThreads) r_io[i] = r_alt[i];
+  }
   const int k0 = kp_offset[f], nrows = 2 * (kp_offset[f + 1] - k0);
   const int nrows4 = (nrows + 3) & ~3;
   // J and the residual rows in one round trip (unconditional loads from clamped addresses, masked afterwards)
@@ -890,7 +909,19 @@ void launch_frame_normal(int F, int n, const int* d_kp_offset, double huber, con
   static DeviceOnce attr_set;
   if (attr_set.first(current_device()))
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_frame_normal), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  BODYFIT_LAUNCH(k_frame_normal, dim3(F), dim3(kStepThreads), lds, s, F, n, d_kp_offset, huber, d_r, d_J, d_out);
+  BODYFIT_LAUNCH(k_frame_normal, dim3(F), dim3(kStepThreads), lds, s, F, n, d_kp_offset, huber, const_cast<double*>(d_r), d_J,
+                 (const double*)nullptr, (const double*)nullptr, (const double*)nullptr, 0, d_out);
+}
+void launch_frame_normal_sel(int F, int n, const int* d_kp_offset, double huber, double* d_r, const double* d_J,
+                             const double* d_r_alt, const double* d_J_alt, const double* d_sel, int total_rows, double* d_out,
+                             hipStream_t s) {
+  if (F <= 0) return;
+  const size_t lds = (size_t)(kRowsMax * kJLd + kRowsMax) * sizeof(double);
+  static DeviceOnce attr_set;
+  if (attr_set.first(current_device()))
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_frame_normal), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  BODYFIT_LAUNCH(k_frame_normal, dim3(F), dim3(kStepThreads), lds, s, F, n, d_kp_offset, huber, d_r, d_J, d_r_alt, d_J_alt, d_sel,
+                 total_rows, d_out);
 }
 
 }  // namespace bodyfit

@@ -129,7 +129,7 @@ __global__ __launch_bounds__(1024) void k_win_init(WinProblem P, WinBuf W, const
     const bool finite = (c == c) && c < 1e300;
     st[kWsActive] = finite ? 1.0 : 0.0;
     st[kWsTermination] = finite ? 1.0 : 2.0;
-    st[kWsAccepted] = 1.0; st[kWsGmax] = 0.0; st[kWsNewCost] = c;
+    st[kWsAccepted] = 1.0; st[kWsGmax] = 0.0; st[kWsNewCost] = c; st[kWsJsel] = 0.0;
     *W.fail = 0;
   }
 }
@@ -1137,6 +1137,7 @@ __device__ __forceinline__ bool accept_core(const WinProblem& P, const WinBuf& W
       if (rad < 1e-32) { st[kWsActive] = 0.0; st[kWsTermination] = 2.0; }
     }
     st[kWsAccepted] = accept ? 1.0 : 0.0;
+    st[kWsJsel] = accept ? 1.0 : 2.0;     // (single-GPU loop: the candidate sweep also left the candidate's Jacobian)
     st[kWsHasCand] = 0.0;
     acc_flag = accept ? 1 : 0;
   }
@@ -1161,7 +1162,10 @@ __global__ __launch_bounds__(1024) void k_win_accept(WinProblem P, WinBuf W, con
     if (tid == 0) W.fin[mode == 1 ? 0 : 5] = c;
     return;
   }
-  if (st[kWsHasCand] == 0.0) return;
+  if (st[kWsHasCand] == 0.0) {
+    if (tid == 0) st[kWsJsel] = 2.0;     // no candidate was produced (inactive solve, failed factorisation): nothing moved
+    return;
+  }
   const double new_cost = (mode == 2) ? W.fin[0] : window_cost(P, r_new, red, tid, 1024);
   (void)accept_core(P, W, x, beta, x_new, beta_new, new_cost, tid, 1024);
 }
