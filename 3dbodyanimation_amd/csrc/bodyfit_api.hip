@@ -1323,7 +1323,7 @@ static int solve_window_device(bodyfit_problem* p, double* frame_params, double*
                  o_xn = take((size_t)(F + 1) * npose * 8), o_bn = take(nb * 8), o_rn = take((size_t)std::max(1, p->lay.total_rows) * 8),
                  o_cn = take((size_t)F * 4), o_sched = take(sched.size() * 4), o_const = take((size_t)npose),
                  o_xl = take(npose * 8), o_sh = take(npose * 8), o_dh = take(npose * 8), o_xln = take(npose * 8), o_sl = take(npose * 8),
-                 o_Jn = take(sharded ? 8 : (size_t)std::max(1, p->lay.reproj_rows) * p->lay.n_cols * 8),
+                 o_Jn = take((size_t)std::max(1, p->lay.reproj_rows) * p->lay.n_cols * 8),
                  o_cg = take(112 * 8), o_send = take(sharded ? (size_t)iface_doubles(112) * 8 : 8),
                  o_gath = take(sharded ? (size_t)N * iface_doubles(112) * 8 : 8);
     if (!p->win_pool || p->win_pool_bytes < off) {
@@ -1381,17 +1381,11 @@ static int solve_window_device(bodyfit_problem* p, double* frame_params, double*
     if (halo)
       HIP_TRY(hipMemcpyAsync(d_x + (size_t)F * npose, d_gath + (size_t)(R + 1) * 2 * npose, npose * sizeof(double), hipMemcpyDeviceToDevice, st));
   }
-  auto jac_sweep = [&]() -> int {
-    int rc = sweep(p, d_x, d_b, 1, false, st);
-    if (rc) return rc;
-    launch_frame_normal(F, n, p->d.kp_offset, p->desc.huber_delta, p->d_r, p->d_J, p->d_frame_normal, st);
-    return BODYFIT_OK;
-  };
-  // One GPU: the loop never sweeps twice at the same point.  The sweep at a candidate also leaves the candidate's Jacobian
-  // (second buffers); the next iteration's k_frame_normal takes the starting point's (r, J), the accepted candidate's, or
-  // nothing at all (rejected step: the panels are current), as the device's own record says (W.status[kWsJsel]).  (The
-  // sharded loop still re-sweeps: its decision is taken across ranks after the candidate sweep.)
-  int rc = sharded ? jac_sweep() : sweep(p, d_x, d_b, 1, false, st);
+  // The loop never sweeps twice at the same point.  The sweep at a candidate also leaves the candidate's Jacobian (second
+  // buffers); the next iteration's k_frame_normal takes the starting point's (r, J), the accepted candidate's, or nothing at
+  // all (rejected step: the panels are current), as the device's own record says (W.status[kWsJsel]; sharded solves: every
+  // rank's k_win_decide writes the same).
+  int rc = sweep(p, d_x, d_b, 1, false, st);
   if (rc) return rc;
   if (!sharded) {
     launch_win_init(P, W, p->d_r, 0, st);
@@ -1403,16 +1397,11 @@ static int solve_window_device(bodyfit_problem* p, double* frame_params, double*
   }
   int n_sweeps = 1;
   double status[kWsCount] = {0};
-  bool need_jac = false, first = true;
+  bool first = true;
   const size_t rhs = (size_t)kWinRhs * kWinBlock;
   for (int it = 0; it < opt->max_iters; ++it) {
-    if (!sharded) {
-      launch_frame_normal_sel(F, n, p->d.kp_offset, p->desc.huber_delta, p->d_r, p->d_J, d_rn, d_Jn, W.status + kWsJsel,
-                              p->lay.total_rows, p->d_frame_normal, st);
-    } else if (need_jac) {
-      if ((rc = jac_sweep())) return rc;
-      ++n_sweeps;
-    }
+    launch_frame_normal_sel(F, n, p->d.kp_offset, p->desc.huber_delta, p->d_r, p->d_J, d_rn, d_Jn, W.status + kWsJsel,
+                            p->lay.total_rows, p->d_frame_normal, st);
     // ---- beta block and per-frame blocks ----
     if (!sharded) {
       launch_win_beta(P, W, p->d_frame_normal, p->d_r, first ? 1 : 0, 0, st);
@@ -1494,7 +1483,7 @@ static int solve_window_device(bodyfit_problem* p, double* frame_params, double*
       launch_win_accept(P, W, d_rn, d_x, d_b, d_xn, d_bn, 0, st);
     } else {
       // the candidate is evaluated whatever the decision will be (it is taken once, below, from everybody's scalars)
-      rc = sweep(p, d_xn, d_bn, 0, false, st, nullptr, d_rn, d_compn);
+      rc = sweep(p, d_xn, d_bn, 1, false, st, nullptr, d_rn, d_compn, nullptr, 0, nullptr, false, d_Jn);
       if (rc) return rc;
       ++n_sweeps;
       launch_win_accept(P, W, d_rn, d_x, d_b, d_xn, d_bn, 3, st);       // this shard's cost at the candidate -> W.fin[5]
@@ -1506,14 +1495,11 @@ static int solve_window_device(bodyfit_problem* p, double* frame_params, double*
     if (!opt->verbose && (it & 3) != 3 && it + 1 < opt->max_iters) {
       // The device takes every decision itself, so the host only looks at the status record every fourth iteration (a
       // read-back drains the launch pipeline: ~30 us of a ~250 us iteration at 20 frames).  Iterations launched after the
-      // solve has terminated leave the state untouched (every kernel checks the active / candidate flags); the sharded loop
-      // issues its Jacobian sweep unconditionally in between (after a rejected step it recomputes the same normals).
-      need_jac = true;
+      // solve has terminated leave the state untouched (every kernel checks the active / candidate flags).
       continue;
     }
     HIP_TRY(hipMemcpyAsync(status, W.status, sizeof(status), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
-    need_jac = true;
     if (opt->verbose && R == 0)
       std::printf("[bodyfit-dev] it %3d cost %.6e radius %.3e accepted %d gmax %.2e\n", (int)status[kWsIters], status[kWsCost],
                   status[kWsRadius], (int)status[kWsAccepted], status[kWsGmax]);

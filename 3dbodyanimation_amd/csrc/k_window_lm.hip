@@ -1272,7 +1272,10 @@ __global__ __launch_bounds__(256) void k_win_decide(WinProblem P, WinBuf W, doub
   __syncthreads();
   finish_core(P, W, x, beta, x_new, beta_new, pm, dn, xn, gm, tid);
   __syncthreads();
-  if (W.status[kWsHasCand] == 0.0) return;
+  if (W.status[kWsHasCand] == 0.0) {
+    if (tid == 0) W.status[kWsJsel] = 2.0;   // nothing moved
+    return;
+  }
   const bool accepted = accept_core(P, W, x, beta, x_new, beta_new, cost, tid, 256);
   if (accepted && tid < NP) {
     if (x_halo) x_halo[tid] = xn_halo[tid];
