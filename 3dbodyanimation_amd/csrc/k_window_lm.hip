@@ -1075,32 +1075,32 @@ __global__ __launch_bounds__(256) void k_win_tail(WinProblem P, WinBuf W, const 
   dn = block_sum_n(dn, red, tid, 4);
   xn = block_sum_n(xn, red, tid, 4);
   if (tid == 0) {
+    // the partial is at the memory side before the ticket is taken: write-through stores and this wave's vmcnt(0) (cdna guide,
+    // Guideline 16 R1), not an agent-scope release fence (buffer_wbl2 writes back every dirty line of the XCD's L2)
     double* o = W.part + (size_t)f * kWinPart + 112;
-    o[0] = pm; o[1] = dn; o[2] = xn;
-    __threadfence();                                        // the partial is visible device-wide before the ticket is taken
+    store_f64_through(o, pm); store_f64_through(o + 1, dn); store_f64_through(o + 2, xn);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     // two-level ticket: groups of 32 frames, then the groups (atomics on ONE word serialise at ~40 ns each: 1024 of them
     // were two thirds of this kernel at 1024 frames)
     const int grp = f >> 5, ngrp = (F + 31) >> 5, gsize = min(32, F - 32 * grp);
     int last = 0;
     if (atomicAdd(W.ticket + 1 + grp, 1) == gsize - 1) {
-      W.ticket[1 + grp] = 0;
-      __threadfence();
+      __hip_atomic_store(W.ticket + 1 + grp, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (for the next launch)
       last = (atomicAdd(W.ticket, 1) == ngrp - 1) ? 1 : 0;
     }
     s_last = last;
   }
   __syncthreads();
   if (!s_last) return;
-  // ---- the last workgroup: every frame's partial is in L2 (read past this CU's L1), decide ----
-  __threadfence();
-  if (tid == 0) *W.ticket = 0;
+  // ---- the last workgroup: every frame's partial is at the memory side (sc1 loads: past this XCD's L2), decide ----
+  if (tid == 0) __hip_atomic_store(W.ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   pm = 0.0; dn = 0.0; xn = 0.0;
   double gm = 0.0;
   for (int g = tid; g < F; g += 256) {
     const double* o = W.part + (size_t)g * kWinPart + 112;
-    pm += __builtin_nontemporal_load(o);
-    dn += __builtin_nontemporal_load(o + 1);
-    xn += __builtin_nontemporal_load(o + 2);
+    pm += __hip_atomic_load(o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    dn += __hip_atomic_load(o + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    xn += __hip_atomic_load(o + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     gm = fmax(gm, W.gmaxp[g]);
   }
   pm = block_sum_n(pm, red, tid, 4);
