@@ -1,0 +1,46 @@
+"""Randomised stress of the one-launch sweep's in-launch protocols (two signals per frame, per-unit start, counted waits, fold
+ticket): random frame counts 1..1500, several launches each with changing parameters, every output word against the two-launch
+sweep of the same build.  Run on the GPU box: python tools/stress_one_launch.py [n_sizes] [seed]."""
+import importlib
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.getcwd())
+api = importlib.import_module("3dbodyanimation_amd.api")
+synth = importlib.import_module("3dbodyanimation_amd.synth")
+n_sizes = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+model = synth.make_model(0)
+gm = api.Model(model)
+w, mu, cov = synth.make_gmm(0)
+gmm = api.Gmm(w, mu, cov)
+t0 = time.time()
+sizes = sorted(set([1, 31, 32, 33, 255, 256, 257, 511, 513] + [int(x) for x in rng.integers(1, 1500, n_sizes)]))
+for F in sizes:
+    seq = synth.make_sequence(model, F, seed=int(rng.integers(1 << 30)), ragged=bool(rng.integers(2)))
+    shared = bool(rng.integers(2))
+    kw = dict(n_cols=86, use_shape=True, want_mesh=True)
+    if shared:
+        kw.update(beta_pose=5.0, beta_shape=25.0, lambda_temporal=3.0)
+    else:
+        kw.update(beta_per_frame=True, beta_pose=20.0, gmm=gmm, beta_shape=30.0)
+    os.environ["BODYFIT_ONE_LAUNCH"] = "1"
+    one = api.Problem.from_sequence(gm, seq, **kw)
+    os.environ["BODYFIT_ONE_LAUNCH"] = "0"
+    two = api.Problem.from_sequence(gm, seq, **kw)
+    os.environ.pop("BODYFIT_ONE_LAUNCH")
+    for it in range(3):
+        x = seq.gt_params + rng.normal(scale=0.03, size=seq.gt_params.shape)
+        b = (seq.gt_beta + 0.1 * rng.normal(size=10)) if shared else (np.tile(seq.gt_beta, (F, 1)) + 0.1 * rng.normal(size=(F, 10)))
+        for _ in range(int(rng.integers(1, 4))):       # back-to-back launches at the same point first (stale-operand check)
+            r1, J1, c1 = one.evaluate(x, b, True)
+        r2, J2, c2 = two.evaluate(x, b, True)
+        j1, cl1 = one.forward(x, b)
+        j2, cl2 = two.forward(x, b)
+        assert np.array_equal(r1, r2) and np.array_equal(J1, J2) and np.array_equal(c1, c2), (F, it, "residuals / Jacobian")
+        assert np.array_equal(j1, j2) and np.array_equal(cl1, cl2), (F, it, "joints / cloud")
+    one.close(); two.close()
+print(f"{len(sizes)} sizes x 3 points ok in {time.time() - t0:.1f} s: {sizes[:12]} ...")
