@@ -6,8 +6,8 @@
 //   k_sweep_roles     the whole sweep as ONE launch whose workgroups take one of three roles (by block index):
 //                       frame role  frame_part_inl.h for one frame; publishes the frame's mesh operands (blend coefficients,
 //                                   skinning transforms: 2 KB) inside the launch
-//                       mesh role   mesh_role_inl.h for one 32-vertex tile x one group of 256 frames; waits for the group's
-//                                   frames, then blends and skins
+//                       mesh role   mesh_role_inl.h for one 32-vertex tile x one group of 256 frames; each of its eight waves
+//                                   waits for ITS 32 frames' blend coefficients, blends, checks their transforms, skins
 //                       prior role  priors_inl.h for one 16-frame tile
 //                     Every role fits 128 VGPRs and 80 KiB of LDS, so TWO workgroups share a CU: at 256 frames all 256 frame
 //                     workgroups (a latency chain that issues on a few percent of its slots) and all 216 mesh workgroups
@@ -16,11 +16,13 @@
 //                     Against the two launches this removes the dependent kernel boundary and, above all, overlaps the two
 //                     halves of the sweep in time instead of running them one after the other.
 //
-// In-launch hand-off (cdna guide, Guideline 16, R1): producers store the operands write-through (sc1), every storing wave
-// (ONE wave per frame workgroup: no barrier needed) drains (s_waitcnt vmcnt(0)), then one lane adds 1 to the counter of the
-// frame's 32-frame unit (agent-scope atomic, executed at the memory side); consumers poll the eight counters of their group
-// (one 32-byte line) with sc1 loads from one wave, workgroup barrier, then read the operands with sc1 loads only.  Nothing is
-// reset between launches: every launch adds exactly the unit's frame count, so a complete unit reads epoch x count.
+// In-launch hand-off (cdna guide, Guideline 16, R1): producers store the operands write-through (sc1); each of the two storing
+// waves of a frame workgroup (wave 0: blend coefficients, wave 7: skinning transforms) drains (s_waitcnt vmcnt(0)) and then adds
+// 1 to ITS counter of the frame's 32-frame unit (agent-scope atomics, executed at the memory side; two counters per unit, each
+// on a line of its own).  A mesh wave polls the coefficient counter of its own unit with sc1 loads, starts its blend, looks at
+// the transform counter a few k-steps before it needs the transforms, and reads all operands with sc1 loads only; the prior
+// workgroups wait for the transform counters of their whole group.  Nothing is reset between launches: every launch adds
+// exactly the unit's frame count, so a complete unit reads epoch x count.
 //
 // Progress: a mesh workgroup waits only for frame workgroups, which wait for nothing; frame workgroups precede the mesh
 // workgroups that need them in block order, and the hardware dispatches blocks in order.  HIP does not promise that
