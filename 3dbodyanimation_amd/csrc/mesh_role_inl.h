@@ -9,7 +9,7 @@
 //             14 k-steps of v_mfma_f32_32x32x16_bf16, operands split hi + lo in bf16, three products per k-step.
 //             Thirteen of the tile's fourteen operand slabs (6 KiB per k-step) are RESIDENT in LDS: they are requested by
 //             LDS-DMA at the very start, before the wait for the frame workgroups' hand-off (the operands do not depend on
-//             the pose), so the whole 78 KiB stream hides under that wait; the fourteenth slab goes L2 -> registers one
+//             the pose; as a trickle, so that the frame workgroups' own loads are not delayed), so the 78 KiB stream hides under that wait; the fourteenth slab goes L2 -> registers one
 //             k-step ahead of its use.  The blend itself has no barrier and no operand traffic per k-step.
 //   skinning  per accumulator row (two consecutive frames x 32 vertices): gather the vertex's <= 4 joint transforms from
 //             the wave's own ring of four rows in LDS (2,304 bytes per row, filled by LDS-DMA straight from the frame
@@ -20,8 +20,10 @@
 // Every vector-memory operation of the skinning phase is issued in fixed per-row sets, so each "has my DMA landed" wait is
 // a counted s_waitcnt vmcnt(N) with N known at compile time (vmcnt retires in order).
 // Hand-off (cdna guide, Guideline 16 R1): the frame workgroups store blend coefficients and transforms write-through
-// (sc1) and publish per 32-frame unit; here wave 0 polls the group's counters, a workgroup barrier follows, and every
-// load of the handed-off bytes is an sc1 load (buffer_load ... sc1 to registers, buffer_load ... lds sc1 to LDS).
+// (sc1) and publish them per 32-frame unit with two counters (coefficients first, transforms ~1 us later).  Here each wave
+// waits for the coefficient counter of ITS unit and starts its blend at once; the transform counter is looked at four
+// k-steps ahead of the barrier behind which the first transform rows are requested.  Every load of the handed-off bytes is
+// an sc1 load (buffer_load ... sc1 to registers, buffer_load ... lds sc1 to LDS).
 #pragma once
 #include <hip/hip_ext.h>
 
