@@ -144,6 +144,7 @@ struct bodyfit_problem {
   bool fused_enabled = true, fused_unchecked = false;
   double* d_frame_partials = nullptr; // [F][258] per-frame beta partials written by k_frame_resjac (shared-beta problems)
   int partials_tiles = 0;             // prior tiles that added their plain-cost rows behind the frame rows
+  std::vector<double> gmm_jt;   // [K][nJ - 1][prior rows][3]: beta_pose L_k^T per joint block, what a GMM prior block's Jacobian is (host path)
   unsigned long long role_timeout_ticks = kRoleTimeoutDefault;   // bound of the one-launch sweep's in-launch waits
   double* armed_out66 = nullptr;      // bodyfit_arm_shared_reduction: where a folding sweep deposits [cost | g_beta | H_bb]
   unsigned fold_count = 0;            // tickets taken by the folding sweeps since the sync buffer was zeroed
@@ -736,6 +737,20 @@ int bodyfit_problem_create(const bodyfit_model* m, const bodyfit_problem_desc* d
   L.shape_rows = (desc->beta_shape > 0.0 && has_beta && nS > 0) ? (desc->beta_per_frame ? F * nS : nS) : 0;
   p->n_pairs = desc->lambda_temporal > 0.0 ? (F - 1 + (desc->temporal_halo ? 1 : 0)) : 0;
   L.temporal_rows = p->n_pairs * (6 + 3 * (nJ - 1));
+  if (p->has_gmm) {
+    // the GMM prior block's Jacobian per mixture component and joint block, in Ceres' layout (include/Sim3BA.h:293-299)
+    const int D = 3 * (nJ - 1), nRes = L.prior_rows_per_frame;
+    const size_t Kc = desc->gmm->prec_cho.size() / ((size_t)D * D);
+    p->gmm_jt.assign(Kc * (nJ - 1) * nRes * 3, 0.0);
+    for (size_t k = 0; k < Kc; ++k) {
+      const double* Lk = desc->gmm->prec_cho.data() + k * D * D;
+      for (int j = 0; j < nJ - 1; ++j) {
+        double* Jb = p->gmm_jt.data() + (k * (nJ - 1) + j) * nRes * 3;
+        for (int row = 0; row < D; ++row)
+          for (int c = 0; c < 3; ++c) Jb[(size_t)row * 3 + c] = Lk[(size_t)(3 * j + c) * D + row] * desc->beta_pose;
+      }
+    }
+  }
   p->row_prior = L.reproj_rows;
   p->row_shape = p->row_prior + F * L.prior_rows_per_frame;
   p->row_temporal = p->row_shape + L.shape_rows;
@@ -1791,8 +1806,12 @@ static void serve_block(bodyfit_problem* p, int kind, int index, int frame, doub
       for (int j = 0; j < nJ - 1; ++j) {
         if (!jacobians[j]) continue;
         double* Jb = jacobians[j];  // nRes x 3 row-major (include/Sim3BA.h:293,306)
-        std::fill(Jb, Jb + (size_t)nRes * 3, 0.0);
-        if (p->has_gmm) {
+        if (!(p->has_gmm && !p->gmm_jt.empty())) std::fill(Jb, Jb + (size_t)nRes * 3, 0.0);
+        if (p->has_gmm && !p->gmm_jt.empty()) {
+          // beta_pose L_k^T, one joint's three columns as the contiguous [nRes][3] block Ceres asks for (built once per problem:
+          // the transposed walk over L_k was most of a prior block's Evaluate)
+          std::memcpy(Jb, p->gmm_jt.data() + ((size_t)comp * (nJ - 1) + j) * nRes * 3, (size_t)nRes * 3 * sizeof(double));
+        } else if (p->has_gmm) {
           const double* Lk = p->desc.gmm->prec_cho.data() + (size_t)comp * D * D;
           for (int row = 0; row < D; ++row)
             for (int c = 0; c < 3; ++c) Jb[(size_t)row * 3 + c] = Lk[(size_t)(3 * j + c) * D + row] * bp;  // :298-299
