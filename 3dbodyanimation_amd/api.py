@@ -57,7 +57,7 @@ class FitOptions(C.Structure):
 class FitSummary(C.Structure):
     _fields_ = [("iterations", C.c_int), ("termination", C.c_int), ("usable", C.c_int), ("n_successful", C.c_int),
                 ("n_unsuccessful", C.c_int), ("n_sweeps", C.c_int), ("initial_cost", C.c_double),
-                ("final_cost", C.c_double)]
+                ("final_cost", C.c_double), ("n_sweeps_issued", C.c_int)]
 
 
 class _OverlayDesc(C.Structure):
@@ -100,6 +100,16 @@ class Rccl:
         h = C.c_void_p()
         _check(load_library().bodyfit_rccl_wrap(C.c_void_p(nccl_comm_ptr), rank, size, C.byref(h)))
         return cls(h)
+
+    def count(self) -> tuple[int, int]:
+        """(ranks, this rank) as RCCL itself reports them (ncclCommCount, ncclCommUserRank)."""
+        n, r = C.c_int(), C.c_int()
+        _check(load_library().bodyfit_rccl_count(self.h, C.byref(n), C.byref(r)))
+        return n.value, r.value
+
+    def allreduce_shared(self, d_buf66_ptr: int, stream: int | None = None):
+        """The evaluation path's one collective: ncclAllReduce(sum, f64) of the 66 doubles, in place, on `stream`."""
+        _check(load_library().bodyfit_allreduce_shared_rccl(self.h, d_buf66_ptr, stream))
 
     def close(self):
         if self.h:
@@ -172,6 +182,9 @@ def load_library():
     lib.bodyfit_rccl_wrap.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
     lib.bodyfit_rccl_destroy.argtypes = [C.c_void_p]
     lib.bodyfit_rccl_destroy.restype = None
+    lib.bodyfit_allreduce_shared_rccl.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.bodyfit_rccl_count.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    lib.bodyfit_sweep_status.argtypes = [C.c_void_p, C.c_void_p]
     lib.bodyfit_launch_count.argtypes = []
     lib.bodyfit_launch_count.restype = C.c_long
     lib.bodyfit_last_exchange_count.argtypes = [C.c_void_p]
@@ -376,6 +389,11 @@ class Problem:
 
     def reduce_shared_device(self, d_out_ptr: int | None = None, stream: int | None = None):
         _check(load_library().bodyfit_reduce_shared_device(self.h, d_out_ptr, stream))
+
+    def sweep_status(self, stream: int | None = None):
+        """Waits for `stream`; raises if an asynchronous one-launch sweep since the last check left its cloud incomplete
+        (bodyfit_sweep_status: the problem then uses the two-launch sweep, so evaluating again gives the whole result)."""
+        _check(load_library().bodyfit_sweep_status(self.h, stream))
 
     def arm_shared_reduction(self, d_out_ptr: int | None):
         """Following Jacobian sweeps deposit [cost | g_beta | H_bb] in d_out_ptr at their own tail when they can (one-launch

@@ -142,6 +142,10 @@ struct bodyfit_problem {
   long last_exchanges = 0;             // all-gathers issued by the last sharded solve (tests: exchanges per iteration)
   unsigned fused_epoch = 0;
   bool fused_enabled = true, fused_unchecked = false;
+  long fused_timeouts = 0;             // one-launch sweeps found incomplete (bodyfit_internal_fused_timeouts)
+  hipStream_t async_stream = nullptr;  // stream of the last bodyfit_evaluate_device / bodyfit_reduce_shared_device
+  bool async_pending = false;          // ... and whether anything was enqueued there since the last synchronous entry point
+  hipEvent_t async_event = nullptr;
   double* d_frame_partials = nullptr; // [F][258] per-frame beta partials written by k_frame_resjac (shared-beta problems)
   int partials_tiles = 0;             // prior tiles that added their plain-cost rows behind the frame rows
   std::vector<double> gmm_jt;   // [K][nJ - 1][prior rows][3]: beta_pose L_k^T per joint block, what a GMM prior block's Jacobian is (host path)
@@ -191,19 +195,41 @@ bool chol_lower(std::vector<double>& A, int n) {
   return true;
 }
 
-// The bounded waits of the one-launch sweep set an error word instead of hanging; the synchronous entry points read it after
-// their stream synchronisation.
-int fused_check(bodyfit_problem* p) {
-  if (!p->fused_unchecked || !p->d_fused) return BODYFIT_OK;
+// The bounded waits of the one-launch sweep's mesh role set an error word instead of hanging (the tile's part of the cloud is
+// then missing; r, J, joints and the folded reduction never depend on a wait).  fused_timed_out reads and clears the word
+// (the caller has synchronised the stream the sweep ran on) and switches the problem to the two-launch sweep for the rest of
+// its life.  The synchronous entry points re-issue their sweep at once, so their callers never see the event; asynchronous
+// callers ask bodyfit_sweep_status.
+bool fused_timed_out(bodyfit_problem* p) {
+  if (!p->fused_unchecked || !p->d_fused) return false;
   p->fused_unchecked = false;
   unsigned err = 0;
-  if (hipMemcpy(&err, p->d_fused, sizeof(err), hipMemcpyDeviceToHost) != hipSuccess) return BODYFIT_OK;
-  if (err) {
-    (void)hipMemset(p->d_fused, 0, 4);
-    p->fused_enabled = false;   // fall back to the two-launch sweep for the rest of this problem's life
-    return fail(BODYFIT_ERR_HIP, "one-launch sweep: an in-launch wait timed out (results of that sweep are incomplete); "
+  if (hipMemcpy(&err, p->d_fused, sizeof(err), hipMemcpyDeviceToHost) != hipSuccess) return false;
+  if (!err) return false;
+  (void)hipMemset(p->d_fused, 0, 4);
+  p->fused_enabled = false;
+  ++p->fused_timeouts;
+  return true;
+}
+int fused_check(bodyfit_problem* p) {
+  if (fused_timed_out(p))
+    return fail(BODYFIT_ERR_HIP, "one-launch sweep: an in-launch wait timed out (the cloud of that sweep is incomplete); "
                                  "the problem now uses the two-launch sweep");
-  }
+  return BODYFIT_OK;
+}
+
+// bodyfit_evaluate_batch (and the other entry points that own a stream) may run while asynchronous sweeps of the same problem
+// are still in flight on a caller's stream: both write the problem's r / J / partials and the one-launch sweep's counters, so
+// they must not overlap.  The asynchronous entry points only note their stream (no event per sweep: that would cost the
+// resident path a microsecond per step); the synchronous ones record ONE event behind everything enqueued there so far and
+// make their own stream wait for it.
+int order_after_async(bodyfit_problem* p, hipStream_t own) {
+  if (!p->async_pending) return BODYFIT_OK;
+  p->async_pending = false;
+  if (p->async_stream == own) return BODYFIT_OK;   // same stream: ordered anyway
+  if (!p->async_event) HIP_TRY(hipEventCreateWithFlags(&p->async_event, hipEventDisableTiming));
+  HIP_TRY(hipEventRecord(p->async_event, p->async_stream));
+  HIP_TRY(hipStreamWaitEvent(own, p->async_event, 0));
   return BODYFIT_OK;
 }
 
@@ -822,6 +848,7 @@ void bodyfit_problem_destroy(bodyfit_problem* p) {
   (void)hipSetDevice(p->m->device);
   if (p->lm_stream) (void)hipStreamDestroy(p->lm_stream);
   if (p->copy_stream) (void)hipStreamDestroy(p->copy_stream);
+  if (p->async_event) (void)hipEventDestroy(p->async_event);
   delete p;
 }
 
@@ -849,6 +876,8 @@ int bodyfit_evaluate_device(bodyfit_problem* p, const double* d_frame_params, co
   HIP_TRY(hipSetDevice(p->m->device));
   // Eager launches.  A hipGraph capture of this fork/join sweep was measured SLOWER on MI355X / ROCm 7.2
   // (256 frames: 79.8 us per replay vs 59.8 us eager), so no graph is used here.
+  p->async_stream = static_cast<hipStream_t>(stream);
+  p->async_pending = true;
   return sweep(p, d_frame_params, d_beta, want_jacobian, p->desc.want_mesh != 0, static_cast<hipStream_t>(stream));
 }
 
@@ -936,41 +965,45 @@ int bodyfit_evaluate_batch(bodyfit_problem* p, const double* frame_params, const
   // the structurally non-zero column blocks cross PCIe (BODYFIT_PACKED_J=0: the dense panel, as with a caller's buffer)
   static const bool packed_enabled = [] { const char* e = std::getenv("BODYFIT_PACKED_J"); return !(e && e[0] == '0'); }();
   const bool packed = wj && !jacobian && packed_enabled && p->lay.n_cols <= 128;
+  if (int ro = order_after_async(p, st)) return ro;   // behind any asynchronous sweep of this problem still in flight
   if (packed && !p->pk_ready)
     if (int rcp = build_pack_tables(p, st)) return rcp;
   if (wj && !packed) HIP_TRY(p->c_J.ensure(nJ));
   std::memcpy(p->c_params.data(), frame_params, npar * sizeof(double));
   if (nbeta) std::memcpy(p->c_beta.data(), beta, nbeta * sizeof(double));
   p->c_npar = npar; p->c_nbeta = nbeta;
-  HIP_TRY(hipMemcpyAsync(p->d_params, p->c_params.data(), npar * sizeof(double), hipMemcpyHostToDevice, st));
-  if (nbeta) HIP_TRY(hipMemcpyAsync(p->d_beta, p->c_beta.data(), nbeta * sizeof(double), hipMemcpyHostToDevice, st));
-  int rc = sweep(p, p->d_params, has_beta ? p->d_beta : nullptr, wj, p->desc.want_mesh != 0, st);
-  if (rc) return rc;
   static const bool pack_direct = [] { const char* e = std::getenv("BODYFIT_PACK_DIRECT"); return !(e && e[0] == '0'); }();
-  const bool one_kernel_down = wj && packed && pack_direct;   // residuals and components ride on the packing kernel
-  if (!one_kernel_down) {
-    HIP_TRY(hipMemcpyAsync(p->c_r.data(), p->d_r, nr * sizeof(double), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(p->c_comp.data(), p->d_comp, (size_t)p->d.F * sizeof(int), hipMemcpyDeviceToHost, st));
+  for (int attempt = 0;; ++attempt) {   // (a one-launch sweep whose in-launch wait ran out is re-issued as two launches)
+    HIP_TRY(hipMemcpyAsync(p->d_params, p->c_params.data(), npar * sizeof(double), hipMemcpyHostToDevice, st));
+    if (nbeta) HIP_TRY(hipMemcpyAsync(p->d_beta, p->c_beta.data(), nbeta * sizeof(double), hipMemcpyHostToDevice, st));
+    int rc = sweep(p, p->d_params, has_beta ? p->d_beta : nullptr, wj, p->desc.want_mesh != 0, st);
+    if (rc) return rc;
+    const bool one_kernel_down = wj && packed && pack_direct;   // residuals and components ride on the packing kernel
+    if (!one_kernel_down) {
+      HIP_TRY(hipMemcpyAsync(p->c_r.data(), p->d_r, nr * sizeof(double), hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipMemcpyAsync(p->c_comp.data(), p->d_comp, (size_t)p->d.F * sizeof(int), hipMemcpyDeviceToHost, st));
+    }
+    size_t n_down = 0;
+    const double* src_down = nullptr;
+    double* dst_down = nullptr;
+    // (measured and rejected: the Jacobian's two halves on two streams / copy engines — 234 against 221 us per sweep)
+    if (one_kernel_down) {
+      // the packing kernel stores straight into the page-locked host cache (it is device-addressable), residuals and GMM
+      // components with it: ONE kernel behind the sweep instead of a kernel and three copy commands (219 -> 207 -> see DESIGN 6)
+      launch_pack_jacobian(p->lay.n_keypoints, p->lay.n_cols, m->nJ - 1, p->d_J, p->d_pk_mask, p->d_pk_off, p->c_Jp.data(), p->d_r,
+                           (int)nr, p->c_r.data(), p->d_comp, p->d.F, p->c_comp.data(), st);
+    } else if (wj && packed) {
+      launch_pack_jacobian(p->lay.n_keypoints, p->lay.n_cols, m->nJ - 1, p->d_J, p->d_pk_mask, p->d_pk_off, p->d_Jp, nullptr, 0,
+                           nullptr, nullptr, 0, nullptr, st);
+      n_down = (size_t)p->pk_off[p->lay.n_keypoints]; src_down = p->d_Jp; dst_down = p->c_Jp.data();
+    } else if (wj) {
+      n_down = nJ; src_down = p->d_J; dst_down = p->c_J.data();
+    }
+    if (n_down) HIP_TRY(hipMemcpyAsync(dst_down, src_down, n_down * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (attempt == 0 && fused_timed_out(p)) continue;
+    break;
   }
-  size_t n_down = 0;
-  const double* src_down = nullptr;
-  double* dst_down = nullptr;
-  // (measured and rejected: the Jacobian's two halves on two streams / copy engines — 234 against 221 us per sweep)
-  if (one_kernel_down) {
-    // the packing kernel stores straight into the page-locked host cache (it is device-addressable), residuals and GMM
-    // components with it: ONE kernel behind the sweep instead of a kernel and three copy commands (219 -> 207 -> see DESIGN 6)
-    launch_pack_jacobian(p->lay.n_keypoints, p->lay.n_cols, m->nJ - 1, p->d_J, p->d_pk_mask, p->d_pk_off, p->c_Jp.data(), p->d_r,
-                         (int)nr, p->c_r.data(), p->d_comp, p->d.F, p->c_comp.data(), st);
-  } else if (wj && packed) {
-    launch_pack_jacobian(p->lay.n_keypoints, p->lay.n_cols, m->nJ - 1, p->d_J, p->d_pk_mask, p->d_pk_off, p->d_Jp, nullptr, 0,
-                         nullptr, nullptr, 0, nullptr, st);
-    n_down = (size_t)p->pk_off[p->lay.n_keypoints]; src_down = p->d_Jp; dst_down = p->c_Jp.data();
-  } else if (wj) {
-    n_down = nJ; src_down = p->d_J; dst_down = p->c_J.data();
-  }
-  if (n_down) HIP_TRY(hipMemcpyAsync(dst_down, src_down, n_down * sizeof(double), hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipStreamSynchronize(st));
-  if (int fc = fused_check(p)) return fc;
   p->cache_valid = true;
   p->cache_has_jac = wj != 0;
   p->cache_packed = packed;
@@ -993,6 +1026,7 @@ int bodyfit_internal_frame_normals(bodyfit_problem* p, const double* frame_param
   const size_t nbeta = has_beta ? (size_t)(p->desc.beta_per_frame ? F * m->nS : m->nS) : 0;
   const size_t nH = (size_t)F * kNormalRows * kNormalLd;
   if (!p->d_frame_normal) HIP_TRY(p->mem.alloc(&p->d_frame_normal, nH));
+  if (int ro = order_after_async(p, nullptr)) return ro;
   HIP_TRY(hipMemcpyAsync(p->d_params, frame_params, npar * sizeof(double), hipMemcpyHostToDevice, nullptr));
   if (nbeta) HIP_TRY(hipMemcpyAsync(p->d_beta, beta, nbeta * sizeof(double), hipMemcpyHostToDevice, nullptr));
   int rc = sweep(p, p->d_params, has_beta ? p->d_beta : nullptr, 1, false, nullptr);
@@ -1032,6 +1066,8 @@ int bodyfit_reduce_shared_device(bodyfit_problem* p, double* d_out66, void* stre
   const int npose = 7 + 3 * (p->m->nJ - 1);
   const int shared_shape_rows = (!p->desc.beta_per_frame) ? p->lay.shape_rows : 0;
   if (p->fold_fresh && d_out66 && d_out66 == p->armed_out66) return BODYFIT_OK;   // the sweep's own tail has written it
+  p->async_stream = static_cast<hipStream_t>(stream);
+  p->async_pending = true;
   if (p->d_frame_partials && p->partials_fresh) {
     // the sweep's k_frame_resjac already reduced every frame's reprojection rows: sum the per-frame partials and the
     // prior / temporal rows, pack
@@ -1206,7 +1242,7 @@ int bodyfit_internal_solve_batched_device(bodyfit_problem* p, double* frame_para
       s2.termination = (fl[f] & kLmActive) ? 1 : ((fl[f] & kLmTermMask) >> kLmTermShift);
       s2.usable = s2.termination != 2;
       s2.n_successful = ok[f]; s2.n_unsuccessful = bad[f];
-      s2.n_sweeps = n_sweeps;
+      s2.n_sweeps = n_sweeps; s2.n_sweeps_issued = n_sweeps;
       s2.initial_cost = c0[f]; s2.final_cost = c1[f];
     }
   }
@@ -1530,12 +1566,12 @@ static int solve_window_device(bodyfit_problem* p, double* frame_params, double*
     summary->termination = status[kWsActive] != 0.0 ? 1 : (int)status[kWsTermination];
     summary->usable = summary->termination != 2;
     summary->n_successful = (int)status[kWsOk]; summary->n_unsuccessful = (int)status[kWsBad];
-    // the evaluations the solve NEEDED, from the device's own record (one at the start, one per iteration at the candidate, one
-    // with the Jacobian per accepted step: what the host loop issues).  The loop above issues more: between two status reads it
-    // runs ahead of the decisions (a Jacobian sweep after a rejected step, up to three iterations past the termination; those
-    // kernels find the solve inactive and leave the state alone): n_sweeps - issued = that slack, (void)n_sweeps below.
-    summary->n_sweeps = 1 + (int)status[kWsIters] + (int)status[kWsOk];
-    (void)n_sweeps;
+    // the evaluations the solve NEEDED, from the device's own record: one at the start and one per iteration at the candidate —
+    // that sweep also leaves the candidate's Jacobian (second buffers), so an accepted step costs no sweep of its own.  The loop
+    // ISSUES a few more: between two status reads it runs up to three iterations past the termination (those kernels find the
+    // solve inactive and leave the state alone); n_sweeps_issued is the host's own count.
+    summary->n_sweeps = 1 + (int)status[kWsIters];
+    summary->n_sweeps_issued = n_sweeps;
     summary->initial_cost = status[kWsInitialCost]; summary->final_cost = status[kWsCost];
   }
   return BODYFIT_OK;
@@ -1638,6 +1674,44 @@ int bodyfit_solve_sharded_rccl(bodyfit_problem* p, double* frame_params, double*
   return rc;
 }
 
+// The evaluation path's only collective ("one ncclAllReduce(sum, ncclDouble) per evaluation on [cost, g_beta, H_bb]"),
+// in place on the caller's device buffer and stream: behind bodyfit_evaluate_device + bodyfit_reduce_shared_device (or the
+// armed sweep's own tail) on the same stream it needs no host synchronisation and no Python hop.
+int bodyfit_allreduce_shared_rccl(bodyfit_rccl* comm, double* d_buf66, void* stream) {
+  if (!comm || !comm->tr.comm || !d_buf66) return fail(BODYFIT_ERR_INVALID, "bodyfit_allreduce_shared_rccl: bad argument");
+  RcclApi& A = RcclApi::get();
+  if (!A.ok()) return fail(BODYFIT_ERR_HIP, A.error);
+  const int rc = A.AllReduce(d_buf66, d_buf66, 66, RcclApi::kDouble, RcclApi::kSum, comm->tr.comm, static_cast<hipStream_t>(stream));
+  if (rc != 0) return fail(BODYFIT_ERR_HIP, std::string("ncclAllReduce: ") + (A.GetErrorString ? A.GetErrorString(rc) : "error"));
+  return BODYFIT_OK;
+}
+
+// ranks of the communicator as RCCL itself reports them (ncclCommCount), and this process's rank in it (ncclCommUserRank)
+int bodyfit_rccl_count(bodyfit_rccl* comm, int* n_ranks, int* rank) {
+  if (!comm || !comm->tr.comm) return fail(BODYFIT_ERR_INVALID, "bodyfit_rccl_count: bad argument");
+  RcclApi& A = RcclApi::get();
+  if (!A.ok() || !A.CommCount || !A.CommUserRank) return fail(BODYFIT_ERR_HIP, A.ok() ? "librccl lacks ncclCommCount" : A.error);
+  int n = 0, r = 0;
+  int rc = A.CommCount(comm->tr.comm, &n);
+  if (rc == 0) rc = A.CommUserRank(comm->tr.comm, &r);
+  if (rc != 0) return fail(BODYFIT_ERR_HIP, std::string("ncclCommCount: ") + (A.GetErrorString ? A.GetErrorString(rc) : "error"));
+  if (n_ranks) *n_ranks = n;
+  if (rank) *rank = r;
+  return BODYFIT_OK;
+}
+
+// Status of the problem's asynchronous sweeps (bodyfit_evaluate_device) enqueued on `stream` so far: waits for the stream,
+// then reads the one-launch sweep's error word.
+int bodyfit_sweep_status(bodyfit_problem* p, void* stream) {
+  if (!p) return fail(BODYFIT_ERR_INVALID, "null argument");
+  HIP_TRY(hipSetDevice(p->m->device));
+  HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+  if (p->async_stream == static_cast<hipStream_t>(stream)) p->async_pending = false;
+  return fused_check(p);
+}
+
+long bodyfit_internal_fused_timeouts(const bodyfit_problem* p) { return p ? p->fused_timeouts : 0; }
+
 long bodyfit_last_exchange_count(const bodyfit_problem* p) { return p ? p->last_exchanges : 0; }
 long bodyfit_launch_count(void) { return g_launch_count.load(std::memory_order_relaxed); }
 
@@ -1691,25 +1765,30 @@ int bodyfit_writeback_batch(bodyfit_problem* p, const double* frame_params, cons
   double* d_upd = p->d_writeback;
   double* d_R0n = d_upd + (size_t)p->n_param_rows * npose;
   double* d_px = d_R0n + (size_t)F * 9;
+  if (int ro = order_after_async(p, nullptr)) return ro;
   HIP_TRY(hipMemcpyAsync(p->d_params, frame_params, npar * sizeof(double), hipMemcpyHostToDevice, nullptr));
   if (nbeta) HIP_TRY(hipMemcpyAsync(p->d_beta, beta, nbeta * sizeof(double), hipMemcpyHostToDevice, nullptr));
   launch_writeback_prepare(F, npose, p->d_params, p->d.R0, d_upd, d_R0n, nullptr);
-  int rc = sweep(p, d_upd, nbeta ? p->d_beta : nullptr, 0, p->desc.want_mesh != 0, nullptr, nullptr, nullptr, nullptr,
-                 nullptr, 0, d_R0n);
-  if (rc) return rc;
-  launch_mean_pixel_error(F, m->nJ, p->d.kp_offset, p->d.kp_id, p->d.kp_uv, p->d_joints, p->d.fx, p->d.fy, p->d.cx,
-                          p->d.cy, d_px, nullptr);
-  if (R0_out) HIP_TRY(hipMemcpyAsync(R0_out, d_R0n, (size_t)F * 9 * sizeof(double), hipMemcpyDeviceToHost, nullptr));
-  if (mean_px) HIP_TRY(hipMemcpyAsync(mean_px, d_px, (size_t)F * sizeof(double), hipMemcpyDeviceToHost, nullptr));
-  if (joints)
-    HIP_TRY(hipMemcpyAsync(joints, p->d_joints, (size_t)F * m->nJ * 3 * sizeof(double), hipMemcpyDeviceToHost, nullptr));
-  if (cloud) {
-    const size_t row = (size_t)m->V * 3 * sizeof(float), pitch = (size_t)m->d.nVTiles * kVTile * 3 * sizeof(float);
-    HIP_TRY(hipMemcpy2DAsync(cloud, row, p->d_cloud, pitch, row, (size_t)F, hipMemcpyDeviceToHost, nullptr));
+  for (int attempt = 0;; ++attempt) {   // (a one-launch sweep whose in-launch wait ran out is re-issued as two launches)
+    int rc = sweep(p, d_upd, nbeta ? p->d_beta : nullptr, 0, p->desc.want_mesh != 0, nullptr, nullptr, nullptr, nullptr,
+                   nullptr, 0, d_R0n);
+    if (rc) return rc;
+    launch_mean_pixel_error(F, m->nJ, p->d.kp_offset, p->d.kp_id, p->d.kp_uv, p->d_joints, p->d.fx, p->d.fy, p->d.cx,
+                            p->d.cy, d_px, nullptr);
+    if (R0_out) HIP_TRY(hipMemcpyAsync(R0_out, d_R0n, (size_t)F * 9 * sizeof(double), hipMemcpyDeviceToHost, nullptr));
+    if (mean_px) HIP_TRY(hipMemcpyAsync(mean_px, d_px, (size_t)F * sizeof(double), hipMemcpyDeviceToHost, nullptr));
+    if (joints)
+      HIP_TRY(hipMemcpyAsync(joints, p->d_joints, (size_t)F * m->nJ * 3 * sizeof(double), hipMemcpyDeviceToHost, nullptr));
+    if (cloud) {
+      const size_t row = (size_t)m->V * 3 * sizeof(float), pitch = (size_t)m->d.nVTiles * kVTile * 3 * sizeof(float);
+      HIP_TRY(hipMemcpy2DAsync(cloud, row, p->d_cloud, pitch, row, (size_t)F, hipMemcpyDeviceToHost, nullptr));
+    }
+    HIP_TRY(hipStreamSynchronize(nullptr));
+    HIP_TRY(hipGetLastError());
+    if (attempt == 0 && fused_timed_out(p)) continue;
+    break;
   }
-  HIP_TRY(hipStreamSynchronize(nullptr));
-  HIP_TRY(hipGetLastError());
-  return fused_check(p);
+  return BODYFIT_OK;
 }
 
 int bodyfit_forward(bodyfit_problem* p, const double* frame_params, const double* beta, double* joints,
@@ -1724,18 +1803,23 @@ int bodyfit_forward(bodyfit_problem* p, const double* frame_params, const double
   p->cache_valid = false;
   const size_t npar = (size_t)p->n_param_rows * npose;
   const size_t nbeta = (has_beta && beta) ? (size_t)(p->desc.beta_per_frame ? p->d.F * m->nS : m->nS) : 0;
+  if (int ro = order_after_async(p, nullptr)) return ro;
   HIP_TRY(hipMemcpy(p->d_params, frame_params, npar * sizeof(double), hipMemcpyHostToDevice));
   if (nbeta) HIP_TRY(hipMemcpy(p->d_beta, beta, nbeta * sizeof(double), hipMemcpyHostToDevice));
-  int rc = sweep(p, p->d_params, nbeta ? p->d_beta : nullptr, 0, cloud != nullptr, nullptr);
-  if (rc) return rc;
-  if (joints)
-    HIP_TRY(hipMemcpy(joints, p->d_joints, (size_t)p->d.F * m->nJ * 3 * sizeof(double), hipMemcpyDeviceToHost));
-  if (cloud) {
-    const size_t row = (size_t)m->V * 3 * sizeof(float), pitch = (size_t)m->d.nVTiles * kVTile * 3 * sizeof(float);
-    HIP_TRY(hipMemcpy2D(cloud, row, p->d_cloud, pitch, row, (size_t)p->d.F, hipMemcpyDeviceToHost));
+  for (int attempt = 0;; ++attempt) {   // (a one-launch sweep whose in-launch wait ran out is re-issued as two launches)
+    int rc = sweep(p, p->d_params, nbeta ? p->d_beta : nullptr, 0, cloud != nullptr, nullptr);
+    if (rc) return rc;
+    if (joints)
+      HIP_TRY(hipMemcpy(joints, p->d_joints, (size_t)p->d.F * m->nJ * 3 * sizeof(double), hipMemcpyDeviceToHost));
+    if (cloud) {
+      const size_t row = (size_t)m->V * 3 * sizeof(float), pitch = (size_t)m->d.nVTiles * kVTile * 3 * sizeof(float);
+      HIP_TRY(hipMemcpy2D(cloud, row, p->d_cloud, pitch, row, (size_t)p->d.F, hipMemcpyDeviceToHost));
+    }
+    HIP_TRY(hipDeviceSynchronize());
+    if (attempt == 0 && fused_timed_out(p)) continue;
+    break;
   }
-  HIP_TRY(hipDeviceSynchronize());
-  return fused_check(p);
+  return BODYFIT_OK;
 }
 
 double bodyfit_mean_pixel_error(int n_kp, const int* jid, const double* uv, const double* joints, double fx,

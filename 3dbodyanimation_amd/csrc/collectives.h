@@ -31,6 +31,8 @@ struct RcclApi {
   int (*CommDestroy)(comm_t) = nullptr;
   int (*AllGather)(const void*, void*, size_t, int, comm_t, hipStream_t) = nullptr;
   int (*AllReduce)(const void*, void*, size_t, int, int, comm_t, hipStream_t) = nullptr;
+  int (*CommCount)(comm_t, int*) = nullptr;
+  int (*CommUserRank)(comm_t, int*) = nullptr;
   const char* (*GetErrorString)(int) = nullptr;
   std::string error;
   static constexpr int kDouble = 8, kSum = 0;   // ncclFloat64, ncclSum
@@ -49,6 +51,8 @@ struct RcclApi {
       a.AllGather = reinterpret_cast<decltype(a.AllGather)>(sym("ncclAllGather"));
       a.AllReduce = reinterpret_cast<decltype(a.AllReduce)>(sym("ncclAllReduce"));
       a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(sym("ncclGetErrorString"));
+      a.CommCount = reinterpret_cast<decltype(a.CommCount)>(sym("ncclCommCount"));
+      a.CommUserRank = reinterpret_cast<decltype(a.CommUserRank)>(sym("ncclCommUserRank"));
       return a;
     }();
     return api;

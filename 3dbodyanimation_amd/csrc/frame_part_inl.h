@@ -608,14 +608,8 @@ __device__ __forceinline__ void frame_part(const DevModel& M, const DevProblem& 
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (lane == 0) __hip_atomic_fetch_add(const_cast<int*>(sWalkDone), 256, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   }
-  if (kFused && wave == 0) {
-    STAMP_REAL(13);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    STAMP_REAL(14);
-    if (lane == 0 && mc.featA)
-      (void)__hip_atomic_fetch_add(fu.flag + (size_t)(f / kFTile) * kUnitCounterStride + kUnitCoefOffset, 1u, __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT);
-  }
+  // (one-launch sweep: the blend coefficients are not this role's any more — the coefficient role publishes them ~2 us into
+  //  the launch, mesh_role_inl.h — so wave 0 has no stores to drain and nothing to signal here)
   if (wave == 7) {
     STAMP(13);
     for (int spin = 0; spin < (1 << 20) && *sWalkDone < 257; ++spin) __builtin_amdgcn_s_sleep(1);

@@ -804,7 +804,7 @@ extern "C" int bodyfit_solve(bodyfit_problem* p, double* frame_params, double* b
       s.usable = (g.termination != 2) ? 1 : 0;   // ceres::Solver::Summary::IsSolutionUsable
       s.n_successful = g.n_ok; s.n_unsuccessful = g.n_bad;
       s.initial_cost = g.initial_cost; s.final_cost = g.cost;
-      s.n_sweeps = n_sweeps;
+      s.n_sweeps = n_sweeps; s.n_sweeps_issued = n_sweeps;
     }
   }
   return BODYFIT_OK;

@@ -892,8 +892,9 @@ void launch_lm_step(const LmProblem& P, const LmState& S, double* d_r, double* d
                     hipStream_t s) {
   static DeviceOnce attr;
   const size_t lds = lm_step_lds_bytes();
-  if (attr.first(current_device()))
+  attr.run(current_device(), [&] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_lm_step), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  });
   BODYFIT_LAUNCH(k_lm_step, dim3(P.F), dim3(kStepThreads), lds, s, P, S, d_r, d_J, d_comp,
                      LmCandidate{d_r_cand, d_J_cand, d_comp_cand}, d_constant, first_iter);
 }
@@ -907,8 +908,9 @@ void launch_frame_normal(int F, int n, const int* d_kp_offset, double huber, con
   if (F <= 0) return;
   const size_t lds = (size_t)(kRowsMax * kJLd + kRowsMax) * sizeof(double);
   static DeviceOnce attr_set;
-  if (attr_set.first(current_device()))
+  attr_set.run(current_device(), [&] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_frame_normal), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  });
   BODYFIT_LAUNCH(k_frame_normal, dim3(F), dim3(kStepThreads), lds, s, F, n, d_kp_offset, huber, const_cast<double*>(d_r), d_J,
                  (const double*)nullptr, (const double*)nullptr, (const double*)nullptr, 0, d_out);
 }
@@ -918,8 +920,9 @@ void launch_frame_normal_sel(int F, int n, const int* d_kp_offset, double huber,
   if (F <= 0) return;
   const size_t lds = (size_t)(kRowsMax * kJLd + kRowsMax) * sizeof(double);
   static DeviceOnce attr_set;
-  if (attr_set.first(current_device()))
+  attr_set.run(current_device(), [&] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_frame_normal), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  });
   BODYFIT_LAUNCH(k_frame_normal, dim3(F), dim3(kStepThreads), lds, s, F, n, d_kp_offset, huber, d_r, d_J, d_r_alt, d_J_alt, d_sel,
                  total_rows, d_out);
 }

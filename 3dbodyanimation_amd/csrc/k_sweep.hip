@@ -3,7 +3,9 @@
 //
 //   k_frame_resjac    frame_part_inl.h as its own launch: residuals + analytic Jacobian, one workgroup per frame
 //   k_mesh_blend_lbs  mesh_part_inl.h as its own launch: one workgroup per 32-vertex tile, all frames
-//   k_sweep_roles     the whole sweep as ONE launch whose workgroups take one of three roles (by block index):
+//   k_sweep_roles     the whole sweep as ONE launch whose workgroups take one of four roles (by block index):
+//                       coefficient role  mesh_role_inl.h coef_role: the blend coefficients of 16 frames from their raw
+//                                   parameters (f32 Rodrigues), published ~2 us into the launch; the first blocks
 //                       frame role  frame_part_inl.h for one frame; publishes the frame's mesh operands (blend coefficients,
 //                                   skinning transforms: 2 KB) inside the launch
 //                       mesh role   mesh_role_inl.h for one 32-vertex tile x one group of 256 frames; each of its eight waves
@@ -26,8 +28,13 @@
 //
 // Progress: a mesh workgroup waits only for frame workgroups, which wait for nothing; frame workgroups precede the mesh
 // workgroups that need them in block order, and the hardware dispatches blocks in order.  HIP does not promise that
-// order, so every wait is bounded: after FusedSync::timeout_ticks (50 ms) the workgroup sets the problem's error word and leaves, the host
-// reports the sweep as failed and the problem falls back to the two-launch sweep.
+// order, so every wait is bounded — by POLLS (FusedSync::timeout_ticks / 110: a poll is ~1.1 us of a running wave), not by wall
+// time since role entry: a wave that is descheduled (several processes time-slicing one GPU, serialised counter passes) does
+// not poll, so preemption cannot make a wait expire.  A mesh workgroup whose wait runs out sets the problem's error word and
+// leaves (its tile of the cloud is not written); the synchronous entry points then re-issue the sweep as two launches, the
+// asynchronous ones report it through bodyfit_sweep_status.  A prior workgroup whose wait runs out simply goes on: it waits
+// only to keep out of the frame workgroups' way and needs nothing they produce, so r, J, the joints and the folded
+// reduction are complete whatever happens to the waits.
 #include <hip/hip_ext.h>
 
 #include "bodyfit_device.h"
@@ -195,9 +202,11 @@ __global__ __launch_bounds__(kThreads, 4) void k_sweep_roles(RoleArgs by_value) 
   int role = 2, idx = 0, grp = 0;
   {
     const int nG = (F + kRoleGroup - 1) / kRoleGroup;
-    int pos = (int)blockIdx.x;
+    const int nC = (F + kCoefFrames - 1) / kCoefFrames;   // coefficient blocks: the first of the launch
+    int pos = (int)blockIdx.x - nC;
     const int n0 = min(kRoleGroup, F);
-    if (pos < n0) { role = 0; idx = pos; }
+    if (pos < 0) { role = 3; idx = (int)blockIdx.x; }
+    else if (pos < n0) { role = 0; idx = pos; }
     else {
       pos -= n0;
       bool found = false;
@@ -216,10 +225,18 @@ __global__ __launch_bounds__(kThreads, 4) void k_sweep_roles(RoleArgs by_value) 
       }
     }
   }
-  if (role == 0) {
+  if (role == 3) {
     const DevModel M = A->M;
     const DevProblem Pb = A->Pb;
     const MeshCoef mc = A->mc;
+    coef_role(M, Pb, A->params, A->beta, mc, idx, A->sy.flag, lds);
+    return;
+  }
+  if (role == 0) {
+    const DevModel M = A->M;
+    const DevProblem Pb = A->Pb;
+    MeshCoef mc = A->mc;
+    mc.featA = nullptr;   // the blend coefficients are the coefficient role's (mesh_role_inl.h): transforms and joints only
     FusedFrame fu;
     fu.flag = A->sy.flag;
     fu.epoch = A->sy.epoch;
@@ -248,36 +265,27 @@ __global__ __launch_bounds__(kThreads, 4) void k_sweep_roles(RoleArgs by_value) 
   // rejected: three looks in flight ~0.27 us apart (the step was no shorter, the hand-off itself came later: the producers'
   // adds queue behind the looks); other sleeps between looks (2, 20: no difference).  The polling wave must have no operand
   // stream of its own in flight: loads return in issue order, and a look issued behind LDS-DMA pieces came back 3 us late.
-  auto wait_flags = [&]() -> bool {   // prior role: all eight units of the group, polled by wave 7 (lane u: counter u)
-    volatile unsigned* ctrl = reinterpret_cast<volatile unsigned*>(lds + kRoleCtrlOff);
+  const unsigned max_polls = (unsigned)min(kRoleTimeoutTicks / 110ull, 0x7fffffffull);
+  auto wait_flags = [&]() {   // prior role: all eight units of the group, polled by wave 7 (lane u: counter u)
     const int tid = threadIdx.x, lane = tid & 63;
     if ((tid >> 6) == kPollWave) {
       const int fbeg = grp * kRoleGroup, nf = min(kRoleGroup, F - fbeg);
       const int nu = (nf + kFTile - 1) / kFTile;
       const unsigned want = epoch * (unsigned)min(kFTile, nf - min(lane, 7) * kFTile);
       const unsigned* ctr = flag_base + (size_t)(grp * (kRoleGroup / kFTile) + min(lane, 7)) * kUnitCounterStride;
-      unsigned action = 0;
       const unsigned long long t_enter = __builtin_amdgcn_s_memrealtime();
-      for (;;) {
+      for (unsigned polls = 0;; ++polls) {
         const unsigned got = __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (__all(lane >= nu || got == want)) break;
-        const unsigned long long el = __builtin_amdgcn_s_memrealtime() - t_enter;
-        if (el > kRoleTimeoutTicks) { action = 1; break; }
-        if (el < 300) {
+        if (polls >= max_polls) break;     // (nothing here depends on the frames: go on)
+        if (__builtin_amdgcn_s_memrealtime() - t_enter < 300) {
           for (int i = 0; i < 6 && __builtin_amdgcn_s_memrealtime() - t_enter < 300; ++i) __builtin_amdgcn_s_sleep(20);
         } else {
           __builtin_amdgcn_s_sleep(9);
         }
       }
-      if (lane == 0) ctrl[0] = action;
     }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    const unsigned action = ctrl[0];
-    if (action != 0) {
-      if (tid == 0) __hip_atomic_store(error_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      return false;
-    }
-    return true;
   };
   if (role == 2) {
     // The prior residuals depend on nothing the frame workgroups produce; they wait all the same: a prior workgroup is eight
@@ -285,8 +293,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_sweep_roles(RoleArgs by_value) 
     // against 9.6), which every mesh workgroup then waited for.  Behind the hand-off it only meets a Jacobian sweep.
     const PriorArgs pa = A->pa;
     if (idx >= pa.n_tiles) return;
-    if (!wait_flags()) return;
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // the control word has been read by every wave
+    wait_flags();
     prior_block(pa, idx, A->params, reinterpret_cast<double*>(lds));
     if (A->fold.ticket)
       fold_tail(A->fold.ticket, A->fold.want, A->fold.n_partials, A->fold.partials, A->fold.beta, A->fold.shape_rows,
@@ -303,12 +310,11 @@ __global__ __launch_bounds__(kThreads, 4) void k_sweep_roles(RoleArgs by_value) 
   const unsigned want = epoch * (unsigned)max(0, min(kFTile, F - (grp * kRoleGroup + my_unit * kFTile)));
   const unsigned* ctr = flag_base + (size_t)(grp * (kRoleGroup / kFTile) + my_unit) * kUnitCounterStride;
   auto wait_unit = [&](const unsigned* c) -> bool {
-    for (;;) {
+    for (unsigned polls = 0;; ++polls) {
       const unsigned got = __hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (got == want) return true;
-      const unsigned long long el = __builtin_amdgcn_s_memrealtime() - t_role;
-      if (el > kRoleTimeoutTicks) return false;
-      if (el < 300) {
+      if (polls >= max_polls) return false;
+      if (__builtin_amdgcn_s_memrealtime() - t_role < 300) {
         for (int i = 0; i < 6 && __builtin_amdgcn_s_memrealtime() - t_role < 300; ++i) __builtin_amdgcn_s_sleep(20);
       } else {
         __builtin_amdgcn_s_sleep(9);   // (2 and 20 measured: no difference)
@@ -330,9 +336,10 @@ void launch_frame_resjac(const DevModel& M, const DevProblem& P, const double* d
   if (P.F <= 0) return;
   const size_t lds = frame_lds_bytes(M.nL);
   static DeviceMax lds_granted;
-  if (lds_granted.raise(current_device(), lds, 48 * 1024))
+  lds_granted.raise(current_device(), lds, 48 * 1024, [&](size_t want) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_frame_resjac), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)lds);
+                              (int)want);
+  });
   BODYFIT_LAUNCH_EXT(k_frame_resjac, dim3(P.F + priors.n_tiles), dim3(kThreads), lds, s, ev_start, ev_stop, 0, M, P,
                         d_params, d_beta, d_r, d_J, d_joints, mc, want_jac, priors);
 }
@@ -342,9 +349,10 @@ void launch_mesh(const DevModel& M, const DevProblem& P, const MeshCoef& mc, flo
   if (P.F <= 0) return;
   if ((size_t)P.nFTiles * kFTile * M.nVTiles * kVTile * 12 >= ((size_t)1 << 32)) return;   // refused at problem creation
   static DeviceOnce attr;
-  if (attr.first(current_device()))
+  attr.run(current_device(), [&] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_mesh_blend_lbs),
                               hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+  });
   BODYFIT_LAUNCH_EXT(k_mesh_blend_lbs, dim3(M.nVTiles + pa.n_tiles), dim3(64 * kWaves), kLdsBytes, s, ev_start, ev_stop,
                         0, M, P, mc, d_cloud, pa, d_params);
 }
@@ -360,11 +368,12 @@ void launch_sweep_roles(const DevModel& M, const DevProblem& P, const double* d_
                         double* d_J, double* d_joints, const MeshCoef& mc, int want_jac, const PriorArgs& pa, float* d_cloud,
                         const FusedSync& sy, const FoldTail& fold, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop) {
   static DeviceOnce attr;
-  if (attr.first(current_device()))
+  attr.run(current_device(), [&] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_sweep_roles), hipFuncAttributeMaxDynamicSharedMemorySize,
                               kRoleLdsBytes);
+  });
   const int nG = (P.F + kRoleGroup - 1) / kRoleGroup;
-  const int grid = P.F + nG * M.nVTiles + pa.n_tiles;
+  const int grid = (P.F + kCoefFrames - 1) / kCoefFrames + P.F + nG * M.nVTiles + pa.n_tiles;
   RoleArgs A;
   A.M = M; A.Pb = P; A.Pb.feat_perm = 1; A.params = d_params; A.beta = d_beta; A.r_out = d_r; A.J_out = d_J;
   A.joints_out = d_joints; A.mc = mc; A.want_jac = want_jac; A.pa = pa; A.cloud_f = d_cloud; A.sy = sy; A.fold = fold;

@@ -1304,14 +1304,14 @@ void launch_win_assemble(const WinProblem& P, const WinBuf& W, const double* d_H
 }
 void launch_cr_factor(const WinBuf& W, const int* d_elim, int n_elim, hipStream_t s) {
   static DeviceOnce attr;
-  if (attr.first(current_device())) {
+  attr.run(current_device(), [&] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_cr_factor), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)win_factor_lds_bytes());
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_cr_update), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)win_update_lds_bytes());
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_cr_back), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)win_back_lds_bytes());
-  }
+  });
   if (n_elim > 0) BODYFIT_LAUNCH(k_cr_factor, dim3(2 * n_elim), dim3(kCrThreads), win_factor_lds_bytes(), s, W, d_elim, n_elim);
 }
 void launch_cr_update(const WinBuf& W, const int* d_surv, int n_surv, hipStream_t s) {

@@ -226,6 +226,122 @@ __device__ __forceinline__ void role_skin_row(const RoleCtx& C, const RoleLane& 
   asm volatile("" ::: "memory");
 }
 
+// ---- coefficient role: the blend coefficients (MFMA A fragments) of 16 frames --------------------------------------------
+// The A operand of the blend is [vec(R_j - I), j = 1..23 | beta | 1 1 0..] per frame: it depends on the frame's raw parameters
+// only.  When the frame role produced it (round 3), a mesh wave could not start its blend before 5.2 us (table round trip,
+// phase B's Rodrigues + gradient, phase C's pack, drain, signal) + detection = 7.4 us into the launch.  This role computes
+// nothing else: parameters -> Rodrigues in f32 (the mesh is an f32 product split in bf16 hi + lo: the f64 rotation of the frame
+// role, rounded to f32, and the f32 rotation differ by ~1e-7 relative on coefficients that multiply centimetre-scale
+// directions; mesh tolerance 5e-6 m) -> fragments, write-through -> one agent-scope add of its frame count to the unit's
+// coefficient counter.  Its blocks are the FIRST of the launch, two per 32-frame unit.
+constexpr int kCoefFrames = 16;
+constexpr int kCoefLdsFloats = kCoefFrames * 16 * kBlendKSteps;   // [16 frames][224 coefficients]
+#ifdef BODYFIT_STAMPS
+#define CSTAMP(i)                                                                                              \
+  do {                                                                                                         \
+    if (Pb.dbg && threadIdx.x == 0) {                                                                          \
+      unsigned long long t_;                                                                                   \
+      asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                          \
+      Pb.dbg[kStampBase - 8192 + (size_t)blk * 16 + (i)] = t_;                                                 \
+    }                                                                                                          \
+  } while (0)
+#else
+#define CSTAMP(i)
+#endif
+
+__device__ __forceinline__ void coef_role(const DevModel& M, const DevProblem& Pb, const double* __restrict__ params,
+                                          const double* __restrict__ beta, const MeshCoef& mc, int blk, unsigned* flag_base,
+                                          unsigned char* lds_generic) {
+  constexpr int kK = 16 * kBlendKSteps;   // 224
+  float* sf = reinterpret_cast<float*>(lds_generic);
+  const int tid = threadIdx.x;
+  const int nJ = M.nJ, nS = M.nS, npose = 7 + 3 * (nJ - 1);
+  const int f0 = blk * kCoefFrames, nf = min(kCoefFrames, Pb.F - f0);
+  const int nrot = kCoefFrames * (nJ - 1);                       // (frame, joint) items: 368 <= 512, one pass
+  CSTAMP(0);
+  // every load first (one round trip)
+  const int fr = min(tid / (nJ - 1), kCoefFrames - 1), j = tid - (tid / (nJ - 1)) * (nJ - 1);
+  const double* aa = params + (size_t)(f0 + min(fr, nf - 1)) * npose + 7 + 3 * j;
+  const double a0d = aa[0], a1d = aa[1], a2d = aa[2];
+  const int bfr = min(tid / kMaxShape, kCoefFrames - 1), bk = tid % kMaxShape;
+  double bv = 0.0;
+  if (Pb.use_shape && beta && bk < nS) bv = beta[(size_t)(f0 + min(bfr, nf - 1)) * Pb.beta_stride + bk];
+  if (tid < nrot) {
+    const float a0 = (float)a0d, a1 = (float)a1d, a2 = (float)a2d;
+    const float th2 = a0 * a0 + a1 * a1 + a2 * a2;
+    float R[9];
+    if (th2 > 1e-20f) {
+      const float ith = rsqrtf(th2), th = th2 * ith;
+      float sh, ch;
+      sincosf(0.5f * th, &sh, &ch);
+      const float st = 2.0f * sh * ch, omc = 2.0f * sh * sh;    // 1 - cos without cancellation
+      const float w0 = a0 * ith, w1 = a1 * ith, w2 = a2 * ith;
+      // R - I = sin [w]x + (1 - cos) (w w^T - I)
+      R[0] = omc * (w0 * w0 - 1.0f); R[1] = omc * w0 * w1 - st * w2; R[2] = omc * w0 * w2 + st * w1;
+      R[3] = omc * w1 * w0 + st * w2; R[4] = omc * (w1 * w1 - 1.0f); R[5] = omc * w1 * w2 - st * w0;
+      R[6] = omc * w2 * w0 - st * w1; R[7] = omc * w2 * w1 + st * w0; R[8] = omc * (w2 * w2 - 1.0f);
+    } else {   // first-order branch (the frame role's own: include/Sim3BA.h:61 through ceres::AngleAxisRotatePoint)
+      R[0] = 0.0f; R[1] = -a2; R[2] = a1; R[3] = a2; R[4] = 0.0f; R[5] = -a0; R[6] = -a1; R[7] = a0; R[8] = 0.0f;
+    }
+    const float on = (Pb.pose_blend && fr < nf) ? 1.0f : 0.0f;
+#pragma unroll
+    for (int e = 0; e < 9; ++e) sf[fr * kK + 9 * j + e] = on * R[e];
+  }
+  if (tid < kCoefFrames * kMaxShape) sf[bfr * kK + kPoseFeat + bk] = (bfr < nf) ? (float)bv : 0.0f;
+  if (tid < kCoefFrames * (kK - kPoseFeat - kMaxShape)) {     // the template's two slots (coefficient 1.0), then K's padding
+    const int pf = tid / (kK - kPoseFeat - kMaxShape), pk = tid % (kK - kPoseFeat - kMaxShape);
+    sf[pf * kK + kPoseFeat + kMaxShape + pk] = (pk < 2 && pf < nf) ? 1.0f : 0.0f;
+  }
+  if (9 * (nJ - 1) < kPoseFeat) {   // (models with fewer joints: the unused pose slots)
+    for (int i = tid; i < kCoefFrames * (kPoseFeat - 9 * (nJ - 1)); i += kThreads)
+      sf[(i / (kPoseFeat - 9 * (nJ - 1))) * kK + 9 * (nJ - 1) + i % (kPoseFeat - 9 * (nJ - 1))] = 0.0f;
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  CSTAMP(1);
+  // fragments: item = (k-step, hi / lo, k-half, frame): 16 bytes = eight consecutive coefficients of one frame
+  const int unit = f0 / kFTile, phi0 = f0 % kFTile;
+  unsigned char* base = reinterpret_cast<unsigned char*>(mc.featA) + (size_t)unit * kBlendKSteps * 2048;
+#pragma unroll
+  for (int u = 0; u < (kCoefFrames * kBlendKSteps * 4 + kThreads - 1) / kThreads; ++u) {
+    const int it = tid + u * kThreads;
+    if (it < kCoefFrames * kBlendKSteps * 4) {
+      const int kstep = it >> 6, rem = it & 63, hl = rem >> 5, h = (rem >> 4) & 1, fl = rem & 15;
+      const int phi = phi0 + fl;
+      // MFMA row of the frame inside its unit: accumulator register i of half-wave h holds frame 2 i + h (frame_part_inl.h)
+      const int row = Pb.feat_perm ? (8 * (phi >> 3) + 4 * (phi & 1) + ((phi >> 1) & 3)) : phi;
+      const float4 v0 = *reinterpret_cast<const float4*>(sf + fl * kK + kstep * 16 + 8 * h);
+      const float4 v1 = *reinterpret_cast<const float4*>(sf + fl * kK + kstep * 16 + 8 * h + 4);
+      const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+      uint32_t pk[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        uint16_t b[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const uint16_t hi = f32_to_bf16(x[2 * q + t]);
+          b[t] = hl == 0 ? hi : f32_to_bf16(x[2 * q + t] - bf16_to_f32(hi));
+        }
+        pk[q] = (uint32_t)b[0] | ((uint32_t)b[1] << 16);
+      }
+      typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_;
+      const u32x4_ val = {pk[0], pk[1], pk[2], pk[3]};
+      void* dst = base + (size_t)kstep * 2048 + feat_frag_off(h * 32 + row, hl);
+      asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(val) : "memory");
+    }
+  }
+  // hand-off (cdna guide, Guideline 16 R1): every storing wave's stores have left, then ONE add for the block's frames
+  CSTAMP(2);
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+  CSTAMP(3);
+  if (tid == 0 && nf > 0)
+    (void)__hip_atomic_fetch_add(flag_base + (size_t)unit * kUnitCounterStride + kUnitCoefOffset, (unsigned)nf, __ATOMIC_RELAXED,
+                                 __HIP_MEMORY_SCOPE_AGENT);
+#ifdef BODYFIT_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  CSTAMP(4);
+#endif
+}
+
 // One workgroup: vertex tile `vtile`, frames [256 group, 256 group + 256).  flags_ready: the caller has waited for the
 // group's hand-off flags (or the operands are from an earlier launch).  `lds`: kRoleLdsBytes.
 // unit_ctr / unit_want: this wave's unit counters (k_sweep.hip; word 0: transforms, word kUnitCoefOffset: blend coefficients) and

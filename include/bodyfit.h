@@ -154,9 +154,22 @@ int bodyfit_evaluate_batch(bodyfit_problem* p, const double* frame_params, const
                            double* residuals, double* jacobian, int* gmm_comp, int want_jacobian);
 
 /* Device-pointer form (inputs already resident in HBM, asynchronous on `stream`, a hipStream_t
- * passed as void*; NULL = the default stream).  Results stay in the problem's device buffers.  */
+ * passed as void*; NULL = the default stream).  Results stay in the problem's device buffers.
+ * One problem, one sweep at a time: successive calls must be ordered (same stream, or events); the synchronous entry points
+ * (bodyfit_evaluate_batch, bodyfit_forward, bodyfit_writeback_batch, bodyfit_frame_normals) order themselves behind whatever
+ * was enqueued through this call (they run on a private stream / the NULL stream).
+ * Errors of an asynchronous sweep.  With want_mesh the sweep is ONE launch whose mesh workgroups wait, inside the launch, for
+ * operands the frame workgroups publish (k_sweep.hip).  Every such wait is bounded; a mesh workgroup whose wait runs out leaves
+ * its 32-vertex tile of the cloud unwritten and sets an error word.  Residuals, Jacobian, joints, GMM components and the
+ * shared reduction (bodyfit_reduce_shared_device / bodyfit_arm_shared_reduction) never depend on a wait and are complete
+ * regardless.  The synchronous entry points notice the word and re-issue their sweep as two launches themselves; a caller of
+ * THIS function learns of it from bodyfit_sweep_status, which it should call before it consumes the cloud.             */
 int bodyfit_evaluate_device(bodyfit_problem* p, const double* d_frame_params, const double* d_beta,
                             int want_jacobian, void* stream);
+/* Waits for `stream`, then reports whether every asynchronous sweep of the problem since the last check completed:
+ * BODYFIT_OK, or BODYFIT_ERR_HIP ("... timed out"): the cloud of at least one of them is incomplete; the problem uses the
+ * two-launch sweep from then on, so re-issuing the evaluation gives the complete result.                                */
+int bodyfit_sweep_status(bodyfit_problem* p, void* stream);
 
 typedef struct bodyfit_device_views {
   double* residuals;    /* [total_rows]          */
@@ -183,6 +196,8 @@ int bodyfit_reduce_shared_device(bodyfit_problem* p, double* d_out66, void* stre
  * (two-launch sweep, longer shards) leave the work to bodyfit_reduce_shared_device as before; the numbers are
  * bit-identical either way.  d_out66 = NULL disarms.                                                             */
 int bodyfit_arm_shared_reduction(bodyfit_problem* p, double* d_out66);
+/* (A timed-out in-launch wait — see bodyfit_evaluate_device — does not touch the 66 doubles: the frame and prior workgroups
+ *  that produce them wait for nothing they need.)                                                                  */
 
 /* Measurement aid: `iters` sweeps with HIP events around every kernel on `stream`;
  * avg_ms[5] = average launch duration (ms) of {frame_resjac, 0 (the prior workgroups ride on another launch),
@@ -251,9 +266,12 @@ typedef struct bodyfit_fit_summary {
   int termination;          /* 0 convergence, 1 iteration limit, 2 failure */
   int usable;               /* Summary::IsSolutionUsable() */
   int n_successful, n_unsuccessful;
-  int n_sweeps;             /* device evaluations the solve needed: 1 + one per iteration + one per accepted step (the
-                               device window LM issues a few more speculatively between two status reads) */
+  int n_sweeps;             /* device evaluations the solve needed.  Device window LM: 1 + one per iteration (the sweep at a
+                               candidate also leaves its Jacobian); host loop and the batched LM in its four-launch form: 1 + one
+                               per iteration + one per accepted step */
   double initial_cost, final_cost;
+  int n_sweeps_issued;      /* ... and the sweeps actually launched: the device window LM runs up to three iterations ahead of
+                               the host's status reads (they find the solve terminated and change nothing); 0 = same as n_sweeps */
 } bodyfit_fit_summary;
 int bodyfit_solve(bodyfit_problem* p, double* frame_params, double* beta, const unsigned char* param_constant,
                   int independent_frames, const bodyfit_fit_options* options, bodyfit_fit_summary* summaries,
@@ -297,6 +315,12 @@ int bodyfit_rccl_wrap(void* nccl_comm, int rank, int size, bodyfit_rccl** out);
 void bodyfit_rccl_destroy(bodyfit_rccl* c);
 int bodyfit_solve_sharded_rccl(bodyfit_problem* p, double* frame_params, double* beta, const unsigned char* param_constant,
                                bodyfit_rccl* comm, const bodyfit_fit_options* options, bodyfit_fit_summary* summary);
+/* The evaluation path's one collective (include/MultiFrameBA.h:64-68 — the shared shape block — summed over the
+ * shards): ncclAllReduce(sum, f64) of the 66 doubles [cost | g_beta | upper H_bb], in place on the device buffer, on `stream`:
+ * behind bodyfit_evaluate_device + bodyfit_reduce_shared_device on the same stream it needs no host synchronisation.    */
+int bodyfit_allreduce_shared_rccl(bodyfit_rccl* comm, double* d_buf66, void* stream);
+/* ranks of the communicator and this process's rank, as RCCL reports them (ncclCommCount, ncclCommUserRank) */
+int bodyfit_rccl_count(bodyfit_rccl* comm, int* n_ranks, int* rank);
 /* all-gathers issued by the problem's last sharded solve (tests assert the number of exchanges per iteration) */
 long bodyfit_last_exchange_count(const bodyfit_problem* p);
 

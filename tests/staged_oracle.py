@@ -52,7 +52,7 @@ def _mean_px(om, seqf, r0, t, jaa, w):
 
 
 def run_multi(om, kp_offset, kp_id, kp_uv, intr, max_iters_s1=1000, skip=10, wsize=20, overlap=5, beta_pose=5.0,
-              beta_shape=25.0, lambda_t=3.0, stage2_iters=60, follow=None):
+              beta_shape=25.0, lambda_t=3.0, stage2_iters=60, follow=None, perturb=None):
     """follow: the product's per-stage snapshots (drivers.run_multi(trace=...)).  The staged fit is a chain of unconverged,
     ill-conditioned solves (frames without keypoints leave their Sim3 scale undetermined; stage 2 stops after a fixed
     iteration count): one window amplifies a 1e-12 difference of its starting state to ~1e-5, the next one to ~1e-3, although
@@ -91,6 +91,8 @@ def run_multi(om, kp_offset, kp_id, kp_uv, intr, max_iters_s1=1000, skip=10, wsi
 
     def snap(ids):
         mine.append(dict(ids=list(ids), poses=poses.copy(), r0=r0.copy(), t=t.copy(), joint_aa=jaa.copy(), w=w.copy()))
+        if perturb is not None:                      # perturb(stage index, live state): the amplification experiment of
+            perturb(len(mine) - 1, dict(poses=poses, r0=r0, t=t, joint_aa=jaa, w=w))   # tests/test_oracle.py
         if follow is not None:
             ref = follow[len(mine) - 1]
             assert ref["ids"] == list(ids)

@@ -229,3 +229,44 @@ def test_staging_against_the_checkers_staged_run(gpu_model, model):
         # (the log's pixel error is NOT compared here: it is taken without the Sim3 scale (Q5) and so depends on where along the
         #  exact null direction (s, t) -> (c s, c t) a converged single-frame fit happens to stop — two correct solvers differ
         #  there (tests/test_gpu_fit.py::gauge_free_diff); the multi-frame stages above walk identical paths and do compare it)
+
+
+@pytest.mark.gpu
+def test_unforced_staged_run_on_a_well_conditioned_sequence(gpu_model, model):
+    """The staged comparison WITHOUT teacher forcing: drivers.run_multi (HIP evaluator, device window LM, device write-back)
+    and tests/staged_oracle.run_multi (dense numpy LM over the oracle evaluator, oracle forward) each run the whole of
+    src/main_multi_frame.cpp:85-217 on their own — anchors 0,10,20,30 with the shared beta, the beta hand-down (:154), windows
+    [0,20) [15,35) [30,35) with the beta lock (Q9), poses carried from window to window in the overlaps, the compounded root
+    orientations (Q8) — and only the END of every stage is compared, at the north star's 1e-4.  A staging mistake that bites
+    across stages (which copy of w or r[0] a later window starts from, Q7's never-written anchor poses) would show here and not
+    in the stage-by-stage test above.  The input is well conditioned so that the chain does not amplify rounding (every frame
+    has its 25 keypoints, every solve runs to Ceres' convergence tests instead of an iteration cap): checker against perturbed
+    checker stays at the size of the perturbation on this sequence, while on the reference's keypoint files it grows by 1e7
+    (tests/test_oracle.py::test_staged_chain_on_the_reference_keypoints_amplifies_a_perturbation)."""
+    import staged_oracle
+    from oracle import oracle
+    F = 35
+    sq = synth.make_sequence(model, F, seed=3)
+    seq = drivers.KeypointSequence(sq.kp_offset, sq.kp_id, sq.kp_uv, [f"frame_{f:04d}.json" for f in range(F)])
+    om = oracle.OracleModel(model)
+    kw = dict(max_iters_s1=200, stage2_iters=200)
+    trace = []
+    got = drivers.run_multi(gpu_model, seq, sq.intr, trace=trace, **kw)
+    want = staged_oracle.run_multi(om, sq.kp_offset, sq.kp_id, sq.kp_uv, sq.intr, **kw)
+    assert [st["ids"] for st in trace] == [st["ids"] for st in want["stages"]]
+    assert len(trace) == 4 and trace[0]["ids"] == [0, 10, 20, 30] and trace[3]["ids"] == list(range(30, 35))
+    # every solve ended by a convergence test, not by the cap
+    assert got["stage1"].iterations == want["stage1"]["iterations"] < 200
+    assert all(s.iterations < 200 for s in got["stage2"])
+    worst = 0.0
+    for st_got, st_want in zip(trace, want["stages"]):
+        for key in ("poses", "w", "r0", "t", "joint_aa"):
+            d = float(np.abs(st_got[key] - st_want[key]).max())
+            worst = max(worst, d)
+            assert d < 1e-4, (st_got["ids"][0], key, d)
+    print(f"unforced staged run: largest difference over all stages {worst:.2e}")
+    assert np.abs(got["w"][[0, 15, 30]]).max() < 1e-3 and np.abs(got["w"][1]).max() > 1e-2          # Q9
+    assert np.abs(trace[2]["r0"][15:20] - trace[1]["r0"][15:20]).max() > 1e-4                       # Q8
+    px_got = np.array([r[1] for r in got["log"]]); px_want = np.array([r[1] for r in want["log"]])
+    assert [r[0] for r in got["log"]] == [r[0] for r in want["log"]]
+    assert np.abs(px_got - px_want).max() < 1e-3 * max(1.0, np.abs(px_want).max())

@@ -228,3 +228,24 @@ def test_c5_stage1_103_anchors_against_the_checkers_lm(api, synth, model, gpu_mo
         assert (summ[0].iterations, summ[0].n_successful) == (info["iterations"], info["n_ok"])
         assert abs(summ[0].final_cost - info["final_cost"]) < 1e-8 * info["final_cost"]
         assert np.abs(x - xo).max() < 1e-6 and np.abs(b - bo).max() < 1e-6
+
+
+@pytest.mark.parametrize("F", [545, 1024])
+def test_one_long_window_against_the_checkers_lm(api, synth, model, gpu_model, oracle_mod, omodel, F):
+    """BASELINE configs[4] as ONE window (what `bench.py --workload c5 --fit` and the north star's strong-scaling figure are
+    quoted on; include/MultiFrameBA.h:33-177 with every frame of the sequence, solver configuration :144-151): the device
+    window LM (block cyclic reduction over 10 / 11 levels + beta Schur) against the checker's LM — oracle evaluator under
+    oracle/lm_dense.py in scipy.sparse form — iterate for iterate from the reference's initial state
+    (src/main_multi_frame.cpp:96-100) over 8 iterations, which contain accepted steps and a rejected one."""
+    seq = synth.make_sequence(model, F, seed=3)
+    prob = api.Problem.from_sequence(gpu_model, seq, n_cols=86, use_shape=True, beta_pose=5.0, beta_shape=25.0,
+                                     lambda_temporal=3.0)
+    kw = dict(max_iters=8, scale_bounds=(-1e300, 1e300))
+    x, b, summ = prob.solve(seq.init_params, np.zeros(10), independent=False, **kw)
+    xo, bo, info = _lm(oracle_mod).solve(omodel, seq, seq.init_params, np.zeros(10), n_cols=86, use_shape=True, beta_pose=5.0,
+                                        beta_shape=25.0, lam=3.0, sparse=True, **kw)
+    assert info["n_bad"] >= 1 and info["n_ok"] >= 5
+    assert (summ[0].iterations, summ[0].n_successful) == (info["iterations"], info["n_ok"])
+    assert abs(summ[0].initial_cost - info["initial_cost"]) < 1e-9 * info["initial_cost"]
+    assert abs(summ[0].final_cost - info["final_cost"]) < 1e-8 * info["final_cost"]
+    assert np.abs(x - xo).max() < 1e-6 and np.abs(b - bo).max() < 1e-6

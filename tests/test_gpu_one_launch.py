@@ -172,6 +172,47 @@ def test_one_launch_against_oracle(model):
         assert np.abs(cloud[f] - co).max() < 5e-6
 
 
+def test_one_launch_against_oracle_at_the_bench_config(model):
+    """k_sweep_roles DIRECTLY against the oracle at the configuration bench.py times (BASELINE configs[2] / SURVEY 8d C3): 256
+    independent frames, 25 keypoints each, per-frame beta (86 columns), GMM pose prior, per-frame shape prior, mesh on — every
+    residual row (reprojection, 70 GMM rows per frame, 10 shape rows per frame), the whole Jacobian panel, the chosen mixture
+    components, the posed joints and the cloud of frames out of every 32-frame unit."""
+    from oracle import oracle
+    import torch
+    m, gm = model
+    F = 256
+    seq = synth.make_sequence(m, F, seed=0)
+    w, mu, cov = synth.make_gmm(0)
+    prob = _problem(gm, seq, True, gmm=api.Gmm(w, mu, cov))
+    ogmm = oracle.OracleGmm(w, mu, cov)
+    rng = np.random.default_rng(3)
+    x = seq.gt_params + 0.05 * rng.standard_normal(seq.gt_params.shape)
+    beta = np.tile(seq.gt_beta, (F, 1)) + 0.3 * rng.standard_normal((F, 10))
+    # the sweep as the bench issues it: device-resident parameters, one launch on a stream, and it IS the role-split kernel
+    dev = torch.device("cuda", 0)
+    dx, db = torch.from_numpy(x).to(dev), torch.from_numpy(beta).to(dev)
+    prof = prob.profile_sweep(dx.data_ptr(), db.data_ptr(), True, False, 2, torch.cuda.current_stream().cuda_stream)
+    assert prof["sweep_roles"] > 0 and prof["frame_resjac"] == 0 and prof["mesh_blend_lbs"] == 0
+    r, J, comp = prob.evaluate(x, beta, True)
+    om = oracle.OracleModel(m)
+    ro, Jo = om.evaluate_batch(seq, x, beta, 86, True, True, mode=0)
+    K2 = prob.layout.reproj_rows
+    assert K2 == 2 * 25 * F and r.shape[0] == K2 + 70 * F + 10 * F
+    assert np.abs(r[:K2] - ro).max() < 1e-9
+    assert J.shape == Jo.shape and np.abs(J - Jo).max() <= 1e-9 * max(1.0, np.abs(Jo).max())
+    rp = r[K2:K2 + 70 * F].reshape(F, 70)
+    for f in range(F):
+        rpo, _, k = oracle.pose_prior(ogmm, 20.0, x[f, 7:])
+        assert comp[f] == k and np.abs(rp[f] - rpo).max() < 1e-8
+    assert len(set(comp.tolist())) > 1
+    assert np.abs(r[K2 + 70 * F:] - 30.0 * beta.reshape(-1)).max() < 1e-12
+    joints, cloud = prob.forward(x, beta)
+    for f in (0, 31, 32, 77, 100, 129, 191, 255):
+        jo, co = om.forward(x[f], beta[f], seq.R0[f])
+        assert np.abs(joints[f] - jo).max() < 1e-10
+        assert np.abs(cloud[f] - co).max() < 5e-6
+
+
 @pytest.mark.parametrize("F", [2, 17, 40, 128, 240])
 def test_reduction_at_the_sweeps_own_tail(model, F):
     """bodyfit_arm_shared_reduction: the last frame / prior workgroup of a one-launch Jacobian sweep sums the per-frame partials

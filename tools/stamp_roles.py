@@ -34,7 +34,9 @@ torch.cuda.synchronize()
 raw = buf.cpu().numpy()
 fr = raw[:F * 8 * 16].reshape(F, 8, 16).astype(np.float64)
 ms = raw[BASE:BASE + nG * nvt * 8 * 16].reshape(nG * nvt, 8, 16).astype(np.float64)
-t0 = min(fr[:, 0, 10].min(), ms[:, :, 0].min())
+nC = (F + 15) // 16
+cf = raw[BASE - 8192:BASE - 8192 + nC * 16].reshape(nC, 16).astype(np.float64)
+t0 = min(fr[:, 0, 10].min(), ms[:, :, 0].min(), cf[:, 0].min())
 us = lambda a: (a - t0) / 100.0
 def q(a):
     a = np.asarray(a, dtype=np.float64).ravel()
@@ -47,9 +49,9 @@ c0 = w7[:, 2]   # start of phase C (shader cycles)
 print("frame role wave 7, shader cycles into phase C: walks done", q(w7[:, 13] - c0), "| wave 6 + 0 seen", q(w7[:, 14] - c0),
       "| operands stored", q(w7[:, 15] - c0), "| end of C", q(w7[:, 3] - c0))
 print("                   own stores drained (us)", q(us(w7[:, 9])), "| signalled (us)", q(us(w7[:, 12])), "| waiting for wave 0's drain", q((w7[:, 12] - w7[:, 9]) / 100))
-print("frame role: blend coefficients published (wave 0) ", q(us(fr[:, 0, 14])), "| slowest frame of each 32-frame unit:", np.round([us(fr[u * 32:(u + 1) * 32, 0, 14]).max() for u in range((F + 31) // 32)][:8], 2))
+print("coef role: entry", q(us(cf[:, 0])), "| fragments in LDS", q(us(cf[:, 1])), "| stores issued", q(us(cf[:, 2])))
+print("           drained", q(us(cf[:, 3])), "| signalled (add acknowledged)", q(us(cf[:, 4])))
 print("frame role: transforms published (wave 7), slowest frame of each unit:", np.round([us(fr[u * 32:(u + 1) * 32, 7, 12]).max() for u in range((F + 31) // 32)][:8], 2))
-print("frame role wave 0: blend coefficients drain starts (us)", q(us(fr[:, 0, 13])), "| drained", q(us(fr[:, 0, 14])), "| drain time", q((fr[:, 0, 14] - fr[:, 0, 13]) / 100))
 pub = us(fr[:, 7, 12])
 late = np.argsort(pub)[-24:]
 print("frame role: latest 24 hand-offs (frame: us):", " ".join(f"{int(i)}:{pub[i]:.1f}" for i in late))
