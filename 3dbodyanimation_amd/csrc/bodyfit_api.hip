@@ -178,6 +178,11 @@ struct bodyfit_problem {
 
 namespace {
 
+int env_int(const char* name, int dflt) {
+  const char* e = std::getenv(name);
+  return (e && *e) ? std::atoi(e) : dflt;
+}
+
 bool chol_lower(std::vector<double>& A, int n) {
   for (int j = 0; j < n; ++j) {
     double d = A[(size_t)j * n + j];
@@ -288,6 +293,9 @@ int sweep(bodyfit_problem* p, const double* d_params, const double* d_beta, int 
     sy.epoch = ++p->fused_epoch;
     sy.resident_blocks = 2 * m->n_cus;
     sy.timeout_ticks = p->role_timeout_ticks;
+    static const int tune_prio = env_int("BODYFIT_MESH_PRIO", 2), tune_start = env_int("BODYFIT_TRICKLE_START", 120),
+                     tune_sleep = env_int("BODYFIT_TRICKLE_SLEEP", 7);
+    sy.mesh_prio_early = tune_prio; sy.trickle_start = tune_start; sy.trickle_sleep = tune_sleep;
     p->fused_unchecked = true;
     FoldTail fold{};
     const int n_partials = p->d.F + pa.n_tiles;

@@ -126,6 +126,10 @@ struct FusedSync {
   unsigned epoch;              // launch number, >= 1
   int resident_blocks;         // blocks resident from the start of the launch (2 per CU)
   unsigned long long timeout_ticks;   // bound of every in-launch wait (s_memrealtime ticks, 100 MHz); kRoleTimeoutDefault
+  // tuning (defaults: RoleTuning; BODYFIT_MESH_PRIO / BODYFIT_TRICKLE_START / BODYFIT_TRICKLE_SLEEP override them for A/B runs)
+  int mesh_prio_early;         // s_setprio of a mesh wave during k-steps 0-8 (the frame role runs at 2 and still owes the transforms)
+  int trickle_start;           // operand stream of a mesh workgroup that runs beside its frames: first slab this many 10 ns ticks
+  int trickle_sleep;           // after entry, then s_sleep(this) between slabs
 };
 constexpr unsigned long long kRoleTimeoutDefault = 5000000;   // 50 ms: give up, set the error word, the host falls back
 constexpr int kRoleMaxFrames = 16384;

@@ -267,6 +267,7 @@ __device__ __forceinline__ void frame_part(const DevModel& M, const DevProblem& 
   //      predicated).  Written as load-store loops the phase compiled to one dependent L2 round trip per loop trip. --------
   constexpr int kSdPasses = (kMaxLandmarks * 3 * kMaxShape + kThreads - 1) / kThreads;   // 2
   constexpr int kPasses = (720 + kLoaders - 1) / kLoaders;                                 // 24 x 3 x 10 doubles: 2
+  const bool coef_wave = kFused && wave == 5 && mc.featA != nullptr;
   const int tj_c = min(tid, nJ - 1);
   const int par_in = M.parent[tj_c];
   const unsigned anc_in = M.anc_mask[tj_c];
@@ -372,6 +373,42 @@ __device__ __forceinline__ void frame_part(const DevModel& M, const DevProblem& 
     for (int k = 0; k < kMaxShape; ++k) acc += sv[k] * sbeta[min(k, nS > 0 ? nS - 1 : 0)];
     sPart[row] = acc;
   }
+  if (coef_wave) {
+    // One-launch sweep, wave 5 (nothing else to do in this phase): the rotations behind the mesh role's blend coefficients (MFMA A
+    // fragments: [vec(R_j - I) | beta | 1 1 0 ..] of this frame in bf16 hi + lo), in f32, straight from the raw parameters —
+    // not from wave 0's f64 rotations, which exist only at the end of this phase: round 3 packed those in phase C and
+    // published them 5.2 us into the launch.  (The mesh is an f32 product split in bf16: the f64 rotation rounded to f32 and
+    // the f32 rotation differ by ~1e-7 relative on coefficients that multiply centimetre-scale directions; mesh tolerance
+    // 5e-6 m.)  23 lanes one joint each, the lanes from 32 on beta, the template's two slots (coefficient 1.0) and K's padding
+    // -> 224 floats of scratch (sW .. sB are free until phase C / D).  Packing, storing and signalling: top of phase C (all of
+    // it here made this wave the phase's longest by 1.9 k cycles; the rotations in phase A, under the table loads, from a copy
+    // of the parameters wave 5 requests first, published at 3.3 us but stretched phases A and B by 0.9 k cycles each: 23.8
+    // against 21.5 us per step).
+    float* cf = reinterpret_cast<float*>(sW);
+    const int nfeat = 9 * (nJ - 1);
+    if (lane < nJ - 1) {
+      const float a0 = (float)sx[7 + 3 * lane], a1 = (float)sx[8 + 3 * lane], a2 = (float)sx[9 + 3 * lane];
+      const float th2 = a0 * a0 + a1 * a1 + a2 * a2;
+      float st = 1.0f, omc = 0.0f, w0 = a0, w1 = a1, w2 = a2;      // first-order branch: R - I = [a]x
+      if (th2 > 1e-20f) {
+        const float ith = rsqrtf(th2), th = th2 * ith;
+        float sh, ch;
+        sincosf(0.5f * th, &sh, &ch);
+        st = 2.0f * sh * ch; omc = 2.0f * sh * sh;                  // 1 - cos without cancellation
+        w0 = a0 * ith; w1 = a1 * ith; w2 = a2 * ith;
+      }
+      const float on = Pb.pose_blend ? 1.0f : 0.0f;
+      float* o = cf + 9 * lane;                                     // R - I = sin [w]x + (1 - cos) (w w^T - I)
+      o[0] = on * (omc * (w0 * w0 - 1.0f)); o[1] = on * (omc * w0 * w1 - st * w2); o[2] = on * (omc * w0 * w2 + st * w1);
+      o[3] = on * (omc * w1 * w0 + st * w2); o[4] = on * (omc * (w1 * w1 - 1.0f)); o[5] = on * (omc * w1 * w2 - st * w0);
+      o[6] = on * (omc * w2 * w0 - st * w1); o[7] = on * (omc * w2 * w1 + st * w0); o[8] = on * (omc * (w2 * w2 - 1.0f));
+    } else if (lane >= 32 && lane - 32 < 16 * kBlendKSteps - kPoseFeat) {
+      const int i = lane - 32;                                        // slot 207 + i: beta_i, the template's two slots, padding
+      cf[kPoseFeat + i] = (i < nS) ? (float)sbeta[i] : ((i == kMaxShape || i == kMaxShape + 1) ? 1.0f : 0.0f);
+    }
+    if (lane < 32)
+      for (int k = nfeat + lane; k < kPoseFeat; k += 32) cf[k] = 0.0f;   // (models with fewer joints: the unused pose slots)
+  }
   if (o_lane) {   // 3 nJ <= 72 < 128: one item per lane
     const int i = o_i;
     double o = o_pre, jc = jc_pre;
@@ -466,6 +503,41 @@ __device__ __forceinline__ void frame_part(const DevModel& M, const DevProblem& 
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (lane == 0) __hip_atomic_fetch_add(const_cast<int*>(sWalkDone), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   }
+  if (coef_wave) {
+    // the 56 fragments of the blend coefficients out of the scratch wave 5 filled in phase B, write-through; drain; ONE
+    // agent-scope add to the coefficient counter of the frame's 32-frame unit (cdna guide, Guideline 16 R1) — all in front of
+    // this wave's landmark loads (vmcnt would cover them too)
+    const float* cf = reinterpret_cast<const float*>(sW);
+    if (lane < kBlendKSteps * 4) {
+      const int kstep = lane >> 2, h = (lane >> 1) & 1, hl = lane & 1;
+      const float4 v0 = *reinterpret_cast<const float4*>(cf + 16 * kstep + 8 * h);
+      const float4 v1 = *reinterpret_cast<const float4*>(cf + 16 * kstep + 8 * h + 4);
+      const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+      uint32_t pk[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        uint16_t b[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const uint16_t hi = f32_to_bf16(x[2 * q + t]);
+          b[t] = hl == 0 ? hi : f32_to_bf16(x[2 * q + t] - bf16_to_f32(hi));
+        }
+        pk[q] = (uint32_t)b[0] | ((uint32_t)b[1] << 16);
+      }
+      // MFMA row of this frame inside its 32-frame tile: accumulator register i of half-wave h holds frame 2 i + h, so that one
+      // register row covers two CONSECUTIVE frames (2,304 contiguous bytes of transforms)
+      const int ftile = f / kFTile, phi = f % kFTile;
+      const int row = 8 * (phi >> 3) + 4 * (phi & 1) + ((phi >> 1) & 3);
+      uint4* dst = reinterpret_cast<uint4*>(reinterpret_cast<unsigned char*>(mc.featA) + ((size_t)ftile * kBlendKSteps + kstep) * 2048 +
+                                            feat_frag_off(h * 32 + row, hl));
+      store_operand16<true>(dst, make_uint4(pk[0], pk[1], pk[2], pk[3]));
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    STAMP_REAL(14);
+    if (lane == 0)
+      (void)__hip_atomic_fetch_add(fu.flag + (size_t)(f / kFTile) * kUnitCounterStride + kUnitCoefOffset, 1u, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+  }
   double pdv0[27];
   if (lm_wave0) lm_load(lm_l, pdv0);
   for (int i = tid; i < 208; i += kThreads) {
@@ -527,7 +599,7 @@ __device__ __forceinline__ void frame_part(const DevModel& M, const DevProblem& 
   // thing, in the shadow of its landmark posedirs loads, and they have long left when it says so (below).  (Measured and
   // rejected: on wave 6, the phase's lightest wave, in front of its chain walk — wave 0 is this phase's longest wave by 1.8 k
   // cycles — : wave 7 then waits for wave 6's later walk, the transforms go out 2 us later and the phase is no shorter.)
-  if (wave == 0 && mc.featA) {
+  if (!kFused && wave == 0 && mc.featA) {
     // MFMA row of this frame inside its 32-frame tile.  feat_perm (k_sweep_roles' mesh role): accumulator register i of the
     // half-wave h holds frame 2 i + h, so that one register row covers two CONSECUTIVE frames (2,304 contiguous bytes of
     // transforms); otherwise (k_mesh_blend_lbs) the natural order, register i <-> frames 8 (i >> 2) + (i & 3) + 4 h.
@@ -608,8 +680,7 @@ __device__ __forceinline__ void frame_part(const DevModel& M, const DevProblem& 
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (lane == 0) __hip_atomic_fetch_add(const_cast<int*>(sWalkDone), 256, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   }
-  // (one-launch sweep: the blend coefficients are not this role's any more — the coefficient role publishes them ~2 us into
-  //  the launch, mesh_role_inl.h — so wave 0 has no stores to drain and nothing to signal here)
+  // (one-launch sweep: the blend coefficients left at the top of this phase, by wave 5)
   if (wave == 7) {
     STAMP(13);
     for (int spin = 0; spin < (1 << 20) && *sWalkDone < 257; ++spin) __builtin_amdgcn_s_sleep(1);

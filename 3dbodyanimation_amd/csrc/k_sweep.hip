@@ -3,9 +3,7 @@
 //
 //   k_frame_resjac    frame_part_inl.h as its own launch: residuals + analytic Jacobian, one workgroup per frame
 //   k_mesh_blend_lbs  mesh_part_inl.h as its own launch: one workgroup per 32-vertex tile, all frames
-//   k_sweep_roles     the whole sweep as ONE launch whose workgroups take one of four roles (by block index):
-//                       coefficient role  mesh_role_inl.h coef_role: the blend coefficients of 16 frames from their raw
-//                                   parameters (f32 Rodrigues), published ~2 us into the launch; the first blocks
+//   k_sweep_roles     the whole sweep as ONE launch whose workgroups take one of three roles (by block index):
 //                       frame role  frame_part_inl.h for one frame; publishes the frame's mesh operands (blend coefficients,
 //                                   skinning transforms: 2 KB) inside the launch
 //                       mesh role   mesh_role_inl.h for one 32-vertex tile x one group of 256 frames; each of its eight waves
@@ -202,11 +200,9 @@ __global__ __launch_bounds__(kThreads, 4) void k_sweep_roles(RoleArgs by_value) 
   int role = 2, idx = 0, grp = 0;
   {
     const int nG = (F + kRoleGroup - 1) / kRoleGroup;
-    const int nC = (F + kCoefFrames - 1) / kCoefFrames;   // coefficient blocks: the first of the launch
-    int pos = (int)blockIdx.x - nC;
+    int pos = (int)blockIdx.x;
     const int n0 = min(kRoleGroup, F);
-    if (pos < 0) { role = 3; idx = (int)blockIdx.x; }
-    else if (pos < n0) { role = 0; idx = pos; }
+    if (pos < n0) { role = 0; idx = pos; }
     else {
       pos -= n0;
       bool found = false;
@@ -225,18 +221,10 @@ __global__ __launch_bounds__(kThreads, 4) void k_sweep_roles(RoleArgs by_value) 
       }
     }
   }
-  if (role == 3) {
-    const DevModel M = A->M;
-    const DevProblem Pb = A->Pb;
-    const MeshCoef mc = A->mc;
-    coef_role(M, Pb, A->params, A->beta, mc, idx, A->sy.flag, lds);
-    return;
-  }
   if (role == 0) {
     const DevModel M = A->M;
     const DevProblem Pb = A->Pb;
-    MeshCoef mc = A->mc;
-    mc.featA = nullptr;   // the blend coefficients are the coefficient role's (mesh_role_inl.h): transforms and joints only
+    const MeshCoef mc = A->mc;
     FusedFrame fu;
     fu.flag = A->sy.flag;
     fu.epoch = A->sy.epoch;
@@ -324,7 +312,8 @@ __global__ __launch_bounds__(kThreads, 4) void k_sweep_roles(RoleArgs by_value) 
   auto fail = [&]() {
     if (threadIdx.x == 0) __hip_atomic_store(error_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   };
-  mesh_role(M, Pb, mc, A->cloud_f, idx, grp, lds, (int)blockIdx.x < A->sy.resident_blocks, ctr, want, wait_unit, fail);
+  mesh_role(M, Pb, mc, A->cloud_f, idx, grp, lds, (int)blockIdx.x < A->sy.resident_blocks, ctr, want, wait_unit, fail,
+            A->sy.mesh_prio_early, A->sy.trickle_start, A->sy.trickle_sleep);
 #endif
 }
 
@@ -373,7 +362,7 @@ void launch_sweep_roles(const DevModel& M, const DevProblem& P, const double* d_
                               kRoleLdsBytes);
   });
   const int nG = (P.F + kRoleGroup - 1) / kRoleGroup;
-  const int grid = (P.F + kCoefFrames - 1) / kCoefFrames + P.F + nG * M.nVTiles + pa.n_tiles;
+  const int grid = P.F + nG * M.nVTiles + pa.n_tiles;
   RoleArgs A;
   A.M = M; A.Pb = P; A.Pb.feat_perm = 1; A.params = d_params; A.beta = d_beta; A.r_out = d_r; A.J_out = d_J;
   A.joints_out = d_joints; A.mc = mc; A.want_jac = want_jac; A.pa = pa; A.cloud_f = d_cloud; A.sy = sy; A.fold = fold;

@@ -100,6 +100,9 @@ struct RoleLane {                // per-lane constants of the skinning rows
 
 struct RoleCtx {
   lds_u8* ring;                  // LDS base (region A, then region T)
+  unsigned ring_addr;            // ... as an integer + lane * 16: the B-fragment reads take their address from it (an LDS read
+                                 // through a pointer hipcc can trace is made to wait for every LDS-DMA in flight, i.e. for region
+                                 // A while k-steps 0-8 read region T)
   lds_u8* trow;                  // this wave's transform ring slots 0-2 (region T)
   lds_u8* trow3;                 // ... and slot 3 (region A)
   __amdgpu_buffer_rsrc_t dirs_rsrc, skin_rsrc;   // the model's operand blocks; the hand-off buffer of transforms
@@ -151,11 +154,12 @@ __device__ __forceinline__ void role_blend_step(const RoleCtx& C, const __amdgpu
     }
     acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, blo, acc[c], 0, 0, 0);
     acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo, bhi, acc[c], 0, 0, 0);
-    if constexpr (S + 1 < kResident) {   // the next k-step's fragments of this coordinate, under the other coordinates' products
-      const lds_u8* sl = C.ring + role_slab_off(S + 1) + (c * 2) * 1024 + C.lane * 16;
-      bq[c][0] = *reinterpret_cast<lds_u32x4*>(sl);
-      bq[c][1] = *reinterpret_cast<lds_u32x4*>(sl + 1024);
-    } else if constexpr (S + 1 < kBlendKSteps) {   // the 14th k-step is not resident: L2 -> registers, a k-step of matrix work ahead
+    if constexpr (S + 1 < kResident && S + 1 != kRegionTSlabs) {   // the next k-step's fragments of this coordinate, under the other
+                                                                   // coordinates' products (slab 9: behind the barrier, mesh_role)
+      const unsigned sl = C.ring_addr + (unsigned)(role_slab_off(S + 1) + (c * 2) * 1024);
+      bq[c][0] = *(lds_u32x4*)(size_t)(sl);
+      bq[c][1] = *(lds_u32x4*)(size_t)(sl + 1024u);
+    } else if constexpr (S + 1 >= kResident && S + 1 < kBlendKSteps) {   // the 14th k-step is not resident: L2 -> registers, a k-step of matrix work ahead
       const unsigned so = C.dirs_soff + (unsigned)((S + 1) * kSlabBytes + (c * 2) * 1024);
       bq[c][0] = __builtin_amdgcn_raw_buffer_load_b128(C.dirs_rsrc, (unsigned)(C.lane * 16), so, 0);
       bq[c][1] = __builtin_amdgcn_raw_buffer_load_b128(C.dirs_rsrc, (unsigned)(C.lane * 16), so + 1024, 0);
@@ -171,8 +175,8 @@ __device__ __forceinline__ void role_blend_step(const RoleCtx& C, const __amdgpu
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
     __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);                                        // MFMA
-    if constexpr (S + 1 < kResident) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);       // DS read
-    else if constexpr (S + 1 < kBlendKSteps) __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);   // VMEM read
+    if constexpr (S + 1 < kResident && S + 1 != kRegionTSlabs) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);       // DS read
+    else if constexpr (S + 1 >= kResident && S + 1 < kBlendKSteps) __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);   // VMEM read
   }
   if constexpr (S + 3 < kBlendKSteps) __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);     // VMEM read
   __builtin_amdgcn_sched_barrier(0);
@@ -226,121 +230,21 @@ __device__ __forceinline__ void role_skin_row(const RoleCtx& C, const RoleLane& 
   asm volatile("" ::: "memory");
 }
 
-// ---- coefficient role: the blend coefficients (MFMA A fragments) of 16 frames --------------------------------------------
+// ---- where the blend coefficients (MFMA A fragments) come from ------------------------------------------------------------------
 // The A operand of the blend is [vec(R_j - I), j = 1..23 | beta | 1 1 0..] per frame: it depends on the frame's raw parameters
-// only.  When the frame role produced it (round 3), a mesh wave could not start its blend before 5.2 us (table round trip,
-// phase B's Rodrigues + gradient, phase C's pack, drain, signal) + detection = 7.4 us into the launch.  This role computes
-// nothing else: parameters -> Rodrigues in f32 (the mesh is an f32 product split in bf16 hi + lo: the f64 rotation of the frame
-// role, rounded to f32, and the f32 rotation differ by ~1e-7 relative on coefficients that multiply centimetre-scale
-// directions; mesh tolerance 5e-6 m) -> fragments, write-through -> one agent-scope add of its frame count to the unit's
-// coefficient counter.  Its blocks are the FIRST of the launch, two per 32-frame unit.
-constexpr int kCoefFrames = 16;
-constexpr int kCoefLdsFloats = kCoefFrames * 16 * kBlendKSteps;   // [16 frames][224 coefficients]
-#ifdef BODYFIT_STAMPS
-#define CSTAMP(i)                                                                                              \
-  do {                                                                                                         \
-    if (Pb.dbg && threadIdx.x == 0) {                                                                          \
-      unsigned long long t_;                                                                                   \
-      asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                          \
-      Pb.dbg[kStampBase - 8192 + (size_t)blk * 16 + (i)] = t_;                                                 \
-    }                                                                                                          \
-  } while (0)
-#else
-#define CSTAMP(i)
-#endif
-
-__device__ __forceinline__ void coef_role(const DevModel& M, const DevProblem& Pb, const double* __restrict__ params,
-                                          const double* __restrict__ beta, const MeshCoef& mc, int blk, unsigned* flag_base,
-                                          unsigned char* lds_generic) {
-  constexpr int kK = 16 * kBlendKSteps;   // 224
-  float* sf = reinterpret_cast<float*>(lds_generic);
-  const int tid = threadIdx.x;
-  const int nJ = M.nJ, nS = M.nS, npose = 7 + 3 * (nJ - 1);
-  const int f0 = blk * kCoefFrames, nf = min(kCoefFrames, Pb.F - f0);
-  const int nrot = kCoefFrames * (nJ - 1);                       // (frame, joint) items: 368 <= 512, one pass
-  CSTAMP(0);
-  // every load first (one round trip)
-  const int fr = min(tid / (nJ - 1), kCoefFrames - 1), j = tid - (tid / (nJ - 1)) * (nJ - 1);
-  const double* aa = params + (size_t)(f0 + min(fr, nf - 1)) * npose + 7 + 3 * j;
-  const double a0d = aa[0], a1d = aa[1], a2d = aa[2];
-  const int bfr = min(tid / kMaxShape, kCoefFrames - 1), bk = tid % kMaxShape;
-  double bv = 0.0;
-  if (Pb.use_shape && beta && bk < nS) bv = beta[(size_t)(f0 + min(bfr, nf - 1)) * Pb.beta_stride + bk];
-  if (tid < nrot) {
-    const float a0 = (float)a0d, a1 = (float)a1d, a2 = (float)a2d;
-    const float th2 = a0 * a0 + a1 * a1 + a2 * a2;
-    float R[9];
-    if (th2 > 1e-20f) {
-      const float ith = rsqrtf(th2), th = th2 * ith;
-      float sh, ch;
-      sincosf(0.5f * th, &sh, &ch);
-      const float st = 2.0f * sh * ch, omc = 2.0f * sh * sh;    // 1 - cos without cancellation
-      const float w0 = a0 * ith, w1 = a1 * ith, w2 = a2 * ith;
-      // R - I = sin [w]x + (1 - cos) (w w^T - I)
-      R[0] = omc * (w0 * w0 - 1.0f); R[1] = omc * w0 * w1 - st * w2; R[2] = omc * w0 * w2 + st * w1;
-      R[3] = omc * w1 * w0 + st * w2; R[4] = omc * (w1 * w1 - 1.0f); R[5] = omc * w1 * w2 - st * w0;
-      R[6] = omc * w2 * w0 - st * w1; R[7] = omc * w2 * w1 + st * w0; R[8] = omc * (w2 * w2 - 1.0f);
-    } else {   // first-order branch (the frame role's own: include/Sim3BA.h:61 through ceres::AngleAxisRotatePoint)
-      R[0] = 0.0f; R[1] = -a2; R[2] = a1; R[3] = a2; R[4] = 0.0f; R[5] = -a0; R[6] = -a1; R[7] = a0; R[8] = 0.0f;
-    }
-    const float on = (Pb.pose_blend && fr < nf) ? 1.0f : 0.0f;
-#pragma unroll
-    for (int e = 0; e < 9; ++e) sf[fr * kK + 9 * j + e] = on * R[e];
-  }
-  if (tid < kCoefFrames * kMaxShape) sf[bfr * kK + kPoseFeat + bk] = (bfr < nf) ? (float)bv : 0.0f;
-  if (tid < kCoefFrames * (kK - kPoseFeat - kMaxShape)) {     // the template's two slots (coefficient 1.0), then K's padding
-    const int pf = tid / (kK - kPoseFeat - kMaxShape), pk = tid % (kK - kPoseFeat - kMaxShape);
-    sf[pf * kK + kPoseFeat + kMaxShape + pk] = (pk < 2 && pf < nf) ? 1.0f : 0.0f;
-  }
-  if (9 * (nJ - 1) < kPoseFeat) {   // (models with fewer joints: the unused pose slots)
-    for (int i = tid; i < kCoefFrames * (kPoseFeat - 9 * (nJ - 1)); i += kThreads)
-      sf[(i / (kPoseFeat - 9 * (nJ - 1))) * kK + 9 * (nJ - 1) + i % (kPoseFeat - 9 * (nJ - 1))] = 0.0f;
-  }
-  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-  CSTAMP(1);
-  // fragments: item = (k-step, hi / lo, k-half, frame): 16 bytes = eight consecutive coefficients of one frame
-  const int unit = f0 / kFTile, phi0 = f0 % kFTile;
-  unsigned char* base = reinterpret_cast<unsigned char*>(mc.featA) + (size_t)unit * kBlendKSteps * 2048;
-#pragma unroll
-  for (int u = 0; u < (kCoefFrames * kBlendKSteps * 4 + kThreads - 1) / kThreads; ++u) {
-    const int it = tid + u * kThreads;
-    if (it < kCoefFrames * kBlendKSteps * 4) {
-      const int kstep = it >> 6, rem = it & 63, hl = rem >> 5, h = (rem >> 4) & 1, fl = rem & 15;
-      const int phi = phi0 + fl;
-      // MFMA row of the frame inside its unit: accumulator register i of half-wave h holds frame 2 i + h (frame_part_inl.h)
-      const int row = Pb.feat_perm ? (8 * (phi >> 3) + 4 * (phi & 1) + ((phi >> 1) & 3)) : phi;
-      const float4 v0 = *reinterpret_cast<const float4*>(sf + fl * kK + kstep * 16 + 8 * h);
-      const float4 v1 = *reinterpret_cast<const float4*>(sf + fl * kK + kstep * 16 + 8 * h + 4);
-      const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-      uint32_t pk[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        uint16_t b[2];
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          const uint16_t hi = f32_to_bf16(x[2 * q + t]);
-          b[t] = hl == 0 ? hi : f32_to_bf16(x[2 * q + t] - bf16_to_f32(hi));
-        }
-        pk[q] = (uint32_t)b[0] | ((uint32_t)b[1] << 16);
-      }
-      typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_;
-      const u32x4_ val = {pk[0], pk[1], pk[2], pk[3]};
-      void* dst = base + (size_t)kstep * 2048 + feat_frag_off(h * 32 + row, hl);
-      asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(val) : "memory");
-    }
-  }
-  // hand-off (cdna guide, Guideline 16 R1): every storing wave's stores have left, then ONE add for the block's frames
-  CSTAMP(2);
-  asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-  CSTAMP(3);
-  if (tid == 0 && nf > 0)
-    (void)__hip_atomic_fetch_add(flag_base + (size_t)unit * kUnitCounterStride + kUnitCoefOffset, (unsigned)nf, __ATOMIC_RELAXED,
-                                 __HIP_MEMORY_SCOPE_AGENT);
-#ifdef BODYFIT_STAMPS
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  CSTAMP(4);
-#endif
-}
+// only.  In round 3 wave 0 of the frame role packed it in phase C from the f64 rotations and published it 5.2 us into the launch;
+// with the hand-off across XCDs (write-through drain, agent-scope add, the consumer's sc1 look: each a trip through the fabric of
+// 0.4-1 us) a mesh wave saw it at 7.2 us.  Now wave 5 of the frame role computes it in phase B, in f32, from the raw parameters
+// (frame_part_inl.h): ~2 us earlier.  Measured on the way and rejected (profiles/r4_*_stamps*.txt):
+//   * a dedicated coefficient role, 16 blocks in front of the launch, one copy published across XCDs: no earlier than round 3
+//     (fragments in LDS at 1.9 us, but stores drained at 4.5 us behind the mesh role's operand stream, signalled 4.9, seen 7.0);
+//   * the hand-off kept INSIDE an XCD's L2 (every item computed once per XCD into a copy of its own, plain stores, flag words):
+//     as 128 extra blocks it pushed the launch past its 512 resident workgroups (a hundred mesh workgroups entered at 5.7 us);
+//     by waves 6 and 7 of the mesh workgroups (no piece of the operand stream) it took one wave 5 us per eight frames; by four
+//     waves of every frame workgroup (eight frames each, no LDS, two rotations per thread) 12 k cycles of phase B — each of them
+//     1,300 instructions of selects —: 33 us per step.  What was learnt about L2-local signalling: a look at a flag must be a
+//     SCALAR load with glc (straight to the L2); a vector load with sc0 (workgroup scope) may hit in the CU's L1 — the first look
+//     parked the line there and every later one read that copy until the wait ran out —, with sc1 it goes past the L2.
 
 // One workgroup: vertex tile `vtile`, frames [256 group, 256 group + 256).  flags_ready: the caller has waited for the
 // group's hand-off flags (or the operands are from an earlier launch).  `lds`: kRoleLdsBytes.
@@ -350,12 +254,14 @@ __device__ __forceinline__ void coef_role(const DevModel& M, const DevProblem& P
 template <typename WaitUnit, typename Fail>
 __device__ __forceinline__ void mesh_role(const DevModel& M, const DevProblem& Pb, const MeshCoef& mc, float* __restrict__ cloud_f,
                                           int vtile, int group, unsigned char* lds_generic, bool beside_its_frames,
-                                          const unsigned* unit_ctr, unsigned unit_want, WaitUnit wait_unit, Fail fail) {
+                                          const unsigned* unit_ctr, unsigned unit_want, WaitUnit wait_unit, Fail fail,
+                                          int prio_early, int trickle_start, int trickle_sleep) {
   RoleCtx C;
   C.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   C.lane = threadIdx.x & 63;
   lds_u8* lds = (lds_u8*)lds_generic;
   C.ring = lds;
+  C.ring_addr = (unsigned)(size_t)lds + (unsigned)C.lane * 16u;
   C.trow = lds + kRegionABytes + C.wave * kTWaveBytes;
   C.trow3 = lds + C.wave * kTSlot3Bytes;
   C.dirs_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(M.dirsB), 0, M.nVTiles * kBBytes, 0x00020000);
@@ -370,31 +276,26 @@ __device__ __forceinline__ void mesh_role(const DevModel& M, const DevProblem& P
   C.slab_voff = C.piece * 1024 + C.lane * 16;
   const int col = C.lane & 31, h = C.lane >> 5;
   const int v = vtile * kVTile + col;
-
   RSTAMP(0);
-  // one look at the unit's counter before anything else (loads return in order: it is back before the operand stream below):
-  // a workgroup dispatched late finds its frames long handed over and never polls
-  unsigned look0 = 0;
-  asm volatile("global_load_dword %0, %1, off sc1" : "=v"(look0) : "v"(unit_ctr + kUnitCoefOffset) : "memory");
-  // ---- independent of the frame workgroups: thirteen of the tile's fourteen operand slabs (78 KiB), the lane's skinning
-  //      weights.  They land under the wait for the hand-off. -----------------------------------------------------------
+  // ---- independent of every other workgroup: the tile's operand slabs, the lane's skinning weights --------------------------
   const uint32_t widx = M.wIdx[(size_t)vtile * 32 + col];
   const float4 wv = reinterpret_cast<const float4*>(M.wVal)[(size_t)vtile * 32 + col];
-  // A workgroup that is resident from the start of the launch runs BESIDE the frame workgroups it waits for: its stream is a
-  // trickle, not a burst — requested all at once (17 MB chip-wide) it stretched the frame workgroups' table loads by 900
-  // cycles and their hand-off by 2 us, which every mesh workgroup then waits for; nothing needs it before the hand-off:
-  // one slab per ~0.25 us from 1.2 us on (past the frame workgroups' table loads).  A workgroup dispatched later (more
-  // frames than one group: its frames were handed over long ago) requests everything at once.
+  // First the nine slabs of region T (k-steps 0-8), which is all the blend needs before its barrier in front of k-step 9; the
+  // four slabs of region A follow behind the first barrier, under the first k-steps.
+  // A workgroup that is resident from the start of the launch runs BESIDE the frame workgroups: its stream is a trickle, not a
+  // burst — requested all at once (17 MB chip-wide) it stretched the frame workgroups' table loads by 900 cycles and their
+  // hand-off of the transforms by 2 us: one slab per ~0.25 us from 1.2 us on (past the frame workgroups' table loads).  A
+  // workgroup dispatched later (more frames than one group) requests everything at once.
   if (C.wave < 6) {   // six pieces per slab: waves 6 and 7 have none
     if (beside_its_frames) {
       const unsigned long long t_in = __builtin_amdgcn_s_memrealtime();
-      while (__builtin_amdgcn_s_memrealtime() - t_in < 120) __builtin_amdgcn_s_sleep(8);
+      while (__builtin_amdgcn_s_memrealtime() - t_in < (unsigned long long)trickle_start) __builtin_amdgcn_s_sleep(8);
     }
 #pragma unroll 1
-    for (int s = 0; s < kResident; ++s) {
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(C.dirs_rsrc, (__attribute__((address_space(3))) void*)(C.ring + role_slab_off(s) + C.piece * 1024),
-                                               16, C.slab_voff, C.dirs_soff + (unsigned)s * kSlabBytes, 0, 0);
-      if (beside_its_frames) __builtin_amdgcn_s_sleep(7);
+    for (int s = 0; s < kRegionTSlabs; ++s) {
+      role_dma_slab(C, s);
+      if (beside_its_frames)
+        for (int z = 0; z < trickle_sleep; ++z) __builtin_amdgcn_s_sleep(1);
     }
   }
   RoleLane L;
@@ -409,26 +310,51 @@ __device__ __forceinline__ void mesh_role(const DevModel& M, const DevProblem& P
   L.out_off = (unsigned)h * stride + (unsigned)v * 12;
   const __amdgpu_buffer_rsrc_t cloud =
       __builtin_amdgcn_make_buffer_rsrc(cloud_f, 0, (int)((unsigned)nFT * kFTile * stride), 0x00020000);
-  const __amdgpu_buffer_rsrc_t feat_rsrc =
-      __builtin_amdgcn_make_buffer_rsrc(mc.featA, 0, nFT * kBlendKSteps * 2 * 1024, 0x00020000);
   const unsigned feat_off = (unsigned)((active ? ftile : 0) * kBlendKSteps * 2 * 1024);
 
-  // every wave's pieces of the resident slabs have landed (requested microseconds ago), the control word is clear
-  volatile unsigned* ctrl = reinterpret_cast<volatile unsigned*>(lds_generic + kRoleCtrlOff);
+  // every wave's pieces of slabs 0-8 have landed, the control word is clear
+  // (an LDS pointer, not a generic one: a FLAT store anywhere in front of the blend makes hipcc's wait-count pass drain vmcnt
+  //  and lgkmcnt to 0 at the next use of any loaded register — the first product then waits for every fragment load in flight)
+  volatile __attribute__((address_space(3))) unsigned* ctrl =
+      (volatile __attribute__((address_space(3))) unsigned*)(lds + kRoleCtrlOff);
   if (threadIdx.x == 0) ctrl[0] = 0u;
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" : "+v"(look0)::"memory");
-  // ---- this wave's 32-frame unit has published its BLEND COEFFICIENTS (the transforms follow ~2 us later and are needed in
-  //      front of k-step 9 only): each wave waits for ITS unit alone and starts its blend at once (the
-  //      units' slowest frames are 6.6-8.2 us after the launch's start: a wave that starts early has the SIMD to itself for the
-  //      first nine k-steps; the workgroup meets again at the barrier in front of k-step 9).  A wait that runs out leaves a mark
-  //      the whole workgroup acts on behind that barrier. ------------------------------------------------------------------
-  if (active && look0 != unit_want && !wait_unit(unit_ctr + kUnitCoefOffset)) ctrl[0] = 1u;
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0) in a form hipcc's wait-count pass sees: region T is not "in flight" any more
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  // ---- this wave's 32-frame unit has published its BLEND COEFFICIENTS (frame role, wave 5: ~3.5 us into the launch; the
+  //      transforms follow at ~6 us and are needed in front of k-step 9 only): each wave waits for ITS unit alone (sc1 looks: a
+  //      round trip to the memory side) and starts its blend at once.  A wait that runs out leaves a mark the whole workgroup
+  //      acts on behind the barrier of k-step 9. ------------------------------------------------------------------------------
+  if (active && !wait_unit(unit_ctr + kUnitCoefOffset)) ctrl[0] = 1u;
   RSTAMP(1);
-  // from here on the mesh role is the launch's critical path: the frame workgroup beside it is past its hand-off
-  __builtin_amdgcn_s_setprio(3);
+  // from here on the mesh role is the launch's critical path
+  // ... but until its transforms are in (k-step 9) it must not take issue slots from the frame workgroup beside it, which still
+  // owes them (at priority 3 from here, the blend stretched the frame role's phase C from 7.3 k to 9.4 k cycles and then waited
+  // 6.7 k cycles for the transforms in front of k-step 9)
+  if (prio_early == 0) __builtin_amdgcn_s_setprio(0);
+  else if (prio_early == 1) __builtin_amdgcn_s_setprio(1);
+  else if (prio_early == 2) __builtin_amdgcn_s_setprio(2);
+  else __builtin_amdgcn_s_setprio(3);
 
   f32x16 acc[3];
   u32x4 a[3][2], bq[3][2];
+  const __amdgpu_buffer_rsrc_t feat_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(mc.featA, 0, nFT * kBlendKSteps * 2 * 1024, 0x00020000);
+  // One straight-line block from the first fragment load to k-step 8 (a branch with loads in flight makes hipcc's wait-count
+  // pass fall back to vmcnt(0) at the join — here: the first product would wait for region A to land).  Region A (slabs
+  // 9-12) is requested by EVERY wave behind its first fragment loads (loads return in order), waves 6 and 7 asking for pieces
+  // 0 and 1 a second time (same bytes to the same place, an L2 hit); it lands under k-steps 0-8 and is waited for together with
+  // the transform counter's look below.
+  RSTAMP(2);
+#define RB(S) RCYC(S); role_blend_step<S>(C, feat_rsrc, feat_off, acc, a, bq)
+  // Two things happen on the way: (1) in front of k-step 9 the workgroup's waves meet (barrier): every wave has read slabs 0-8
+  // (region T) into registers and every wave's pieces of region A have landed, region T becomes the waves' transform rings;
+  // (2) the unit's TRANSFORMS (handed over across XCDs by the frame role's wave 7, 6-8 us into the launch, + 1-2 us until a
+  // look from here sees them) are needed only by the rows' LDS-DMA, which takes ~1 us to land: one look at their counter in
+  // front of k-step 7, acted on behind k-step 10 (eight fragment loads are issued behind it, so it is back at vmcnt(8)), rows
+  // 0-2 requested there, under the last three k-steps.  (Round 3 and the first forms of this round waited for the transforms
+  // in front of k-step 9, at the barrier: with the blend starting 1.3 us earlier than then, that is where it stood — 4.6 k
+  // cycles — until the slowest of the unit's 32 frames had handed over.)
+  unsigned look1 = unit_want;
   if (active) {
 #pragma unroll
     for (int ks = 0; ks < 3; ++ks) {
@@ -436,39 +362,41 @@ __device__ __forceinline__ void mesh_role(const DevModel& M, const DevProblem& P
       a[ks][0] = __builtin_amdgcn_raw_buffer_load_b128(feat_rsrc, feat_frag_off(C.lane, 0), soff, kLoadSc1);
       a[ks][1] = __builtin_amdgcn_raw_buffer_load_b128(feat_rsrc, feat_frag_off(C.lane, 1), soff, kLoadSc1);
     }
-  }
-  RSTAMP(2);
-  if (active) {
+    __builtin_amdgcn_sched_barrier(0);   // (all six fragment loads in front of the slab requests: loads return in order)
+#pragma unroll
+    for (int s = kRegionTSlabs; s < kResident; ++s) role_dma_slab(C, s);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-      const lds_u8* sl = C.ring + role_slab_off(0) + (c * 2) * 1024 + C.lane * 16;
-      bq[c][0] = *reinterpret_cast<lds_u32x4*>(sl);
-      bq[c][1] = *reinterpret_cast<lds_u32x4*>(sl + 1024);
+      const unsigned sl = C.ring_addr + (unsigned)(role_slab_off(0) + (c * 2) * 1024);
+      bq[c][0] = *(lds_u32x4*)(size_t)(sl);
+      bq[c][1] = *(lds_u32x4*)(size_t)(sl + 1024u);
     }
-  }
-#define RB(S) RCYC(S); role_blend_step<S>(C, feat_rsrc, feat_off, acc, a, bq)
-  // the unit's transforms: one look at their counter four k-steps (~1.5 us) ahead of the barrier behind which the first rows are
-  // requested; eight fragment loads are issued behind it, so it is back at vmcnt(8).  Normally complete; else poll (bounded).
-  unsigned look1 = unit_want;
-  if (active) {
-    RB(0); RB(1); RB(2); RB(3); RB(4);
+    RB(0); RB(1); RB(2); RB(3); RB(4); RB(5); RB(6);
     asm volatile("global_load_dword %0, %1, off sc1" : "=v"(look1) : "v"(unit_ctr) : "memory");
-    RB(5); RB(6); RB(7); RB(8);
+    RB(7); RB(8);
+    // this wave's pieces of region A have landed: everything but the look and the four fragment loads behind it
+    asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+  } else {   // (a wave without a unit still carries its pieces of region A)
+#pragma unroll
+    for (int s = kRegionTSlabs; s < kResident; ++s) role_dma_slab(C, s);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  if (active) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {   // slab 9's fragments (k-step 8 could not request them: region A was still landing)
+      const unsigned sl = C.ring_addr + (unsigned)(role_slab_off(kRegionTSlabs) + (c * 2) * 1024);
+      bq[c][0] = *(lds_u32x4*)(size_t)(sl);
+      bq[c][1] = *(lds_u32x4*)(size_t)(sl + 1024u);
+    }
+    RB(9); RB(10);
     asm volatile("s_waitcnt vmcnt(8)" : "+v"(look1)::"memory");
     if (look1 != unit_want && !wait_unit(unit_ctr)) ctrl[0] = 1u;
-  }
-  // k-step 9: every wave has read slabs 0-8 (region T) into registers, and slab 9 too (its reads were issued in k-step 8):
-  // region T becomes the waves' transform rings, rows 0-2 are requested now and land under the last five k-steps
-  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-  if (ctrl[0] != 0u) {   // (workgroup-uniform: written before the barrier) a unit never arrived: leave, the host falls back
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    fail();
-    return;
-  }
-  if (active) {
-    role_dma_row(C, 0); role_dma_row(C, 1); role_dma_row(C, 2);
+    else { role_dma_row(C, 0); role_dma_row(C, 1); role_dma_row(C, 2); }
     asm volatile("" ::: "memory");
-    RB(9); RB(10); RB(11); RB(12); RB(13);
+    __builtin_amdgcn_s_setprio(3);
+    RB(11); RB(12); RB(13);
   }
 #undef RB
   RCYC(14);
@@ -476,6 +404,11 @@ __device__ __forceinline__ void mesh_role(const DevModel& M, const DevProblem& P
   __builtin_amdgcn_sched_barrier(0);   // (MFMAs are not memory operations: without this the last ones drift into the skinning rows)
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   __builtin_amdgcn_sched_barrier(0);
+  if (ctrl[0] != 0u) {   // (workgroup-uniform: written before the barrier) a unit never arrived: leave, the host re-issues
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    fail();
+    return;
+  }
   if (!active) return;
   RSTAMP(3);
   role_dma_row(C, 3);

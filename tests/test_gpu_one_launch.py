@@ -53,6 +53,16 @@ def _problem(gm, seq, fused, shared=False, gmm=None):
                                          gmm=gmm, beta_shape=30.0, want_mesh=True)
 
 
+def _timeouts(p):
+    """one-launch sweeps of the problem whose in-launch wait ran out (the synchronous entry points re-issue those as two launches
+    without telling: the tests must look, or a broken hand-off would pass as a slow success)"""
+    import ctypes as C
+    lib = api.load_library()
+    lib.bodyfit_internal_fused_timeouts.argtypes = [C.c_void_p]
+    lib.bodyfit_internal_fused_timeouts.restype = C.c_long
+    return lib.bodyfit_internal_fused_timeouts(p.h)
+
+
 def _compare(pf, pt, x, beta):
     rf, Jf, cf = pf.evaluate(x, beta, True)
     rt, Jt, ct = pt.evaluate(x, beta, True)
@@ -63,6 +73,7 @@ def _compare(pf, pt, x, beta):
     np.testing.assert_allclose(Jf, Jt, rtol=0, atol=1e-9)
     np.testing.assert_allclose(jf, jt, rtol=0, atol=1e-12)
     np.testing.assert_allclose(clf, clt, rtol=0, atol=2e-6)
+    assert _timeouts(pf) == 0
     return rf, Jf, clf
 
 
@@ -283,10 +294,13 @@ def test_reduction_at_the_tail_of_a_shard(model):
 
 
 def test_a_wait_that_runs_out_is_reported_and_the_problem_falls_back(model):
-    """Every in-launch wait is bounded.  With the bound set to one tick (test hook) the mesh and prior workgroups give up at
-    once: the sweep must come back (no hang), the next synchronous entry point must report the incomplete sweep, and from
-    then on the problem uses the two-launch sweep — whose results are the reference ones."""
+    """Every in-launch wait is bounded (by polls).  With the bound set to zero polls (test hook: one tick) the mesh workgroups give
+    up at once and the prior workgroups go on without waiting: the sweep must come back (no hang); r, J, components and the folded
+    reduction never depend on a wait and are complete; the synchronous entry points notice the incomplete cloud, re-issue the
+    sweep as two launches themselves and return the reference results; an asynchronous caller learns of it from
+    bodyfit_sweep_status; from then on the problem uses the two-launch sweep."""
     import ctypes as C
+    import torch
     m, gm = model
     F = 40
     seq = synth.make_sequence(m, F, seed=3)
@@ -298,16 +312,44 @@ def test_a_wait_that_runs_out_is_reported_and_the_problem_falls_back(model):
     good = _problem(gm, seq, False, gmm=gmm)
     r_ref, J_ref, _ = good.evaluate(x, beta, True)
     _, cloud_ref = good.forward(x, beta)
-    prob = _problem(gm, seq, True, gmm=gmm)
     lib = api.load_library()
     lib.bodyfit_internal_set_role_timeout.argtypes = [C.c_void_p, C.c_ulonglong]
+    lib.bodyfit_internal_fused_timeouts.argtypes = [C.c_void_p]
+    lib.bodyfit_internal_fused_timeouts.restype = C.c_long
+    # (a) synchronous entry point: re-issued inside the call
+    prob = _problem(gm, seq, True, gmm=gmm)
     assert lib.bodyfit_internal_set_role_timeout(prob.h, 1) == 0
-    with pytest.raises(api.BodyfitError, match="timed out"):
-        prob.evaluate(x, beta, True)
+    _, cloud = prob.forward(x, beta)
+    assert lib.bodyfit_internal_fused_timeouts(prob.h) == 1
+    assert np.array_equal(cloud, cloud_ref)
     r, J, _ = prob.evaluate(x, beta, True)          # two launches from here on
     assert np.array_equal(r, r_ref) and np.array_equal(J, J_ref)
-    _, cloud = prob.forward(x, beta)
-    assert np.array_equal(cloud, cloud_ref)
     before = api.launch_count()
     prob.evaluate(x, beta, True)
     assert api.launch_count() - before >= 2
+    assert lib.bodyfit_internal_fused_timeouts(prob.h) == 1
+    # (b) asynchronous caller: evaluate_device + reduce_shared_device, then bodyfit_sweep_status
+    prob2 = _problem(gm, seq, True, shared=True)
+    good2 = _problem(gm, seq, False, shared=True)
+    dev = torch.device("cuda", 0)
+    dx, db = torch.from_numpy(x).to(dev), torch.from_numpy(seq.gt_beta).to(dev)
+    out, out_ref = torch.zeros(66, dtype=torch.float64, device=dev), torch.zeros(66, dtype=torch.float64, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    good2.evaluate_device(dx.data_ptr(), db.data_ptr(), True, st)
+    good2.reduce_shared_device(out_ref.data_ptr(), st)
+    good2.sweep_status(st)                                     # nothing to report
+    prob2.arm_shared_reduction(out.data_ptr())
+    assert lib.bodyfit_internal_set_role_timeout(prob2.h, 1) == 0
+    prob2.evaluate_device(dx.data_ptr(), db.data_ptr(), True, st)
+    prob2.reduce_shared_device(out.data_ptr(), st)
+    with pytest.raises(api.BodyfitError, match="timed out"):
+        prob2.sweep_status(st)
+    # the 66 doubles of THAT sweep (every frame's robustified J_beta, r and the prior rows) are complete all the same: only the
+    # cloud was cut short
+    assert np.array_equal(out.cpu().numpy(), out_ref.cpu().numpy())
+    prob2.sweep_status(st)                                     # reported once
+    prob2.evaluate_device(dx.data_ptr(), db.data_ptr(), True, st)   # now two launches: complete
+    prob2.sweep_status(st)
+    _, cloud2 = prob2.forward(x, seq.gt_beta)
+    _, cloud2_ref = good2.forward(x, seq.gt_beta)
+    assert np.array_equal(cloud2, cloud2_ref)

@@ -34,9 +34,9 @@ torch.cuda.synchronize()
 raw = buf.cpu().numpy()
 fr = raw[:F * 8 * 16].reshape(F, 8, 16).astype(np.float64)
 ms = raw[BASE:BASE + nG * nvt * 8 * 16].reshape(nG * nvt, 8, 16).astype(np.float64)
-nC = (F + 15) // 16
+nC = 2 * ((F + 31) // 32)
 cf = raw[BASE - 8192:BASE - 8192 + nC * 16].reshape(nC, 16).astype(np.float64)
-t0 = min(fr[:, 0, 10].min(), ms[:, :, 0].min(), cf[:, 0].min())
+t0 = min(fr[:, 0, 10].min(), ms[:, :, 0].min())
 us = lambda a: (a - t0) / 100.0
 def q(a):
     a = np.asarray(a, dtype=np.float64).ravel()
@@ -49,8 +49,7 @@ c0 = w7[:, 2]   # start of phase C (shader cycles)
 print("frame role wave 7, shader cycles into phase C: walks done", q(w7[:, 13] - c0), "| wave 6 + 0 seen", q(w7[:, 14] - c0),
       "| operands stored", q(w7[:, 15] - c0), "| end of C", q(w7[:, 3] - c0))
 print("                   own stores drained (us)", q(us(w7[:, 9])), "| signalled (us)", q(us(w7[:, 12])), "| waiting for wave 0's drain", q((w7[:, 12] - w7[:, 9]) / 100))
-print("coef role: entry", q(us(cf[:, 0])), "| fragments in LDS", q(us(cf[:, 1])), "| stores issued", q(us(cf[:, 2])))
-print("           drained", q(us(cf[:, 3])), "| signalled (add acknowledged)", q(us(cf[:, 4])))
+print("frame role: blend coefficients drained, about to be signalled (wave 5, top of phase C)", q(us(fr[:, 5, 14])), "| slowest frame of each unit:", np.round([us(fr[u * 32:(u + 1) * 32, 5, 14]).max() for u in range((F + 31) // 32)][:8], 2))
 print("frame role: transforms published (wave 7), slowest frame of each unit:", np.round([us(fr[u * 32:(u + 1) * 32, 7, 12]).max() for u in range((F + 31) // 32)][:8], 2))
 pub = us(fr[:, 7, 12])
 late = np.argsort(pub)[-24:]
