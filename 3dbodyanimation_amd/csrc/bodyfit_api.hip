@@ -166,6 +166,9 @@ struct bodyfit_problem {
   // probe sweep found non-zero cross PCIe, k_pack_jacobian's layout
   Pinned<double> c_Jp;
   std::vector<unsigned> pk_mask, pk_off;   // [K] block masks, [K + 1] offsets (doubles) into the packed buffer
+  std::vector<short> pk_src;               // [K][32]: where block b of keypoint k starts inside the keypoint's packed row, -1: absent
+                                           // (bodyfit_evaluate_block_cached serves a block with one table look-up instead of a walk
+                                           // over the mask)
   unsigned* d_pk_mask = nullptr;
   unsigned* d_pk_off = nullptr;
   double* d_Jp = nullptr;
@@ -921,6 +924,7 @@ static int build_pack_tables(bodyfit_problem* p, hipStream_t st) {
   const int nblocks = 3 + (nJ - 1) + (has_beta ? 1 : 0);
   p->pk_mask.assign((size_t)K, 0u);
   p->pk_off.assign((size_t)K + 1, 0u);
+  p->pk_src.assign((size_t)K * 32, (short)-1);
   size_t total = 0;
   for (int k = 0; k < K; ++k) {
     const double* J0 = p->c_J.data() + (size_t)(2 * k) * n;
@@ -936,6 +940,16 @@ static int build_pack_tables(bodyfit_problem* p, hipStream_t st) {
     }
     p->pk_mask[k] = mask;
     p->pk_off[k] = (unsigned)total;
+    {
+      short* src = p->pk_src.data() + (size_t)k * 32;
+      int at = 0;
+      for (int blk = 0; blk < 32; ++blk) {
+        const int sz = blk == 0 ? 1 : (blk < 3 + (nJ - 1) ? 3 : n - npose);
+        const bool present = blk < nblocks && ((mask >> blk) & 1u);
+        src[blk] = present ? (short)at : (short)-1;
+        if (present) at += sz;
+      }
+    }
     total += 2 * (size_t)ncol;
   }
   if (total >= ((size_t)1 << 32)) return fail(BODYFIT_ERR_INVALID, "packed Jacobian exceeds 2^32 doubles");
@@ -1458,6 +1472,16 @@ static int solve_window_device(bodyfit_problem* p, double* frame_params, double*
   double status[kWsCount] = {0};
   bool first = true;
   const size_t rhs = (size_t)kWinRhs * kWinBlock;
+  // Sharded solves: a rank whose own work fails (a kernel launch, a HIP call) must not simply return — its peers would wait for
+  // it in the next all-gather for ever.  It marks slot 6 of its scalars (`poison`), keeps taking part in the exchanges of the
+  // iteration, and k_win_decide ends the solve on EVERY rank in that same iteration (kWsPoison).  Only a failure of the
+  // transport itself still returns at once (the process group / RCCL needs a timeout for that case).
+  int poison = BODYFIT_OK;
+  std::string poison_msg;
+  if (sharded) HIP_TRY(hipMemsetAsync(W.fin, 0, 8 * sizeof(double), st));
+  // test hook (tests/test_gpu_sharded_solve.py): BODYFIT_TEST_POISON="<rank>:<iteration>" makes that rank's sweep "fail" there
+  int test_poison_rank = -1, test_poison_iter = -1;
+  if (const char* tp = std::getenv("BODYFIT_TEST_POISON")) (void)std::sscanf(tp, "%d:%d", &test_poison_rank, &test_poison_iter);
   for (int it = 0; it < opt->max_iters; ++it) {
     launch_frame_normal_sel(F, n, p->d.kp_offset, p->desc.huber_delta, p->d_r, p->d_J, d_rn, d_Jn, W.status + kWsJsel,
                             p->lay.total_rows, p->d_frame_normal, st);
@@ -1543,9 +1567,14 @@ static int solve_window_device(bodyfit_problem* p, double* frame_params, double*
     } else {
       // the candidate is evaluated whatever the decision will be (it is taken once, below, from everybody's scalars)
       rc = sweep(p, d_xn, d_bn, 1, false, st, nullptr, d_rn, d_compn, nullptr, 0, nullptr, false, d_Jn);
-      if (rc) return rc;
+      if (R == test_poison_rank && it == test_poison_iter) rc = fail(BODYFIT_ERR_HIP, "test hook: this rank's sweep failed");
+      if (rc && !poison) { poison = rc; poison_msg = g_err; }
       ++n_sweeps;
       launch_win_accept(P, W, d_rn, d_x, d_b, d_xn, d_bn, 3, st);       // this shard's cost at the candidate -> W.fin[5]
+      if (poison) {
+        static const double one = 1.0;
+        (void)hipMemcpyAsync(W.fin + 6, &one, sizeof(double), hipMemcpyHostToDevice, st);
+      }
       if ((rc = gather(W.fin, 8, "allgather (scalars)"))) return rc;
       launch_win_decide(P, W, d_x, d_b, d_xn, d_bn, d_gath, N, halo ? d_x + (size_t)F * npose : nullptr, d_xn + (size_t)F * npose,
                         has_left ? d_xl : nullptr, d_xln, st);
@@ -1569,6 +1598,11 @@ static int solve_window_device(bodyfit_problem* p, double* frame_params, double*
   HIP_TRY(hipMemcpyAsync(frame_params, d_x, (size_t)rows_x * npose * sizeof(double), hipMemcpyDeviceToHost, st));
   HIP_TRY(hipMemcpyAsync(beta, d_b, (size_t)nb * sizeof(double), hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
+  if (sharded && (poison || status[kWsPoison] != 0.0)) {
+    if (summary) { summary->iterations = (int)status[kWsIters]; summary->termination = 2; summary->usable = 0; }
+    if (poison) return fail(poison, "sharded solve: this rank failed (" + poison_msg + "); every rank left at the same exchange");
+    return fail(BODYFIT_ERR_HIP, "sharded solve: another rank reported a device failure; every rank left at the same exchange");
+  }
   if (summary) {
     summary->iterations = (int)status[kWsIters];
     summary->termination = status[kWsActive] != 0.0 ? 1 : (int)status[kWsTermination];
@@ -1857,22 +1891,38 @@ static void serve_block(bodyfit_problem* p, int kind, int index, int frame, doub
     residuals[0] = p->c_r[2 * (size_t)index];
     residuals[1] = p->c_r[2 * (size_t)index + 1];
     if (jacobians && p->cache_packed) {
-      // packed cache: [present columns of row 0 | of row 1] of this keypoint, blocks in order; the others are zero
-      const unsigned mask = p->pk_mask[index], o0 = p->pk_off[index], nc = (p->pk_off[index + 1] - o0) >> 1;
+      // packed cache: [present columns of row 0 | of row 1] of this keypoint, blocks in order; the others are zero.  Where a
+      // block starts comes from a per-keypoint table made with the pack tables (no walk over the mask: at C3 the 6,400
+      // reprojection blocks of an evaluation point were most of the Ceres-side time); 3-column blocks written as six stores
+      const unsigned o0 = p->pk_off[index], nc = (p->pk_off[index + 1] - o0) >> 1;
       const double* P0 = p->c_Jp.data() + o0;
       const double* P1 = P0 + nc;
-      const int nblocks = 3 + (nJ - 1) + (has_beta ? 1 : 0);
-      int at = 0;
-      for (int blk = 0; blk < nblocks; ++blk) {
-        const int sz = blk == 0 ? 1 : (blk < 3 + (nJ - 1) ? 3 : nS);
-        const bool present = (mask >> blk) & 1u;
-        if (jacobians[blk]) {
-          for (int i = 0; i < sz; ++i) {
-            jacobians[blk][i] = present ? P0[at + i] : 0.0;
-            jacobians[blk][sz + i] = present ? P1[at + i] : 0.0;
+      const short* src = p->pk_src.data() + (size_t)index * 32;
+      const int nj3 = 3 + (nJ - 1);
+      if (double* J = jacobians[0]) {
+        const int a = src[0];
+        J[0] = a >= 0 ? P0[a] : 0.0; J[1] = a >= 0 ? P1[a] : 0.0;
+      }
+      for (int blk = 1; blk < nj3; ++blk) {
+        double* J = jacobians[blk];
+        if (!J) continue;
+        const int a = src[blk];
+        if (a >= 0) {
+          J[0] = P0[a]; J[1] = P0[a + 1]; J[2] = P0[a + 2];
+          J[3] = P1[a]; J[4] = P1[a + 1]; J[5] = P1[a + 2];
+        } else {
+          J[0] = J[1] = J[2] = J[3] = J[4] = J[5] = 0.0;
+        }
+      }
+      if (has_beta) {
+        if (double* J = jacobians[nj3]) {
+          const int a = src[nj3];
+          if (a >= 0) {
+            for (int i = 0; i < nS; ++i) { J[i] = P0[a + i]; J[nS + i] = P1[a + i]; }
+          } else {
+            for (int i = 0; i < 2 * nS; ++i) J[i] = 0.0;
           }
         }
-        if (present) at += sz;
       }
     } else if (jacobians) {
       const double* J0 = p->c_J.data() + (size_t)(2 * index) * L.n_cols;

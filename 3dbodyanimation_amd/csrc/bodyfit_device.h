@@ -218,6 +218,7 @@ enum {   // status record of the window LM (doubles), read back by the host once
   kWsCost = 0, kWsRadius, kWsDec, kWsModel, kWsHasCand, kWsIters, kWsOk, kWsBad, kWsTermination, kWsActive,
   kWsInitialCost, kWsAccepted, kWsGmax, kWsNewCost,
   kWsJsel,          // which Jacobian the next k_frame_normal reads: 0 the starting point's, 1 the accepted candidate's, 2 none (rejected)
+  kWsPoison,        // sharded solves: some rank reported a device failure in its scalars (slot 6); the solve has ended on every rank
   kWsCount = 16
 };
 struct WinProblem {

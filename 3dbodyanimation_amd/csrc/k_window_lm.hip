@@ -1261,12 +1261,23 @@ __global__ __launch_bounds__(256) void k_win_decide(WinProblem P, WinBuf W, doub
                                                     const double* __restrict__ xn_halo, double* __restrict__ x_left,
                                                     const double* __restrict__ xn_left) {
   const int tid = threadIdx.x;
-  double pm = 0.0, dn = 0.0, xn = 0.0, gm = 0.0, fl = 0.0, cost = 0.0;
+  double pm = 0.0, dn = 0.0, xn = 0.0, gm = 0.0, fl = 0.0, cost = 0.0, poison = 0.0;
   for (int r = 0; r < N; ++r) {
     const double* o = g + (size_t)r * 8;
     pm += o[0]; dn += o[1]; xn += o[2];
     gm = fmax(gm, o[3]); fl = fmax(fl, o[4]);
     cost += o[5];
+    poison = fmax(poison, o[6]);
+  }
+  if (poison != 0.0) {
+    // A rank could not produce its part of this iteration (a failed launch / HIP call: bodyfit_api.hip puts a 1 in slot 6 of its
+    // scalars and keeps taking part in the exchanges).  Every rank reads the same gathered scalars, so every rank ends the solve
+    // HERE, in the same iteration: nothing moves, the host loops find the solve inactive at their next status read and return.
+    if (tid == 0) {
+      W.status[kWsActive] = 0.0; W.status[kWsTermination] = 2.0; W.status[kWsHasCand] = 0.0; W.status[kWsJsel] = 2.0;
+      W.status[kWsPoison] = poison;
+    }
+    return;
   }
   if (tid == 0 && fl != 0.0) *W.fail = 1;
   __syncthreads();

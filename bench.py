@@ -9,6 +9,9 @@ One "step" = one pass of the hot path over one batch of synthetic frames, inputs
   workgroup and a mesh workgroup share a CU and run at the same time; the mesh operands are handed over inside the launch).
   BODYFIT_ONE_LAUNCH=0 gives the two-launch form (k_frame_resjac, k_mesh_blend_lbs) for A/B runs
   [-> reduce_shared + RCCL all-reduce of 66 doubles for the shared-shape workload].
+`python bench.py --gpus N` starts its N ranks itself (a child torch.distributed.run) when no launcher did; at every N the line
+carries `value` = C3 (weak scaling, no collective) and `c5_strong` = configs[4] sharded over the same ranks (sweep with the
+RCCL all-reduce, fit with the RCCL all-gathers).
 One "eval" = all of that for one frame.
 
 Workloads
@@ -31,6 +34,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+RECORD_OUT = sys.stdout   # where the JSON record goes (main() points it at a private copy of the original stdout)
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 HBM_COPY_GBS = 6290.0  # the guide's measured copy rate, reported beside the spec fraction
 # algorithmic bytes (SURVEY.md §8d / BASELINE.md §4), f32 model tensors read once per launch
@@ -221,9 +225,139 @@ def c5_fit(args, api, synth, model, gm, dist, rank, world, local_rank):
                          "note": "the Jacobian sweep of one shard inside the fit (no mesh); a fit iteration is latency-bound: "
                                  "cyclic-reduction levels of 76 x 76 f64 block factorisations"},
         }
-        print(json.dumps(out))
+        print(json.dumps(out), file=RECORD_OUT, flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def self_launch(n_gpus):
+    """The N > 1 form of the driver's contract when no launcher set the rank environment: one child
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py <same flags>`;
+    rank 0's JSON line is relayed on stdout, everything else the ranks print goes to stderr, the exit code is the child's."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: what RCCL needs on this pool's hosts
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in proc.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if line is not None:
+        print(line, flush=True)
+    sys.exit(proc.returncode if proc.returncode else (0 if line is not None else 1))
+
+
+def c5_strong(args, api, synth, model, gm, dist, rank, world, local_rank):
+    """BASELINE.json configs[4] on THIS run's ranks, reported beside the C3 value in the same line: one 1024-frame multi-frame
+    window (shared beta, L2 pose prior, temporal links: OptimizeMultiFrame, include/MultiFrameBA.h:33-177) sharded over the N
+    ranks by frame.
+      sweep  the evaluation every LM iteration needs: the shard's residual + Jacobian + mesh sweep, the shared-beta reduction at the
+             sweep's own tail (or one reduce launch for shards of more than 256 frames), and ONE ncclAllReduce(sum, f64) of the 66
+             doubles [cost | g_beta | H_bb] issued by the library on the same stream (bodyfit_allreduce_shared_rccl): no host
+             synchronisation and no Python hop between sweep and collective
+      fit    the window fitted to convergence from the reference's initial state by bodyfit_solve_sharded_rccl (three
+             ncclAllGather per LM iteration on the solve's device buffers)
+    The communicator is the library's own (ncclCommInitRank from an id rank 0 draws); `rccl_ranks` is what RCCL itself reports
+    for it (ncclCommCount).  Rehearsals on a one-GPU box (BENCH_BACKEND=gloo, every rank on cuda:0) use torch.distributed's
+    gloo for the collective and the host-callback transport for the fit, and say so."""
+    import torch
+    sharded = importlib.import_module("3dbodyanimation_amd.sharded")
+    Fw = args.window
+    backend = os.environ.get("BENCH_BACKEND", "nccl")
+    dev = torch.device("cuda", local_rank)
+    full = synth.make_sequence(model, Fw, seed=0)
+    shard = sharded.make_shard(Fw, world, rank)
+    sl = sharded.slice_sequence(full, shard)
+    kw = dict(n_cols=86, use_shape=True, beta_pose=5.0, beta_shape=25.0 if shard.owns_shape_prior else 0.0, lambda_temporal=3.0,
+              temporal_halo=shard.halo)
+    prob = api.Problem(gm, sl["kp_offset"], sl["kp_id"], sl["kp_uv"], sl["intr"], sl["R0"], want_mesh=True, **kw)
+    rccl = sharded.make_rccl(api, dist, rank, world, local_rank) if backend == "nccl" else None
+    rccl_ranks = rccl.count()[0] if rccl is not None else None
+    d_params = torch.from_numpy(np.ascontiguousarray(full.gt_params[shard.f0:shard.f1 + (1 if shard.halo else 0)] + 0.01)).to(dev)
+    d_beta = torch.from_numpy(np.ascontiguousarray(full.gt_beta + 0.01)).to(dev)
+    d_red = torch.zeros(66, dtype=torch.float64, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    prob.arm_shared_reduction(d_red.data_ptr())
+
+    def step():
+        prob.evaluate_device(d_params.data_ptr(), d_beta.data_ptr(), True, stream)
+        prob.reduce_shared_device(d_red.data_ptr(), stream)
+        if rccl is not None:
+            rccl.allreduce_shared(d_red.data_ptr(), stream)
+        elif world > 1:
+            h = d_red.cpu()
+            dist.all_reduce(h)
+            d_red.copy_(h)
+
+    def bracket(fn, n):
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            out = fn()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else None)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, out
+
+    for _ in range(args.warmup):
+        step()
+    dt_sweep, _ = bracket(step, args.steps)
+    prob.sweep_status(stream)          # (asynchronous sweeps: their in-launch waits all came through)
+    total = d_red.cpu().numpy().copy()
+    # the fit: a problem without the mesh (the LM never reads it), same shard
+    fprob = api.Problem(gm, sl["kp_offset"], sl["kp_id"], sl["kp_uv"], sl["intr"], sl["R0"], **kw)
+    comm = sharded.TorchComm(api, dist, rank, world, device=None) if (rccl is None and world > 1) else None
+    x0 = sharded.local_params(full.init_params, shard)
+
+    def fit():
+        if rccl is not None and world > 1:
+            return fprob.solve_sharded_rccl(x0, np.zeros(10), rccl, max_iters=1000)
+        if world > 1:
+            return fprob.solve_sharded(x0, np.zeros(10), comm.c, max_iters=1000)
+        x, b, sm = fprob.solve(x0, np.zeros(10), independent=False, max_iters=1000, scale_bounds=(-1e300, 1e300), solver=3)
+        return x, b, sm[0]
+
+    fit()
+    n_fit = 2
+    dt_fit, (_, _, summ) = bracket(fit, n_fit)
+    out = None
+    if rank == 0:
+        out = {
+            "workload": f"C5: one {Fw}-frame multi-frame window (25 keypoints per frame, shared beta, L2 pose prior 5, shape prior 25, "
+                        f"temporal 3, mesh on in the sweep) sharded by frame over {world} GPU(s)",
+            "scaling": "strong", "window": Fw, "n_gpus": world, "frames_per_gpu": shard.n_local,
+            "rccl_ranks": rccl_ranks,
+            "transport": ("RCCL (library-owned communicator): ncclAllReduce for the evaluation, ncclAllGather for the fit, on the "
+                          "work's own stream") if rccl is not None else "torch.distributed gloo on host buffers (one-GPU rehearsal)",
+            "sweep": {"evals_per_s": Fw * args.steps / dt_sweep, "us_per_step": dt_sweep / args.steps * 1e6, "steps": args.steps,
+                      "collective": "one all-reduce (sum, f64) of 66 doubles per step" if world > 1 or rccl is not None else None,
+                      "reduced_cost": float(total[0])},
+            "fit": {"frames_per_s": Fw * n_fit / dt_fit, "seconds": dt_fit / n_fit, "iterations": summ.iterations,
+                    "successful": summ.n_successful, "termination": summ.termination, "initial_cost": summ.initial_cost,
+                    "final_cost": summ.final_cost, "ms_per_iteration": dt_fit / n_fit * 1e3 / max(1, summ.iterations),
+                    "exchanges_total": fprob.last_exchange_count() if world > 1 else 0,
+                    "exchanges_per_iteration": ((fprob.last_exchange_count() - 4) / max(1, summ.iterations)) if world > 1 else 0},
+        }
+    if rccl is not None:
+        rccl.close()
+    return out
 
 
 def main():
@@ -239,6 +373,8 @@ def main():
     ap.add_argument("--no-ceres-path", action="store_true", help="skip the Ceres-kept-path record (needs g++ on the box)")
     ap.add_argument("--cpu-sample-frames", type=int, default=0)
     ap.add_argument("--no-fit", action="store_true", help="skip the frames/sec-to-convergence record")
+    ap.add_argument("--no-c5-strong", action="store_true",
+                    help="skip the c5_strong object (configs[4] sharded over this run's ranks: sweep with the RCCL all-reduce, fit)")
     ap.add_argument("--fit", action="store_true",
                     help="with --workload c5: a step is one complete LM fit of the window (frames/sec to convergence), sharded "
                          "over the GPUs by bodyfit_solve_sharded; defaults then to --steps 5 --warmup 1")
@@ -249,6 +385,20 @@ def main():
         if "--warmup" not in sys.argv:
             args.warmup = 1
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N ranks as a CHILD torch.distributed.run (one process per
+        # GPU, RCCL over xGMI) and relay its line.  Nothing in this process has touched the GPU yet (not even `import torch`),
+        # and it never does: a process that has initialised the GPU must not be replaced or forked into ranks.
+        return self_launch(args.gpus)
+
+    # stdout carries ONE line, the JSON record.  Libraries write there too (RCCL prints a version banner on stdout when a
+    # communicator is created): from here on file descriptor 1 points at stderr and the record goes out through a private copy
+    # of the original stdout.
+    global RECORD_OUT
+    sys.stdout.flush()
+    RECORD_OUT = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
 
@@ -256,8 +406,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus} "
+                         f"(or without a launcher at all: bench.py then starts its ranks itself)")
     # rehearsal switches (tests only): BENCH_SHARE_DEVICE0=1 puts every rank on cuda:0 and BENCH_BACKEND=gloo replaces
     # RCCL, so the N > 1 code path can be exercised on a one-GPU box; the driver's runs use neither
     if os.environ.get("BENCH_SHARE_DEVICE0"):
@@ -316,15 +466,22 @@ def main():
     torch.cuda.set_stream(work_stream)
     stream = work_stream.cuda_stream
 
+    rccl = None
     if with_reduce:
         prob.arm_shared_reduction(d_red.data_ptr())   # shards of <= 256 frames: the reduction rides on the sweep's tail
+        if world > 1 and os.environ.get("BENCH_BACKEND", "nccl") == "nccl":
+            rccl = sharded.make_rccl(api, dist, rank, world, local_rank)
 
     def step():
         prob.evaluate_device(d_params.data_ptr(), d_beta.data_ptr(), True, stream)
         if with_reduce:
             prob.reduce_shared_device(d_red.data_ptr(), stream)
-            if world > 1:
-                dist.all_reduce(d_red)
+            if rccl is not None:      # ncclAllReduce issued by the library on the sweep's stream (bodyfit_allreduce_shared_rccl)
+                rccl.allreduce_shared(d_red.data_ptr(), stream)
+            elif world > 1:           # one-GPU rehearsal over gloo
+                h = d_red.cpu()
+                dist.all_reduce(h)
+                d_red.copy_(h)
 
     for _ in range(args.warmup):
         step()
@@ -345,6 +502,11 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    # configs[4] on the same ranks, in the same line (default workload only: `value` stays the C3 figure at every N)
+    strong = None
+    if args.workload == "c3" and not args.no_c5_strong:
+        strong = c5_strong(args, api, synth, model, gm, dist, rank, world, local_rank)
+
     # per-kernel durations with HIP events on the launch stream (same inputs, same stream)
     prof = prob.profile_sweep(d_params.data_ptr(), d_beta.data_ptr(), True, with_reduce, min(100, max(10, args.steps)), stream)
 
@@ -356,8 +518,13 @@ def main():
                "frame_resjac": F * (608 + 80 + 500 + 400 + 34_400 + 24 * 12 * 4 + 217 * 4)}
         pmc_name = {"mesh_blend_lbs": "k_mesh_blend_lbs", "frame_resjac": "k_frame_resjac", "sweep_roles": "k_sweep_roles"}
         fused = prof.get("sweep_roles", 0.0) > 0.0
-        if fused:   # the sweep was ONE launch (frame, mesh and prior roles side by side): its bytes are the two parts' bytes
-            alg = {"sweep_roles": alg["mesh_blend_lbs"] + alg["frame_resjac"]}
+        if fused:
+            # the sweep was ONE launch (frame, mesh and prior roles side by side): the kernel IS the pipeline, so its algorithmic
+            # bytes are SURVEY.md 8d's B(F) = B_model + F B_frame exactly (49,705,648 B at 256 frames) — the same figure
+            # `pipeline` divides by the step time.  (Rounds 2-3 summed the two launches' own figures here, which count the
+            # in-launch hand-off — transforms + coefficients, 2,020 B per frame — on both sides and leave the dense J_regressor out:
+            # +0.8 %.)
+            alg = {"sweep_roles": B_MODEL_ALL + F * B_FRAME_ALL}
         # HBM bytes per launch: rocprofv3 cannot run inside this process, so `traffic` is what the committed --pmc passes
         # of THIS command measured (tools/profile_round.sh writes profiles/rN_xx_pmc_traffic.json: FETCH_SIZE doubled per the
         # gfx950 note + WRITE_SIZE); `traffic_source` names that file.  Null when no committed pass matches the workload
@@ -399,11 +566,16 @@ def main():
                          "traffic_source": (os.path.relpath(pm_src, ROOT) + " (rocprofv3 --pmc passes of this command, "
                                             "committed; not measured in this run)") if pm else None,
                          "algorithmic_bytes_per_launch": bytes_launch, "avg_launch_ms": prof[dom],
+                         "algorithmic_bytes_definition": ("SURVEY.md 8d: B(F) = 19,347,120 (f32 model tensors, read once per launch) + "
+                                                         "F x 118,588 (params, keypoints, r, J, posed vertices)") if fused else
+                                                        "per kernel: the model tensors it reads + its per-frame inputs and outputs",
                          "kernels": kernels},
             "kernel_ms": prof,
             "pipeline": {"algorithmic_bytes_per_step": B_MODEL_ALL + F * B_FRAME_ALL, "achieved_GBps": whole,
                          "frac_of_hbm_peak": whole / HBM_PEAK_GBS, "frac_of_measured_copy_rate": whole / HBM_COPY_GBS},
         }
+        if strong is not None:
+            out["c5_strong"] = strong
         if world == 1:
             # the rate a kept ceres::Solve would see: host parameters up, one sweep, residuals + Jacobian down (page-locked
             # mirrors, the problem's own stream); never `value`
@@ -449,7 +621,7 @@ def main():
                 # on all 256 hardware threads of the box is ten times SLOWER (fork/join of the OpenMP pool per evaluation)
                 fit["cpu_baseline"] = fit_bench.cpu_fit_baseline(synth, model, threads=min(8, os.cpu_count() or 8))
             out["fit"] = fit
-        print(json.dumps(out))
+        print(json.dumps(out), file=RECORD_OUT, flush=True)
     if world > 1:
         dist.destroy_process_group()
 

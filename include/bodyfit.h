@@ -291,9 +291,13 @@ int bodyfit_solve(bodyfit_problem* p, double* frame_params, double* beta, const 
  *                                "gloo" in the tests, MPI in a C++ host).  Only `allgather` is called; `allreduce` may be NULL.
  *   bodyfit_solve_sharded_rccl   RCCL on the solve's device buffers and stream (ncclAllGather over xGMI): no host staging and no
  *                                stream synchronisation between the host's status reads (every fourth iteration).
- * Both callbacks / RCCL calls must be entered by every rank of the communicator the same number of times; a rank that fails
- * (HIP error, failed transport) returns an error while its peers wait in the next exchange, so give the process group / RCCL a
- * timeout.
+ * Both callbacks / RCCL calls must be entered by every rank of the communicator the same number of times.  Failures:
+ *   - a rank whose own device work fails inside an LM iteration (a kernel launch, a HIP call) does NOT leave on its own: it marks
+ *     its scalars, keeps taking part in that iteration's exchanges, and the decision kernel ends the solve on EVERY rank in the
+ *     same iteration; all ranks then return an error (the failing one its own, the others "another rank reported a device
+ *     failure") after the same number of exchanges — nobody is left waiting;
+ *   - a failure of the transport itself (a callback that returns non-zero, an RCCL error) returns at once on the rank that saw
+ *     it; its peers may be waiting in that exchange, so give the process group / RCCL a timeout.
  *   frame_params [F_local (+1 halo row)][76] in/out: the halo row is refreshed from the neighbour by the solve. */
 typedef struct bodyfit_comm {
   int rank, size;

@@ -145,30 +145,34 @@ inline int AddResidualBlocks(ceres::Problem* problem, bodyfit_problem* p, const 
   std::vector<int> reproj_sizes = {1, 3, 3};
   for (int j = 0; j < 23; ++j) reproj_sizes.push_back(3);
   if (with_beta) reproj_sizes.push_back(nS);
+  // Block order = the reference's: per frame its reprojection blocks and then its pose prior (include/MultiFrameBA.h:71-112,
+  // include/Sim3BA.h:417-462), [a frame's own shape prior with --opt-shape batches], then the shared shape prior (:115-118),
+  // then the temporal links (:121-142).  (Ceres hands contiguous runs of residual blocks to its evaluation threads: with every
+  // pose prior at the end of the list — the 70 x 69 GMM Jacobian is 38 KB per block — one thread got all of them.)
+  const std::vector<int> prior_sizes(23, 3);
+  const int n_shape_blocks = L.shape_rows > 0 ? L.shape_rows / nS : 0;
   for (int f = 0; f < n_frames; ++f) {
     std::vector<double*> blocks = T.blocks(f);
-    if (with_beta) blocks.push_back(beta + (opt.beta_per_frame ? (size_t)f * nS : 0));
+    std::vector<double*> rb = blocks;
+    if (with_beta) rb.push_back(beta + (opt.beta_per_frame ? (size_t)f * nS : 0));
     for (int k = kp_offset[f]; k < kp_offset[f + 1]; ++k) {
       ceres::LossFunction* loss = opt.huber_delta > 0.0 ? new ceres::HuberLoss(opt.huber_delta) : nullptr;
-      problem->AddResidualBlock(new Block(p, 0, k, 2, reproj_sizes, opt.with_callback), loss, blocks);
+      problem->AddResidualBlock(new Block(p, 0, k, 2, reproj_sizes, opt.with_callback), loss, rb);
+      ++added;
+    }
+    if (L.prior_rows_per_frame > 0) {
+      problem->AddResidualBlock(new Block(p, 1, f, L.prior_rows_per_frame, prior_sizes, opt.with_callback), nullptr,
+                                std::vector<double*>(blocks.begin() + 3, blocks.end()));
+      ++added;
+    }
+    if (n_shape_blocks > 1 && f < n_shape_blocks) {   // beta per frame: the frame's own ShapePriorL2Analytic
+      problem->AddResidualBlock(new Block(p, 2, f, nS, {nS}), nullptr, std::vector<double*>{beta + (size_t)f * nS});
       ++added;
     }
   }
-  if (L.prior_rows_per_frame > 0) {
-    const std::vector<int> sizes(23, 3);
-    for (int f = 0; f < n_frames; ++f) {
-      std::vector<double*> fb = T.blocks(f);
-      problem->AddResidualBlock(new Block(p, 1, f, L.prior_rows_per_frame, sizes, opt.with_callback), nullptr,
-                                std::vector<double*>(fb.begin() + 3, fb.end()));
-      ++added;
-    }
-  }
-  if (L.shape_rows > 0) {
-    const int n_shape_blocks = L.shape_rows / nS;
-    for (int i = 0; i < n_shape_blocks; ++i) {
-      problem->AddResidualBlock(new Block(p, 2, i, nS, {nS}), nullptr, std::vector<double*>{beta + (size_t)i * nS});
-      ++added;
-    }
+  if (n_shape_blocks == 1) {
+    problem->AddResidualBlock(new Block(p, 2, 0, nS, {nS}), nullptr, std::vector<double*>{beta});
+    ++added;
   }
   if (L.temporal_rows > 0) {
     const int n_pairs = L.temporal_rows / 75;

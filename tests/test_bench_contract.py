@@ -23,6 +23,7 @@ def _last_json(out):
 def test_bench_single_gpu_line():
     out = subprocess.run([sys.executable, "bench.py", "--steps", "10", "--warmup", "3", "--no-cpu-baseline"], cwd=ROOT,
                          capture_output=True, text=True, timeout=300)
+    assert len([l for l in out.stdout.splitlines() if l.strip()]) == 1, out.stdout[:600]   # ONE line (RCCL's banner goes to stderr)
     d = _last_json(out.stdout)
     assert KEYS <= set(d), sorted(KEYS - set(d))
     assert d["n_gpus"] == 1 and d["steps"] == 10 and d["warmup"] == 3 and d["vs_baseline"] is None
@@ -45,6 +46,36 @@ def test_bench_single_gpu_line():
     assert d["pcie_inclusive_evals_per_s"] > 0
     cp = d["ceres_path"]
     assert cp["c3"]["points_per_s"] > 0 and cp["c3"]["blocks"] == 256 * 25 + 2 * 256 and cp["c4_window"]["blocks_per_s"] > 0
+    # configs[4] in the same line: at N = 1 the whole 1024-frame window on the one GPU, through a ONE-rank RCCL communicator of the
+    # library (the all-reduce really is issued: rccl_ranks is what ncclCommCount reports)
+    cs = d["c5_strong"]
+    assert cs["n_gpus"] == 1 and cs["window"] == 1024 and cs["frames_per_gpu"] == 1024 and cs["rccl_ranks"] == 1
+    assert cs["sweep"]["evals_per_s"] > 1e6 and cs["fit"]["frames_per_s"] > 100 and cs["fit"]["termination"] == 0
+    assert cs["fit"]["final_cost"] < 0.05 * cs["fit"]["initial_cost"]
+
+
+@pytest.mark.gpu
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher (no WORLD_SIZE): bench.py starts its ranks itself as a child torch.distributed.run
+    and relays rank 0's line — the form a driver that just runs `bench.py --gpus N` gets.  Rehearsed with both ranks on cuda:0
+    over gloo.  The line keeps C3 as `value` (weak scaling) and carries configs[4] sharded over the two ranks as `c5_strong`:
+    the sweep with its all-reduce, the fit with three exchanges per LM iteration."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(BENCH_SHARE_DEVICE0="1", BENCH_BACKEND="gloo")
+    out = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "5", "--warmup", "2", "--window", "64",
+                          "--no-cpu-baseline"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines                                   # ONE JSON line on stdout, whatever the ranks printed
+    d = json.loads(lines[0])
+    assert KEYS <= set(d)
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 1e5 and d["steps"] == 5
+    assert abs(d["value"] - 2 * d["config"]["frames_per_gpu"] / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    cs = d["c5_strong"]
+    assert cs["n_gpus"] == 2 and cs["window"] == 64 and cs["frames_per_gpu"] == 32 and cs["scaling"] == "strong"
+    assert cs["sweep"]["evals_per_s"] > 0 and cs["sweep"]["collective"]
+    assert cs["fit"]["termination"] == 0 and cs["fit"]["final_cost"] < 0.05 * cs["fit"]["initial_cost"]
+    assert cs["fit"]["exchanges_per_iteration"] == 3
 
 
 @pytest.mark.gpu

@@ -89,3 +89,87 @@ def test_rccl_transport_single_rank(monkeypatch):
     assert (summ.iterations, summ.n_successful) == (s2[0].iterations, s2[0].n_successful)
     assert abs(summ.final_cost - s2[0].final_cost) <= 1e-9 * s2[0].final_cost
     assert np.abs(x[:, 1:] - x2[:, 1:]).max() < 1e-7 and np.abs(b - b2).max() < 1e-7
+
+
+def test_rccl_allreduce_of_the_shared_reduction_single_rank():
+    """The evaluation path's one collective issued BY THE LIBRARY (bodyfit_allreduce_shared_rccl: ncclAllReduce(sum, f64) of the
+    66 doubles, in place, on the sweep's stream — SURVEY 8e; the shared shape block of include/MultiFrameBA.h:64-68 summed over
+    the shards).  One GPU, so a communicator of one rank: the call must go through RCCL (ncclCommCount reports the rank count),
+    run stream-ordered behind the sweep + the reduction at the sweep's own tail with no host synchronisation in between, and
+    leave the sum of one shard = that shard's numbers."""
+    import torch
+    sys.path.insert(0, ROOT)
+    api = importlib.import_module("3dbodyanimation_amd.api")
+    synth = importlib.import_module("3dbodyanimation_amd.synth")
+    model = synth.make_model(0)
+    F = 48
+    seq = synth.make_sequence(model, F, seed=4)
+    gm = api.Model(model, device=0)
+    prob = api.Problem.from_sequence(gm, seq, n_cols=86, use_shape=True, beta_pose=5.0, beta_shape=25.0, lambda_temporal=3.0,
+                                     want_mesh=True)
+    comm = api.Rccl.create(api.Rccl.unique_id(), 0, 1, 0)
+    assert comm.count() == (1, 0)
+    dev = torch.device("cuda", 0)
+    x = torch.from_numpy(seq.gt_params + 0.02).to(dev)
+    b = torch.from_numpy(seq.gt_beta + 0.1).to(dev)
+    ref = torch.zeros(66, dtype=torch.float64, device=dev)
+    out = torch.zeros(66, dtype=torch.float64, device=dev)
+    work = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(work):
+        st = work.cuda_stream
+        prob.evaluate_device(x.data_ptr(), b.data_ptr(), True, st)
+        prob.reduce_shared_device(ref.data_ptr(), st)              # a reduce launch: the reference numbers
+        prob.arm_shared_reduction(out.data_ptr())
+        for _ in range(3):                                         # sweep -> (tail reduction) -> all-reduce, back to back
+            prob.evaluate_device(x.data_ptr(), b.data_ptr(), True, st)
+            prob.reduce_shared_device(out.data_ptr(), st)
+            comm.allreduce_shared(out.data_ptr(), st)
+        prob.sweep_status(st)
+    assert torch.equal(out, ref) and float(ref[0]) > 0
+    comm.close()
+
+
+def _poison_worker(rank, world, port, F, iters, fail_rank, fail_iter, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["BODYFIT_TEST_POISON"] = f"{fail_rank}:{fail_iter}"
+    import datetime
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60))
+    api = importlib.import_module("3dbodyanimation_amd.api")
+    synth = importlib.import_module("3dbodyanimation_amd.synth")
+    sharded = importlib.import_module("3dbodyanimation_amd.sharded")
+    model = synth.make_model(0)
+    seq = synth.make_sequence(model, F, seed=6)
+    gm = api.Model(model, device=0)
+    shard = sharded.make_shard(F, world, rank)
+    sl = sharded.slice_sequence(seq, shard)
+    prob = api.Problem(gm, sl["kp_offset"], sl["kp_id"], sl["kp_uv"], sl["intr"], sl["R0"], n_cols=86, use_shape=True,
+                       beta_pose=5.0, beta_shape=25.0 if shard.owns_shape_prior else 0.0, lambda_temporal=3.0,
+                       temporal_halo=shard.halo)
+    comm = sharded.TorchComm(api, dist, rank, world, device=None)
+    msg = ""
+    try:
+        prob.solve_sharded(sharded.local_params(seq.init_params, shard), np.zeros(10), comm.c, max_iters=iters)
+    except api.BodyfitError as e:
+        msg = str(e)
+    with open(os.path.join(out_dir, f"rank{rank}.txt"), "w") as fh:
+        fh.write(f"{prob.last_exchange_count()}\n{msg}\n")
+    dist.barrier()               # both ranks are still in step: a rank stuck in an exchange would hang here (60 s bound)
+    dist.destroy_process_group()
+
+
+def test_a_failing_rank_takes_every_rank_out_at_the_same_exchange(tmp_path):
+    """Cross-rank failure propagation of bodyfit_solve_sharded (include/bodyfit.h): rank 1's sweep 'fails' in LM iteration 5
+    (test hook).  It must not simply return — rank 0 would wait for it in the next all-gather for ever; it marks its scalars,
+    both ranks' decision kernels end the solve in that same iteration, and BOTH calls return an error after the SAME number of
+    exchanges (no hang: the process group's 60 s timeout is never reached)."""
+    world, F, iters = 2, 40, 30
+    port = 29900 + (os.getpid() % 1000)
+    mp.spawn(_poison_worker, args=(world, port, F, iters, 1, 5, str(tmp_path)), nprocs=world, join=True)
+    res = [open(tmp_path / f"rank{r}.txt").read().splitlines() for r in range(world)]
+    n0, n1 = int(res[0][0]), int(res[1][0])
+    assert n0 == n1 and n0 >= 4 + 3 * 6                      # iterations 0 .. 5 were exchanged completely
+    assert n0 <= 4 + 3 * (5 + 4)                             # ... and at most three more before the status read
+    assert "another rank reported a device failure" in res[0][1]
+    assert "this rank failed" in res[1][1] and "test hook" in res[1][1]
