@@ -166,5 +166,151 @@ __device__ __forceinline__ bool diag_factor16_dpp(double (&av)[16], double (&bv)
   return okp;
 }
 
+
+// ---- the same factorisation with the block spread over ALL 64 lanes (round 4) -------------------------------------------------
+// diag_factor16_dpp keeps one row per lane: a rank-1 update of the block is one instruction per COLUMN, sixteen useful lanes
+// each, 31 f64 instructions per pivot at the start of a block; measured 330-416 cycles per pivot (tools/ubench/
+// cr_factor_phases.hip), 42 % of a window-LM iteration and 72 % of the batched LM.  Here the block lives in the layout of an
+// f64 16 x 16 MFMA accumulator, four registers per lane:
+//     a[q], lane (m = lane & 15, kk = lane >> 4)  =  A[kk + 4 q][m]          (the FULL symmetric block, both triangles)
+//     b[q]                                         =  the appended rows (identity -> L^-T), same layout
+// A rank-1 update  A[r][m] -= A[r][c] A[c][m] / piv  of the WHOLE block is then four instructions (one per q), sixty-four
+// useful lanes each:   a[q] += row_newbcast:c(a[q]) * w,   w[m] = -A[c][m] / piv for m > c, 0 otherwise
+// — the broadcast inside a 16-lane row hands every column m the row's entry of column c, and w is row c of A (by symmetry its
+// entries ARE column c), copied from the row of lanes it lives in to all four with two lane-swap instructions (gfx950:
+// v_permlane16_swap / v_permlane32_swap).  Eight updates per pivot (A and the appended rows) whatever the pivot, and NO scaling
+// inside the loop: the columns stay unscaled (A~[r][m] = L[r][m] L[m][m]; the appended rows likewise, see the derivation in
+// DESIGN.md 6 round 4) and are multiplied by 1 / L[m][m] = rsqrt(A~[m][m]) once at the end.  Per pivot: 8 f64 FMAs through DPP,
+// a reciprocal with two Newton steps, one product, ~10 cheap 32-bit moves / swaps / selects.
+// On return a[q] holds L (valid for rows >= column), b[q] the appended rows times L^-T (valid for columns >= row), inv_col
+// (every lane of column m) 1 / L[m][m].  Columns >= nvalid must hold identity padding (unit diagonal, zero couplings).
+namespace acc16 {
+// One-instruction asm statements in issue order, as in dpp16 above: hipcc keeps them where they are written, so the NEXT
+// pivot's dependent chain (copy row C + 1 to all rows -> pivot -> reciprocal + two Newton steps -> w) is interleaved by hand
+// with the current pivot's eight updates.  Hazards kept by construction: a VGPR written by a VALU instruction is read through
+// DPP two or more instructions later; the result of v_rcp_f64 is read one or more instructions later
+// (tools/check_dpp_hazards.py checks the first on the shipped ISA at every build).
+struct Chain {            // the next pivot's chain state
+  unsigned tl, th, ul, uh;  // halves of the two copies being swapped
+  double v, piv, r, e, w;
+};
+__device__ __forceinline__ void mov2(unsigned& dl, unsigned& dh, const double& x) {
+  asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %3" : "=&v"(dl), "=&v"(dh) : "v"(__builtin_bit_cast(uint2, x).x), "v"(__builtin_bit_cast(uint2, x).y));
+}
+template <int C>
+__device__ __forceinline__ void fmac_row_bcast(double& acc, const double& w) {   // acc += acc[lane C of the 16-lane row] * w
+  if constexpr (C == 0)   // (hipcc may copy the freshly loaded block into the registers it picked for the loop right in front of
+                          //  the first update: two wait states between such a copy and the DPP read)
+    asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(w), "n"(C));
+  else
+    asm volatile("v_fmac_f64_dpp %0, %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(w), "n"(C));
+}
+// stage 1: both copies of the register that holds row CN; first swap (rows inside the pairs {0,1}, {2,3})
+template <int CN>
+__device__ __forceinline__ void chain_swap16(Chain& ch, const double& src) {
+  mov2(ch.tl, ch.th, src);
+  mov2(ch.ul, ch.uh, src);
+  if constexpr ((CN & 1) == 0)   // t = [x0 x0 x2 x2]
+    asm volatile("v_permlane16_swap_b32 %0, %2\n\tv_permlane16_swap_b32 %1, %3" : "+v"(ch.tl), "+v"(ch.th), "+v"(ch.ul), "+v"(ch.uh));
+  else                           // t = [x1 x1 x3 x3]
+    asm volatile("v_permlane16_swap_b32 %2, %0\n\tv_permlane16_swap_b32 %3, %1" : "+v"(ch.tl), "+v"(ch.th), "+v"(ch.ul), "+v"(ch.uh));
+}
+// stage 2: second swap (across the halves): v = row CN % 4 in every row
+template <int CN>
+__device__ __forceinline__ void chain_swap32(Chain& ch) {
+  asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %3" : "=&v"(ch.ul), "=&v"(ch.uh) : "v"(ch.tl), "v"(ch.th));
+  if constexpr ((CN & 3) < 2)
+    asm volatile("v_permlane32_swap_b32 %0, %2\n\tv_permlane32_swap_b32 %1, %3" : "+v"(ch.tl), "+v"(ch.th), "+v"(ch.ul), "+v"(ch.uh));
+  else
+    asm volatile("v_permlane32_swap_b32 %2, %0\n\tv_permlane32_swap_b32 %3, %1" : "+v"(ch.tl), "+v"(ch.th), "+v"(ch.ul), "+v"(ch.uh));
+  asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %3" : "=&v"(reinterpret_cast<uint2&>(ch.v).x), "=&v"(reinterpret_cast<uint2&>(ch.v).y) : "v"(ch.tl), "v"(ch.th));
+}
+template <int CN>
+__device__ __forceinline__ void chain_pivot(Chain& ch) {   // (ch.v was written two or more instructions ago)
+  asm volatile("v_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(ch.piv) : "v"(ch.v), "n"(CN));
+}
+__device__ __forceinline__ void chain_rcp(Chain& ch) { asm volatile("v_rcp_f64 %0, %1" : "=v"(ch.r) : "v"(ch.piv)); }
+__device__ __forceinline__ void chain_err(Chain& ch) { asm volatile("v_fma_f64 %0, -%1, %2, 1.0" : "=v"(ch.e) : "v"(ch.piv), "v"(ch.r)); }
+__device__ __forceinline__ void chain_nr(Chain& ch) { asm volatile("v_fma_f64 %0, %1, %0, %0" : "+v"(ch.r) : "v"(ch.e)); }
+// w[m] = -A[CN][m] / piv for the columns m > CN still to be updated, 0 for the others (gt: this lane's m > CN)
+__device__ __forceinline__ void chain_w(Chain& ch, bool gt) {
+  asm volatile("v_mul_f64 %0, %1, -%2" : "=v"(ch.w) : "v"(ch.r), "v"(ch.v));
+  ch.w = gt ? ch.w : 0.0;
+}
+
+// pivot C: its w is in `cur`; the chain of pivot C + 1 is built in `nxt` under the eight updates
+template <int C>
+__device__ __forceinline__ void pivot(double (&a)[4], double (&b)[4], int m, const Chain& cur, Chain& nxt) {
+  constexpr int CN = C + 1;
+  constexpr int Q1 = (CN < 16) ? CN / 4 : 0;
+  constexpr int o0 = (Q1 + 1) & 3, o1 = (Q1 + 2) & 3, o2 = (Q1 + 3) & 3;
+  fmac_row_bcast<C>(a[Q1], cur.w);                       // the register that holds row C + 1 first: the next chain starts on it
+  if constexpr (CN < 16) {
+    chain_swap16<CN>(nxt, a[Q1]);
+    fmac_row_bcast<C>(a[o0], cur.w);
+    chain_swap32<CN>(nxt);
+    fmac_row_bcast<C>(a[o1], cur.w);
+    fmac_row_bcast<C>(a[o2], cur.w);
+    chain_pivot<CN>(nxt);
+    fmac_row_bcast<C>(b[0], cur.w);
+    chain_rcp(nxt);
+    fmac_row_bcast<C>(b[1], cur.w);
+    chain_err(nxt);
+    chain_nr(nxt);
+    fmac_row_bcast<C>(b[2], cur.w);
+    chain_err(nxt);
+    chain_nr(nxt);
+    fmac_row_bcast<C>(b[3], cur.w);
+    chain_w(nxt, m > CN);
+  } else {
+    fmac_row_bcast<C>(a[o0], cur.w); fmac_row_bcast<C>(a[o1], cur.w); fmac_row_bcast<C>(a[o2], cur.w);
+    fmac_row_bcast<C>(b[0], cur.w); fmac_row_bcast<C>(b[1], cur.w); fmac_row_bcast<C>(b[2], cur.w); fmac_row_bcast<C>(b[3], cur.w);
+  }
+}
+template <int C>
+__device__ __forceinline__ void pivots_from(double (&a)[4], double (&b)[4], int m, int nvalid, Chain& cur) {
+  if constexpr (C < 16) {
+    if (C < nvalid) {   // (uniform)
+      Chain nxt;
+      pivot<C>(a, b, m, cur, nxt);
+      if constexpr (C + 1 < 16) pivots_from<C + 1>(a, b, m, nvalid, nxt);
+    }
+  }
+}
+}  // namespace acc16
+
+__device__ __forceinline__ bool diag_factor16_acc(double (&a)[4], double (&b)[4], int lane, double& inv_col, int nvalid = 16) {
+  const int m = lane & 15;
+  {
+    acc16::Chain c0;                                   // pivot 0's chain, nothing to hide it under
+    acc16::chain_swap16<0>(c0, a[0]);
+    acc16::chain_swap32<0>(c0);
+    asm volatile("s_nop 1");
+    acc16::chain_pivot<0>(c0);
+    acc16::chain_rcp(c0);
+    asm volatile("s_nop 0");
+    acc16::chain_err(c0); acc16::chain_nr(c0); acc16::chain_err(c0); acc16::chain_nr(c0);
+    acc16::chain_w(c0, m > 0);
+    if (nvalid > 0) acc16::pivots_from<0>(a, b, m, nvalid, c0);
+  }
+  // the diagonal of the unscaled factor: column m's pivot sits in register m / 4, row m % 4, lane column m
+  double d = (m < 4) ? a[0] : (m < 8 ? a[1] : (m < 12 ? a[2] : a[3]));
+  {
+    const int src = ((m & 3) << 4) | m;       // lane (m, m % 4)
+    const long long bits = __double_as_longlong(d);
+    const int lo = __builtin_amdgcn_ds_bpermute(src << 2, (int)(bits & 0xffffffffll));
+    const int hi = __builtin_amdgcn_ds_bpermute(src << 2, (int)(bits >> 32));
+    d = __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+  }
+  const bool okp = __all((d > 0.0) && (d < 1e300));
+  double inv = __builtin_amdgcn_rsq(d);
+  inv = inv * (1.5 - 0.5 * d * inv * inv);
+  inv = inv * (1.5 - 0.5 * d * inv * inv);
+  inv_col = inv;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) { a[q] *= inv; b[q] *= inv; }
+  return okp;
+}
+
 }  // namespace
 }  // namespace bodyfit

@@ -543,27 +543,26 @@ __global__ __launch_bounds__(kStepThreads) void k_lm_step(LmProblem P, LmState S
   //     strict upper triangle of the block, its diagonal 1 / L_cc in invd): the panel solve and the back substitution
   //     become products on the matrix cores
   auto diag_block = [&](int p) {
-    // every 16-lane group holds the block (row rr per lane) and, as the appended row of the same lane, row rr of the identity
-    // (dense_inl.h: column values travel by DPP row broadcast)
+    // the block and the identity below it spread over all 64 lanes of wave 0 in the layout of an f64 16 x 16 accumulator
+    // (dense_inl.h diag_factor16_acc): lane (m, kk), register q <-> row kk + 4 q, column m
     const int c0 = 16 * p;
-    const int rr = lane & 15, grp = lane >> 4;
-    double a[16], b[16], iv[16];
-    const double* src = M + (c0 + rr) * kMLd + c0;
+    const int m = lane & 15, kk = lane >> 4;
+    double a[4], b[4], invc;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) { a[k] = src[k]; b[k] = (k == rr) ? 1.0 : 0.0; }
-    const bool okp = diag_factor16_dpp(a, b, iv, min(16, n - c0));
-    // lower triangle: rows of L (group 0 stores); strict upper triangle: rows of L_pp^-T (group 1 stores its copy)
-    if (grp < 2) {
-      double* dst = M + (c0 + rr) * kMLd + c0;
-#pragma unroll
-      for (int k = 0; k < 16; ++k)
-        if ((grp == 0) == (k <= rr)) dst[k] = (grp == 0) ? a[k] : b[k];
+    for (int q = 0; q < 4; ++q) {   // (the FULL symmetric block, mirrored from its lower triangle: the strict upper triangle of a
+      const int r = kk + 4 * q, lo = max(r, m), hi = min(r, m);   //  factored tile holds L^-T, and only the lower one is kept up to date)
+      a[q] = M[(c0 + lo) * kMLd + c0 + hi];
+      b[q] = (r == m) ? 1.0 : 0.0;
     }
-    if (lane == 0) {
+    const bool okp = diag_factor16_acc(a, b, lane, invc, min(16, n - c0));
+    // lower triangle: rows of L; strict upper triangle: rows of L_pp^-T; its diagonal 1 / L_cc in invd
 #pragma unroll
-      for (int k = 0; k < 16; ++k) invd[c0 + k] = iv[k];
-      if (!okp) red[8] = 0.0;
+    for (int q = 0; q < 4; ++q) {
+      const int r = kk + 4 * q;
+      M[(c0 + r) * kMLd + c0 + m] = (r >= m) ? a[q] : b[q];
     }
+    if (kk == 0) invd[c0 + m] = invc;
+    if (lane == 0 && !okp) red[8] = 0.0;
   };
   if (wave == 0) diag_block(0);
   __syncthreads();

@@ -451,28 +451,26 @@ __global__ __launch_bounds__(kCrThreads) void k_cr_factor(WinBuf W, const int* _
   CR_STAMP(1);
   constexpr int NPAN = WB / 16;   // 5
   double* Linv = stat + 8;        // [16][17]: L_pp^-T of the current panel
-  // (a) diagonal block p + identity below it, in the registers of wave 0: lanes 0-15 rows of the block, lanes 16-31 rows of I
+  // (a) diagonal block p + identity below it, in the registers of wave 0, spread over all 64 lanes in the layout of an f64
+  //     16 x 16 accumulator (dense_inl.h diag_factor16_acc): lane (m, kk), register q <-> row kk + 4 q, column m
   auto diag_block = [&](int p) {
-    // every 16-lane group holds the block (row rr per lane) and, as the appended row of the same lane, row rr of the identity
     const int c0 = 16 * p;
-    const int rr = lane & 15, grp = lane >> 4;
-    double av[16], bv[16], iv[16];
-    const double* src = M + (c0 + rr) * LD + c0;
+    const int m = lane & 15, kk = lane >> 4;
+    double av[4], bv[4], invc;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) { av[k] = src[k]; bv[k] = (k == rr) ? 1.0 : 0.0; }
-    const bool okp = diag_factor16_dpp(av, bv, iv, min(16, NP - c0));
-    if (grp == 0) {
-      double* dst = M + (c0 + rr) * LD + c0;
+    for (int q = 0; q < 4; ++q) {   // (the FULL symmetric block: only its lower triangle is kept up to date in LDS, mirror it)
+      const int r = kk + 4 * q, lo = max(r, m), hi = min(r, m);
+      av[q] = M[(c0 + lo) * LD + c0 + hi];
+      bv[q] = (r == m) ? 1.0 : 0.0;
+    }
+    const bool okp = diag_factor16_acc(av, bv, lane, invc, min(16, NP - c0));
+    double* Lg = W.Li + ((size_t)j * (WB / 16) + p) * 256;   // kept for the way down (k_cr_back)
 #pragma unroll
-      for (int k = 0; k < 16; ++k)
-        if (k <= rr) dst[k] = av[k];
-    } else if (grp == 1) {
-#pragma unroll
-      for (int k = 0; k < 16; ++k) Linv[rr * 17 + k] = bv[k];   // row rr of L_pp^-T
-    } else if (grp == 2 && side == 0) {                          // kept for the way down (k_cr_back)
-      double* Lg = W.Li + ((size_t)j * (WB / 16) + p) * 256 + rr * 16;
-#pragma unroll
-      for (int k = 0; k < 16; ++k) Lg[k] = (k >= rr) ? bv[k] : 0.0;
+    for (int q = 0; q < 4; ++q) {
+      const int r = kk + 4 * q;
+      if (r >= m) M[(c0 + r) * LD + c0 + m] = av[q];           // L (lower triangle)
+      Linv[r * 17 + m] = bv[q];                                // row r of L_pp^-T (zero left of the diagonal)
+      if (side == 0) Lg[r * 16 + m] = bv[q];
     }
     if (lane == 0 && !okp) stat[0] = 0.0;
   };

@@ -352,8 +352,12 @@ def c5_strong(args, api, synth, model, gm, dist, rank, world, local_rank):
             "fit": {"frames_per_s": Fw * n_fit / dt_fit, "seconds": dt_fit / n_fit, "iterations": summ.iterations,
                     "successful": summ.n_successful, "termination": summ.termination, "initial_cost": summ.initial_cost,
                     "final_cost": summ.final_cost, "ms_per_iteration": dt_fit / n_fit * 1e3 / max(1, summ.iterations),
+                    # (four exchanges at the start; the host looks at the device's status every fourth iteration, so up to three
+                    #  iterations are launched — and exchanged — beyond the last one the solve counts)
                     "exchanges_total": fprob.last_exchange_count() if world > 1 else 0,
-                    "exchanges_per_iteration": ((fprob.last_exchange_count() - 4) / max(1, summ.iterations)) if world > 1 else 0},
+                    "iterations_launched": ((fprob.last_exchange_count() - 4) // 3) if world > 1 else summ.iterations,
+                    "exchanges_per_iteration": ((fprob.last_exchange_count() - 4) / max(1, (fprob.last_exchange_count() - 4) // 3))
+                                               if world > 1 else 0},
         }
     if rccl is not None:
         rccl.close()

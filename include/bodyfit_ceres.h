@@ -118,6 +118,9 @@ class Block : public ceres::CostFunction {
     return (cached_ ? bodyfit_evaluate_block_cached(p_, kind_, index_, parameters, residuals, jacobians)
                     : bodyfit_evaluate_block(p_, kind_, index_, parameters, residuals, jacobians)) == BODYFIT_OK;
   }
+  /* which block of the bodyfit_problem this is (bodyfit_evaluate_block's kind / index) */
+  int kind() const { return kind_; }
+  int index() const { return index_; }
 
  private:
   bodyfit_problem* p_;

@@ -96,7 +96,10 @@ int main(int argc, char** argv) {
   // what ceres::Problem::Evaluate does: callback, then every block with its parameter pointers and Jacobian buffers
   cb.PrepareForEvaluation(true, true);
   const int ncol = F * 76 + 10;
-  std::vector<double> r_all, J_all;   // rows in block order, dense columns [F x 76 | beta]
+  // rows in the batched evaluation's layout [reprojection | pose prior | shape prior | temporal] (the blocks come in the
+  // reference's order, frame by frame: each block's rows go where bodyfit_evaluate_batch has them), dense columns [F x 76 | beta]
+  std::vector<double> r_all((size_t)L.total_rows, 0.0), J_all((size_t)L.total_rows * (F * 76 + 10), 0.0);
+  size_t rows_seen = 0;
   int bad = 0;
   for (const auto& rec : problem.records()) {
     const ceres::CostFunction& cf = *rec->cost;
@@ -109,9 +112,15 @@ int main(int argc, char** argv) {
     for (size_t b = 0; b < sizes.size(); ++b) { jb[b].assign((size_t)nr * sizes[b], 0.0); jp[b] = jb[b].data(); }
     if (sizes.size() > 5) jp[5] = nullptr;          // a constant parameter block: jacobians[b] == NULL
     if (!cf.Evaluate(rec->blocks.data(), r.data(), jp.data())) ++bad;
-    const size_t row0 = r_all.size();
-    r_all.insert(r_all.end(), r.begin(), r.end());
-    J_all.resize((row0 + nr) * (size_t)ncol, 0.0);
+    const auto* blk = dynamic_cast<const bodyfit_ceres::Block*>(rec->cost.get());
+    if (!blk) { ++bad; continue; }
+    const int nS_ = 10;
+    const size_t row0 = blk->kind() == 0 ? (size_t)2 * blk->index()
+                      : blk->kind() == 1 ? (size_t)L.reproj_rows + (size_t)blk->index() * L.prior_rows_per_frame
+                      : blk->kind() == 2 ? (size_t)L.reproj_rows + (size_t)F * L.prior_rows_per_frame + (size_t)blk->index() * nS_
+                                         : (size_t)L.reproj_rows + (size_t)F * L.prior_rows_per_frame + L.shape_rows + (size_t)3 * blk->index();
+    for (int i = 0; i < nr; ++i) r_all[row0 + i] = r[i];
+    rows_seen += nr;
     for (size_t b = 0; b < sizes.size(); ++b) {
       if (!jp[b]) continue;
       const size_t col = column_of(rec->blocks[b]);
@@ -125,7 +134,7 @@ int main(int argc, char** argv) {
   packed(x);
   if (bodyfit_evaluate_batch(bp, x.data(), beta.data(), r_ref.data(), J_ref.data(), nullptr, 1) != BODYFIT_OK) return 1;
   double dr = 0.0, dj = 0.0;
-  if ((int)r_all.size() != L.total_rows) ++bad;
+  if ((int)rows_seen != L.total_rows) ++bad;
   for (size_t i = 0; i < r_all.size() && i < r_ref.size(); ++i) dr = std::fmax(dr, std::fabs(r_all[i] - r_ref[i]));
   for (int fr = 0; fr < F; ++fr)
     for (int k = koff[fr]; k < koff[fr + 1]; ++k)

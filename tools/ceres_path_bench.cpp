@@ -5,6 +5,7 @@
 // tests/cpp/ceres_double exactly the way ceres::Problem::Evaluate drives them (include/Sim3BA.h:263-264,420,476-479).
 // usage: ceres_path_bench <blob> <mode: c3 | c4> <seconds>      (blob: the format of tests/test_gpu_cpp_api.py)
 // prints one JSON object.
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -98,11 +99,18 @@ int main(int argc, char** argv) {
   const size_t nrec = recs.size();
   std::atomic<long> generation{0}, done{0};
   std::atomic<bool> failed{false}, quit{false};
+  // the order the blocks are walked in: the problem's own (= the reference's: per frame its reprojection blocks, then its pose
+  // prior), or — second measurement — sorted by kind (all reprojection blocks, then all priors: what bodyfit_ceres.h did before
+  // round 4; contiguous thread ranges then hand every 38 KB GMM prior Jacobian to the last thread)
+  std::vector<size_t> order(nrec);
+  for (size_t i = 0; i < nrec; ++i) order[i] = i;
   auto run_range = [&](int t) {
     const size_t b0 = nrec * t / threads, b1 = nrec * (t + 1) / threads;
     Scratch& sc = scratch[t];
-    for (size_t i = b0; i < b1; ++i)
-      if (!recs[i]->cost->Evaluate(recs[i]->blocks.data(), sc.r.data(), sc.jp.data())) failed.store(true);
+    for (size_t i = b0; i < b1; ++i) {
+      const auto& rec = recs[order[i]];
+      if (!rec->cost->Evaluate(rec->blocks.data(), sc.r.data(), sc.jp.data())) failed.store(true);
+    }
   };
   std::vector<std::thread> pool;
   for (int t = 1; t < threads; ++t)
@@ -146,11 +154,32 @@ int main(int argc, char** argv) {
     ++n;
     el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   }
+  // second measurement: the same points with the blocks walked kind by kind
+  auto kind_rank = [&](size_t i) {
+    const int nr = recs[i]->cost->num_residuals();
+    return nr == 2 ? 0 : (nr >= 69 ? 1 : (nr == 10 ? 2 : 3));
+  };
+  std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return kind_rank(a) < kind_rank(b); });
+  int n2 = 0;
+  double t_sweep2 = 0.0, el2 = 0.0;
+  const auto t02 = std::chrono::steady_clock::now();
+  while (el2 < 0.5 * seconds) {
+    const auto a = std::chrono::steady_clock::now();
+    poses[n2 % F].rootT[0] += 1e-6;
+    cb.PrepareForEvaluation(true, true);
+    const auto b = std::chrono::steady_clock::now();
+    t_sweep2 += std::chrono::duration<double>(b - a).count();
+    if (!evaluate_blocks()) return 1;
+    ++n2;
+    el2 = std::chrono::duration<double>(std::chrono::steady_clock::now() - t02).count();
+  }
   quit.store(true);
   for (auto& th : pool) th.join();
   std::printf("{\"mode\": \"%s\", \"frames\": %d, \"blocks\": %d, \"block_threads\": %d, \"points\": %d, \"points_per_s\": %.1f, "
-              "\"evals_per_s\": %.1f, \"blocks_per_s\": %.1f, \"sweep_with_copies_us\": %.1f, \"blocks_us_per_point\": %.1f}\n",
-              mode.c_str(), F, n_blocks, threads, n, n / el, n / el * F, n / el * n_blocks, t_sweep / n * 1e6, (el - t_sweep) / n * 1e6);
+              "\"evals_per_s\": %.1f, \"blocks_per_s\": %.1f, \"sweep_with_copies_us\": %.1f, \"blocks_us_per_point\": %.1f, "
+              "\"blocks_us_per_point_kind_by_kind\": %.1f}\n",
+              mode.c_str(), F, n_blocks, threads, n, n / el, n / el * F, n / el * n_blocks, t_sweep / n * 1e6, (el - t_sweep) / n * 1e6,
+              (el2 - t_sweep2) / std::max(1, n2) * 1e6);
   bodyfit_problem_destroy(bp);
   bodyfit_model_destroy(model);
   return 0;
