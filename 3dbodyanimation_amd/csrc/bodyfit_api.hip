@@ -298,7 +298,8 @@ int sweep(bodyfit_problem* p, const double* d_params, const double* d_beta, int 
     sy.timeout_ticks = p->role_timeout_ticks;
     static const int tune_prio = env_int("BODYFIT_MESH_PRIO", 2), tune_start = env_int("BODYFIT_TRICKLE_START", 120),
                      tune_sleep = env_int("BODYFIT_TRICKLE_SLEEP", 7);
-    sy.mesh_prio_early = tune_prio; sy.trickle_start = tune_start; sy.trickle_sleep = tune_sleep;
+    static const int tune_jscope = env_int("BODYFIT_J_SCOPE", 1);
+    sy.mesh_prio_early = tune_prio; sy.trickle_start = tune_start; sy.trickle_sleep = tune_sleep; sy.j_scope = tune_jscope;
     p->fused_unchecked = true;
     FoldTail fold{};
     const int n_partials = p->d.F + pa.n_tiles;

@@ -130,6 +130,7 @@ struct FusedSync {
   int mesh_prio_early;         // s_setprio of a mesh wave during k-steps 0-8 (the frame role runs at 2 and still owes the transforms)
   int trickle_start;           // operand stream of a mesh workgroup that runs beside its frames: first slab this many 10 ns ticks
   int trickle_sleep;           // after entry, then s_sleep(this) between slabs
+  int j_scope;                 // frame role: cache policy of the Jacobian panel's stores (frame_part_inl.h store_J)
 };
 constexpr unsigned long long kRoleTimeoutDefault = 5000000;   // 50 ms: give up, set the error word, the host falls back
 constexpr int kRoleMaxFrames = 16384;

@@ -53,9 +53,12 @@ __device__ __forceinline__ void store_through(double* p, double v) {
 #ifndef BODYFIT_J_THROUGH
 #define BODYFIT_J_THROUGH 1
 #endif
+// scope: 0 system (sc0 sc1, rounds 1-3), 1 agent (sc1: the form the mesh role's cloud stores use), 2 plain
 template <bool kFused>
-__device__ __forceinline__ void store_J(double* p, double v) {
+__device__ __forceinline__ void store_J(double* p, double v, int scope = 0) {
   if constexpr (kFused && !BODYFIT_J_THROUGH) *p = v;
+  else if (scope == 1) store_f64_through(p, v);
+  else if (scope == 2) *p = v;
   else store_through(p, v);
 }
 
@@ -189,6 +192,7 @@ constexpr int TAB_KPID = 96;                   // KC
 struct FusedFrame {
   unsigned* flag;                 // counter of 32-frame unit u at flag[u * kUnitCounterStride]: += 1 once a frame's mesh operands are published
   unsigned epoch;                 // this launch's number
+  int j_scope;                    // Jacobian panel stores: 0 system-scope write-through, 1 agent-scope write-through, 2 plain (BODYFIT_J_SCOPE)
 };
 
 // Barrier between two phases.  The phases only exchange LDS data, so the fused kernel waits for the LDS counter alone:
@@ -847,6 +851,11 @@ __device__ __forceinline__ void frame_part(const DevModel& M, const DevProblem& 
   STAMP(5);
   // ---- E. independent items: mesh operands + posed joints, landmark Jacobian terms, first keypoint chunk ----------
   if (wave == 6 && lane < min(KC, k_end - k_begin)) stage_kp(lane, k_begin);
+  // (Measured and rejected, round 4: wave 7 — the least loaded here — writing the FK-joint keypoints' entries of the joint columns
+  //  in this phase, ahead of phase F's sweep: they need none of this phase's landmark terms, and 42 % of the panel's stores would
+  //  leave ~3 us earlier.  One wave's fourteen iterations of write-through stores took 16 k cycles — a wave's write-through
+  //  stores are paced by their acknowledgements, ~600 cycles per store instruction here —: 23.0-23.3 against 21.3-21.8 us per
+  //  step on the same box, profiles/r4_x10_stamps_early_fk_rows.txt.)
   if (nL > 0 && want_jac) {
     // d q_l / d theta_{k,c} for landmark l, complete, left in LM_PD[l][3 (k - 1) + c] for the Jacobian sweep:
     //   Ablend . (pd[:, 9(k-1):9k] . vec(dR_{k,c}))   the inner products were parked here by phase C (same lane mapping:
@@ -966,8 +975,8 @@ __device__ __forceinline__ void frame_part(const DevModel& M, const DevProblem& 
             const double* o = sLm + (id - nJ) * LM_STRIDE + LM_PD + kc * 3;   // complete since phase E
             d0 = o[0]; d1 = o[1]; d2 = o[2];
           }
-          store_J<kFused>(J_out + (size_t)(2 * kg) * ncols + 7 + kc, G[0] * d0 + G[1] * d1 + G[2] * d2);
-          store_J<kFused>(J_out + (size_t)(2 * kg + 1) * ncols + 7 + kc, G[3] * d0 + G[4] * d1 + G[5] * d2);
+          store_J<kFused>(J_out + (size_t)(2 * kg) * ncols + 7 + kc, G[0] * d0 + G[1] * d1 + G[2] * d2, fu.j_scope);
+          store_J<kFused>(J_out + (size_t)(2 * kg + 1) * ncols + 7 + kc, G[3] * d0 + G[4] * d1 + G[5] * d2, fu.j_scope);
         }
       }
       // (2) Sim3 columns (7) and shape columns (ncols - npose) per keypoint
@@ -1013,8 +1022,8 @@ __device__ __forceinline__ void frame_part(const DevModel& M, const DevProblem& 
           j0 = G[0] * d0 + G[1] * d1 + G[2] * d2;
           j1 = G[3] * d0 + G[4] * d1 + G[5] * d2;
         }
-        store_J<kFused>(J_out + (size_t)(2 * kg) * ncols + col, j0);
-        store_J<kFused>(J_out + (size_t)(2 * kg + 1) * ncols + col, j1);
+        store_J<kFused>(J_out + (size_t)(2 * kg) * ncols + col, j0, fu.j_scope);
+        store_J<kFused>(J_out + (size_t)(2 * kg + 1) * ncols + col, j1, fu.j_scope);
         if (fold && c >= 7) { sJb[(2 * kk) * kMaxShape + c - 7] = j0; sJb[(2 * kk + 1) * kMaxShape + c - 7] = j1; }
       }
     }

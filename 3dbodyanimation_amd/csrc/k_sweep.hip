@@ -228,6 +228,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_sweep_roles(RoleArgs by_value) 
     FusedFrame fu;
     fu.flag = A->sy.flag;
     fu.epoch = A->sy.epoch;
+    fu.j_scope = A->sy.j_scope;
     // a frame workgroup is the launch's critical path; the mesh workgroup it shares the CU with has slack
     __builtin_amdgcn_s_setprio(2);
     frame_part<true>(M, Pb, A->params, A->beta, A->r_out, A->J_out, A->joints_out, mc, A->want_jac,

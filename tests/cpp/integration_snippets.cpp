@@ -54,6 +54,18 @@ ceres::Solve(options, &problem, &summary);
 // [/snippet]
 }
 
+// ---- multi-GPU: one evaluation of a frame shard, the all-reduce issued by the library ----------------------------------------
+// [snippet:sharded_eval]
+// one evaluation of the shard on `stream`: sweep, the 66 doubles [cost | g_beta | upper H_bb] of the local frames, their sum over
+// the ranks — include/MultiFrameBA.h:64-68 (the shared shape block) seen from N GPUs; nothing synchronises the host
+int evaluate_shared(bodyfit_problem* shard, bodyfit_rccl* rc, const double* d_frame_params, const double* d_beta,
+                    double* d_buf66 /* armed once: bodyfit_arm_shared_reduction(shard, d_buf66) */, void* stream) {
+  if (bodyfit_evaluate_device(shard, d_frame_params, d_beta, /*want_jacobian=*/1, stream)) return 1;
+  if (bodyfit_reduce_shared_device(shard, d_buf66, stream)) return 1;   // (launches nothing when the sweep's own tail did it)
+  return bodyfit_allreduce_shared_rccl(rc, d_buf66, stream);            // ncclAllReduce(sum, f64), in place, on `stream`
+}   // before the cloud of these sweeps is consumed: bodyfit_sweep_status(shard, stream)
+// [/snippet]
+
 // ---- multi-GPU: one window sharded over the ranks, MPI as the host transport ---------------------------------------------
 // [snippet:sharded_mpi]
 static int ar(void*, double* buf, int n, int op) {

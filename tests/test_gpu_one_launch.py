@@ -353,3 +353,39 @@ def test_a_wait_that_runs_out_is_reported_and_the_problem_falls_back(model):
     _, cloud2 = prob2.forward(x, seq.gt_beta)
     _, cloud2_ref = good2.forward(x, seq.gt_beta)
     assert np.array_equal(cloud2, cloud2_ref)
+
+
+def test_synchronous_entry_points_order_themselves_behind_asynchronous_sweeps(model):
+    """bodyfit_evaluate_batch runs on a stream of its own and bodyfit_forward on the NULL stream, while bodyfit_evaluate_device
+    runs wherever the caller says; all of them write the problem's residual / Jacobian / cloud buffers and the one-launch sweep's
+    counters.  A synchronous call issued while asynchronous sweeps of the same problem are still queued on a NON-BLOCKING caller
+    stream must wait for them (one event recorded behind them at that moment): otherwise two k_sweep_roles of one problem run
+    together, the counters of the in-launch hand-off stop being launch-number x frame-count, and a wait runs out."""
+    import torch
+    m, gm = model
+    F = 256
+    seq = synth.make_sequence(m, F, seed=17)
+    gmm = api.Gmm(*synth.make_gmm(0))
+    pf, pt = _problem(gm, seq, True, gmm=gmm), _problem(gm, seq, False, gmm=gmm)
+    rng = np.random.default_rng(9)
+    dev = torch.device("cuda", 0)
+    side = torch.cuda.Stream(device=dev)          # torch streams are non-blocking: no implicit ordering with the NULL stream
+    xa = seq.gt_params + 0.2 * rng.standard_normal(seq.gt_params.shape)
+    ba = np.tile(seq.gt_beta, (F, 1)) + rng.standard_normal((F, 10))
+    dxa, dba = torch.from_numpy(xa).to(dev), torch.from_numpy(ba).to(dev)
+    torch.cuda.synchronize()
+    for it in range(3):
+        xb = seq.gt_params + 0.05 * rng.standard_normal(seq.gt_params.shape)
+        bb = np.tile(seq.gt_beta, (F, 1)) + 0.3 * rng.standard_normal((F, 10))
+        for _ in range(40):                       # ~1 ms of queued sweeps at another point
+            pf.evaluate_device(dxa.data_ptr(), dba.data_ptr(), True, side.cuda_stream)
+        r, J, c = pf.evaluate(xb, bb, True)       # own stream
+        jn, cl = pf.forward(xb, bb)               # NULL stream
+        r2, J2, c2 = pt.evaluate(xb, bb, True)
+        j2, cl2 = pt.forward(xb, bb)
+        assert np.array_equal(c, c2)
+        np.testing.assert_allclose(r, r2, rtol=0, atol=1e-10)
+        np.testing.assert_allclose(J, J2, rtol=0, atol=1e-9)
+        np.testing.assert_allclose(cl, cl2, rtol=0, atol=2e-6)
+        assert _timeouts(pf) == 0
+    torch.cuda.synchronize()
