@@ -372,6 +372,10 @@ def main():
     ap.add_argument("--workload", default="c3", choices=["c3", "c5"])
     ap.add_argument("--frames-per-gpu", type=int, default=256)
     ap.add_argument("--window", type=int, default=1024)
+    ap.add_argument("--prewarm", type=int, default=1000,
+                    help="untimed sweeps in FRONT of the --warmup steps: a fresh process's first ~500 launches run 8-15 %% slower "
+                         "(clock ramp, first-touch of the model: 23-25 us per step against 21 once warm, profiles/r4_y_variant_ab.txt); "
+                         "the driver's --warmup 5 alone leaves the timed steps on that ramp.  Reported as prewarm_steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pcie", action="store_true", help="(kept for old command lines: the host-pointer rate is always reported)")
     ap.add_argument("--no-ceres-path", action="store_true", help="skip the Ceres-kept-path record (needs g++ on the box)")
@@ -487,6 +491,12 @@ def main():
                 dist.all_reduce(h)
                 d_red.copy_(h)
 
+    # the GPU's clock (and the caches' view of the model) settle over the first few hundred launches of a process: untimed
+    # sweeps first, then the contract's W warmup steps and its K timed steps
+    for i in range(args.prewarm):
+        prob.evaluate_device(d_params.data_ptr(), d_beta.data_ptr(), True, stream)
+        if i % 256 == 255:
+            torch.cuda.synchronize()      # (keeps the queue short; nothing is timed here)
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -506,13 +516,14 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    # per-kernel durations with HIP events on the launch stream (same inputs, same stream), right behind the timed steps — the
+    # same warm device — and over at least 100 launches
+    prof = prob.profile_sweep(d_params.data_ptr(), d_beta.data_ptr(), True, with_reduce, max(100, min(400, args.steps)), stream)
+
     # configs[4] on the same ranks, in the same line (default workload only: `value` stays the C3 figure at every N)
     strong = None
     if args.workload == "c3" and not args.no_c5_strong:
         strong = c5_strong(args, api, synth, model, gm, dist, rank, world, local_rank)
-
-    # per-kernel durations with HIP events on the launch stream (same inputs, same stream)
-    prof = prob.profile_sweep(d_params.data_ptr(), d_beta.data_ptr(), True, with_reduce, min(100, max(10, args.steps)), stream)
 
     if rank == 0:
         ms_step = dt / args.steps * 1e3
@@ -562,7 +573,7 @@ def main():
         out = {
             "metric": "SMPL residual+Jacobian evals/sec (6890v, 10 beta, 24 joints)",
             "value": evals_s, "unit": "evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_step, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
+            "prewarm_steps": args.prewarm, "ms_per_step": ms_step, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "f64 residual/Jacobian; f32 mesh (f32 + split-bf16 MFMA blend)", "data": "synthetic",
             "config": {"workload": wl_name, "frames_per_gpu": F, "keypoints_per_frame": 25, "n_cols": 86},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",

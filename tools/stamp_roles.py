@@ -96,3 +96,21 @@ print("   ", np.median(steps[:, :4], axis=(0, 1)).astype(int), "|", np.median(st
 print("mesh role skinning rows, shader cycles (median over tiles and waves):")
 print("   ", np.median(rows, axis=(0, 1)).astype(int))
 print("blend total cycles (median)", int(np.median(cy[:, :, 14] - cy[:, :, 0])), " skin total", int(np.median(cy[:, :, 32] - cy[:, :, 16])))
+# ---- the launch's tail: when do the workgroups end, and which end last -------------------------------------------------
+fe = us(fr[:, :, 11]).max(axis=1)            # frame workgroup f: its last wave's end
+me = us(ms[:, :, 4]).max(axis=1)             # mesh workgroup (tile): its last wave's end
+pc = [50, 75, 90, 95, 99, 100]
+print("tail: frame workgroups end, percentiles", pc, np.round(np.percentile(fe, pc), 2))
+print("tail: mesh workgroups end,  percentiles", pc, np.round(np.percentile(me, pc), 2))
+xcd_f = fr[:, 0, 9].astype(int)
+print("tail: frame workgroups' end by XCD (median / max):", " ".join(f"{x}:{np.median(fe[xcd_f == x]):.1f}/{fe[xcd_f == x].max():.1f}" for x in range(8)))
+nv = ms.shape[0]
+xcd_m = (np.arange(nv) + F) % 8 if nG == 1 else None   # block order: frames, then mesh tiles (one group): XCD = block % 8
+if xcd_m is not None:
+    print("tail: mesh workgroups' end by XCD (median / max): ", " ".join(f"{x}:{np.median(me[xcd_m == x]):.1f}/{me[xcd_m == x].max():.1f}" for x in range(8)))
+    late = np.argsort(me)[-12:]
+    print("tail: latest 12 mesh workgroups (tile: end us | blend start of its waves min..max | slowest wave):",
+          " ".join(f"{int(t)}:{me[t]:.1f}|{us(ms[t, :, 2]).min():.1f}..{us(ms[t, :, 2]).max():.1f}|w{int(np.argmax(ms[t, :, 4]))}" for t in late))
+    w_end = us(ms[:, :, 4])
+    print("tail: mesh waves' end by wave number (median):", np.round(np.median(w_end, axis=0), 2))
+    print("tail: mesh waves' own-unit-seen by wave number (median):", np.round(np.median(us(ms[:, :, 1]), axis=0), 2))
