@@ -4,6 +4,7 @@
 #include "../../3dbodyanimation_amd/csrc/k_window_lm.hip"
 
 #include <cstdio>
+#include <cstring>
 #include <vector>
 namespace bodyfit { std::atomic<long> g_launch_count{0}; }
 int main() {
@@ -39,5 +40,16 @@ int main() {
     prev = st[6 + 4 * p];
   }
   printf("store blocks                  %6llu\ntotal                         %6llu cycles\n", st[24] - st[22], st[24] - st[0]);
+  // the outputs of frame 1, as a checksum that is sensitive to every bit (compare two builds of the kernel)
+  auto sum = [&](const double* d, size_t off, size_t n) {
+    std::vector<double> h(n);
+    hipMemcpy(h.data(), d + off, n * 8, hipMemcpyDeviceToHost);
+    unsigned long long x = 1469598103934665603ull;
+    for (double v : h) { unsigned long long b; memcpy(&b, &v, 8); x = (x ^ b) * 1099511628211ull; }
+    return x;
+  };
+  const size_t bb = (size_t)WBk * WBk;
+  printf("outputs: L %016llx  Pt %016llx  Qt %016llx  Yt %016llx  Li %016llx\n", sum(W.L, bb, bb), sum(W.Pt, bb, bb), sum(W.Qt, bb, bb),
+         sum(W.Yt, (size_t)WRk * WBk, (size_t)WRk * WBk), sum(W.Li, 5 * 256, 5 * 256));
   return 0;
 }
