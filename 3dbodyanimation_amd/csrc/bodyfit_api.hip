@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <map>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -38,17 +39,73 @@ int fail(int code, const std::string& msg) {
       return fail(BODYFIT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));        \
   } while (0)
 
+// Device blocks of destroyed problems, kept for the next problem of the same shape.  The reference's staged drivers
+// (src/main_multi_frame.cpp:109-217: anchors, then one solve per sliding window, an update() after each) create and destroy
+// two problems per stage; hipFree synchronises the device and unmaps — 0.6 ms per problem, 12 of the 149 ms of a staged
+// 128-frame run (tools/run_multi_breakdown.py).  A block is reused only for a request of exactly its size on its device;
+// contents are unspecified, as hipMalloc's are (problem creation clears what it needs cleared).  Bounded: beyond kLimit bytes
+// per device a block is freed at once; bodyfit_model_destroy empties its device's list.  Nothing is freed at process exit (the
+// runtime may be gone by then).
+class BlockPool {
+ public:
+  static BlockPool& get() { static BlockPool* p = new BlockPool; return *p; }
+  void* take(int dev, size_t bytes) {
+    std::lock_guard<std::mutex> g(mu_);
+    auto& f = free_[dev];
+    auto it = f.find(bytes);
+    if (it == f.end()) return nullptr;
+    void* p = it->second;
+    f.erase(it);
+    held_[dev] -= bytes;
+    return p;
+  }
+  void give(int dev, size_t bytes, void* p) {
+    {
+      std::lock_guard<std::mutex> g(mu_);
+      if (held_[dev] + bytes <= kLimit) {
+        free_[dev].emplace(bytes, p);
+        held_[dev] += bytes;
+        return;
+      }
+    }
+    (void)hipFree(p);
+  }
+  void trim(int dev) {
+    std::multimap<size_t, void*> drop;
+    {
+      std::lock_guard<std::mutex> g(mu_);
+      drop.swap(free_[dev]);
+      held_[dev] = 0;
+    }
+    for (auto& kv : drop) (void)hipFree(kv.second);
+  }
+ private:
+  static constexpr size_t kLimit = (size_t)1 << 30;
+  std::mutex mu_;
+  std::map<int, std::multimap<size_t, void*>> free_;
+  std::map<int, size_t> held_;
+};
+
 struct Allocs {
-  std::vector<void*> ptrs;
+  struct Block { void* p; size_t bytes; int dev; };
+  std::vector<Block> blocks;
+  bool pooled = false;   // problems: blocks go back to the BlockPool (the owner has synchronised the device first)
   ~Allocs() {
-    for (void* p : ptrs) (void)hipFree(p);
+    for (const Block& b : blocks) {
+      if (pooled) BlockPool::get().give(b.dev, b.bytes, b.p);
+      else (void)hipFree(b.p);
+    }
   }
   template <typename T>
   hipError_t alloc(T** out, size_t n) {
-    void* p = nullptr;
-    hipError_t e = hipMalloc(&p, std::max<size_t>(n, 1) * sizeof(T));
+    const size_t bytes = std::max<size_t>(n, 1) * sizeof(T);
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    void* p = pooled ? BlockPool::get().take(dev, bytes) : nullptr;
+    hipError_t e = hipSuccess;
+    if (!p) e = hipMalloc(&p, bytes);
     if (e == hipSuccess) {
-      ptrs.push_back(p);
+      blocks.push_back(Block{p, bytes, dev});
       *out = static_cast<T*>(p);
     }
     return e;
@@ -634,6 +691,7 @@ int bodyfit_model_create(const bodyfit_model_desc* desc, int device, bodyfit_mod
 void bodyfit_model_destroy(bodyfit_model* m) {
   if (!m) return;
   (void)hipSetDevice(m->device);
+  BlockPool::get().trim(m->device);   // (blocks of this device's destroyed problems)
   delete m;
 }
 
@@ -754,6 +812,7 @@ int bodyfit_problem_create(const bodyfit_model* m, const bodyfit_problem_desc* d
 
   HIP_TRY(hipSetDevice(m->device));
   std::unique_ptr<bodyfit_problem> p(new bodyfit_problem());
+  p->mem.pooled = true;
   p->m = m;
   p->desc = *desc;
   p->desc.kp_offset = nullptr; p->desc.kp_id = nullptr; p->desc.kp_uv = nullptr; p->desc.R0 = nullptr;
@@ -861,6 +920,9 @@ void bodyfit_problem_destroy(bodyfit_problem* p) {
   if (p->lm_stream) (void)hipStreamDestroy(p->lm_stream);
   if (p->copy_stream) (void)hipStreamDestroy(p->copy_stream);
   if (p->async_event) (void)hipEventDestroy(p->async_event);
+  // the problem's blocks go to the BlockPool, not to hipFree: what hipFree did implicitly — wait for every kernel that may
+  // still touch them — is done here once
+  (void)hipDeviceSynchronize();
   delete p;
 }
 
