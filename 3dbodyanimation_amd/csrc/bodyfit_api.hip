@@ -1492,6 +1492,13 @@ static int solve_window_device(bodyfit_problem* p, double* frame_params, double*
   P.shape_rows = p->lay.shape_rows; P.row_shape = p->row_shape; P.row_temporal = p->row_temporal;
   P.huber = p->desc.huber_delta; P.beta_pose = p->desc.beta_pose; P.beta_shape = p->desc.beta_shape;
   P.lambda_t = p->desc.lambda_temporal; P.scale_lo = opt->scale_lo; P.scale_hi = opt->scale_hi;
+  {
+    // every sweep of this loop is a Jacobian sweep without frame flags: with a shared shape block (the partials exist) it leaves
+    // the point's cost as F + tiles partial sums (sweep(): dp.beta_partials, pa.plain_cost)
+    const bool priors = p->desc.beta_pose > 0.0 || (p->lay.shape_rows > 0 && p->desc.beta_shape > 0.0) || p->desc.lambda_temporal > 0.0;
+    P.cost_partials = (p->d_frame_partials && n > npose && m->nS == kMaxShape) ? p->d_frame_partials : nullptr;
+    P.cost_tiles = priors ? (F + 15) / 16 : 0;
+  }
   const int rows_x = F + halo;
   HIP_TRY(hipMemcpyAsync(d_x, frame_params, (size_t)rows_x * npose * sizeof(double), hipMemcpyHostToDevice, st));
   HIP_TRY(hipMemcpyAsync(d_b, beta, (size_t)nb * sizeof(double), hipMemcpyHostToDevice, st));

@@ -227,6 +227,11 @@ struct WinProblem {
   int halo;                         // shard of a window: a temporal pair links the last frame to the next shard's first
   int prior_rows, row_prior, shape_rows, row_shape, row_temporal;
   double huber, beta_pose, beta_shape, lambda_t, scale_lo, scale_hi;
+  // the cost of the point a Jacobian sweep has just evaluated, as that sweep's own per-workgroup partials ([F + cost_tiles]
+  // rows of kReducePartial doubles: frame rows carry 1/2 sum rho over their keypoints in slot 0, prior tiles 1/2 |r|^2 of their
+  // rows in slot 1); null: the cost is summed from the residual vector
+  const double* cost_partials;
+  int cost_tiles;
 };
 struct WinBuf {
   double *D, *U, *L, *Pt, *Qt;      // [F][80][80]: diagonal blocks, couplings, factors, solved couplings (transposed)
