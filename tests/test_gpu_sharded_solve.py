@@ -50,7 +50,7 @@ def _worker(rank, world, port, F, iters, out_path):
 
 
 # (2, 1024, 6): BASELINE configs[4] at its real size, two shards of 512 frames
-@pytest.mark.parametrize("world,F,iters", [(2, 9, 12), (3, 14, 12), (2, 40, 8), (2, 1024, 6)])
+@pytest.mark.parametrize("world,F,iters", [(2, 9, 12), (3, 14, 12), (2, 40, 8), (2, 1024, 6), (5, 43, 6)])   # (5 ranks + this process: the box admits six on its GPU)
 def test_sharded_solve_equals_unsharded(tmp_path, world, F, iters):
     out = str(tmp_path / "res.npz")
     port = 29700 + (os.getpid() % 1500) + world * 11 + F

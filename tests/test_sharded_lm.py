@@ -69,7 +69,7 @@ def _worker(rank, world, port, F, out_path):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,F", [(1, 5), (2, 5), (3, 7), (3, 3)])
+@pytest.mark.parametrize("world,F", [(1, 5), (2, 5), (3, 7), (3, 3), (8, 19)])   # (8: the node the north star names)
 def test_sharded_lm_equals_dense_lm(tmp_path, world, F):
     out = str(tmp_path / "res.npz")
     port = 29600 + world * 7 + F
