@@ -190,12 +190,15 @@ struct RoleArgs {
 };
 typedef const __attribute__((address_space(4))) RoleArgs* RoleArgP;
 
-__global__ __launch_bounds__(kThreads, 4) void k_sweep_roles(RoleArgs by_value) {
+// F and nVT, which the role of a block is decoded from, are leading scalar arguments: with -amdgpu-kernarg-preload-count they are in
+// SGPRs when the wave starts, and the decode no longer waits for a scalar load of its own in front of the role's operand loads.
+static_assert(alignof(RoleArgs) == 8, "kernel-argument segment: [int F][int nVT][RoleArgs at offset 8]");
+__global__ __launch_bounds__(kThreads, 4) void k_sweep_roles(int F_arg, int nVT_arg, RoleArgs by_value) {
   (void)by_value;
 #if defined(__HIP_DEVICE_COMPILE__)   // (the host pass only needs the stub; it cannot copy structs out of address space 4)
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-  const RoleArgP A = (RoleArgP)__builtin_amdgcn_kernarg_segment_ptr();
-  const int F = A->Pb.F, nVT = A->M.nVTiles;
+  const RoleArgP A = (RoleArgP)((const __attribute__((address_space(4))) unsigned char*)__builtin_amdgcn_kernarg_segment_ptr() + 8);
+  const int F = F_arg, nVT = nVT_arg;
   // ---- role of this block: [frames 0][frames 1][mesh 0][frames 2][mesh 1] ... [mesh nG-1][prior tiles] ----------------
   int role = 2, idx = 0, grp = 0;
   {
@@ -367,7 +370,7 @@ void launch_sweep_roles(const DevModel& M, const DevProblem& P, const double* d_
   RoleArgs A;
   A.M = M; A.Pb = P; A.Pb.feat_perm = 1; A.params = d_params; A.beta = d_beta; A.r_out = d_r; A.J_out = d_J;
   A.joints_out = d_joints; A.mc = mc; A.want_jac = want_jac; A.pa = pa; A.cloud_f = d_cloud; A.sy = sy; A.fold = fold;
-  BODYFIT_LAUNCH_EXT(k_sweep_roles, dim3(grid), dim3(kThreads), kRoleLdsBytes, s, ev_start, ev_stop, 0, A);
+  BODYFIT_LAUNCH_EXT(k_sweep_roles, dim3(grid), dim3(kThreads), kRoleLdsBytes, s, ev_start, ev_stop, 0, P.F, M.nVTiles, A);
 }
 
 }  // namespace bodyfit

@@ -429,7 +429,11 @@ __device__ unsigned long long g_cr_stamps[64];
 #else
 #define CR_STAMP(i)
 #endif
-__global__ __launch_bounds__(kCrThreads) void k_cr_factor(WinBuf W, const int* __restrict__ elim, int n_elim) {
+// (the pointers of the kernel's first loads come as leading scalar arguments: with -mllvm -amdgpu-kernarg-preload-count they are
+//  in SGPRs when the wave starts, one scalar round trip earlier than fields of the by-value struct)
+__global__ __launch_bounds__(kCrThreads) void k_cr_factor(const int* __restrict__ elim, const double* __restrict__ Dp,
+                                                          const double* __restrict__ Up, const double* __restrict__ Rtp,
+                                                          int n_elim, WinBuf W) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   double* M = sm;                          // [kCrRowsMax][LD]
   double* invd = sm + kCrRowsMax * LD;     // [WB]
@@ -446,9 +450,9 @@ __global__ __launch_bounds__(kCrThreads) void k_cr_factor(WinBuf W, const int* _
     // the node's blocks: all three requested before any lands in LDS (one round trip)
     BlockRegs<WB> rD, rU;
     BlockRegs<WR> rR;
-    block_load<WB>(rD, W.D + (size_t)j * WB * WB, tid);
-    if (nU) block_load<WB>(rU, W.U + (size_t)(side == 0 ? a : j) * WB * WB, tid);
-    if (side == 0) block_load<WR>(rR, W.Rt + (size_t)j * WR * WB, tid);
+    block_load<WB>(rD, Dp + (size_t)j * WB * WB, tid);
+    if (nU) block_load<WB>(rU, Up + (size_t)(side == 0 ? a : j) * WB * WB, tid);
+    if (side == 0) block_load<WR>(rR, Rtp + (size_t)j * WR * WB, tid);
     block_to_lds<WB, false, true>(rD, M, tid);
     if (nU) {
       if (side == 0) block_to_lds<WB>(rU, M + WB * LD, tid);              // row i of U_a
@@ -594,7 +598,9 @@ __device__ __forceinline__ d4 tile_xyT(const double* X, const double* Y, int ti,
 
 // ---- cyclic reduction: Schur updates of one remaining frame a (left eliminated neighbour jl, right one jr, next
 //      remaining frame b).  Four workgroups per frame: diagonal block (two halves of its tiles), coupling block, rhs. -----
-__global__ __launch_bounds__(kCrThreads) void k_cr_update(WinBuf W, const int* __restrict__ surv, int n_surv, int split) {
+__global__ __launch_bounds__(kCrThreads) void k_cr_update(const int* __restrict__ surv, int n_surv, int split,
+                                                          double* __restrict__ Dp, const double* __restrict__ Qtp,
+                                                          const double* __restrict__ Ptp, WinBuf W) {   // (leading scalars: k_cr_factor)
   extern __shared__ __attribute__((aligned(16))) double sm[];
   double* X0 = sm;                 // [WB][LD]
   double* X1 = sm + WB * LD;       // [WB][LD]
@@ -613,10 +619,10 @@ __global__ __launch_bounds__(kCrThreads) void k_cr_update(WinBuf W, const int* _
   // accumulator tiles of the wave (read-modify-write of global memory), one round trip instead of one per trip / per tile.
   if (part == 0) {
     // D_a -= Qt_jl Qt_jl^T + Pt_jr Pt_jr^T  (15 lower tiles over 8 waves: tiles wave and wave + 8)
-    double* D = W.D + (size_t)a * WB * WB;
+    double* D = Dp + (size_t)a * WB * WB;
     BlockRegs<WB> r0, r1;
-    if (jl >= 0) block_load<WB>(r0, W.Qt + (size_t)jl * WB * WB, tid);
-    if (jr >= 0) block_load<WB>(r1, W.Pt + (size_t)jr * WB * WB, tid);
+    if (jl >= 0) block_load<WB>(r0, Qtp + (size_t)jl * WB * WB, tid);
+    if (jr >= 0) block_load<WB>(r1, Ptp + (size_t)jr * WB * WB, tid);
     int tis[2], tjs[2];
     d4 acc[2];
 #pragma unroll
@@ -686,7 +692,8 @@ __global__ __launch_bounds__(kCrThreads) void k_cr_update(WinBuf W, const int* _
 // L2: 16 consecutive doubles per lane group), then  Xt L = Zt  solved panel by panel from the last one: the products with
 // the already known panels on the matrix cores, the 16 x 16 diagonal blocks through their explicit inverses (computed
 // here, one block per wave, while the other waves form Zt).
-__global__ __launch_bounds__(kCrThreads) void k_cr_back(WinBuf W, const int* __restrict__ elim, int n_elim) {
+__global__ __launch_bounds__(kCrThreads) void k_cr_back(const int* __restrict__ elim, const double* __restrict__ Lp,
+                                                        const double* __restrict__ Xtp, int n_elim, WinBuf W) {   // (leading scalars: k_cr_factor)
   extern __shared__ __attribute__((aligned(16))) double sm[];
   double* Ls = sm;                     // [WB][LD]
   double* Zt = sm + WB * LD;           // [WR][LD]   right-hand sides, overwritten by the solution panel by panel
@@ -699,9 +706,9 @@ __global__ __launch_bounds__(kCrThreads) void k_cr_back(WinBuf W, const int* __r
   {
     BlockRegs<WB> rL;
     BlockRegs<WR> rA, rB;
-    block_load<WB>(rL, W.L + (size_t)j * WB * WB, tid);
-    if (a >= 0) block_load<WR>(rA, W.Xt + (size_t)a * WR * WB, tid);
-    if (b >= 0) block_load<WR>(rB, W.Xt + (size_t)b * WR * WB, tid);
+    block_load<WB>(rL, Lp + (size_t)j * WB * WB, tid);
+    if (a >= 0) block_load<WR>(rA, Xtp + (size_t)a * WR * WB, tid);
+    if (b >= 0) block_load<WR>(rB, Xtp + (size_t)b * WR * WB, tid);
     block_to_lds<WB>(rL, Ls, tid);
     if (a >= 0) block_to_lds<WR>(rA, Xa, tid);
     if (b >= 0) block_to_lds<WR>(rB, Xb, tid);
@@ -1331,16 +1338,18 @@ void launch_cr_factor(const WinBuf& W, const int* d_elim, int n_elim, hipStream_
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_cr_back), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)win_back_lds_bytes());
   });
-  if (n_elim > 0) BODYFIT_LAUNCH(k_cr_factor, dim3(2 * n_elim), dim3(kCrThreads), win_factor_lds_bytes(), s, W, d_elim, n_elim);
+  if (n_elim > 0)
+    BODYFIT_LAUNCH(k_cr_factor, dim3(2 * n_elim), dim3(kCrThreads), win_factor_lds_bytes(), s, d_elim, W.D, W.U, W.Rt, n_elim, W);
 }
 void launch_cr_update(const WinBuf& W, const int* d_surv, int n_surv, hipStream_t s) {
   if (n_surv > 0) {
     const int split = 4 * n_surv <= 256 ? 1 : 0;        // (the diagonal block in two workgroups where CUs are idle anyway)
-    BODYFIT_LAUNCH(k_cr_update, dim3((split ? 4 : 3) * n_surv), dim3(kCrThreads), win_update_lds_bytes(), s, W, d_surv, n_surv, split);
+    BODYFIT_LAUNCH(k_cr_update, dim3((split ? 4 : 3) * n_surv), dim3(kCrThreads), win_update_lds_bytes(), s, d_surv, n_surv, split,
+                   W.D, W.Qt, W.Pt, W);
   }
 }
 void launch_cr_back(const WinBuf& W, const int* d_elim, int n_elim, hipStream_t s) {
-  if (n_elim > 0) BODYFIT_LAUNCH(k_cr_back, dim3(n_elim), dim3(kCrThreads), win_back_lds_bytes(), s, W, d_elim, n_elim);
+  if (n_elim > 0) BODYFIT_LAUNCH(k_cr_back, dim3(n_elim), dim3(kCrThreads), win_back_lds_bytes(), s, d_elim, W.L, W.Xt, n_elim, W);
 }
 void launch_win_schur_part(const WinProblem& P, const WinBuf& W, hipStream_t s) {
   BODYFIT_LAUNCH(k_win_schur_part, dim3(P.F), dim3(128), 0, s, P, W);

@@ -48,6 +48,16 @@ int main() {
     for (double v : h) { unsigned long long b; memcpy(&b, &v, 8); x = (x ^ b) * 1099511628211ull; }
     return x;
   };
+  {   // launch to launch, 200 launches (what the stamps cannot see: the time in front of the first stamp)
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int rep = 0; rep < 3; ++rep) {
+      hipEventRecord(e0);
+      for (int i = 0; i < 200; ++i) launch_cr_factor(W, d_elim, 1, 0);
+      hipEventRecord(e1); hipEventSynchronize(e1);
+      float ms; hipEventElapsedTime(&ms, e0, e1);
+      printf("launch to launch: %.2f us per k_cr_factor\n", ms / 200 * 1e3);
+    }
+  }
   const size_t bb = (size_t)WBk * WBk;
   printf("outputs: L %016llx  Pt %016llx  Qt %016llx  Yt %016llx  Li %016llx\n", sum(W.L, bb, bb), sum(W.Pt, bb, bb), sum(W.Qt, bb, bb),
          sum(W.Yt, (size_t)WRk * WBk, (size_t)WRk * WBk), sum(W.Li, 5 * 256, 5 * 256));

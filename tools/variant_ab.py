@@ -68,7 +68,7 @@ if __name__ == "__main__":
             env = dict(os.environ, BODYFIT_LIB=lib)
             for item in filter(None, kv.split(",")):
                 k, _, v = item.partition("=")
-                env["BODYFIT_" + k] = v
+                env[k[4:] if k.startswith("ENV:") else "BODYFIT_" + k] = v     # (ENV:NAME=value: any variable, as it stands)
             out = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", str(a.F), str(a.iters)], env=env,
                                  capture_output=True, text=True, timeout=600)
             line = [l for l in out.stdout.splitlines() if l.startswith("{")]
