@@ -495,21 +495,25 @@ int bodyfit_model_create(const bodyfit_model_desc* desc, int device, bodyfit_mod
   DevModel& d = m->d;
   d.V = V; d.nJ = nJ; d.nS = nS; d.P = P; d.nL = nL; d.nLevels = maxd;
   d.nVTiles = (V + kVTile - 1) / kVTile;
-  HIP_TRY(m->mem.upload(&d.parent, m->parent));
+  // (parent, anc_mask, anc_chain, offset, dS, Jc0, Sc and the landmark tables: one block, bodyfit_device.h kTab*)
+  std::vector<unsigned char> tabA(kTabBytes, 0);
+  auto put = [&](int off, const void* src, size_t bytes) { if (bytes) std::memcpy(tabA.data() + off, src, bytes); };
+  if (nJ > kMaxJoints || nS > kMaxShape) return fail(BODYFIT_ERR_INVALID, "model: at most 24 joints and 10 shape coefficients");
+  put(kTabParent, m->parent.data(), m->parent.size() * sizeof(int));
   HIP_TRY(m->mem.upload(&d.level_off, level_off));
   HIP_TRY(m->mem.upload(&d.level_joint, level_joint));
-  HIP_TRY(m->mem.upload(&d.anc_mask, anc));
+  put(kTabAnc, anc.data(), anc.size() * sizeof(unsigned));
   // the same ancestors as a packed walk list: nearest first, 5 bits each, 0-terminated (joint ids 1..23; depth <= 12)
   std::vector<unsigned long long> chain(nJ, 0ull);
   for (int j = 1; j < nJ; ++j) {
     int lvl = 0;
     for (int k = m->parent[j]; k > 0 && lvl < 12; k = m->parent[k], ++lvl) chain[j] |= (unsigned long long)k << (5 * lvl);
   }
-  HIP_TRY(m->mem.upload(&d.anc_chain, chain));
-  HIP_TRY(m->mem.upload(&d.offset, m->offset));
-  HIP_TRY(m->mem.upload(&d.dS, dS));
-  HIP_TRY(m->mem.upload(&d.Jc0, Jc0));
-  HIP_TRY(m->mem.upload(&d.Sc, Sc));
+  put(kTabChain, chain.data(), chain.size() * sizeof(unsigned long long));
+  put(kTabOffset, m->offset.data(), m->offset.size() * sizeof(double));
+  put(kTabDS, dS.data(), dS.size() * sizeof(double));
+  put(kTabJc0, Jc0.data(), Jc0.size() * sizeof(double));
+  put(kTabSc, Sc.data(), Sc.size() * sizeof(double));
 
   // landmark slots of the frame kernel: the caller's one-hot landmarks, then the pseudo-vertices of the regressor rows.
   // A row  k = sum_i a_i posed(v_i),  posed(v) = sum_j W_vj (A_j (rest_v - Jc_j) + P_j),  collapses per skinning joint j to
@@ -580,11 +584,28 @@ int bodyfit_model_create(const bodyfit_model_desc* desc, int device, bodyfit_mod
             pd[((size_t)l * 27 + a * 9 + k % 9) * 32 + k / 9] += c * desc->posedirs[((size_t)vid * 3 + a) * P + k];
         }
     }
-    HIP_TRY(m->mem.upload(&d.lm_woff, woff));
-    HIP_TRY(m->mem.upload(&d.lm_wj, wj));
-    HIP_TRY(m->mem.upload(&d.lm_ww, ww));
-    HIP_TRY(m->mem.upload(&d.lm_vt, vt));
-    HIP_TRY(m->mem.upload(&d.lm_sd, sd));
+    put(kTabLmWoff, woff.data(), woff.size() * sizeof(int));
+    put(kTabLmWj, wj.data(), wj.size() * sizeof(int));
+    put(kTabLmWw, ww.data(), ww.size() * sizeof(double));
+    put(kTabLmVt, vt.data(), vt.size() * sizeof(double));
+    put(kTabLmSd, sd.data(), sd.size() * sizeof(double));
+    {
+      const unsigned char* dev = nullptr;
+      HIP_TRY(m->mem.upload(&dev, tabA));
+      d.tabA = dev;
+      d.parent = reinterpret_cast<const int*>(dev + kTabParent);
+      d.anc_mask = reinterpret_cast<const unsigned*>(dev + kTabAnc);
+      d.anc_chain = reinterpret_cast<const unsigned long long*>(dev + kTabChain);
+      d.offset = reinterpret_cast<const double*>(dev + kTabOffset);
+      d.dS = reinterpret_cast<const double*>(dev + kTabDS);
+      d.Jc0 = reinterpret_cast<const double*>(dev + kTabJc0);
+      d.Sc = reinterpret_cast<const double*>(dev + kTabSc);
+      d.lm_woff = reinterpret_cast<const int*>(dev + kTabLmWoff);
+      d.lm_wj = reinterpret_cast<const int*>(dev + kTabLmWj);
+      d.lm_ww = reinterpret_cast<const double*>(dev + kTabLmWw);
+      d.lm_vt = reinterpret_cast<const double*>(dev + kTabLmVt);
+      d.lm_sd = reinterpret_cast<const double*>(dev + kTabLmSd);
+    }
     HIP_TRY(m->mem.upload(&d.lm_pd, pd));
     d.lm_gcount = nullptr;
     if (nReg > 0) {
@@ -860,18 +881,26 @@ int bodyfit_problem_create(const bodyfit_model* m, const bodyfit_problem_desc* d
   d.pose_blend = (desc->pose_blend && m->P > 0) ? 1 : 0;
   d.nFTiles = (F + kFTile - 1) / kFTile;
   d.fx = desc->fx; d.fy = desc->fy; d.cx = desc->cx; d.cy = desc->cy;
-  HIP_TRY(p->mem.upload(&d.kp_offset, p->kp_offset));
   {
     // the device copies carry one keypoint chunk (32 entries) of zero padding: k_frame_resjac prefetches a frame's first
-    // chunk with unconditional loads
+    // chunk with unconditional loads.  One block for the three tables (bodyfit_device.h ptab_*_off).
     std::vector<int> ids(p->kp_id);
     for (int& id : ids)        // a regressor row is addressed by the first of its landmark slots on the device
       if (id >= nJ + m->nL) id = nJ + m->reg_slot[id - nJ - m->nL];
     std::vector<double> uv(p->kp_uv);
     ids.resize(ids.size() + 32, 0);
     uv.resize(uv.size() + 64, 0.0);
-    HIP_TRY(p->mem.upload(&d.kp_id, ids));
-    HIP_TRY(p->mem.upload(&d.kp_uv, uv));
+    const int id_off = ptab_id_off(F), uv_off = ptab_uv_off(F, K);
+    std::vector<unsigned char> ptab((size_t)uv_off + uv.size() * sizeof(double), 0);
+    std::memcpy(ptab.data(), p->kp_offset.data(), p->kp_offset.size() * sizeof(int));
+    std::memcpy(ptab.data() + id_off, ids.data(), ids.size() * sizeof(int));
+    std::memcpy(ptab.data() + uv_off, uv.data(), uv.size() * sizeof(double));
+    const unsigned char* dev = nullptr;
+    HIP_TRY(p->mem.upload(&dev, ptab));
+    d.ptab = dev;
+    d.kp_offset = reinterpret_cast<const int*>(dev);
+    d.kp_id = reinterpret_cast<const int*>(dev + id_off);
+    d.kp_uv = reinterpret_cast<const double*>(dev + uv_off);
   }
   std::vector<double> R0(desc->R0, desc->R0 + (size_t)F * 9);
   HIP_TRY(p->mem.upload(&d.R0, R0));

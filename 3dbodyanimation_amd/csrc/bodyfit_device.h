@@ -21,8 +21,31 @@ constexpr int kFTile = 32;         // frames per MFMA row tile
 constexpr int kPoseFeat = 207;     // 9 x 23 pose-corrective features
 constexpr int kBlendKSteps = 14;   // K = 207 pose features + 10 shape coefficients = 217 -> 224 = 14 x 16 (bf16 32x32x16)
 
+// The small model tables the frame role reads in its first phase live in ONE device block at fixed offsets (sized for the
+// maxima), and a problem's keypoint tables in another: the one-launch sweep then needs two pointers for them instead of
+// sixteen, few enough to arrive as preloaded kernel arguments (k_sweep.hip FrameHead).  DevModel's / DevProblem's own pointers
+// point into the same blocks.
+constexpr int kTabParent = 0;                                   // int[32]
+constexpr int kTabAnc = kTabParent + 32 * 4;                    // unsigned[32]
+constexpr int kTabChain = kTabAnc + 32 * 4;                     // unsigned long long[32]
+constexpr int kTabLmWoff = kTabChain + 32 * 8;                  // int[kMaxLandmarks + 8]
+constexpr int kTabLmWj = kTabLmWoff + (kMaxLandmarks + 8) * 4;  // int[kMaxLandmarks][kMaxLmNnz]
+constexpr int kTabLmWw = kTabLmWj + kMaxLandmarks * kMaxLmNnz * 4;       // double[kMaxLandmarks][kMaxLmNnz]
+constexpr int kTabLmVt = kTabLmWw + kMaxLandmarks * kMaxLmNnz * 8;       // double[kMaxLandmarks][3]
+constexpr int kTabLmSd = kTabLmVt + kMaxLandmarks * 3 * 8;               // double[kMaxLandmarks][3][kMaxShape]
+constexpr int kTabDS = kTabLmSd + kMaxLandmarks * 3 * kMaxShape * 8;     // double[kMaxJoints][3][kMaxShape]
+constexpr int kTabSc = kTabDS + kMaxJoints * 3 * kMaxShape * 8;
+constexpr int kTabOffset = kTabSc + kMaxJoints * 3 * kMaxShape * 8;      // double[kMaxJoints][3]
+constexpr int kTabJc0 = kTabOffset + kMaxJoints * 3 * 8;
+constexpr int kTabBytes = kTabJc0 + kMaxJoints * 3 * 8;
+static_assert(kTabLmWw % 8 == 0 && kTabChain % 8 == 0, "f64 / u64 tables on 8-byte offsets");
+// a problem's keypoint block: [kp_offset int[F + 1]] [kp_id int[K + 32]] [kp_uv double[2 (K + 32)]], each on a 16-byte offset
+__host__ __device__ inline int ptab_id_off(int F) { return ((F + 1) * 4 + 15) & ~15; }
+__host__ __device__ inline int ptab_uv_off(int F, int K) { return ptab_id_off(F) + (((K + 32) * 4 + 15) & ~15); }
+
 struct DevModel {
   int V, nJ, nS, P, nL, nLevels, nVTiles;
+  const unsigned char* tabA;   // the block above
   // skeleton, f64
   const int* parent;           // [nJ]
   const int* level_off;        // [nLevels+1]  joints of depth d+1
@@ -51,6 +74,7 @@ struct DevModel {
 
 struct DevProblem {
   int F, K, ncols, use_shape, beta_stride, pose_blend, nFTiles;
+  const unsigned char* ptab;   // the keypoint block above (kp_offset / kp_id / kp_uv point into it)
   int feat_perm;          // row order of the blend-coefficient fragments (frame_part_inl.h), set per launch
   const int* kp_offset;   // [F+1]
   const int* kp_id;       // [K]

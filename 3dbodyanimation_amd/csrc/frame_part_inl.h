@@ -189,6 +189,20 @@ constexpr int TAB_KPID = 96;                   // KC
 
 // What the one-launch sweep (k_sweep_roles) adds to the frame part: the frame's mesh operands are handed to the mesh
 // workgroups inside the launch.
+// What phase A of the frame role reads, as k_sweep_roles' leading scalar kernel arguments (preloaded into SGPRs with the wave:
+// -amdgpu-kernarg-preload-count): the two table blocks (bodyfit_device.h kTab*, ptab_*_off), the per-launch pointers and the
+// dimensions, so that the phase's loads do not wait for a scalar load of the by-value argument struct first.
+struct FrameHead {
+  const unsigned char* mtab;      // DevModel::tabA
+  const unsigned char* ptab;      // DevProblem::ptab
+  const double* R0;               // DevProblem::R0 (or the launch's override)
+  int F, K;
+  int dims;                       // nJ | nS << 6 | nL << 10 | ncols << 16 | use_shape << 24 | beta_stride << 25 | has mesh operands << 29
+};
+__host__ __device__ inline int frame_head_dims(int nJ, int nS, int nL, int ncols, int use_shape, int beta_stride, int has_coef) {
+  return nJ | (nS << 6) | (nL << 10) | (ncols << 16) | ((use_shape ? 1 : 0) << 24) | (beta_stride << 25) | ((has_coef ? 1 : 0) << 29);
+}
+
 struct FusedFrame {
   unsigned* flag;                 // counter of 32-frame unit u at flag[u * kUnitCounterStride]: += 1 once a frame's mesh operands are published
   unsigned epoch;                 // this launch's number
@@ -221,13 +235,36 @@ template <bool kFused>
 __device__ __forceinline__ void frame_part(const DevModel& M, const DevProblem& Pb, const double* __restrict__ params,
                                            const double* __restrict__ beta, double* __restrict__ r_out,
                                            double* __restrict__ J_out, double* __restrict__ joints_out, const MeshCoef& mc,
-                                           int want_jac, double* sm, int f, const FusedFrame& fu) {
+                                           int want_jac, double* sm, int f, const FusedFrame& fu, const FrameHead& hd) {
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
-  const int nJ = M.nJ, nS = M.nS, P = M.P, nL = M.nL;
-  const int ncols = Pb.ncols;
+  // dimensions and the pointers of phase A: in the one-launch sweep from the preloaded head (nothing of M / Pb / mc is touched
+  // before the phase's loads are out: their scalar loads are then still in flight), otherwise from the structs
+  const int nJ = kFused ? (hd.dims & 63) : M.nJ, nS = kFused ? ((hd.dims >> 6) & 15) : M.nS, nL = kFused ? ((hd.dims >> 10) & 63) : M.nL;
+  const int ncols = kFused ? ((hd.dims >> 16) & 255) : Pb.ncols;
   const int npose = 7 + 3 * (nJ - 1);
-  const bool use_shape = Pb.use_shape != 0;
+  const bool use_shape = kFused ? (((hd.dims >> 24) & 1) != 0) : (Pb.use_shape != 0);
+  const int beta_stride = kFused ? ((hd.dims >> 25) & 15) : Pb.beta_stride;
+  const unsigned char* const mtab = kFused ? hd.mtab : M.tabA;
+  const unsigned char* const ptab = kFused ? hd.ptab : Pb.ptab;
+  const int* const t_parent = reinterpret_cast<const int*>(mtab + kTabParent);
+  const unsigned* const t_anc = reinterpret_cast<const unsigned*>(mtab + kTabAnc);
+  const unsigned long long* const t_chain = reinterpret_cast<const unsigned long long*>(mtab + kTabChain);
+  const int* const t_lm_woff = reinterpret_cast<const int*>(mtab + kTabLmWoff);
+  const int* const t_lm_wj = reinterpret_cast<const int*>(mtab + kTabLmWj);
+  const double* const t_lm_ww = reinterpret_cast<const double*>(mtab + kTabLmWw);
+  const double* const t_lm_vt = reinterpret_cast<const double*>(mtab + kTabLmVt);
+  const double* const t_lm_sd = reinterpret_cast<const double*>(mtab + kTabLmSd);
+  const double* const t_dS = reinterpret_cast<const double*>(mtab + kTabDS);
+  const double* const t_Sc = reinterpret_cast<const double*>(mtab + kTabSc);
+  const double* const t_offset = reinterpret_cast<const double*>(mtab + kTabOffset);
+  const double* const t_Jc0 = reinterpret_cast<const double*>(mtab + kTabJc0);
+  const int t_F = kFused ? hd.F : Pb.F, t_K = kFused ? hd.K : Pb.K;
+  const int* const t_kp_offset = reinterpret_cast<const int*>(ptab);
+  const int* const t_kp_id = reinterpret_cast<const int*>(ptab + ptab_id_off(t_F));
+  const double* const t_kp_uv = reinterpret_cast<const double*>(ptab + ptab_uv_off(t_F, t_K));
+  const double* const t_R0 = kFused ? hd.R0 : Pb.R0;
+  const int P = M.P;
   double* sx = sm + OFF_X;
   double* sR = sm + OFF_R;
   double* sdR = sm + OFF_DR;
@@ -263,7 +300,11 @@ __device__ __forceinline__ void frame_part(const DevModel& M, const DevProblem& 
     Pb.dbg[((size_t)f * 8) * 16 + 9] = xcc & 0xf;
   }
 #endif
-  if (Pb.frame_flags && !(Pb.frame_flags[f] & Pb.frame_mask)) return;   // frame already converged (device LM)
+  // frame already converged (device LM).  Not in the one-launch sweep, which never carries frame flags: the test would put a
+  // scalar round trip of its own (the flag pointer, ~0.2 us) in front of the role's operand loads
+  if constexpr (!kFused) {
+    if (Pb.frame_flags && !(Pb.frame_flags[f] & Pb.frame_mask)) return;
+  }
   constexpr int kLoaders = kThreads;
   constexpr bool loader = true;
   // ---- A. small model tables, landmark weights and the frame's parameters into LDS: every load of the phase is issued
@@ -271,57 +312,57 @@ __device__ __forceinline__ void frame_part(const DevModel& M, const DevProblem& 
   //      predicated).  Written as load-store loops the phase compiled to one dependent L2 round trip per loop trip. --------
   constexpr int kSdPasses = (kMaxLandmarks * 3 * kMaxShape + kThreads - 1) / kThreads;   // 2
   constexpr int kPasses = (720 + kLoaders - 1) / kLoaders;                                 // 24 x 3 x 10 doubles: 2
-  const bool coef_wave = kFused && wave == 5 && mc.featA != nullptr;
+  const bool coef_wave = kFused && wave == 5 && ((hd.dims >> 29) & 1) != 0;
   const int tj_c = min(tid, nJ - 1);
-  const int par_in = M.parent[tj_c];
-  const unsigned anc_in = M.anc_mask[tj_c];
-  const unsigned long long chain_in = M.anc_chain[tj_c];
+  const int par_in = t_parent[tj_c];
+  const unsigned anc_in = t_anc[tj_c];
+  const unsigned long long chain_in = t_chain[tj_c];
   const int nlw = nL * kMaxLmNnz, lw_i = min(tid, max(nlw, 1) - 1);          // <= 256 items: one pass
-  const double lww_in = M.lm_ww[lw_i];
-  const int lwj_in = M.lm_wj[lw_i];
-  const int lwo_in = M.lm_woff[lw_i / kMaxLmNnz];
+  const double lww_in = t_lm_ww[lw_i];
+  const int lwj_in = t_lm_wj[lw_i];
+  const int lwo_in = t_lm_woff[lw_i / kMaxLmNnz];
   const int nsd = nL * 3 * nS, nds = nJ * 3 * nS;
   double sd_in[kSdPasses], t0[kPasses], t1[kPasses];
 #pragma unroll
-  for (int u = 0; u < kSdPasses; ++u) sd_in[u] = M.lm_sd[min(tid + u * kThreads, max(nsd, 1) - 1)];
+  for (int u = 0; u < kSdPasses; ++u) sd_in[u] = t_lm_sd[min(tid + u * kThreads, max(nsd, 1) - 1)];
 #pragma unroll
   for (int u = 0; u < kPasses; ++u) {
     const int i = min(tid + u * kLoaders, max(nds, 1) - 1);
-    t0[u] = M.dS[i];
-    t1[u] = M.Sc[i];
+    t0[u] = t_dS[i];
+    t1[u] = t_Sc[i];
   }
   // the first keypoint chunk depends on kp_offset[f] (a second round trip): its loads are issued here but land in LDS
   // only after the barrier, so phase A waits for one round trip, not two (the staged keypoints are first read in F)
-  const int k_begin0 = Pb.kp_offset[f], nk0 = min(KC, Pb.kp_offset[f + 1] - k_begin0);
+  const int k_begin0 = t_kp_offset[f], nk0 = min(KC, t_kp_offset[f + 1] - k_begin0);
   // model constants phase B needs (chain offsets, centred rest joints, landmark template rows): requested here, with
   // the tables, and consumed from registers after the barrier, so phase B has no round trip of its own
   const int o_i = tid - 128, v_row = tid - 256;
   const bool o_lane = tid >= 128 && o_i < nJ * 3, v_lane = tid >= 256 && v_row < nL * 3;
   double o_pre = 0.0, jc_pre = 0.0, vt_pre = 0.0;
-  if (o_lane) { o_pre = M.offset[o_i]; jc_pre = M.Jc0[o_i]; }
-  if (v_lane) vt_pre = M.lm_vt[v_row];
+  if (o_lane) { o_pre = t_offset[o_i]; jc_pre = t_Jc0[o_i]; }
+  if (v_lane) vt_pre = t_lm_vt[v_row];
   // R0 of this frame for the camera matrices Rr0 = R_root R0, dRr0_c = dR_root,c R0 (36 entries, wave 6 in phase C):
   // lane's column c of R0, requested here
   const int cam_lane = tid - 384;
   const bool cam_on = cam_lane >= 0 && cam_lane < 36;
   double r0c0 = 0.0, r0c1 = 0.0, r0c2 = 0.0;
   if (cam_on) {
-    const double* R0 = Pb.R0 + (size_t)f * 9;
+    const double* R0 = t_R0 + (size_t)f * 9;
     const int c = cam_lane % 3;
     r0c0 = R0[c]; r0c1 = R0[3 + c]; r0c2 = R0[6 + c];
   }
   double x_in = 0.0;
   const bool x_lane = tid >= 128 && tid - 128 < npose, b_lane = tid >= 224 && tid - 224 < nS;
   if (x_lane) x_in = params[(size_t)f * npose + tid - 128];
-  if (b_lane) x_in = (use_shape && beta) ? beta[(size_t)f * Pb.beta_stride + tid - 224] : 0.0;
+  if (b_lane) x_in = (use_shape && beta) ? beta[(size_t)f * beta_stride + tid - 224] : 0.0;
   // issued last and by every lane (the arrays are padded by one chunk): loads return in order, so everything above is
   // waited for with these still in flight
   int kp_id0 = 0;
   double kp_u0 = 0.0, kp_v0 = 0.0;
   if (loader) {
-    kp_id0 = Pb.kp_id[k_begin0 + (tid & (KC - 1))];
-    kp_u0 = Pb.kp_uv[2 * (size_t)(k_begin0 + (tid & (KC - 1)))];
-    kp_v0 = Pb.kp_uv[2 * (size_t)(k_begin0 + (tid & (KC - 1))) + 1];
+    kp_id0 = t_kp_id[k_begin0 + (tid & (KC - 1))];
+    kp_u0 = t_kp_uv[2 * (size_t)(k_begin0 + (tid & (KC - 1)))];
+    kp_v0 = t_kp_uv[2 * (size_t)(k_begin0 + (tid & (KC - 1))) + 1];
   }
   if (tid < nJ) { sParent[tid] = par_in; sAnc[tid] = anc_in; sChain[tid] = chain_in; }
   volatile int* sWalkDone = reinterpret_cast<volatile int*>(sPart + 104);   // phase C: wave 6's chain quantities are in LDS

@@ -78,7 +78,8 @@ __global__ __launch_bounds__(kThreads, 4) void k_frame_resjac(DevModel M, DevPro
   // a frame workgroup that shares its CU with a prior workgroup (256 frames + 16 prior tiles on 256 CUs) is the launch's
   // critical path; the prior workgroup has slack: frame waves win the issue arbitration
   __builtin_amdgcn_s_setprio(2);
-  frame_part<false>(M, Pb, params, beta, r_out, J_out, joints_out, mc, want_jac, sm, (int)blockIdx.x - pa.n_tiles, none);
+  const FrameHead no_head{};
+  frame_part<false>(M, Pb, params, beta, r_out, J_out, joints_out, mc, want_jac, sm, (int)blockIdx.x - pa.n_tiles, none, no_head);
 }
 
 __global__ __launch_bounds__(64 * kWaves) void k_mesh_blend_lbs(DevModel M, DevProblem Pb, MeshCoef mc,
@@ -192,12 +193,20 @@ typedef const __attribute__((address_space(4))) RoleArgs* RoleArgP;
 
 // F and nVT, which the role of a block is decoded from, are leading scalar arguments: with -amdgpu-kernarg-preload-count they are in
 // SGPRs when the wave starts, and the decode no longer waits for a scalar load of its own in front of the role's operand loads.
-static_assert(alignof(RoleArgs) == 8, "kernel-argument segment: [int F][int nVT][RoleArgs at offset 8]");
-__global__ __launch_bounds__(kThreads, 4) void k_sweep_roles(int F_arg, int nVT_arg, RoleArgs by_value) {
+// So is everything phase A of the frame role loads from (FrameHead, frame_part_inl.h): four integers and five pointers, the
+// fourteen dwords the hardware preloads.
+static_assert(alignof(RoleArgs) == 8, "kernel-argument segment: 4 ints, 5 pointers, then RoleArgs at offset 56");
+constexpr int kRoleArgsOffset = 4 * 4 + 5 * 8;
+__global__ __launch_bounds__(kThreads, 4) void k_sweep_roles(int F_arg, int nVT_arg, int K_arg, int dims_arg,
+                                                             const unsigned char* __restrict__ mtab_arg,
+                                                             const unsigned char* __restrict__ ptab_arg,
+                                                             const double* __restrict__ R0_arg, const double* __restrict__ params_arg,
+                                                             const double* __restrict__ beta_arg, RoleArgs by_value) {
   (void)by_value;
 #if defined(__HIP_DEVICE_COMPILE__)   // (the host pass only needs the stub; it cannot copy structs out of address space 4)
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-  const RoleArgP A = (RoleArgP)((const __attribute__((address_space(4))) unsigned char*)__builtin_amdgcn_kernarg_segment_ptr() + 8);
+  const RoleArgP A =
+      (RoleArgP)((const __attribute__((address_space(4))) unsigned char*)__builtin_amdgcn_kernarg_segment_ptr() + kRoleArgsOffset);
   const int F = F_arg, nVT = nVT_arg;
   // ---- role of this block: [frames 0][frames 1][mesh 0][frames 2][mesh 1] ... [mesh nG-1][prior tiles] ----------------
   int role = 2, idx = 0, grp = 0;
@@ -234,8 +243,10 @@ __global__ __launch_bounds__(kThreads, 4) void k_sweep_roles(int F_arg, int nVT_
     fu.j_scope = A->sy.j_scope;
     // a frame workgroup is the launch's critical path; the mesh workgroup it shares the CU with has slack
     __builtin_amdgcn_s_setprio(2);
-    frame_part<true>(M, Pb, A->params, A->beta, A->r_out, A->J_out, A->joints_out, mc, A->want_jac,
-                     reinterpret_cast<double*>(lds), idx, fu);
+    FrameHead hd;
+    hd.mtab = mtab_arg; hd.ptab = ptab_arg; hd.R0 = R0_arg; hd.F = F_arg; hd.K = K_arg; hd.dims = dims_arg;
+    frame_part<true>(M, Pb, params_arg, beta_arg, A->r_out, A->J_out, A->joints_out, mc, A->want_jac,
+                     reinterpret_cast<double*>(lds), idx, fu, hd);
     if (A->fold.ticket)
       fold_tail(A->fold.ticket, A->fold.want, A->fold.n_partials, A->fold.partials, A->fold.beta, A->fold.shape_rows,
                 A->fold.beta_shape, A->fold.out66, lds);
@@ -370,7 +381,9 @@ void launch_sweep_roles(const DevModel& M, const DevProblem& P, const double* d_
   RoleArgs A;
   A.M = M; A.Pb = P; A.Pb.feat_perm = 1; A.params = d_params; A.beta = d_beta; A.r_out = d_r; A.J_out = d_J;
   A.joints_out = d_joints; A.mc = mc; A.want_jac = want_jac; A.pa = pa; A.cloud_f = d_cloud; A.sy = sy; A.fold = fold;
-  BODYFIT_LAUNCH_EXT(k_sweep_roles, dim3(grid), dim3(kThreads), kRoleLdsBytes, s, ev_start, ev_stop, 0, P.F, M.nVTiles, A);
+  const int dims = frame_head_dims(M.nJ, M.nS, M.nL, P.ncols, P.use_shape, P.beta_stride, mc.featA != nullptr);
+  BODYFIT_LAUNCH_EXT(k_sweep_roles, dim3(grid), dim3(kThreads), kRoleLdsBytes, s, ev_start, ev_stop, 0, P.F, M.nVTiles, P.K, dims,
+                     M.tabA, P.ptab, P.R0, d_params, d_beta, A);
 }
 
 }  // namespace bodyfit
