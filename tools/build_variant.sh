@@ -6,7 +6,7 @@ set -e
 cd "$(dirname "$0")/../3dbodyanimation_amd/csrc"
 name=$1; flags=$2
 HIPCC=/opt/rocm/bin/hipcc
-BASE="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function"
+BASE="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -mllvm -amdgpu-kernarg-preload-count=14"   # (the Makefile's HIPFLAGS)
 mkdir -p _obj_var/$name
 if [[ $name == st_* ]]; then
   for f in bodyfit_api k_sweep k_reduce k_lm_batched k_window_lm overlay; do
