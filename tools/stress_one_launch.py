@@ -41,6 +41,8 @@ for F in sizes:
         j1, cl1 = one.forward(x, b)
         j2, cl2 = two.forward(x, b)
         assert np.array_equal(r1, r2) and np.array_equal(J1, J2) and np.array_equal(c1, c2), (F, it, "residuals / Jacobian")
-        assert np.array_equal(j1, j2) and np.array_equal(cl1, cl2), (F, it, "joints / cloud")
+        # (the cloud to 2e-6 m: since round 4 the one-launch sweep's blend coefficients come from f32 rotations — frame role, wave 5 —,
+        #  the two-launch kernel's from the f64 ones: a last-bit difference in f32, as in tests/test_gpu_one_launch.py)
+        assert np.array_equal(j1, j2) and np.abs(cl1 - cl2).max() < 2e-6, (F, it, "joints / cloud")
     one.close(); two.close()
 print(f"{len(sizes)} sizes x 3 points ok in {time.time() - t0:.1f} s: {sizes[:12]} ...")
