@@ -196,7 +196,7 @@ typedef const __attribute__((address_space(4))) RoleArgs* RoleArgP;
 // So is everything phase A of the frame role loads from (FrameHead, frame_part_inl.h): four integers and five pointers, the
 // fourteen dwords the hardware preloads.
 static_assert(alignof(RoleArgs) == 8, "kernel-argument segment: 4 ints, 5 pointers, then RoleArgs at offset 56");
-constexpr int kRoleArgsOffset = 4 * 4 + 5 * 8;
+[[maybe_unused]] constexpr int kRoleArgsOffset = 4 * 4 + 5 * 8;
 __global__ __launch_bounds__(kThreads, 4) void k_sweep_roles(int F_arg, int nVT_arg, int K_arg, int dims_arg,
                                                              const unsigned char* __restrict__ mtab_arg,
                                                              const unsigned char* __restrict__ ptab_arg,
