@@ -376,6 +376,8 @@ def main():
                     help="untimed sweeps in FRONT of the --warmup steps: a fresh process's first ~500 launches run 8-15 %% slower "
                          "(clock ramp, first-touch of the model: 23-25 us per step against 21 once warm, profiles/r4_y_variant_ab.txt); "
                          "the driver's --warmup 5 alone leaves the timed steps on that ramp.  Reported as prewarm_steps")
+    ap.add_argument("--prewarm-rest-ms", type=float, default=2.0,
+                    help="idle time between the untimed sweeps and the warm-up steps (the clock governor's recovery; 0: none)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pcie", action="store_true", help="(kept for old command lines: the host-pointer rate is always reported)")
     ap.add_argument("--no-ceres-path", action="store_true", help="skip the Ceres-kept-path record (needs g++ on the box)")
@@ -497,6 +499,12 @@ def main():
         prob.evaluate_device(d_params.data_ptr(), d_beta.data_ptr(), True, stream)
         if i % 256 == 255:
             torch.cuda.synchronize()      # (keeps the queue short; nothing is timed here)
+    if args.prewarm > 0 and args.prewarm_rest_ms > 0:
+        # ... and a short rest: straight behind a long burst the first launches after a synchronisation run ~5 % slower than
+        # the sustained rate (dispatch durations 20.2-20.7 us against 18.9-19.3 after 1-3 ms of rest and in long runs; after
+        # 10 ms the clock has dropped: 21+) — tools/first_steps.py.  With it the K timed steps read what a 2,000-step run reads
+        torch.cuda.synchronize()
+        time.sleep(args.prewarm_rest_ms * 1e-3)
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -573,7 +581,7 @@ def main():
         out = {
             "metric": "SMPL residual+Jacobian evals/sec (6890v, 10 beta, 24 joints)",
             "value": evals_s, "unit": "evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "prewarm_steps": args.prewarm, "ms_per_step": ms_step, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
+            "prewarm_steps": args.prewarm, "prewarm_rest_ms": args.prewarm_rest_ms if args.prewarm > 0 else 0.0, "ms_per_step": ms_step, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "f64 residual/Jacobian; f32 mesh (f32 + split-bf16 MFMA blend)", "data": "synthetic",
             "config": {"workload": wl_name, "frames_per_gpu": F, "keypoints_per_frame": 25, "n_cols": 86},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
