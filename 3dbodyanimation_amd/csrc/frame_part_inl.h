@@ -199,6 +199,8 @@ struct FrameHead {
   int F, K;
   int dims;                       // nJ | nS << 6 | nL << 10 | ncols << 16 | use_shape << 24 | beta_stride << 25 | has mesh operands << 29
 };
+static_assert(kMaxJoints < 64 && kMaxShape < 16 && kMaxLandmarks < 64 && 7 + 3 * (kMaxJoints - 1) + kMaxShape < 256,
+              "FrameHead::dims: 6 + 4 + 6 + 8 bits for nJ, nS, nL, ncols; beta_stride (0 or nS) in 4");
 __host__ __device__ inline int frame_head_dims(int nJ, int nS, int nL, int ncols, int use_shape, int beta_stride, int has_coef) {
   return nJ | (nS << 6) | (nL << 10) | (ncols << 16) | ((use_shape ? 1 : 0) << 24) | (beta_stride << 25) | ((has_coef ? 1 : 0) << 29);
 }
