@@ -185,6 +185,9 @@ def load_library():
     lib.bodyfit_allreduce_shared_rccl.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     lib.bodyfit_rccl_count.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     lib.bodyfit_sweep_status.argtypes = [C.c_void_p, C.c_void_p]
+    lib.bodyfit_sweep_timeouts.argtypes = [C.c_void_p]
+    lib.bodyfit_sweep_timeouts.restype = C.c_long
+    lib.bodyfit_set_exchange_timeout.argtypes = [C.c_void_p, C.c_double]
     lib.bodyfit_launch_count.argtypes = []
     lib.bodyfit_launch_count.restype = C.c_long
     lib.bodyfit_last_exchange_count.argtypes = [C.c_void_p]
@@ -394,6 +397,14 @@ class Problem:
         """Waits for `stream`; raises if an asynchronous one-launch sweep since the last check left its cloud incomplete
         (bodyfit_sweep_status: the problem then uses the two-launch sweep, so evaluating again gives the whole result)."""
         _check(load_library().bodyfit_sweep_status(self.h, stream))
+
+    def sweep_timeouts(self) -> int:
+        """one-launch sweeps of this problem found incomplete since it was created (bodyfit_sweep_timeouts); 0 in a healthy run"""
+        return int(load_library().bodyfit_sweep_timeouts(self.h))
+
+    def set_exchange_timeout(self, seconds: float):
+        """bound on every exchange / status read of this problem's sharded solves (bodyfit_set_exchange_timeout; 0: none)"""
+        _check(load_library().bodyfit_set_exchange_timeout(self.h, float(seconds)))
 
     def arm_shared_reduction(self, d_out_ptr: int | None):
         """Following Jacobian sweeps deposit [cost | g_beta | H_bb] in d_out_ptr at their own tail when they can (one-launch

@@ -104,6 +104,12 @@ struct Allocs {
     void* p = pooled ? BlockPool::get().take(dev, bytes) : nullptr;
     hipError_t e = hipSuccess;
     if (!p) e = hipMalloc(&p, bytes);
+    if (!p && e != hipSuccess) {
+      // out of memory while the pool sits on up to 1 GiB of blocks of other sizes: give them back and try once more
+      (void)hipGetLastError();
+      BlockPool::get().trim(dev);
+      e = hipMalloc(&p, bytes);
+    }
     if (e == hipSuccess) {
       blocks.push_back(Block{p, bytes, dev});
       *out = static_cast<T*>(p);
@@ -197,6 +203,8 @@ struct bodyfit_problem {
   unsigned char* d_fused = nullptr;
   size_t fused_bytes = 0;
   long last_exchanges = 0;             // all-gathers issued by the last sharded solve (tests: exchanges per iteration)
+  double exchange_timeout_s = 0.0;     // bodyfit_set_exchange_timeout: bound of one exchange / status read of a sharded solve
+  int test_poison_rank = -1, test_poison_iter = -1;   // bodyfit_internal_set_test_poison (tests only)
   unsigned fused_epoch = 0;
   bool fused_enabled = true, fused_unchecked = false;
   long fused_timeouts = 0;             // one-launch sweeps found incomplete (bodyfit_internal_fused_timeouts)
@@ -288,13 +296,16 @@ int fused_check(bodyfit_problem* p) {
 // they must not overlap.  The asynchronous entry points only note their stream (no event per sweep: that would cost the
 // resident path a microsecond per step); the synchronous ones record ONE event behind everything enqueued there so far and
 // make their own stream wait for it.
+// The caller's stream must stay alive until the problem's next synchronous entry point (or bodyfit_sweep_status on it) has
+// returned: the event is recorded on it (include/bodyfit.h, bodyfit_evaluate_device).
 int order_after_async(bodyfit_problem* p, hipStream_t own) {
   if (!p->async_pending) return BODYFIT_OK;
-  p->async_pending = false;
-  if (p->async_stream == own) return BODYFIT_OK;   // same stream: ordered anyway
-  if (!p->async_event) HIP_TRY(hipEventCreateWithFlags(&p->async_event, hipEventDisableTiming));
-  HIP_TRY(hipEventRecord(p->async_event, p->async_stream));
-  HIP_TRY(hipStreamWaitEvent(own, p->async_event, 0));
+  if (p->async_stream != own) {                    // (same stream: ordered anyway)
+    if (!p->async_event) HIP_TRY(hipEventCreateWithFlags(&p->async_event, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(p->async_event, p->async_stream));
+    HIP_TRY(hipStreamWaitEvent(own, p->async_event, 0));
+  }
+  p->async_pending = false;                        // only once the ordering is in place
   return BODYFIT_OK;
 }
 
@@ -353,9 +364,12 @@ int sweep(bodyfit_problem* p, const double* d_params, const double* d_beta, int 
     sy.epoch = ++p->fused_epoch;
     sy.resident_blocks = 2 * m->n_cus;
     sy.timeout_ticks = p->role_timeout_ticks;
-    static const int tune_prio = env_int("BODYFIT_MESH_PRIO", 2), tune_start = env_int("BODYFIT_TRICKLE_START", 120),
-                     tune_sleep = env_int("BODYFIT_TRICKLE_SLEEP", 7);
-    static const int tune_jscope = env_int("BODYFIT_J_SCOPE", 1);
+#ifdef BODYFIT_TUNE_ENV   // diagnostic builds only (tools/sweep_tune.py): the shipped library reads no tuning word from outside
+    static const int tune_prio = env_int("BODYFIT_MESH_PRIO", kTuneMeshPrio), tune_start = env_int("BODYFIT_TRICKLE_START", kTuneTrickleStart),
+                     tune_sleep = env_int("BODYFIT_TRICKLE_SLEEP", kTuneTrickleSleep), tune_jscope = env_int("BODYFIT_J_SCOPE", kTuneJScope);
+#else
+    constexpr int tune_prio = kTuneMeshPrio, tune_start = kTuneTrickleStart, tune_sleep = kTuneTrickleSleep, tune_jscope = kTuneJScope;
+#endif
     sy.mesh_prio_early = tune_prio; sy.trickle_start = tune_start; sy.trickle_sleep = tune_sleep; sy.j_scope = tune_jscope;
     p->fused_unchecked = true;
     FoldTail fold{};
@@ -833,6 +847,9 @@ int bodyfit_problem_create(const bodyfit_model* m, const bodyfit_problem_desc* d
 
   HIP_TRY(hipSetDevice(m->device));
   std::unique_ptr<bodyfit_problem> p(new bodyfit_problem());
+  // a creation that fails half way returns its blocks to the pool, like bodyfit_problem_destroy: behind a device synchronisation
+  // (memsets and uploads may still be in flight on them; later takers use non-blocking streams).  Declared after p: runs first.
+  struct SyncOnFailure { std::unique_ptr<bodyfit_problem>& q; ~SyncOnFailure() { if (q) (void)hipDeviceSynchronize(); } } sync_on_failure{p};
   p->mem.pooled = true;
   p->m = m;
   p->desc = *desc;
@@ -1294,6 +1311,7 @@ int bodyfit_internal_solve_batched_device(bodyfit_problem* p, double* frame_para
   }
   if (!p->lm_stream) HIP_TRY(hipStreamCreateWithFlags(&p->lm_stream, hipStreamNonBlocking));
   hipStream_t st = p->lm_stream;
+  if (int ro = order_after_async(p, st)) return ro;   // (the solve writes the r / J / partials an asynchronous sweep may still be writing)
   HIP_TRY(hipMemsetAsync(S.active_count, 0, sizeof(int), st));
   HIP_TRY(hipMemcpyAsync(S.x, frame_params, (size_t)F * npose * sizeof(double), hipMemcpyHostToDevice, st));
   if (nb) HIP_TRY(hipMemcpyAsync(S.beta, beta, (size_t)F * nb * sizeof(double), hipMemcpyHostToDevice, st));
@@ -1515,6 +1533,7 @@ static int solve_window_device(bodyfit_problem* p, double* frame_params, double*
   if (!p->d_frame_normal) HIP_TRY(p->mem.alloc(&p->d_frame_normal, (size_t)F * kNormalRows * kNormalLd));
   if (!p->lm_stream) HIP_TRY(hipStreamCreateWithFlags(&p->lm_stream, hipStreamNonBlocking));
   hipStream_t st = p->lm_stream;
+  if (int ro = order_after_async(p, st)) return ro;
   WinProblem P{};
   P.F = F; P.K = p->lay.n_keypoints; P.total_rows = p->lay.total_rows; P.nb = nb; P.halo = halo;
   P.prior_rows = p->lay.prior_rows_per_frame; P.row_prior = p->row_prior;
@@ -1542,6 +1561,16 @@ static int solve_window_device(bodyfit_problem* p, double* frame_params, double*
     if (comm->allgather(d_send, d_gath, cnt, st)) return comm_fail(what);
     return BODYFIT_OK;
   };
+  // the host's wait for a status record: bounded for sharded solves with bodyfit_set_exchange_timeout (a peer that left after a
+  // transport failure never enters the collectives queued on the stream)
+  auto wait_status = [&](hipStream_t s2) -> int {
+    hipError_t he = hipSuccess;
+    const int w = wait_stream(s2, sharded ? p->exchange_timeout_s : 0.0, &he);
+    if (w == 1) return fail(BODYFIT_ERR_HIP, "bodyfit_solve_sharded: the solve's stream did not drain within the exchange timeout "
+                                             "(a peer has left the collective); the problem's stream is unusable from here on");
+    if (w < 0) return fail(BODYFIT_ERR_HIP, std::string("status read: ") + hipGetErrorString(he));
+    return BODYFIT_OK;
+  };
   if (sharded) {
     // the boundary rows of the starting point: [first row | last row] of every shard -> the frame in front of this shard's
     // first (d_xl) and the halo row behind its last
@@ -1557,7 +1586,14 @@ static int solve_window_device(bodyfit_problem* p, double* frame_params, double*
   // buffers); the next iteration's k_frame_normal takes the starting point's (r, J), the accepted candidate's, or nothing at
   // all (rejected step: the panels are current), as the device's own record says (W.status[kWsJsel]; sharded solves: every
   // rank's k_win_decide writes the same).
+  // Sharded solves: a rank whose own work fails (a kernel launch, a HIP call) must not simply return — its peers would wait for
+  // it in the next all-gather for ever.  It marks slot 6 of its scalars (`poison`), keeps taking part in the exchanges of the
+  // iteration, and k_win_decide ends the solve on EVERY rank in that same iteration (kWsPoison).  Only a failure of the
+  // transport itself returns at once (bodyfit_set_exchange_timeout bounds how long the peers then wait).
+  int poison = BODYFIT_OK;
+  std::string poison_msg;
   int rc = sweep(p, d_x, d_b, 1, false, st);
+  if (rc && sharded) { poison = rc; poison_msg = g_err; rc = BODYFIT_OK; }   // (between two exchanges: stay in step)
   if (rc) return rc;
   if (!sharded) {
     launch_win_init(P, W, p->d_r, 0, st);
@@ -1571,16 +1607,17 @@ static int solve_window_device(bodyfit_problem* p, double* frame_params, double*
   double status[kWsCount] = {0};
   bool first = true;
   const size_t rhs = (size_t)kWinRhs * kWinBlock;
-  // Sharded solves: a rank whose own work fails (a kernel launch, a HIP call) must not simply return — its peers would wait for
-  // it in the next all-gather for ever.  It marks slot 6 of its scalars (`poison`), keeps taking part in the exchanges of the
-  // iteration, and k_win_decide ends the solve on EVERY rank in that same iteration (kWsPoison).  Only a failure of the
-  // transport itself still returns at once (the process group / RCCL needs a timeout for that case).
-  int poison = BODYFIT_OK;
-  std::string poison_msg;
   if (sharded) HIP_TRY(hipMemsetAsync(W.fin, 0, 8 * sizeof(double), st));
-  // test hook (tests/test_gpu_sharded_solve.py): BODYFIT_TEST_POISON="<rank>:<iteration>" makes that rank's sweep "fail" there
-  int test_poison_rank = -1, test_poison_iter = -1;
-  if (const char* tp = std::getenv("BODYFIT_TEST_POISON")) (void)std::sscanf(tp, "%d:%d", &test_poison_rank, &test_poison_iter);
+  // test hook (tests/test_gpu_sharded_solve.py, bodyfit_internal_set_test_poison): that rank's sweep "fails" in that iteration
+  const int test_poison_rank = p->test_poison_rank, test_poison_iter = p->test_poison_iter;
+  // a HIP call inside the loop: unsharded, its failure returns; sharded, it poisons (this rank stays in the exchanges)
+  auto guard = [&](hipError_t e, const char* what) -> int {
+    if (e == hipSuccess) return BODYFIT_OK;
+    const int rcg = fail(BODYFIT_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+    if (!sharded) return rcg;
+    if (!poison) { poison = rcg; poison_msg = g_err; }
+    return BODYFIT_OK;
+  };
   for (int it = 0; it < opt->max_iters; ++it) {
     launch_frame_normal_sel(F, n, p->d.kp_offset, p->desc.huber_delta, p->d_r, p->d_J, d_rn, d_Jn, W.status + kWsJsel,
                             p->lay.total_rows, p->d_frame_normal, st);
@@ -1597,11 +1634,11 @@ static int solve_window_device(bodyfit_problem* p, double* frame_params, double*
         launch_sum_ranks(d_gath, N, 112, 110, W.Craw, st);
         launch_win_beta(P, W, p->d_frame_normal, p->d_r, 1, 2, st);
         launch_win_assemble(P, W, p->d_frame_normal, p->d_r, d_x, d_const, 1, has_left ? d_xl : nullptr, nullptr, st);
-        HIP_TRY(hipMemcpyAsync(d_send, W.scale, npose * sizeof(double), hipMemcpyDeviceToDevice, st));
-        HIP_TRY(hipMemcpyAsync(d_send + npose, W.scale + (size_t)(F - 1) * npose, npose * sizeof(double), hipMemcpyDeviceToDevice, st));
+        if (int g = guard(hipMemcpyAsync(d_send, W.scale, npose * sizeof(double), hipMemcpyDeviceToDevice, st), "scaling rows")) return g;
+        if (int g = guard(hipMemcpyAsync(d_send + npose, W.scale + (size_t)(F - 1) * npose, npose * sizeof(double), hipMemcpyDeviceToDevice, st), "scaling rows")) return g;
         if ((rc = gather(d_send, 2 * npose, "allgather (scaling rows)"))) return rc;
-        if (halo) HIP_TRY(hipMemcpyAsync(d_sh, d_gath + (size_t)(R + 1) * 2 * npose, npose * sizeof(double), hipMemcpyDeviceToDevice, st));
-        if (has_left) HIP_TRY(hipMemcpyAsync(d_sl, d_gath + ((size_t)(R - 1) * 2 + 1) * npose, npose * sizeof(double), hipMemcpyDeviceToDevice, st));
+        if (halo) if (int g = guard(hipMemcpyAsync(d_sh, d_gath + (size_t)(R + 1) * 2 * npose, npose * sizeof(double), hipMemcpyDeviceToDevice, st), "scaling halo")) return g;
+        if (has_left) if (int g = guard(hipMemcpyAsync(d_sl, d_gath + ((size_t)(R - 1) * 2 + 1) * npose, npose * sizeof(double), hipMemcpyDeviceToDevice, st), "scaling halo")) return g;
       }
       launch_win_assemble(P, W, p->d_frame_normal, p->d_r, d_x, d_const, 0, has_left ? d_xl : nullptr, halo ? d_sh : nullptr, st);
     }
@@ -1619,7 +1656,7 @@ static int solve_window_device(bodyfit_problem* p, double* frame_params, double*
       if ((rc = gather(d_send, iface_doubles(n_extra), "allgather (interface blocks)"))) return rc;
       launch_iface_unpack(Wi, d_gath, N, n_extra, d_cg, st);
       if (!first) {
-        HIP_TRY(hipMemcpyAsync(W.Craw, d_cg, 110 * sizeof(double), hipMemcpyDeviceToDevice, st));
+        if (int g = guard(hipMemcpyAsync(W.Craw, d_cg, 110 * sizeof(double), hipMemcpyDeviceToDevice, st), "beta terms")) return g;
         launch_win_beta(P, W, p->d_frame_normal, p->d_r, 0, 2, st);
       }
       for (size_t l = 0; l < ilevels.size(); ++l) {
@@ -1628,8 +1665,8 @@ static int solve_window_device(bodyfit_problem* p, double* frame_params, double*
         launch_cr_update(Wi, d_sched + lv.surv_off, lv.n_surv, st);
       }
       for (size_t l = ilevels.size(); l-- > 0;) launch_cr_back(Wi, d_sched + ilevels[l].elim_off, ilevels[l].n_elim, st);
-      HIP_TRY(hipMemcpyAsync(W.Xt, Wi.Xt + (size_t)(2 * R) * rhs, rhs * 8, hipMemcpyDeviceToDevice, st));
-      HIP_TRY(hipMemcpyAsync(W.Xt + (size_t)(F - 1) * rhs, Wi.Xt + (size_t)(2 * R + 1) * rhs, rhs * 8, hipMemcpyDeviceToDevice, st));
+      if (int g = guard(hipMemcpyAsync(W.Xt, Wi.Xt + (size_t)(2 * R) * rhs, rhs * 8, hipMemcpyDeviceToDevice, st), "interface solution")) return g;
+      if (int g = guard(hipMemcpyAsync(W.Xt + (size_t)(F - 1) * rhs, Wi.Xt + (size_t)(2 * R + 1) * rhs, rhs * 8, hipMemcpyDeviceToDevice, st), "interface solution")) return g;
     }
     for (size_t l = levels.size(); l-- > 0;) launch_cr_back(W, d_sched + levels[l].elim_off, levels[l].n_elim, st);
     // ---- beta Schur complement, step, model change, decision ----
@@ -1686,7 +1723,7 @@ static int solve_window_device(bodyfit_problem* p, double* frame_params, double*
       continue;
     }
     HIP_TRY(hipMemcpyAsync(status, W.status, sizeof(status), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
+    if (int rw = wait_status(st)) return rw;
     if (opt->verbose && R == 0)
       std::printf("[bodyfit-dev] it %3d cost %.6e radius %.3e accepted %d gmax %.2e\n", (int)status[kWsIters], status[kWsCost],
                   status[kWsRadius], (int)status[kWsAccepted], status[kWsGmax]);
@@ -1696,9 +1733,15 @@ static int solve_window_device(bodyfit_problem* p, double* frame_params, double*
   HIP_TRY(hipMemcpyAsync(status, W.status, sizeof(status), hipMemcpyDeviceToHost, st));
   HIP_TRY(hipMemcpyAsync(frame_params, d_x, (size_t)rows_x * npose * sizeof(double), hipMemcpyDeviceToHost, st));
   HIP_TRY(hipMemcpyAsync(beta, d_b, (size_t)nb * sizeof(double), hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipStreamSynchronize(st));
+  if (int rw = wait_status(st)) return rw;
   if (sharded && (poison || status[kWsPoison] != 0.0)) {
-    if (summary) { summary->iterations = (int)status[kWsIters]; summary->termination = 2; summary->usable = 0; }
+    if (summary) {
+      *summary = bodyfit_fit_summary{};
+      summary->iterations = (int)status[kWsIters]; summary->termination = 2; summary->usable = 0;
+      summary->n_successful = (int)status[kWsOk]; summary->n_unsuccessful = (int)status[kWsBad];
+      summary->n_sweeps = 1 + (int)status[kWsIters]; summary->n_sweeps_issued = n_sweeps;
+      summary->initial_cost = status[kWsInitialCost]; summary->final_cost = status[kWsCost];
+    }
     if (poison) return fail(poison, "sharded solve: this rank failed (" + poison_msg + "); every rank left at the same exchange");
     return fail(BODYFIT_ERR_HIP, "sharded solve: another rank reported a device failure; every rank left at the same exchange");
   }
@@ -1750,7 +1793,7 @@ int bodyfit_solve_sharded(bodyfit_problem* p, double* frame_params, double* beta
   if (!p || !frame_params || !beta || !comm || !comm->allgather || comm->size < 1 || comm->rank < 0 || comm->rank >= comm->size)
     return fail(BODYFIT_ERR_INVALID, "bodyfit_solve_sharded: bad argument");
   HostTransport tr;
-  tr.rank = comm->rank; tr.size = comm->size; tr.cb = comm;
+  tr.rank = comm->rank; tr.size = comm->size; tr.cb = *comm; tr.timeout_s = p->exchange_timeout_s;
   long n = 0;
   const int rc = sharded_common(p, frame_params, beta, param_constant, &tr, opt_in, summary, &n);
   p->last_exchanges = n;
@@ -1810,6 +1853,7 @@ int bodyfit_solve_sharded_rccl(bodyfit_problem* p, double* frame_params, double*
                                bodyfit_rccl* comm, const bodyfit_fit_options* opt_in, bodyfit_fit_summary* summary) {
   if (!p || !frame_params || !beta || !comm || !comm->tr.comm) return fail(BODYFIT_ERR_INVALID, "bodyfit_solve_sharded_rccl: bad argument");
   long n = 0;
+  comm->tr.timeout_s = p->exchange_timeout_s;
   const int rc = sharded_common(p, frame_params, beta, param_constant, &comm->tr, opt_in, summary, &n);
   p->last_exchanges = n;
   return rc;
@@ -1851,7 +1895,22 @@ int bodyfit_sweep_status(bodyfit_problem* p, void* stream) {
   return fused_check(p);
 }
 
-long bodyfit_internal_fused_timeouts(const bodyfit_problem* p) { return p ? p->fused_timeouts : 0; }
+long bodyfit_sweep_timeouts(const bodyfit_problem* p) { return p ? p->fused_timeouts : 0; }
+long bodyfit_internal_fused_timeouts(const bodyfit_problem* p) { return bodyfit_sweep_timeouts(p); }   // (the tests' older name)
+
+int bodyfit_set_exchange_timeout(bodyfit_problem* p, double seconds) {
+  if (!p || !(seconds >= 0.0)) return fail(BODYFIT_ERR_INVALID, "bodyfit_set_exchange_timeout: bad argument");
+  p->exchange_timeout_s = seconds;
+  return BODYFIT_OK;
+}
+
+// Test hook (not part of include/bodyfit.h): rank `rank`'s candidate sweep "fails" in LM iteration `iter` of the problem's
+// next sharded solves (-1, -1: off).  tests/test_gpu_sharded_solve.py.
+int bodyfit_internal_set_test_poison(bodyfit_problem* p, int rank, int iter) {
+  if (!p) return fail(BODYFIT_ERR_INVALID, "null argument");
+  p->test_poison_rank = rank; p->test_poison_iter = iter;
+  return BODYFIT_OK;
+}
 
 long bodyfit_last_exchange_count(const bodyfit_problem* p) { return p ? p->last_exchanges : 0; }
 long bodyfit_launch_count(void) { return g_launch_count.load(std::memory_order_relaxed); }

@@ -143,6 +143,10 @@ constexpr size_t kFusedSyncHeader = 256;  // error word, pad (the counters start
 // unit's 32 adds must not share a line, or a channel, with the other units'.
 constexpr int kUnitCounterStride = 64;    // dwords
 constexpr int kUnitCoefOffset = 32;   // unsigneds: the unit's SECOND counter (blend coefficients published), 128 bytes behind the first
+// tuning words of the one-launch sweep (round 4 read them from the environment; the values are that round's measured optimum:
+// profiles/r4_x_tuning_runs.txt).  A diagnostic build with -DBODYFIT_TUNE_ENV reads them from BODYFIT_MESH_PRIO /
+// BODYFIT_TRICKLE_START / BODYFIT_TRICKLE_SLEEP / BODYFIT_J_SCOPE again.
+constexpr int kTuneMeshPrio = 2, kTuneTrickleStart = 120, kTuneTrickleSleep = 7, kTuneJScope = 1;
 struct FusedSync {
   unsigned* flag;              // [frames / 32, rounded up to whole groups of 8][kUnitCounterStride]: word 0 counts the frames whose
                                // skinning transforms are published, word kUnitCoefOffset those whose blend coefficients are

@@ -14,13 +14,32 @@
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cstring>
+#include <memory>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/bodyfit.h"
+#include "exchange_timeout.h"
 
 namespace bodyfit {
+
+// hipStreamSynchronize with a bound (seconds <= 0: unbounded): a collective that a failed peer never enters would otherwise hold
+// the status read of a sharded solve for ever.  1 = the bound passed (the stream is still busy), 0 = idle, -1 = a HIP error.
+inline int wait_stream(hipStream_t st, double seconds, hipError_t* err) {
+  *err = hipSuccess;
+  if (!(seconds > 0.0)) { *err = hipStreamSynchronize(st); return *err == hipSuccess ? 0 : -1; }
+  const auto t_end = std::chrono::steady_clock::now() + std::chrono::duration<double>(seconds);
+  for (;;) {
+    const hipError_t q = hipStreamQuery(st);
+    if (q == hipSuccess) return 0;
+    if (q != hipErrorNotReady) { *err = q; return -1; }
+    if (std::chrono::steady_clock::now() >= t_end) return 1;
+    std::this_thread::sleep_for(std::chrono::microseconds(20));
+  }
+}
 
 // the few RCCL entry points used, resolved from librccl at run time (signatures: rccl/rccl.h of ROCm 7.2)
 struct RcclApi {
@@ -63,6 +82,8 @@ struct RcclApi {
 struct Transport {
   int rank = 0, size = 1;
   long n_calls = 0;
+  double timeout_s = 0.0;     // bodyfit_set_exchange_timeout: bound of one exchange (0: none)
+  bool timed_out = false;
   std::string error;
   virtual ~Transport() {}
   // every rank's n doubles at d_send -> d_recv [size][n] on every rank, ordered on `st`
@@ -81,17 +102,21 @@ struct RcclTransport : Transport {
 };
 
 struct HostTransport : Transport {
-  const bodyfit_comm* cb = nullptr;
-  std::vector<double> send, recv;
+  bodyfit_comm cb{};
   int allgather(const double* d_send, double* d_recv, int n, hipStream_t st) override {
     ++n_calls;
-    send.resize((size_t)n);
-    recv.resize((size_t)n * size);
-    if (hipMemcpyAsync(send.data(), d_send, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess ||
-        hipStreamSynchronize(st) != hipSuccess) { error = "allgather: device to host copy failed"; return 1; }
-    if (cb->allgather(cb->ctx, send.data(), recv.data(), n)) { error = "allgather callback failed"; return 1; }
-    if (hipMemcpyAsync(d_recv, recv.data(), (size_t)n * size * sizeof(double), hipMemcpyHostToDevice, st) != hipSuccess ||
-        hipStreamSynchronize(st) != hipSuccess) { error = "allgather: host to device copy failed"; return 1; }   // (recv is reused)
+    // (the buffers are shared with the helper thread of a bounded exchange: a callback that outlives the bound still owns them)
+    auto send = std::make_shared<std::vector<double>>((size_t)n);
+    auto recv = std::make_shared<std::vector<double>>((size_t)n * size);
+    hipError_t he = hipMemcpyAsync(send->data(), d_send, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, st);
+    if (he == hipSuccess && wait_stream(st, timeout_s, &he) == 1) { timed_out = true; error = "allgather: the stream did not drain within the exchange timeout"; return 1; }
+    if (he != hipSuccess) { error = "allgather: device to host copy failed"; return 1; }
+    const bodyfit_comm c = cb;
+    const int rc = call_with_timeout([c, send, recv, n]() { return c.allgather(c.ctx, send->data(), recv->data(), n); }, timeout_s, &timed_out);
+    if (timed_out) { error = "allgather callback did not return within the exchange timeout"; return 1; }
+    if (rc) { error = "allgather callback failed"; return 1; }
+    if (hipMemcpyAsync(d_recv, recv->data(), (size_t)n * size * sizeof(double), hipMemcpyHostToDevice, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess) { error = "allgather: host to device copy failed"; return 1; }   // (recv lives until here)
     return 0;
   }
 };

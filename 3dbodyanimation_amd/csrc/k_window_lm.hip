@@ -140,6 +140,7 @@ __global__ __launch_bounds__(1024) void k_win_init(WinProblem P, WinBuf W, const
     st[kWsActive] = finite ? 1.0 : 0.0;
     st[kWsTermination] = finite ? 1.0 : 2.0;
     st[kWsAccepted] = 1.0; st[kWsGmax] = 0.0; st[kWsNewCost] = c; st[kWsJsel] = 0.0;
+    st[kWsPoison] = 0.0;   // (the record lives in the problem's pool: a poisoned solve must not poison the next one)
     *W.fail = 0;
   }
 }

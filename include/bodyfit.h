@@ -36,6 +36,17 @@
  *                              OptimizeMultiFrame (include/MultiFrameBA.h:144-151); the three functions
  *                              themselves are mirrored in include/bodyfit.hpp
  */
+/* Environment variables the library reads.  None is needed in production; none changes a result (the A/B forms are tested
+ * bit-identical to the default), they select between equivalent code paths for measurements and tests:
+ *   BODYFIT_ONE_LAUNCH=0     problems created afterwards sweep as two launches (k_frame_resjac, k_mesh_blend_lbs) instead of one
+ *   BODYFIT_LM_PLAIN=1       the batched LM in its four-launch form (step, residual sweep, accept, Jacobian sweep)
+ *   BODYFIT_PACKED_J=0       bodyfit_evaluate_batch's cache keeps the dense Jacobian panel instead of the packed blocks
+ *   BODYFIT_PACK_DIRECT=0    the packed Jacobian goes down by hipMemcpyAsync instead of by the packing kernel's own stores
+ *   BODYFIT_FORCE_SHARDED=1  a one-rank communicator still takes the sharded code path (how RCCL is exercised on a one-GPU box)
+ *   BODYFIT_WINDOW_MIN=n     shared-beta windows shorter than n frames iterate on the host (default 12)
+ *   BODYFIT_HOST_NORMALS=1   the host loop builds its normal equations on the host; BODYFIT_TIMING=1 prints its phase times
+ * The tuning words of the one-launch sweep (mesh priority, operand pacing, Jacobian store scope) are compile-time constants since
+ * round 5 (csrc/bodyfit_device.h kTune*); round 4 read them from BODYFIT_MESH_PRIO / BODYFIT_TRICKLE_* / BODYFIT_J_SCOPE. */
 #ifndef BODYFIT_H_
 #define BODYFIT_H_
 #include <stddef.h>
@@ -170,6 +181,12 @@ int bodyfit_evaluate_device(bodyfit_problem* p, const double* d_frame_params, co
  * BODYFIT_OK, or BODYFIT_ERR_HIP ("... timed out"): the cloud of at least one of them is incomplete; the problem uses the
  * two-launch sweep from then on, so re-issuing the evaluation gives the complete result.                                */
 int bodyfit_sweep_status(bodyfit_problem* p, void* stream);
+/* One-launch sweeps of this problem found incomplete (an in-launch wait ran out) since it was created, whoever noticed: a
+ * synchronous entry point that re-issued its sweep, or bodyfit_sweep_status.  0 in every healthy run; benchmarks report it. */
+long bodyfit_sweep_timeouts(const bodyfit_problem* p);
+/* Lifetime of `stream`: the synchronous entry points and the device solves order themselves behind the last asynchronous call
+ * by recording an event ON THAT STREAM, so it must stay alive until the problem's next synchronous call (or
+ * bodyfit_sweep_status on it) has returned. */
 
 typedef struct bodyfit_device_views {
   double* residuals;    /* [total_rows]          */
@@ -292,13 +309,21 @@ int bodyfit_solve(bodyfit_problem* p, double* frame_params, double* beta, const 
  *   bodyfit_solve_sharded_rccl   RCCL on the solve's device buffers and stream (ncclAllGather over xGMI): no host staging and no
  *                                stream synchronisation between the host's status reads (every fourth iteration).
  * Both callbacks / RCCL calls must be entered by every rank of the communicator the same number of times.  Failures:
- *   - a rank whose own device work fails inside an LM iteration (a kernel launch, a HIP call) does NOT leave on its own: it marks
+ *   - a rank whose own device work fails (the first sweep, or a kernel launch / HIP call inside an LM iteration) does NOT leave on its own: it marks
  *     its scalars, keeps taking part in that iteration's exchanges, and the decision kernel ends the solve on EVERY rank in the
  *     same iteration; all ranks then return an error (the failing one its own, the others "another rank reported a device
  *     failure") after the same number of exchanges — nobody is left waiting;
  *   - a failure of the transport itself (a callback that returns non-zero, an RCCL error) returns at once on the rank that saw
- *     it; its peers may be waiting in that exchange, so give the process group / RCCL a timeout.
+ *     it; its peers may be waiting in that exchange: bodyfit_set_exchange_timeout (below) bounds that wait inside the library,
+ *     whatever timeout the process group / RCCL has of its own.
  *   frame_params [F_local (+1 halo row)][76] in/out: the halo row is refreshed from the neighbour by the solve. */
+/* A bound, in seconds, on every exchange and every status read of this problem's sharded solves (0, the default: none).  With it
+ * a transport failure cannot strand the peers of the rank that saw it: a host callback that has not returned within the bound
+ * (bodyfit_solve_sharded; the callback then runs on a helper thread, which is left behind with its own copies of the buffers) or a
+ * stream that has not drained (an RCCL collective its peer never entered) ends the solve with BODYFIT_ERR_HIP on that rank too.
+ * The problem's solve stream is not usable after such a return (destroy the problem).  Choose the bound well above one LM
+ * iteration (milliseconds); it is a liveness guard, not a pacing device. */
+int bodyfit_set_exchange_timeout(bodyfit_problem* p, double seconds);
 typedef struct bodyfit_comm {
   int rank, size;
   void* ctx;

@@ -52,13 +52,15 @@ def _mean_px(om, seqf, r0, t, jaa, w):
 
 
 def run_multi(om, kp_offset, kp_id, kp_uv, intr, max_iters_s1=1000, skip=10, wsize=20, overlap=5, beta_pose=5.0,
-              beta_shape=25.0, lambda_t=3.0, stage2_iters=60, follow=None, perturb=None):
+              beta_shape=25.0, lambda_t=3.0, stage2_iters=60, follow=None, perturb=None, sparse=False):
     """follow: the product's per-stage snapshots (drivers.run_multi(trace=...)).  The staged fit is a chain of unconverged,
     ill-conditioned solves (frames without keypoints leave their Sim3 scale undetermined; stage 2 stops after a fixed
     iteration count): one window amplifies a 1e-12 difference of its starting state to ~1e-5, the next one to ~1e-3, although
     every single solve agrees with its counterpart to ~1e-9 from equal inputs.  So the comparison is made stage by stage:
     after each stage this run records ITS OWN state (own solve, own write-back, own bookkeeping), the caller compares it with
-    the product's snapshot of the same stage, and then this run continues from the product's state."""
+    the product's snapshot of the same stage, and then this run continues from the product's state.
+    sparse: the checker's LM in its scipy.sparse form (same rows, same rules: tests/test_oracle.py) — what makes BASELINE
+    configs[3] at its full 128 frames affordable."""
     F = len(kp_offset) - 1
     mine = []
     r0 = np.tile(R0_DEFAULT.reshape(1, 3, 3), (F, 1, 1))
@@ -72,7 +74,7 @@ def run_multi(om, kp_offset, kp_id, kp_uv, intr, max_iters_s1=1000, skip=10, wsi
         seq = _sub(kp_offset, kp_id, kp_uv, ids, intr, r0[ids])
         x, b, info = lm_dense.solve(om, seq, x_init, w_block, n_cols=86, use_shape=bshape > 0.0, beta_pose=beta_pose,
                                     beta_shape=bshape, lam=lambda_t if len(ids) > 1 else 0.0, max_iters=iters,
-                                    scale_bounds=(-1e300, 1e300))
+                                    scale_bounds=(-1e300, 1e300), sparse=sparse)
         for k, f in enumerate(ids):
             r0[f] = _rodrigues(x[k, 1:4]) @ r0[f]
             t[f] = x[k, 4:7]
@@ -99,15 +101,17 @@ def run_multi(om, kp_offset, kp_id, kp_uv, intr, max_iters_s1=1000, skip=10, wsi
             poses[:] = ref["poses"]; r0[:] = ref["r0"]; t[:] = ref["t"]; jaa[:] = ref["joint_aa"]; w[:] = ref["w"]
 
     snap(anchors)
+    infos2 = []
     stride = wsize - overlap
     for s in range(0, F, stride):
         ids = list(range(s, min(s + wsize, F)))
-        x, bw, _ = solve(ids, poses[ids].copy(), w[s].copy(), 1e5, stage2_iters)
+        x, bw, info2 = solve(ids, poses[ids].copy(), w[s].copy(), 1e5, stage2_iters)
+        infos2.append(info2)
         w[s] = bw
         poses[ids] = x
         log(ids)
         snap(ids)
-    return dict(poses=poses, r0=r0, t=t, joint_aa=jaa, w=w, log=rows, stage1=info1, stages=mine)
+    return dict(poses=poses, r0=r0, t=t, joint_aa=jaa, w=w, log=rows, stage1=info1, stage2=infos2, stages=mine)
 
 
 def run_single(om, kp_offset, kp_id, kp_uv, intr, frames, max_iters=100, beta_pose=20.0):

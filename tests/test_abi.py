@@ -83,6 +83,21 @@ def test_per_device_attribute_bookkeeping(tmp_path):
     assert res.returncode == 0 and "ok" in res.stdout, res.stdout
 
 
+def test_exchange_bound_of_the_sharded_solve(tmp_path):
+    """bodyfit_set_exchange_timeout's mechanism (csrc/exchange_timeout.h) on the CPU: two ranks exchanging through blocking
+    callbacks, one rank's transport fails — both are back within the bound (tests/cpp/exchange_timeout_test.cpp; the GPU suite
+    repeats it through bodyfit_solve_sharded over gloo)."""
+    import shutil
+    import subprocess
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "exchange_timeout_test")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-pthread", os.path.join(root, "tests", "cpp", "exchange_timeout_test.cpp"), "-o", exe])
+    res = subprocess.run([exe], capture_output=True, text=True, timeout=60)
+    assert res.returncode == 0 and "ok" in res.stdout, res.stdout
+
+
 def test_host_solver_under_address_and_ub_sanitizers(tmp_path):
     """host_solver.cpp (the Ceres-like LM of bodyfit_solve's host path: bordered block-tridiagonal Cholesky with hand-written AVX2
     kernels, index arithmetic over packed blocks) compiled with -fsanitize=address,undefined and run on a small problem, the

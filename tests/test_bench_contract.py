@@ -32,6 +32,12 @@ def test_bench_single_gpu_line():
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
     assert abs(d["value"] - d["config"]["frames_per_gpu"] / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
     assert "traffic_source" in r
+    # how ms_per_step was taken: the median of >= 7 brackets of K steps behind the prewarm, with the spread and the cold-start
+    # bracket beside it; and no in-launch wait of any timed sweep ran out
+    tm = d["timing"]
+    assert tm["repeats"] >= 7 and len(tm["ms_per_step_all"]) == tm["repeats"]
+    assert tm["ms_per_step_min"] <= tm["ms_per_step_median"] <= tm["ms_per_step_max"] and tm["ms_per_step_median"] == d["ms_per_step"]
+    assert tm["cold_start"]["ms_per_step"] > 0 and d["sweep_timeouts"] == 0
     # the second half of the metric: frames/sec to convergence of c2 / c3 / c4, with iteration and sweep counts
     fit = d["fit"]
     assert fit["unit"] == "frames/s"

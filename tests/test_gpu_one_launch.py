@@ -204,7 +204,10 @@ def test_one_launch_against_oracle_at_the_bench_config(model):
     dx, db = torch.from_numpy(x).to(dev), torch.from_numpy(beta).to(dev)
     prof = prob.profile_sweep(dx.data_ptr(), db.data_ptr(), True, False, 2, torch.cuda.current_stream().cuda_stream)
     assert prof["sweep_roles"] > 0 and prof["frame_resjac"] == 0 and prof["mesh_blend_lbs"] == 0
+    assert _timeouts(prob) == 0
     r, J, comp = prob.evaluate(x, beta, True)
+    # (the synchronous call re-issues a timed-out one-launch sweep as two launches without telling: it must not have had to)
+    assert _timeouts(prob) == 0
     om = oracle.OracleModel(m)
     ro, Jo = om.evaluate_batch(seq, x, beta, 86, True, True, mode=0)
     K2 = prob.layout.reproj_rows
@@ -218,6 +221,7 @@ def test_one_launch_against_oracle_at_the_bench_config(model):
     assert len(set(comp.tolist())) > 1
     assert np.abs(r[K2 + 70 * F:] - 30.0 * beta.reshape(-1)).max() < 1e-12
     joints, cloud = prob.forward(x, beta)
+    assert _timeouts(prob) == 0 and prob.sweep_timeouts() == 0      # ... nor the forward: still the one-launch kernel
     for f in (0, 31, 32, 77, 100, 129, 191, 255):
         jo, co = om.forward(x[f], beta[f], seq.R0[f])
         assert np.abs(joints[f] - jo).max() < 1e-10

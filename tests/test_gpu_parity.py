@@ -491,3 +491,38 @@ def test_packed_cache_serves_every_block_of_the_dense_panel(api, synth, model, g
             assert np.array_equal(Jcat, J[2 * k:2 * k + 2]), (f, k, int(seq.kp_id[k]))
             zero_blocks += sum(1 for j in jacs if not j.any())
     assert zero_blocks > 0   # (the packing has something to leave out: non-ancestor joints of the FK keypoints)
+
+
+def test_a_problem_built_from_pooled_blocks_equals_one_built_from_fresh_memory(api, synth, model, gpu_model, oracle_mod, omodel):
+    """Device blocks of a destroyed problem are kept for the next problem of the same shape (BlockPool, bodyfit_api.hip): the
+    staged drivers create and destroy two problems per stage.  Stale contents are then the NORMAL case for every buffer the
+    creation does not clear (Jacobian, partials, cloud, write-back).  Problem A (one sequence, one set of prior weights) is
+    evaluated, solved and destroyed; problem B — same sizes, other keypoints, other weights — takes A's blocks, and must agree bit
+    for bit with B2, built while B is alive (the pool has nothing of those sizes left: fresh hipMalloc), and with the oracle."""
+    F = 24
+    seq_a = synth.make_sequence(model, F, seed=11)
+    seq_b = synth.make_sequence(model, F, seed=12)
+    kw_a = dict(n_cols=86, use_shape=True, beta_pose=9.0, beta_shape=40.0, lambda_temporal=7.0, want_mesh=True)
+    kw_b = dict(n_cols=86, use_shape=True, beta_pose=5.0, beta_shape=25.0, lambda_temporal=3.0, want_mesh=True)
+    rng = np.random.default_rng(5)
+    xa, xb = random_params(rng, F), random_params(rng, F)
+    ba, bb = rng.normal(size=10), rng.normal(size=10)
+    pa = api.Problem.from_sequence(gpu_model, seq_a, **kw_a)
+    pa.evaluate(xa, ba, True); pa.forward(xa, ba); pa.writeback(xa, ba, want_cloud=True)
+    pa.solve(seq_a.init_params, np.zeros(10), independent=False, max_iters=3, scale_bounds=(-1e300, 1e300), solver=3)
+    pa.close()
+    pb = api.Problem.from_sequence(gpu_model, seq_b, **kw_b)          # takes A's blocks
+    pb2 = api.Problem.from_sequence(gpu_model, seq_b, **kw_b)         # fresh memory
+    rb, Jb, _ = pb.evaluate(xb, bb, True)
+    r2, J2, _ = pb2.evaluate(xb, bb, True)
+    assert np.array_equal(rb, r2) and np.array_equal(Jb, J2)
+    jb, cb = pb.forward(xb, bb); j2, c2 = pb2.forward(xb, bb)
+    assert np.array_equal(jb, j2) and np.array_equal(cb, c2)
+    wb, w2 = pb.writeback(xb, bb, want_cloud=True), pb2.writeback(xb, bb, want_cloud=True)
+    for key in ("R0", "joints", "cloud", "mean_px"):
+        assert np.array_equal(wb[key], w2[key]), key
+    sb = pb.solve(seq_b.init_params, np.zeros(10), independent=False, max_iters=6, scale_bounds=(-1e300, 1e300), solver=3)
+    s2 = pb2.solve(seq_b.init_params, np.zeros(10), independent=False, max_iters=6, scale_bounds=(-1e300, 1e300), solver=3)
+    assert np.array_equal(sb[0], s2[0]) and np.array_equal(sb[1], s2[1]) and sb[2][0].final_cost == s2[2][0].final_cost
+    ro, Jo, _ = _oracle_full(oracle_mod, omodel, seq_b, xb, bb, 86, True, True, 5.0, None, 25.0, 3.0)
+    assert np.abs(rb - ro).max() < 1e-9 and np.abs(Jb - Jo).max() <= 1e-9 * max(1.0, np.abs(Jo).max())

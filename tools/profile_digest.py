@@ -1,6 +1,7 @@
 """Digest gpurun_out/prof_<tag>/ (tools/profile_round.sh) into the small files kept under profiles/:
   <tag>_kernel_stats.csv     rocprofv3 --stats kernel table of the default bench.py run
   <tag>_bench.json           the bench line printed by that run
+  <tag>_kernel_stats_post_prewarm.json   the sweep kernel's launch durations behind the cold bracket and the prewarm sweeps
   <tag>_pmc_traffic.json     HBM bytes per launch and kernel from the FETCH_SIZE / WRITE_SIZE passes"""
 import csv
 import glob
@@ -20,6 +21,35 @@ if st:
 line = open(src + "/bench.json").read().strip()
 bench = json.loads(line)
 json.dump(bench, open(f"profiles/{tag}_bench.json", "w"), indent=1)
+# The --stats table averages over EVERY launch of the run, the clock-ramp launches of the cold bracket and the untimed prewarm
+# sweeps included.  The figure roofline.avg_launch_ms must be reproducible from is the kernel's duration over the launches
+# BEHIND them (the timed brackets and the in-bench HIP-event sample): taken here from the kernel trace itself, in dispatch order.
+tr = glob.glob(src + "/stats/**/*kernel_trace.csv", recursive=True)
+if tr:
+    rows = list(csv.DictReader(open(tr[0])))
+    tm = bench.get("timing", {})
+    skip = int(bench.get("warmup", 0)) + int(bench.get("steps", 0)) + int(tm.get("prewarm_steps", 0))   # cold bracket + prewarm
+    by = defaultdict(list)
+    for r in rows:
+        m = re.search(r"k_[a-z0-9_]+", r["Kernel_Name"])
+        if m:
+            by[m.group(0)].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
+    post = {}
+    for k, v in by.items():
+        v.sort()
+        d = sorted(x[1] for x in v[skip:]) if k in ("k_sweep_roles", "k_frame_resjac", "k_mesh_blend_lbs") else sorted(x[1] for x in v)
+        if not d:
+            continue
+        q = lambda f: d[min(len(d) - 1, int(f * len(d)))]
+        post[k] = {"launches": len(d), "skipped_leading_launches": skip if len(d) != len(v) else 0, "avg_ns": round(sum(d) / len(d), 1),
+                   "median_ns": q(0.5), "p10_ns": q(0.1), "p90_ns": q(0.9), "min_ns": d[0], "max_ns": d[-1]}
+    json.dump({"source": "rocprofv3 --kernel-trace --stats -- python3 bench.py --no-fit --no-ceres-path --no-c5-strong (the kernel "
+                         "trace of the same run as <tag>_kernel_stats.csv), durations = End - Start per dispatch, dispatch order",
+               "note": "sweep kernels: the first warmup + steps + prewarm_steps launches (cold bracket, untimed prewarm) are dropped; "
+                       "what remains are the timed brackets' launches and the in-bench HIP-event sample behind them",
+               "bench_roofline_avg_launch_ms": bench.get("roofline", {}).get("avg_launch_ms"),
+               "bench_ms_per_step_median": bench.get("ms_per_step"), "kernels": post},
+              open(f"profiles/{tag}_kernel_stats_post_prewarm.json", "w"), indent=1)
 kern = defaultdict(dict)
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     vals = defaultdict(list)
