@@ -188,6 +188,7 @@ def load_library():
     lib.bodyfit_sweep_timeouts.argtypes = [C.c_void_p]
     lib.bodyfit_sweep_timeouts.restype = C.c_long
     lib.bodyfit_set_exchange_timeout.argtypes = [C.c_void_p, C.c_double]
+    lib.bodyfit_set_shard_proxy.argtypes = [C.c_void_p, C.c_int, C.c_int]
     lib.bodyfit_launch_count.argtypes = []
     lib.bodyfit_launch_count.restype = C.c_long
     lib.bodyfit_last_exchange_count.argtypes = [C.c_void_p]
@@ -405,6 +406,11 @@ class Problem:
     def set_exchange_timeout(self, seconds: float):
         """bound on every exchange / status read of this problem's sharded solves (bodyfit_set_exchange_timeout; 0: none)"""
         _check(load_library().bodyfit_set_exchange_timeout(self.h, float(seconds)))
+
+    def set_shard_proxy(self, n_ranks: int, rank: int = 0):
+        """measurement aid (bodyfit_set_shard_proxy): sharded solves through a one-rank communicator run as `rank` of `n_ranks`
+        identical shards; n_ranks <= 1 switches it off"""
+        _check(load_library().bodyfit_set_shard_proxy(self.h, int(n_ranks), int(rank)))
 
     def arm_shared_reduction(self, d_out_ptr: int | None):
         """Following Jacobian sweeps deposit [cost | g_beta | H_bb] in d_out_ptr at their own tail when they can (one-launch

@@ -42,7 +42,7 @@ int fail(int code, const std::string& msg) {
 // Device blocks of destroyed problems, kept for the next problem of the same shape.  The reference's staged drivers
 // (src/main_multi_frame.cpp:109-217: anchors, then one solve per sliding window, an update() after each) create and destroy
 // two problems per stage; hipFree synchronises the device and unmaps — 0.6 ms per problem, 12 of the 149 ms of a staged
-// 128-frame run (tools/run_multi_breakdown.py).  A block is reused only for a request of exactly its size on its device;
+// 128-frame run (tools/probes/run_multi_breakdown.py).  A block is reused only for a request of exactly its size on its device;
 // contents are unspecified, as hipMalloc's are (problem creation clears what it needs cleared).  Bounded: beyond kLimit bytes
 // per device a block is freed at once; bodyfit_model_destroy empties its device's list.  Nothing is freed at process exit (the
 // runtime may be gone by then).
@@ -205,6 +205,7 @@ struct bodyfit_problem {
   long last_exchanges = 0;             // all-gathers issued by the last sharded solve (tests: exchanges per iteration)
   double exchange_timeout_s = 0.0;     // bodyfit_set_exchange_timeout: bound of one exchange / status read of a sharded solve
   int test_poison_rank = -1, test_poison_iter = -1;   // bodyfit_internal_set_test_poison (tests only)
+  int proxy_ranks = 0, proxy_rank = 0;                // bodyfit_set_shard_proxy (measurement aid): 0 = off
   unsigned fused_epoch = 0;
   bool fused_enabled = true, fused_unchecked = false;
   long fused_timeouts = 0;             // one-launch sweeps found incomplete (bodyfit_internal_fused_timeouts)
@@ -364,7 +365,7 @@ int sweep(bodyfit_problem* p, const double* d_params, const double* d_beta, int 
     sy.epoch = ++p->fused_epoch;
     sy.resident_blocks = 2 * m->n_cus;
     sy.timeout_ticks = p->role_timeout_ticks;
-#ifdef BODYFIT_TUNE_ENV   // diagnostic builds only (tools/sweep_tune.py): the shipped library reads no tuning word from outside
+#ifdef BODYFIT_TUNE_ENV   // diagnostic builds only (tools/probes/sweep_tune.py): the shipped library reads no tuning word from outside
     static const int tune_prio = env_int("BODYFIT_MESH_PRIO", kTuneMeshPrio), tune_start = env_int("BODYFIT_TRICKLE_START", kTuneTrickleStart),
                      tune_sleep = env_int("BODYFIT_TRICKLE_SLEEP", kTuneTrickleSleep), tune_jscope = env_int("BODYFIT_J_SCOPE", kTuneJScope);
 #else
@@ -1469,13 +1470,16 @@ static int solve_window_device(bodyfit_problem* p, double* frame_params, double*
                                bodyfit_fit_summary* summary, Transport* comm, bool force_sharded) {
   const bodyfit_model* m = p->m;
   const int F = p->d.F, npose = 7 + 3 * (m->nJ - 1), n = p->lay.n_cols, nb = n - npose;
-  const bool sharded = comm != nullptr && (comm->size > 1 || force_sharded);
+  // shard proxy (bodyfit_set_shard_proxy): through a ONE-rank communicator this problem runs as rank proxy_rank of proxy_ranks
+  // identical shards — every kernel, buffer and exchange of that geometry, the gathered slots filled with copies of its own
+  const bool proxy = comm != nullptr && comm->size == 1 && p->proxy_ranks > 1;
+  const bool sharded = comm != nullptr && (comm->size > 1 || force_sharded || proxy);
   const int halo = p->desc.temporal_halo ? 1 : 0;
   if (npose != kFrameParams || nb != kMaxShape || p->desc.beta_per_frame || p->has_gmm)
     return fail(BODYFIT_ERR_INVALID, "device window solver: needs 24 joints, a shared 10-coefficient beta and the L2 pose prior");
   if (halo && !sharded) return fail(BODYFIT_ERR_INVALID, "device window solver: a halo row needs bodyfit_solve_sharded");
   if (sharded && F < 2) return fail(BODYFIT_ERR_INVALID, "bodyfit_solve_sharded: every shard needs at least two frames");
-  const int R = sharded ? comm->rank : 0, N = sharded ? comm->size : 1;
+  const int R = proxy ? p->proxy_rank : (sharded ? comm->rank : 0), N = proxy ? p->proxy_ranks : (sharded ? comm->size : 1);
   const bool has_left = sharded && R > 0;
   if (sharded && (halo != 0) != (R + 1 < N))
     return fail(BODYFIT_ERR_INVALID, "bodyfit_solve_sharded: every shard but the last needs temporal_halo");
@@ -1559,6 +1563,7 @@ static int solve_window_device(bodyfit_problem* p, double* frame_params, double*
   // gather n doubles per rank from d_send into d_gath [N][n]
   auto gather = [&](const double* d_send, int cnt, const char* what) -> int {
     if (comm->allgather(d_send, d_gath, cnt, st)) return comm_fail(what);
+    if (proxy) launch_replicate_ranks(d_gath, cnt, N, st);
     return BODYFIT_OK;
   };
   // the host's wait for a status record: bounded for sharded solves with bodyfit_set_exchange_timeout (a peer that left after a
@@ -1901,6 +1906,14 @@ long bodyfit_internal_fused_timeouts(const bodyfit_problem* p) { return bodyfit_
 int bodyfit_set_exchange_timeout(bodyfit_problem* p, double seconds) {
   if (!p || !(seconds >= 0.0)) return fail(BODYFIT_ERR_INVALID, "bodyfit_set_exchange_timeout: bad argument");
   p->exchange_timeout_s = seconds;
+  return BODYFIT_OK;
+}
+
+int bodyfit_set_shard_proxy(bodyfit_problem* p, int n_ranks, int rank) {
+  if (!p || n_ranks < 0 || (n_ranks > 0 && (rank < 0 || rank >= n_ranks)))
+    return fail(BODYFIT_ERR_INVALID, "bodyfit_set_shard_proxy: bad argument");
+  p->proxy_ranks = n_ranks > 1 ? n_ranks : 0;
+  p->proxy_rank = n_ranks > 1 ? rank : 0;
   return BODYFIT_OK;
 }
 

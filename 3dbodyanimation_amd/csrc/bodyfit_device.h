@@ -301,6 +301,7 @@ void launch_win_accept(const WinProblem& P, const WinBuf& W, const double* d_r_n
 
 // sharded solves (bodyfit_solve_sharded*): the exchange steps
 void launch_sum_ranks(const double* d_g, int N, int stride, int n, double* d_out, hipStream_t s);
+void launch_replicate_ranks(double* d_g, int n, int N, hipStream_t s);
 int iface_doubles(int n_extra);
 void launch_iface_pack(const WinBuf& W, int F, const double* d_extra, int n_extra, double* d_send, hipStream_t s);
 void launch_iface_unpack(const WinBuf& Wi, const double* d_g, int N, int n_extra, double* d_extra_sum, hipStream_t s);

@@ -1195,6 +1195,14 @@ __global__ __launch_bounds__(256) void k_sum_ranks(const double* __restrict__ g,
     out[i] = s;
   }
 }
+// shard proxy (bodyfit_set_shard_proxy, a measurement aid): the one-rank all-gather has filled slot 0; the other N - 1 slots
+// get copies, as if N identical shards had contributed
+__global__ __launch_bounds__(256) void k_replicate_ranks(double* __restrict__ g, int n, int N) {
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const double v = g[i];
+    for (int r = 1; r < N; ++r) g[(size_t)r * n + i] = v;
+  }
+}
 // this shard's contribution to the interface system: [D_first, D_last, U_first, U_last | Rt_first, Rt_last | extra], one
 // contiguous buffer for ONE all-gather
 __global__ __launch_bounds__(256) void k_iface_pack(WinBuf W, int F, const double* __restrict__ extra, int n_extra,
@@ -1382,6 +1390,9 @@ void launch_win_accept(const WinProblem& P, const WinBuf& W, const double* d_r_n
 namespace bodyfit {
 void launch_sum_ranks(const double* d_g, int N, int stride, int n, double* d_out, hipStream_t s) {
   BODYFIT_LAUNCH(k_sum_ranks, dim3((n + 255) / 256), dim3(256), 0, s, d_g, N, stride, n, d_out);
+}
+void launch_replicate_ranks(double* d_g, int n, int N, hipStream_t s) {
+  BODYFIT_LAUNCH(k_replicate_ranks, dim3(std::min(64, (n + 255) / 256)), dim3(256), 0, s, d_g, n, N);
 }
 int iface_doubles(int n_extra) { return 4 * WB * WB + 2 * WR * WB + n_extra; }
 void launch_iface_pack(const WinBuf& W, int F, const double* d_extra, int n_extra, double* d_send, hipStream_t s) {

@@ -337,6 +337,65 @@ def c5_strong(args, api, synth, model, gm, dist, rank, world, local_rank):
     fit()
     n_fit = 2
     dt_fit, (_, _, summ) = bracket(fit, n_fit)
+    # ---- N = 1 only: ONE rank's critical path at the N = 8 geometry, measured alone on this GPU (bodyfit_set_shard_proxy) ----
+    # A 128-frame shard (rank 3 of 8: a left and a right neighbour), its chain reduced with the ends pinned (7 local levels), the
+    # 16-frame interface chain solved as every rank solves it, the three all-gathers per LM iteration and the evaluation's
+    # all-reduce issued on the one-rank RCCL communicator (the gathered slots of the seven other ranks are copies of this shard's:
+    # one small kernel per exchange).  The transport costs nothing here that a launch does not cost, so N = 1 time / proxy time is
+    # an UPPER bound on the strong-scaling speed-up at N = 8 — measured, not projected.
+    proxy = None
+    if world == 1 and rccl is not None and Fw % 8 == 0 and Fw >= 64:
+        Np, Rp = 8, 3
+        sh = sharded.make_shard(Fw, Np, Rp)
+        slp = sharded.slice_sequence(full, sh)
+        kwp = dict(n_cols=86, use_shape=True, beta_pose=5.0, beta_shape=0.0, lambda_temporal=3.0, temporal_halo=True)
+        pfit = api.Problem(gm, slp["kp_offset"], slp["kp_id"], slp["kp_uv"], slp["intr"], slp["R0"], **kwp)
+        pfit.set_shard_proxy(Np, Rp)
+        x0p = sharded.local_params(full.init_params, sh)
+
+        def pfit_run(iters):
+            _, _, sm = pfit.solve_sharded_rccl(x0p, np.zeros(10), rccl, max_iters=iters)
+            return sm
+        pfit_run(20)
+        reps = []
+        for _ in range(3):
+            ta, sa = bracket(lambda: pfit_run(60), 1)
+            tb, sb = bracket(lambda: pfit_run(180), 1)
+            reps.append(((tb - ta) / max(1, sb.iterations - sa.iterations), sa.iterations, sb.iterations, pfit.last_exchange_count()))
+        reps.sort()
+        us_iter_proxy, it_a, it_b, n_ex = reps[1][0] * 1e6, reps[1][1], reps[1][2], reps[1][3]
+        # the shard's evaluation step: sweep (mesh on) + reduction at the sweep's own tail + the one-rank all-reduce
+        psw = api.Problem(gm, slp["kp_offset"], slp["kp_id"], slp["kp_uv"], slp["intr"], slp["R0"], want_mesh=True, **kwp)
+        dpp = torch.from_numpy(np.ascontiguousarray(full.gt_params[sh.f0:sh.f1 + 1] + 0.01)).to(dev)
+        dred2 = torch.zeros(66, dtype=torch.float64, device=dev)
+        psw.arm_shared_reduction(dred2.data_ptr())
+
+        def pstep():
+            psw.evaluate_device(dpp.data_ptr(), d_beta.data_ptr(), True, stream)
+            psw.reduce_shared_device(dred2.data_ptr(), stream)
+            rccl.allreduce_shared(dred2.data_ptr(), stream)
+        for _ in range(50):
+            pstep()
+        ts = sorted(bracket(pstep, 200)[0] for _ in range(5))
+        psw.sweep_status(stream)
+        us_step_proxy = ts[2] / 200 * 1e6
+        us_iter_n1 = dt_fit / n_fit * 1e6 / max(1, summ.iterations)
+        us_step_n1 = dt_sweep / args.steps * 1e6
+        proxy = {
+            "what": f"rank {Rp} of {Np}: a {sh.n_local}-frame shard of the {Fw}-frame window run ALONE on this GPU through the sharded "
+                    "code path (bodyfit_set_shard_proxy): 7 local cyclic-reduction levels with pinned ends, the 16-frame interface "
+                    "chain, three ncclAllGather per LM iteration and the evaluation's ncclAllReduce on the one-rank communicator, "
+                    "the other ranks' gathered slots = copies of this shard's",
+            "frames": sh.n_local, "n_ranks_emulated": Np,
+            "us_per_lm_iteration": us_iter_proxy, "lm_iterations_timed": [it_a, it_b], "exchanges_of_the_longer_solve": n_ex,
+            "us_per_sweep_step": us_step_proxy,
+            "n1_us_per_lm_iteration": us_iter_n1, "n1_us_per_sweep_step": us_step_n1,
+            "fit_speedup_upper_bound_at_8": us_iter_n1 / us_iter_proxy,
+            "sweep_speedup_upper_bound_at_8": us_step_n1 / us_step_proxy,
+            "note": "upper bounds: the transport's xGMI latency (three dependent all-gathers per iteration, one all-reduce per "
+                    "evaluation) is NOT in the proxy; the N = 1 figures are this run's own c5_strong.fit / .sweep",
+        }
+        pfit.close(); psw.close()
     out = None
     if rank == 0:
         out = {
@@ -359,6 +418,8 @@ def c5_strong(args, api, synth, model, gm, dist, rank, world, local_rank):
                     "exchanges_per_iteration": ((fprob.last_exchange_count() - 4) / max(1, (fprob.last_exchange_count() - 4) // 3))
                                                if world > 1 else 0},
         }
+        if proxy is not None:
+            out["shard_proxy"] = proxy
     if rccl is not None:
         rccl.close()
     return out

@@ -350,6 +350,14 @@ int bodyfit_solve_sharded_rccl(bodyfit_problem* p, double* frame_params, double*
 int bodyfit_allreduce_shared_rccl(bodyfit_rccl* comm, double* d_buf66, void* stream);
 /* ranks of the communicator and this process's rank, as RCCL reports them (ncclCommCount, ncclCommUserRank) */
 int bodyfit_rccl_count(bodyfit_rccl* comm, int* n_ranks, int* rank);
+/* Measurement aid for boxes with ONE GPU: this problem's following sharded solves through a one-rank communicator run as rank
+ * `rank` of `n_ranks` IDENTICAL shards — the local chain reduced with its ends pinned, the interface chain of 2 n_ranks frames,
+ * every all-gather issued (on the one-rank communicator; a small kernel then fills the other n_ranks - 1 gathered slots with
+ * copies of this shard's), sums over n_ranks slots, the neighbours' boundary steps.  The problem must be shaped like that rank's
+ * shard (temporal_halo = 1 unless rank == n_ranks - 1).  What it times is ONE rank's critical path at that geometry with the
+ * transport's latency at its lower bound; the fitted numbers belong to a window of n_ranks copies of the shard, not to the
+ * caller's sequence.  n_ranks <= 1 switches it off.  bench.py's c5_strong.shard_proxy uses it. */
+int bodyfit_set_shard_proxy(bodyfit_problem* p, int n_ranks, int rank);
 /* all-gathers issued by the problem's last sharded solve (tests assert the number of exchanges per iteration) */
 long bodyfit_last_exchange_count(const bodyfit_problem* p);
 

@@ -91,6 +91,45 @@ def test_rccl_transport_single_rank(monkeypatch):
     assert np.abs(x[:, 1:] - x2[:, 1:]).max() < 1e-7 and np.abs(b - b2).max() < 1e-7
 
 
+def test_shard_proxy_runs_one_ranks_work_at_the_eight_gpu_geometry():
+    """bodyfit_set_shard_proxy (the measurement aid behind bench.py's c5_strong.shard_proxy): through a ONE-rank RCCL communicator
+    the problem runs as rank 3 of 8 identical shards — the sharded code path with a 16-frame interface chain, three all-gathers
+    per LM iteration, sums over 8 gathered slots.  There is no other implementation of "8 copies of a shard, every copy in the
+    middle" to compare the numbers with; what is checked is that the LM works on that system (cost falls by orders of
+    magnitude, steps accepted, no failed factorisation), that every exchange of the geometry is issued, that the run is
+    deterministic, and that switching the aid off restores the plain one-rank solve."""
+    import torch  # noqa: F401
+    sys.path.insert(0, ROOT)
+    api = importlib.import_module("3dbodyanimation_amd.api")
+    synth = importlib.import_module("3dbodyanimation_amd.synth")
+    sharded = importlib.import_module("3dbodyanimation_amd.sharded")
+    model = synth.make_model(0)
+    Fw, N, R, iters = 256, 8, 3, 24
+    seq = synth.make_sequence(model, Fw, seed=6)
+    gm = api.Model(model, device=0)
+    sh = sharded.make_shard(Fw, N, R)
+    assert sh.n_local == 32 and sh.halo
+    sl = sharded.slice_sequence(seq, sh)
+    prob = api.Problem(gm, sl["kp_offset"], sl["kp_id"], sl["kp_uv"], sl["intr"], sl["R0"], n_cols=86, use_shape=True,
+                       beta_pose=5.0, beta_shape=0.0, lambda_temporal=3.0, temporal_halo=True)
+    comm = api.Rccl.create(api.Rccl.unique_id(), 0, 1, 0)
+    x0 = sharded.local_params(seq.init_params, sh)
+    prob.set_shard_proxy(N, R)
+    x, b, s1 = prob.solve_sharded_rccl(x0, np.zeros(10), comm, max_iters=iters)
+    n_ex = prob.last_exchange_count()
+    n_loop, rem = divmod(n_ex - 4, 3)
+    assert rem == 0 and s1.iterations <= n_loop <= iters
+    assert s1.termination in (0, 1) and s1.usable and s1.n_successful >= 10
+    assert np.isfinite(x).all() and np.isfinite(b).all() and s1.final_cost < 0.02 * s1.initial_cost
+    x2, b2, s2 = prob.solve_sharded_rccl(x0, np.zeros(10), comm, max_iters=iters)
+    assert np.array_equal(x, x2) and np.array_equal(b, b2) and s1.final_cost == s2.final_cost
+    # a shard with a halo row is not a window of its own: without the aid the one-rank solve refuses it
+    prob.set_shard_proxy(0, 0)
+    with pytest.raises(api.BodyfitError):
+        prob.solve_sharded_rccl(x0, np.zeros(10), comm, max_iters=3)
+    comm.close()
+
+
 def test_rccl_allreduce_of_the_shared_reduction_single_rank():
     """The evaluation path's one collective issued BY THE LIBRARY (bodyfit_allreduce_shared_rccl: ncclAllReduce(sum, f64) of the
     66 doubles, in place, on the sweep's stream — SURVEY 8e; the shared shape block of include/MultiFrameBA.h:64-68 summed over

@@ -173,13 +173,51 @@ int main(int argc, char** argv) {
     ++n2;
     el2 = std::chrono::duration<double>(std::chrono::steady_clock::now() - t02).count();
   }
+  // third measurement: where the block time goes — each kind of block alone, same thread pool, same cached sweep (no new sweep
+  // in between: the blocks are served from the cache whatever the point)
+  double kind_us[5] = {0, 0, 0, 0, 0};   // [4]: an empty pass (thread spawn + join alone)
+  long kind_n[5] = {0, 0, 0, 0, 0};
+  {
+    const std::vector<size_t> all = order;            // sorted by kind
+    for (int kd = 0; kd < 5; ++kd) {
+      std::vector<size_t> sub;
+      for (size_t i : all) if (kd < 4 && kind_rank(i) == kd) sub.push_back(i);
+      kind_n[kd] = (long)sub.size();
+      if (sub.empty() && kd < 4) continue;
+      // run_range walks order[nrec * t / threads ...): give it `sub` padded by repetition to nrec entries would distort; instead
+      // time a private pass over `sub` split the same way
+      order = sub;
+      const size_t keep = nrec;
+      (void)keep;
+      auto t_a = std::chrono::steady_clock::now();
+      int reps = 0;
+      while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t_a).count() < 0.15 * seconds) {
+        std::atomic<long> d2{0};
+        std::vector<std::thread> th;
+        auto part = [&](int t) {
+          const size_t b0 = sub.size() * t / threads, b1 = sub.size() * (t + 1) / threads;
+          Scratch& sc = scratch[t];
+          for (size_t i = b0; i < b1; ++i) {
+            const auto& rec = recs[sub[i]];
+            if (!rec->cost->Evaluate(rec->blocks.data(), sc.r.data(), sc.jp.data())) failed.store(true);
+          }
+        };
+        for (int t = 1; t < threads; ++t) th.emplace_back(part, t);
+        part(0);
+        for (auto& x : th) x.join();
+        ++reps;
+      }
+      kind_us[kd] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_a).count() / std::max(1, reps) * 1e6;
+    }
+  }
   quit.store(true);
   for (auto& th : pool) th.join();
   std::printf("{\"mode\": \"%s\", \"frames\": %d, \"blocks\": %d, \"block_threads\": %d, \"points\": %d, \"points_per_s\": %.1f, "
               "\"evals_per_s\": %.1f, \"blocks_per_s\": %.1f, \"sweep_with_copies_us\": %.1f, \"blocks_us_per_point\": %.1f, "
-              "\"blocks_us_per_point_kind_by_kind\": %.1f}\n",
+              "\"blocks_us_per_point_kind_by_kind\": %.1f, \"by_kind_us_incl_thread_spawn\": {\"reproj\": %.1f, \"pose_prior\": %.1f, "
+              "\"shape_prior\": %.1f, \"temporal\": %.1f, \"empty_pass\": %.1f}, \"by_kind_blocks\": [%ld, %ld, %ld, %ld]}\n",
               mode.c_str(), F, n_blocks, threads, n, n / el, n / el * F, n / el * n_blocks, t_sweep / n * 1e6, (el - t_sweep) / n * 1e6,
-              (el2 - t_sweep2) / std::max(1, n2) * 1e6);
+              (el2 - t_sweep2) / std::max(1, n2) * 1e6, kind_us[0], kind_us[1], kind_us[2], kind_us[3], kind_us[4], kind_n[0], kind_n[1], kind_n[2], kind_n[3]);
   bodyfit_problem_destroy(bp);
   bodyfit_model_destroy(model);
   return 0;

@@ -1,8 +1,8 @@
 """C2 / C3 fits (batched LM of independent frames) with the library BODYFIT_LIB names: seconds of 5 repeats each."""
 import importlib, os, sys
 import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import fit_bench
 api = importlib.import_module("3dbodyanimation_amd.api"); synth = importlib.import_module("3dbodyanimation_amd.synth")
 model = synth.make_model(0); gm = api.Model(model)

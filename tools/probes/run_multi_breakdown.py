@@ -2,7 +2,7 @@
 the solves, write-back problems, the rest (host bookkeeping)."""
 import importlib, os, sys, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 api = importlib.import_module("3dbodyanimation_amd.api")
 synth = importlib.import_module("3dbodyanimation_amd.synth")
 drivers = importlib.import_module("3dbodyanimation_amd.drivers")

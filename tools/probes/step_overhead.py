@@ -1,7 +1,7 @@
 """How much of a K-step timing (synchronise, K back-to-back sweeps, synchronise) is fixed cost: t(K) = a + b K fitted over K = 1 ... 200."""
 import importlib, os, sys, time
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 api = importlib.import_module("3dbodyanimation_amd.api"); synth = importlib.import_module("3dbodyanimation_amd.synth")
 m = synth.make_model(0); gm = api.Model(m); seq = synth.make_sequence(m, 256, seed=0); gmm = api.Gmm(*synth.make_gmm(0))
 prob = api.Problem.from_sequence(gm, seq, n_cols=86, use_shape=True, beta_per_frame=True, pose_blend=True, beta_pose=20.0, gmm=gmm,

@@ -1,6 +1,6 @@
 """Randomised stress of the one-launch sweep's in-launch protocols (two signals per frame, per-unit start, counted waits, fold
 ticket): random frame counts 1..1500, several launches each with changing parameters, every output word against the two-launch
-sweep of the same build.  Run on the GPU box: python tools/stress_one_launch.py [n_sizes] [seed]."""
+sweep of the same build.  Run on the GPU box: python tools/probes/stress_one_launch.py [n_sizes] [seed]."""
 import importlib
 import os
 import sys

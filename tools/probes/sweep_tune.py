@@ -4,7 +4,7 @@ import json
 import os
 import sys
 
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import ab_sweep
 
 tag = {k: os.environ.get(k) for k in ("BODYFIT_MESH_PRIO", "BODYFIT_TRICKLE_START", "BODYFIT_TRICKLE_SLEEP", "BODYFIT_J_SCOPE") if os.environ.get(k)}

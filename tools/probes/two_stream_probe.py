@@ -2,7 +2,7 @@
 (two sweeps in flight: the latency chain at the head of one overlaps the store-bound tail of the other)."""
 import importlib, os, sys, time
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 api = importlib.import_module("3dbodyanimation_amd.api")
 synth = importlib.import_module("3dbodyanimation_amd.synth")
 m = synth.make_model(0); gm = api.Model(m); gmm = api.Gmm(*synth.make_gmm(0))
