@@ -1106,9 +1106,18 @@ int bodyfit_evaluate_batch(bodyfit_problem* p, const double* frame_params, const
   p->c_npar = npar; p->c_nbeta = nbeta;
   static const bool pack_direct = [] { const char* e = std::getenv("BODYFIT_PACK_DIRECT"); return !(e && e[0] == '0'); }();
   for (int attempt = 0;; ++attempt) {   // (a one-launch sweep whose in-launch wait ran out is re-issued as two launches)
-    HIP_TRY(hipMemcpyAsync(p->d_params, p->c_params.data(), npar * sizeof(double), hipMemcpyHostToDevice, st));
-    if (nbeta) HIP_TRY(hipMemcpyAsync(p->d_beta, p->c_beta.data(), nbeta * sizeof(double), hipMemcpyHostToDevice, st));
-    int rc = sweep(p, p->d_params, has_beta ? p->d_beta : nullptr, wj, p->desc.want_mesh != 0, st);
+    // The sweep reads the parameters straight from the page-locked mirrors (device-addressable, coherent): 98 KB that every
+    // frame workgroup touches once, at the price of a PCIe round trip on its first load, instead of two copy commands in front
+    // of the launch (BODYFIT_HOST_PARAMS=0: the copies, for A/B runs)
+    static const bool host_params = [] { const char* e = std::getenv("BODYFIT_HOST_PARAMS"); return !(e && e[0] == '0'); }();
+    const double* xs = p->c_params.data();
+    const double* bs = has_beta ? p->c_beta.data() : nullptr;
+    if (!host_params) {
+      HIP_TRY(hipMemcpyAsync(p->d_params, p->c_params.data(), npar * sizeof(double), hipMemcpyHostToDevice, st));
+      if (nbeta) HIP_TRY(hipMemcpyAsync(p->d_beta, p->c_beta.data(), nbeta * sizeof(double), hipMemcpyHostToDevice, st));
+      xs = p->d_params; bs = has_beta ? p->d_beta : nullptr;
+    }
+    int rc = sweep(p, xs, bs, wj, p->desc.want_mesh != 0, st);
     if (rc) return rc;
     const bool one_kernel_down = wj && packed && pack_direct;   // residuals and components ride on the packing kernel
     if (!one_kernel_down) {

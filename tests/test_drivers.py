@@ -274,45 +274,50 @@ def test_unforced_staged_run_on_a_well_conditioned_sequence(gpu_model, model):
 
 @pytest.mark.gpu
 def test_c4_at_its_full_size_against_the_checkers_staged_run(gpu_model, model):
-    """BASELINE configs[3] at its real size — a 128-frame sequence staged as src/main_multi_frame.cpp:109-217 does: 13 anchors
-    (every 10th frame, shared beta), then 9 windows of 20 frames / overlap 5 with the beta lock — UNFORCED: drivers.run_multi
-    (HIP evaluator, device window LM, device write-back) and tests/staged_oracle.run_multi (the checker's LM in its scipy.sparse
-    form over the oracle evaluator, oracle forward, oracle mean_pixel_error) each run the whole chain on their own, every solve
-    to Ceres' convergence tests, and the END of every one of the 10 stages is compared at the north star's 1e-4: the poses
-    (every frame's 76 parameters), the beta copies (Q9), the compounded root orientations (Q8), translations, joint angles,
-    and the log's pixel errors.  (Iteration counts are printed, not compared: at a converged point the LMs' last accepted /
-    rejected steps are decided by rounding, so the termination test trips a few dozen iterations apart while the iterates
-    agree to 1e-9; bench.py's fit.c4 times this very run with the reference's caps 1000 / 60.)"""
+    """BASELINE configs[3] at its real size and with the reference's own settings — a 128-frame sequence staged as
+    src/main_multi_frame.cpp:109-217 does: 13 anchors (every 10th frame, shared beta, up to 1000 iterations), then 9 windows of
+    20 frames / overlap 5 with the beta lock, 60 iterations each — exactly what bench.py's fit.c4 times.  drivers.run_multi (HIP
+    evaluator, device window LM, device write-back) against tests/staged_oracle.run_multi (the checker's LM in its scipy.sparse
+    form over the oracle evaluator, oracle forward, oracle mean_pixel_error), all 10 stages: the poses (every frame's 76
+    parameters), the beta copies (Q9), the compounded root orientations (Q8), translations, joint angles, the LM's iteration and
+    accepted-step counts, and the log's pixel errors.
+    Stage by stage from the same starting state (teacher forcing, as on the reference's keypoint files above), because the chain
+    is not a well-posed thing to compare end to end at this size: a window's 60 unconverged LM iterations amplify a difference of
+    its starting state by up to 4e7 (the checker against ITSELF with the anchors' result perturbed by 1e-9 ends window [0,20)
+    3.7e-2 apart, measured with this sequence), and run to Ceres' convergence tests instead the two LMs stop 30 iterations and
+    1.8e-2 apart in a flat valley (device 213 iterations, checker 184).  From equal states a 60-iteration window agrees to
+    2e-7 or better (checker with the analytic against the dual-number Jacobian: 1.8e-7, 2.9e-11, 1.7e-8 for three windows)."""
     import staged_oracle
     from oracle import oracle
     F = 128
     sq = synth.make_sequence(model, F, seed=0)
     seq = drivers.KeypointSequence(sq.kp_offset, sq.kp_id, sq.kp_uv, [f"frame_{f:04d}.json" for f in range(F)])
     om = oracle.OracleModel(model)
-    kw = dict(max_iters_s1=1000, stage2_iters=1000)
+    kw = dict(max_iters_s1=1000, stage2_iters=60)          # src/main_multi_frame.cpp:29,185
     trace = []
     got = drivers.run_multi(gpu_model, seq, sq.intr, trace=trace, **kw)
-    want = staged_oracle.run_multi(om, sq.kp_offset, sq.kp_id, sq.kp_uv, sq.intr, sparse=True, **kw)
+    want = staged_oracle.run_multi(om, sq.kp_offset, sq.kp_id, sq.kp_uv, sq.intr, sparse=True, follow=trace, **kw)
     assert [st["ids"] for st in trace] == [st["ids"] for st in want["stages"]]
     assert len(trace) == 10 and trace[0]["ids"] == list(range(0, 128, 10)) and len(trace[0]["ids"]) == 13
     assert [st["ids"][0] for st in trace[1:]] == list(range(0, 128, 15)) and trace[-1]["ids"] == list(range(120, 128))
     its_got = [got["stage1"].iterations] + [s.iterations for s in got["stage2"]]
+    ok_got = [got["stage1"].n_successful] + [s.n_successful for s in got["stage2"]]
     its_want = [want["stage1"]["iterations"]] + [i["iterations"] for i in want["stage2"]]
-    term_got = [got["stage1"].termination] + [s.termination for s in got["stage2"]]
+    ok_want = [want["stage1"]["n_ok"]] + [i["n_ok"] for i in want["stage2"]]
     diffs = []
     for st_got, st_want in zip(trace, want["stages"]):
         diffs.append({key: float(np.abs(st_got[key] - st_want[key]).max()) for key in ("poses", "w", "r0", "t", "joint_aa")})
     for k, d in enumerate(diffs):
-        print(f"stage {k}: first frame {trace[k]['ids'][0]:3d}, LM iterations device {its_got[k]} / checker {its_want[k]}, "
-              f"termination {term_got[k]}, largest differences " + ", ".join(f"{key} {v:.1e}" for key, v in d.items()))
-    # every solve ended by a convergence test on both sides
-    assert all(t == 0 for t in term_got) and max(its_got) < 1000 and max(its_want) < 1000
-    assert its_got[0] == its_want[0]                          # (the anchors' solve: far from rounding-decided)
+        print(f"stage {k}: first frame {trace[k]['ids'][0]:3d}, LM iterations / accepted: device {its_got[k]} / {ok_got[k]}, checker "
+              f"{its_want[k]} / {ok_want[k]}; largest differences " + ", ".join(f"{key} {v:.1e}" for key, v in d.items()))
+    assert got["stage1"].termination == 0 and its_got[0] < 1000          # the anchors converge; the windows run into their cap
+    assert its_got == its_want and ok_got == ok_want                     # the same accepted / rejected steps in every solve
     worst = max(max(d.values()) for d in diffs)
     for k, d in enumerate(diffs):
         for key, v in d.items():
             assert v < 1e-4, (k, trace[k]["ids"][0], key, v)
-    print(f"C4 at full size, unforced: largest difference over the 10 stages {worst:.2e}")
+    print(f"C4 at full size, stage by stage: largest difference over the 10 stages {worst:.2e}")
+    assert worst < 1e-5
     assert [r[0] for r in got["log"]] == [r[0] for r in want["log"]] and len(got["log"]) == 13 + 8 * 20 + 8
     px_got = np.array([r[1] for r in got["log"]]); px_want = np.array([r[1] for r in want["log"]])
     assert np.abs(px_got - px_want).max() < 1e-3 * max(1.0, np.abs(px_want).max())

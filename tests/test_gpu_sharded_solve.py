@@ -274,6 +274,12 @@ def _transport_failure_worker(rank, world, port, F, fail_call, bound, out_dir):
     with open(os.path.join(out_dir, f"rank{rank}.txt"), "w") as fh:
         fh.write(f"{dt}\n{calls[0]}\n{msg}\n")
         fh.flush()
+    if rank == 1:
+        # stay alive (and out of the collective) until rank 0 is back: a rank that DIES closes its sockets, which gloo notices
+        # at once — the case the bound is for is the peer that is alive and simply never arrives
+        t_end = time.perf_counter() + 90.0
+        while not os.path.exists(os.path.join(out_dir, "rank0.txt")) and time.perf_counter() < t_end:
+            time.sleep(0.05)
     # rank 0's helper thread still sits in gloo's all_gather (until the process group's own 120 s): leave without tearing
     # the group down in an orderly way — what an application would do after such an error
     os._exit(0)

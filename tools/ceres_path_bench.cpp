@@ -104,8 +104,9 @@ int main(int argc, char** argv) {
   // round 4; contiguous thread ranges then hand every 38 KB GMM prior Jacobian to the last thread)
   std::vector<size_t> order(nrec);
   for (size_t i = 0; i < nrec; ++i) order[i] = i;
+  size_t n_act = nrec;      // how many entries of `order` a pass walks (the per-kind passes walk a subset)
   auto run_range = [&](int t) {
-    const size_t b0 = nrec * t / threads, b1 = nrec * (t + 1) / threads;
+    const size_t b0 = n_act * t / threads, b1 = n_act * (t + 1) / threads;
     Scratch& sc = scratch[t];
     for (size_t i = b0; i < b1; ++i) {
       const auto& rec = recs[order[i]];
@@ -174,8 +175,9 @@ int main(int argc, char** argv) {
     el2 = std::chrono::duration<double>(std::chrono::steady_clock::now() - t02).count();
   }
   // third measurement: where the block time goes — each kind of block alone, same thread pool, same cached sweep (no new sweep
-  // in between: the blocks are served from the cache whatever the point)
-  double kind_us[5] = {0, 0, 0, 0, 0};   // [4]: an empty pass (thread spawn + join alone)
+  // in between: the blocks are served from the cache whatever the point); [4] = a pass over no blocks at all (the pool's
+  // hand-shake alone)
+  double kind_us[5] = {0, 0, 0, 0, 0};
   long kind_n[5] = {0, 0, 0, 0, 0};
   {
     const std::vector<size_t> all = order;            // sorted by kind
@@ -184,37 +186,23 @@ int main(int argc, char** argv) {
       for (size_t i : all) if (kd < 4 && kind_rank(i) == kd) sub.push_back(i);
       kind_n[kd] = (long)sub.size();
       if (sub.empty() && kd < 4) continue;
-      // run_range walks order[nrec * t / threads ...): give it `sub` padded by repetition to nrec entries would distort; instead
-      // time a private pass over `sub` split the same way
-      order = sub;
-      const size_t keep = nrec;
-      (void)keep;
-      auto t_a = std::chrono::steady_clock::now();
+      for (size_t i = 0; i < sub.size(); ++i) order[i] = sub[i];
+      n_act = sub.size();
+      const auto t_a = std::chrono::steady_clock::now();
       int reps = 0;
-      while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t_a).count() < 0.15 * seconds) {
-        std::atomic<long> d2{0};
-        std::vector<std::thread> th;
-        auto part = [&](int t) {
-          const size_t b0 = sub.size() * t / threads, b1 = sub.size() * (t + 1) / threads;
-          Scratch& sc = scratch[t];
-          for (size_t i = b0; i < b1; ++i) {
-            const auto& rec = recs[sub[i]];
-            if (!rec->cost->Evaluate(rec->blocks.data(), sc.r.data(), sc.jp.data())) failed.store(true);
-          }
-        };
-        for (int t = 1; t < threads; ++t) th.emplace_back(part, t);
-        part(0);
-        for (auto& x : th) x.join();
+      while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t_a).count() < 0.1 * seconds) {
+        if (!evaluate_blocks()) return 1;
         ++reps;
       }
       kind_us[kd] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_a).count() / std::max(1, reps) * 1e6;
     }
+    n_act = nrec;
   }
   quit.store(true);
   for (auto& th : pool) th.join();
   std::printf("{\"mode\": \"%s\", \"frames\": %d, \"blocks\": %d, \"block_threads\": %d, \"points\": %d, \"points_per_s\": %.1f, "
               "\"evals_per_s\": %.1f, \"blocks_per_s\": %.1f, \"sweep_with_copies_us\": %.1f, \"blocks_us_per_point\": %.1f, "
-              "\"blocks_us_per_point_kind_by_kind\": %.1f, \"by_kind_us_incl_thread_spawn\": {\"reproj\": %.1f, \"pose_prior\": %.1f, "
+              "\"blocks_us_per_point_kind_by_kind\": %.1f, \"by_kind_us\": {\"reproj\": %.1f, \"pose_prior\": %.1f, "
               "\"shape_prior\": %.1f, \"temporal\": %.1f, \"empty_pass\": %.1f}, \"by_kind_blocks\": [%ld, %ld, %ld, %ld]}\n",
               mode.c_str(), F, n_blocks, threads, n, n / el, n / el * F, n / el * n_blocks, t_sweep / n * 1e6, (el - t_sweep) / n * 1e6,
               (el2 - t_sweep2) / std::max(1, n2) * 1e6, kind_us[0], kind_us[1], kind_us[2], kind_us[3], kind_us[4], kind_n[0], kind_n[1], kind_n[2], kind_n[3]);

@@ -77,7 +77,7 @@ def fit_c2(api, synth, model, gm, repeats=5):
                 launches_per_iteration=round(launches / it, 2), us_per_iteration=round(dt / it * 1e6, 1))
 
 
-def fit_c3(api, synth, model, gm, F=256, repeats=3):
+def fit_c3(api, synth, model, gm, F=256, repeats=5):
     global _api
     _api = api
     seq = synth.make_sequence(model, F, seed=1)
@@ -88,11 +88,23 @@ def fit_c3(api, synth, model, gm, F=256, repeats=3):
     dt, launches, (x, b, s), all_s = _timed(lambda: prob.solve(seq.init_params, np.zeros((F, 10)), independent=True, max_iters=100),
                                              repeats)
     it = max(q.iterations for q in s)
+    # The batch runs as long as its SLOWEST frame (every frame is its own problem with its own Ceres termination tests; one of
+    # the 256 runs into the iteration cap).  Beside the whole batch: the solve capped at the iteration count within which 99 %
+    # of the frames have converged, counted for those frames only — what the batch costs without its stragglers.
+    conv_its = sorted(q.iterations for q in s if q.termination == 0)
+    k99 = conv_its[min(len(conv_its), int(np.ceil(0.99 * F))) - 1] if conv_its else it
+    dt99, _, (_, _, s99), all99 = _timed(lambda: prob.solve(seq.init_params, np.zeros((F, 10)), independent=True, max_iters=k99),
+                                          repeats)
+    n99 = sum(q.termination == 0 for q in s99)
     return dict(frames=F, seconds=dt, seconds_all=all_s, frames_per_s=F / dt, max_iterations=it,
                 mean_iterations=float(np.mean([q.iterations for q in s])), sweeps=s[0].n_sweeps,
                 converged=sum(q.termination == 0 for q in s),
                 initial_cost=float(sum(q.initial_cost for q in s)), final_cost=float(sum(q.final_cost for q in s)),
-                launches_per_iteration=round(launches / max(1, it), 2), us_per_iteration=round(dt / max(1, it) * 1e6, 1))
+                launches_per_iteration=round(launches / max(1, it), 2), us_per_iteration=round(dt / max(1, it) * 1e6, 1),
+                without_stragglers={"iteration_cap": int(k99), "frames_converged": int(n99), "seconds": dt99, "seconds_all": all99,
+                                    "frames_per_s": n99 / dt99,
+                                    "note": "the same batch capped at the iteration count within which 99 % of the frames converge; "
+                                            "frames_per_s counts the converged frames only"})
 
 
 def _staged(api, synth, model, gm, F, seed, repeats):
