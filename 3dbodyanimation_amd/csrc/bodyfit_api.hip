@@ -1051,13 +1051,15 @@ static int build_pack_tables(bodyfit_problem* p, hipStream_t st) {
     p->pk_mask[k] = mask;
     p->pk_off[k] = (unsigned)total;
     {
+      // a present block's [2][size] row-major image (what Ceres asks for) starts at src[blk] inside the keypoint's packed span:
+      // the span holds the present blocks in block order, each as its two rows back to back (k_pack_jacobian's layout)
       short* src = p->pk_src.data() + (size_t)k * 32;
       int at = 0;
       for (int blk = 0; blk < 32; ++blk) {
         const int sz = blk == 0 ? 1 : (blk < 3 + (nJ - 1) ? 3 : n - npose);
         const bool present = blk < nblocks && ((mask >> blk) & 1u);
         src[blk] = present ? (short)at : (short)-1;
-        if (present) at += sz;
+        if (present) at += 2 * sz;
       }
     }
     total += 2 * (size_t)ncol;
@@ -1106,17 +1108,12 @@ int bodyfit_evaluate_batch(bodyfit_problem* p, const double* frame_params, const
   p->c_npar = npar; p->c_nbeta = nbeta;
   static const bool pack_direct = [] { const char* e = std::getenv("BODYFIT_PACK_DIRECT"); return !(e && e[0] == '0'); }();
   for (int attempt = 0;; ++attempt) {   // (a one-launch sweep whose in-launch wait ran out is re-issued as two launches)
-    // The sweep reads the parameters straight from the page-locked mirrors (device-addressable, coherent): 98 KB that every
-    // frame workgroup touches once, at the price of a PCIe round trip on its first load, instead of two copy commands in front
-    // of the launch (BODYFIT_HOST_PARAMS=0: the copies, for A/B runs)
-    static const bool host_params = [] { const char* e = std::getenv("BODYFIT_HOST_PARAMS"); return !(e && e[0] == '0'); }();
-    const double* xs = p->c_params.data();
-    const double* bs = has_beta ? p->c_beta.data() : nullptr;
-    if (!host_params) {
-      HIP_TRY(hipMemcpyAsync(p->d_params, p->c_params.data(), npar * sizeof(double), hipMemcpyHostToDevice, st));
-      if (nbeta) HIP_TRY(hipMemcpyAsync(p->d_beta, p->c_beta.data(), nbeta * sizeof(double), hipMemcpyHostToDevice, st));
-      xs = p->d_params; bs = has_beta ? p->d_beta : nullptr;
-    }
+    // (measured and rejected, round 5: the sweep reading the parameters straight from the page-locked mirrors instead of these two
+    //  copies — 180.2 / 181.8 / 182.9 us per cached sweep against 181.1 / 182.6 / 180.0: no difference)
+    HIP_TRY(hipMemcpyAsync(p->d_params, p->c_params.data(), npar * sizeof(double), hipMemcpyHostToDevice, st));
+    if (nbeta) HIP_TRY(hipMemcpyAsync(p->d_beta, p->c_beta.data(), nbeta * sizeof(double), hipMemcpyHostToDevice, st));
+    const double* xs = p->d_params;
+    const double* bs = has_beta ? p->d_beta : nullptr;
     int rc = sweep(p, xs, bs, wj, p->desc.want_mesh != 0, st);
     if (rc) return rc;
     const bool one_kernel_down = wj && packed && pack_direct;   // residuals and components ride on the packing kernel
@@ -2071,37 +2068,29 @@ static void serve_block(bodyfit_problem* p, int kind, int index, int frame, doub
     residuals[0] = p->c_r[2 * (size_t)index];
     residuals[1] = p->c_r[2 * (size_t)index + 1];
     if (jacobians && p->cache_packed) {
-      // packed cache: [present columns of row 0 | of row 1] of this keypoint, blocks in order; the others are zero.  Where a
-      // block starts comes from a per-keypoint table made with the pack tables (no walk over the mask: at C3 the 6,400
-      // reprojection blocks of an evaluation point were most of the Ceres-side time); 3-column blocks written as six stores
-      const unsigned o0 = p->pk_off[index], nc = (p->pk_off[index + 1] - o0) >> 1;
-      const double* P0 = p->c_Jp.data() + o0;
-      const double* P1 = P0 + nc;
-      const short* src = p->pk_src.data() + (size_t)index * 32;
+      // packed cache: the keypoint's present blocks in block order, each ALREADY in Ceres' layout ([2][size] row-major); the
+      // others are zero.  Where a block starts comes from a per-keypoint table made with the pack tables: a present 3-column
+      // block is one 48-byte copy, an absent one 48 bytes of zeros (at C3 the 6,400 reprojection blocks of an evaluation point
+      // are three quarters of the Ceres-side time)
+      const double* __restrict__ P = p->c_Jp.data() + p->pk_off[index];
+      const short* __restrict__ src = p->pk_src.data() + (size_t)index * 32;
       const int nj3 = 3 + (nJ - 1);
       if (double* J = jacobians[0]) {
         const int a = src[0];
-        J[0] = a >= 0 ? P0[a] : 0.0; J[1] = a >= 0 ? P1[a] : 0.0;
+        if (a >= 0) { J[0] = P[a]; J[1] = P[a + 1]; } else { J[0] = 0.0; J[1] = 0.0; }
       }
       for (int blk = 1; blk < nj3; ++blk) {
-        double* J = jacobians[blk];
+        double* __restrict__ J = jacobians[blk];
         if (!J) continue;
         const int a = src[blk];
-        if (a >= 0) {
-          J[0] = P0[a]; J[1] = P0[a + 1]; J[2] = P0[a + 2];
-          J[3] = P1[a]; J[4] = P1[a + 1]; J[5] = P1[a + 2];
-        } else {
-          J[0] = J[1] = J[2] = J[3] = J[4] = J[5] = 0.0;
-        }
+        if (a >= 0) __builtin_memcpy(J, P + a, 48);
+        else __builtin_memset(J, 0, 48);
       }
       if (has_beta) {
         if (double* J = jacobians[nj3]) {
           const int a = src[nj3];
-          if (a >= 0) {
-            for (int i = 0; i < nS; ++i) { J[i] = P0[a + i]; J[nS + i] = P1[a + i]; }
-          } else {
-            for (int i = 0; i < 2 * nS; ++i) J[i] = 0.0;
-          }
+          if (a >= 0) std::memcpy(J, P + a, (size_t)2 * nS * sizeof(double));
+          else std::memset(J, 0, (size_t)2 * nS * sizeof(double));
         }
       }
     } else if (jacobians) {

@@ -278,22 +278,26 @@ __global__ __launch_bounds__(128) void k_pack_jacobian(int K, int ncols, int njb
     }
     return;
   }
-  if (c >= ncols) return;
+  // The keypoint's packed span: its structurally non-zero column blocks [scale 1][rootAA 3][rootT 3][joint AA 3 each ...][beta: the
+  // rest] (njb: joint blocks = joints - 1) in block order, each block as its two rows back to back — Ceres' [2][size] row-major
+  // block, so the host serves a block with one copy.  Thread = OUTPUT element (consecutive threads store consecutive words: whole
+  // lines cross PCIe); which (block, row, column) that is follows from the mask, the same for the whole workgroup.
   const unsigned m = mask[k];
-  // block of column c and the block's first column: [scale 1][rootAA 3][rootT 3][joint AA 3 each ...][beta: the rest]
-  // (njb: joint blocks = joints - 1)
-  int blk, first;
-  if (c == 0) { blk = 0; first = 0; }
-  else if (c < 7 + 3 * njb) { blk = 1 + (c - 1) / 3; first = 1 + 3 * (blk - 1); }
-  else { blk = 3 + njb; first = 7 + 3 * njb; }
-  if (!((m >> blk) & 1u)) return;
-  int before = 0;                                     // present columns in front of this block
-  for (int b = 0; b < blk; ++b)
-    if ((m >> b) & 1u) before += (b == 0) ? 1 : 3;
-  const unsigned o0 = off[k], nc = (off[k + 1] - o0) >> 1;
-  const int idx = before + (c - first);
-  out[o0 + idx] = J[(size_t)(2 * k) * ncols + c];
-  out[o0 + nc + idx] = J[(size_t)(2 * k + 1) * ncols + c];
+  const unsigned o0 = off[k];
+  const int total = (int)(off[k + 1] - o0);
+  const int nblk = 4 + njb, beta_sz = ncols - (7 + 3 * njb);
+  for (int i = c; i < total; i += 128) {
+    int at = 0, blk = 0, sz = 1, first = 0;
+    for (int b = 0; b < nblk; ++b) {
+      if (!((m >> b) & 1u)) continue;
+      const int s2 = (b == 0) ? 1 : (b < 3 + njb ? 3 : beta_sz);
+      if (i < at + 2 * s2) { blk = b; sz = s2; break; }
+      at += 2 * s2;
+    }
+    first = (blk == 0) ? 0 : (blk < 3 + njb ? 1 + 3 * (blk - 1) : 7 + 3 * njb);
+    const int e = i - at, row = e >= sz ? 1 : 0, col = first + (e - row * sz);
+    out[o0 + i] = J[(size_t)(2 * k + row) * ncols + col];
+  }
 }
 }  // namespace
 void launch_pack_jacobian(int K, int ncols, int n_joint_blocks, const double* d_J, const unsigned* d_mask, const unsigned* d_off,
