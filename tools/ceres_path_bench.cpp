@@ -87,14 +87,29 @@ int main(int argc, char** argv) {
   // (include/Sim3BA.h:476-479, include/MultiFrameBA.h:148).  The same here: a pool of `threads` workers, each with its own
   // scratch, over contiguous ranges of the blocks (argv[4], default 8; 1 = the calling thread alone).
   const int threads = argc > 4 ? std::max(1, std::atoi(argv[4])) : 8;
-  struct Scratch { std::vector<double> r; std::vector<std::vector<double>> jb; std::vector<double*> jp; };
+  // Per-thread scratch laid out the way Ceres lays it out [recalled: scratch_evaluate_preparer.cc, ScratchEvaluatePreparer::Prepare]:
+  // ONE buffer per evaluation thread, sized for the largest residual block, and for each residual block the Jacobian pointers
+  // handed to Evaluate are consecutive in it — jacobians[j] = cursor; cursor += num_residuals * block_size.  (Round 4's driver
+  // gave every parameter block a buffer of its own, 5.6 KB apart: the 27 blocks of a reprojection residual then touched 27
+  // scattered lines and each 38 KB pose-prior block pushed them out of the L1.)
+  struct Scratch { std::vector<double> r; std::vector<double> j; std::vector<double*> jp; };
+  size_t max_jac = 0;
+  for (const auto& rec : problem.records()) {
+    size_t n = 0;
+    for (int sz : rec->cost->parameter_block_sizes()) n += (size_t)rec->cost->num_residuals() * sz;
+    max_jac = std::max(max_jac, n);
+  }
   std::vector<Scratch> scratch(threads);
   for (auto& sc : scratch) {
     sc.r.resize(max_res);
-    sc.jb.assign(max_blocks, std::vector<double>(max_res * 10));
+    sc.j.resize(max_jac);
     sc.jp.resize(max_blocks);
-    for (size_t b = 0; b < max_blocks; ++b) sc.jp[b] = sc.jb[b].data();
   }
+  auto prepare = [](Scratch& sc, const ceres::CostFunction& cost) {
+    double* cursor = sc.j.data();
+    const auto& sizes = cost.parameter_block_sizes();
+    for (size_t b = 0; b < sizes.size(); ++b) { sc.jp[b] = cursor; cursor += (size_t)cost.num_residuals() * sizes[b]; }
+  };
   const auto& recs = problem.records();
   const size_t nrec = recs.size();
   std::atomic<long> generation{0}, done{0};
@@ -110,6 +125,7 @@ int main(int argc, char** argv) {
     Scratch& sc = scratch[t];
     for (size_t i = b0; i < b1; ++i) {
       const auto& rec = recs[order[i]];
+      prepare(sc, *rec->cost);
       if (!rec->cost->Evaluate(rec->blocks.data(), sc.r.data(), sc.jp.data())) failed.store(true);
     }
   };
