@@ -279,21 +279,66 @@ __device__ __forceinline__ void pivots_from(double (&a)[4], double (&b)[4], int 
 }
 }  // namespace acc16
 
-__device__ __forceinline__ bool diag_factor16_acc(double (&a)[4], double (&b)[4], int lane, double& inv_col, int nvalid = 16) {
-  const int m = lane & 15;
-  {
-    acc16::Chain c0;                                   // pivot 0's chain, nothing to hide it under
-    acc16::chain_swap16<0>(c0, a[0]);
-    acc16::chain_swap32<0>(c0);
-    asm volatile("s_nop 1");
-    acc16::chain_pivot<0>(c0);
-    acc16::chain_rcp(c0);
-    asm volatile("s_nop 0");
-    acc16::chain_err(c0); acc16::chain_nr(c0); acc16::chain_err(c0); acc16::chain_nr(c0);
-    acc16::chain_w(c0, m > 0);
-    if (nvalid > 0) acc16::pivots_from<0>(a, b, m, nvalid, c0);
+// ---- round 5: the same factorisation, bit for bit, with the DEAD updates left out -----------------------------------------------
+// tools/ubench/diag16.hip (one wave alone): acc16 takes 228 cycles per pivot for 15 f64 instructions (8.5 cycles of issue each)
+// + 14 32-bit ones (4 each) = 184 cycles of issue — the block is ISSUE-bound on its one wave, not bound by its dependent chain.
+// (Measured and rejected first: taking the reciprocal chain off the row replication — the next two rows kept replicated in
+//  registers and updated like the block, the pivot from p' = x1 - x0 (u r): seven dependent steps instead of sixteen, the same
+//  bits, and 269 cycles per pivot: three more f64 instructions.)  So: fewer instructions.  Of the eight rank-1 updates of a
+// pivot, those of a register none of whose entries is read again are skipped:
+//     a[q] once its rows 4 q .. 4 q + 3 are all <= C   (left of the diagonal they are final, right of it never read),
+//     b[q] while its rows are all > C                  (the appended rows start as the identity: b[r][C] is still exactly 0),
+// which leaves 4 or 5 updates per pivot (4.5 on average) and none at the last.  Same operands in the same operations for every entry that is read: bit-identical to acc16 (diag16: 0 words).
+namespace acc16c {
+using acc16::Chain;
+using acc16::fmac_row_bcast;
+// update number I of pivot C, in issue order: the live registers of the block (the one that holds row C + 1 first: the next
+// pivot's chain starts on it), then the appended rows' registers that can be non-zero in column C
+template <int C, int I>
+__device__ __forceinline__ void upd(double (&a)[4], double (&b)[4], const double& w) {
+  constexpr int qa0 = (C + 1) / 4;                    // first register of the block with a row > C (it holds row C + 1)
+  constexpr int na = (C + 1 < 16) ? 4 - qa0 : 0;
+  constexpr int nb = C / 4 + 1;                       // registers of the appended rows with a row <= C
+  if constexpr (C + 1 < 16) {                         // (pivot 15: w is zero everywhere)
+    if constexpr (I < na) fmac_row_bcast<C>(a[qa0 + I], w);
+    else if constexpr (I < na + nb) fmac_row_bcast<C>(b[I - na], w);
   }
-  // the diagonal of the unscaled factor: column m's pivot sits in register m / 4, row m % 4, lane column m
+}
+template <int C>
+__device__ __forceinline__ void pivot(double (&a)[4], double (&b)[4], int m, const Chain& cur, Chain& nxt) {
+  constexpr int CN = C + 1;
+  if constexpr (CN < 16) {
+    constexpr int n_upd = (4 - CN / 4) + (C / 4 + 1);   // 4 or 5
+    upd<C, 0>(a, b, cur.w);                           // a[(C + 1) / 4]: row C + 1
+    acc16::chain_swap16<CN>(nxt, a[CN / 4]);
+    upd<C, 1>(a, b, cur.w);
+    acc16::chain_swap32<CN>(nxt);
+    upd<C, 2>(a, b, cur.w); upd<C, 3>(a, b, cur.w);   // (two instructions between the last write of nxt.v and its DPP read)
+    acc16::chain_pivot<CN>(nxt);
+    acc16::chain_rcp(nxt);
+    if constexpr (n_upd > 4) upd<C, 4>(a, b, cur.w); else asm volatile("s_nop 0");   // (one between the reciprocal and its first use)
+    acc16::chain_err(nxt);
+    acc16::chain_nr(nxt);
+    acc16::chain_err(nxt);
+    acc16::chain_nr(nxt);
+    acc16::chain_w(nxt, m > CN);
+  }
+}
+template <int C>
+__device__ __forceinline__ void pivots_from(double (&a)[4], double (&b)[4], int m, int nvalid, Chain& cur) {
+  if constexpr (C < 16) {
+    if (C < nvalid) {   // (uniform)
+      Chain nxt;
+      acc16c::pivot<C>(a, b, m, cur, nxt);   // (qualified: Chain lives in acc16, whose pivot would be found too)
+      if constexpr (C + 1 < 16) acc16c::pivots_from<C + 1>(a, b, m, nvalid, nxt);
+    }
+  }
+}
+}  // namespace acc16c
+
+// the common tail: the diagonal of the unscaled factor -> 1 / L[m][m] per column, scale, status
+__device__ __forceinline__ bool diag_factor16_finish(double (&a)[4], double (&b)[4], int m, double& inv_col) {
+  // column m's pivot sits in register m / 4, row m % 4, lane column m
   double d = (m < 4) ? a[0] : (m < 8 ? a[1] : (m < 12 ? a[2] : a[3]));
   {
     const int src = ((m & 3) << 4) | m;       // lane (m, m % 4)
@@ -310,6 +355,42 @@ __device__ __forceinline__ bool diag_factor16_acc(double (&a)[4], double (&b)[4]
 #pragma unroll
   for (int q = 0; q < 4; ++q) { a[q] *= inv; b[q] *= inv; }
   return okp;
+}
+
+__device__ __forceinline__ bool diag_factor16_acc(double (&a)[4], double (&b)[4], int lane, double& inv_col, int nvalid = 16) {
+  const int m = lane & 15;
+  {
+    acc16::Chain c0;                                   // pivot 0's chain, nothing to hide it under
+    acc16::chain_swap16<0>(c0, a[0]);
+    acc16::chain_swap32<0>(c0);
+    asm volatile("s_nop 1");
+    acc16::chain_pivot<0>(c0);
+    acc16::chain_rcp(c0);
+    asm volatile("s_nop 0");
+    acc16::chain_err(c0); acc16::chain_nr(c0); acc16::chain_err(c0); acc16::chain_nr(c0);
+    acc16::chain_w(c0, m > 0);
+    if (nvalid > 0) acc16c::pivots_from<0>(a, b, m, nvalid, c0);
+  }
+  return diag_factor16_finish(a, b, m, inv_col);
+}
+
+// round 4's form (acc16: all eight updates at every pivot).  Not used by the product's kernels any more;
+// kept as the bit-for-bit reference of the form above (tools/ubench/diag16.hip, tests/test_gpu_window_lm.py).
+__device__ __forceinline__ bool diag_factor16_acc_r4(double (&a)[4], double (&b)[4], int lane, double& inv_col, int nvalid = 16) {
+  const int m = lane & 15;
+  {
+    acc16::Chain c0;                                   // pivot 0's chain, nothing to hide it under
+    acc16::chain_swap16<0>(c0, a[0]);
+    acc16::chain_swap32<0>(c0);
+    asm volatile("s_nop 1");
+    acc16::chain_pivot<0>(c0);
+    acc16::chain_rcp(c0);
+    asm volatile("s_nop 0");
+    acc16::chain_err(c0); acc16::chain_nr(c0); acc16::chain_err(c0); acc16::chain_nr(c0);
+    acc16::chain_w(c0, m > 0);
+    if (nvalid > 0) acc16::pivots_from<0>(a, b, m, nvalid, c0);
+  }
+  return diag_factor16_finish(a, b, m, inv_col);
 }
 
 }  // namespace

@@ -613,6 +613,22 @@ def main():
     # per-kernel durations with HIP events on the launch stream (same inputs, same stream), right behind the timed steps — the
     # same warm device — and over at least 100 launches
     prof = prob.profile_sweep(d_params.data_ptr(), d_beta.data_ptr(), True, with_reduce, max(100, min(400, args.steps)), stream)
+    # ... and the kernel's launch PERIOD, by two HIP events on the same stream around a run of back-to-back sweeps: what a launch
+    # costs in steady state (the dispatch's own begin -> end, which profile_sweep reads, plus the dependent-launch boundary of
+    # ~1.2 us).  This is the figure all three clocks reproduce — the K-step timing above, these events, and rocprofv3's kernel
+    # trace of the same command (profiles/<tag>_kernel_stats_post_prewarm.json), whose per-dispatch durations under the tracer
+    # read as the period, not as the bare begin -> end (r5_00: 20.23 us traced against 18.86 us begin -> end and a 20.03 us
+    # period untraced) — so `roofline` is computed from it; the bare figure stays beside it as `kernel_only`.
+    n_ev = max(100, min(400, args.steps))
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for _ in range(10):
+        step()
+    ev0.record(work_stream)
+    for _ in range(n_ev):
+        step()
+    ev1.record(work_stream)
+    torch.cuda.synchronize()
+    period_ms = ev0.elapsed_time(ev1) / n_ev
     prob.sweep_status(stream)
     sweep_timeouts = prob.sweep_timeouts()
 
@@ -651,9 +667,17 @@ def main():
             pm = None
         kernels = {}
         for k in alg:
-            a = alg[k] / (prof[k] * 1e-3) / 1e9
+            # one launch per step (and no reduce launch): the launch period of the step's events IS this kernel's
+            dur = period_ms if (fused and not with_reduce) else prof[k]
+            a = alg[k] / (dur * 1e-3) / 1e9
+            ko = alg[k] / (prof[k] * 1e-3) / 1e9
             kernels[k] = {"achieved": a, "frac": a / HBM_PEAK_GBS, "frac_of_measured_copy_rate": a / HBM_COPY_GBS,
-                          "algorithmic_bytes_per_launch": alg[k], "avg_launch_ms": prof[k],
+                          "algorithmic_bytes_per_launch": alg[k], "avg_launch_ms": dur,
+                          "avg_launch_ms_definition": ("launch period: two HIP events around %d back-to-back launches on the launch "
+                                                       "stream" % n_ev) if dur is period_ms else "dispatch begin -> end (HIP events)",
+                          "kernel_only": {"avg_launch_ms": prof[k], "achieved": ko, "frac": ko / HBM_PEAK_GBS,
+                                          "definition": "the dispatch's own begin -> end timestamps (hipExtLaunchKernelGGL events), "
+                                                        "without the dependent-launch boundary"},
                           "traffic": pm["kernels"].get(pmc_name[k], {}).get("hbm_bytes") if pm else None}
         # matrix-pipe view of the mesh kernel: the blend contraction is 2 x 20670 x 217 flop per frame; it is
         # executed as three bf16 products per k-step on v_mfma_f32_32x32x16_bf16 (216 tiles x 14 k-steps x 9 MFMAs per 32 frames)
@@ -686,7 +710,9 @@ def main():
                          "frac": ach / HBM_PEAK_GBS, "frac_of_measured_copy_rate": ach / HBM_COPY_GBS, "traffic": traffic,
                          "traffic_source": (os.path.relpath(pm_src, ROOT) + " (rocprofv3 --pmc passes of this command, "
                                             "committed; not measured in this run)") if pm else None,
-                         "algorithmic_bytes_per_launch": bytes_launch, "avg_launch_ms": prof[dom],
+                         "algorithmic_bytes_per_launch": bytes_launch, "avg_launch_ms": kernels[dom]["avg_launch_ms"],
+                         "avg_launch_ms_definition": kernels[dom]["avg_launch_ms_definition"],
+                         "kernel_only": kernels[dom]["kernel_only"],
                          "algorithmic_bytes_definition": ("SURVEY.md 8d: B(F) = 19,347,120 (f32 model tensors, read once per launch) + "
                                                          "F x 118,588 (params, keypoints, r, J, posed vertices)") if fused else
                                                         "per kernel: the model tensors it reads + its per-frame inputs and outputs",

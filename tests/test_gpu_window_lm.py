@@ -2,6 +2,8 @@
 Ceres' trust-region logic in small kernels) against the host loop of host_solver.cpp (sequential block-tridiagonal
 Cholesky) on the same problems, and against the dense numpy LM over the oracle evaluator.  Both product solvers restate
 the same algorithm (include/MultiFrameBA.h:144-151 hands it to ceres::Solve), so the iterates agree up to rounding."""
+import os
+
 import numpy as np
 import pytest
 
@@ -87,3 +89,24 @@ def test_device_window_lm_103_anchors(api, synth, model, gpu_model):
     assert (sd.iterations, sd.n_successful) == (sh.iterations, sh.n_successful)
     assert abs(sd.final_cost - sh.final_cost) <= 1e-9 * sh.final_cost
     assert np.abs(xd[:, 1:] - xh[:, 1:]).max() < 1e-7 and np.abs(bd - bh).max() < 1e-7
+
+
+def test_diagonal_block_factorisation_equals_round_4s_bit_for_bit(tmp_path):
+    """dense_inl.h diag_factor16_acc — the 16 x 16 diagonal-block Cholesky inside k_cr_factor, k_lm_step and k_cr_back's block
+    inverses, hand-scheduled one-instruction asm statements — in its round-5 form (the rank-1 updates of registers none of
+    whose entries is read again are left out: 4.5 instead of 8 per pivot) against round 4's (diag_factor16_acc_r4, kept as the
+    reference): every word of L, of the appended rows x L^-T and of 1 / L_mm that a caller reads, on 64 random SPD blocks at
+    four sizes of identity padding, and both against a host Cholesky (tools/ubench/diag16.hip, which also times them)."""
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    exe = str(tmp_path / "diag16")
+    subprocess.check_call([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-I", os.path.join(root, "3dbodyanimation_amd", "csrc"),
+                           "-o", exe, os.path.join(root, "tools", "ubench", "diag16.hip")], stderr=subprocess.DEVNULL)
+    res = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stdout
+    lines = [l for l in res.stdout.splitlines() if l.startswith("nvalid")]
+    assert len(lines) == 4 and all("round 5's: 0;" in l for l in lines), res.stdout
+    for l in lines:
+        assert float(l.split("max")[1]) < 1e-14
