@@ -321,8 +321,10 @@ int bodyfit_solve(bodyfit_problem* p, double* frame_params, double* beta, const 
  * a transport failure cannot strand the peers of the rank that saw it: a host callback that has not returned within the bound
  * (bodyfit_solve_sharded; the callback then runs on a helper thread, which is left behind with its own copies of the buffers) or a
  * stream that has not drained (an RCCL collective its peer never entered) ends the solve with BODYFIT_ERR_HIP on that rank too.
- * The problem's solve stream is not usable after such a return (destroy the problem).  Choose the bound well above one LM
- * iteration (milliseconds); it is a liveness guard, not a pacing device. */
+ * The problem's solve stream is not usable after such a return.  An abandoned callback keeps running on its helper thread: its
+ * `ctx` must stay valid until it returns; and bodyfit_problem_destroy waits for the device, so with the RCCL transport abort or
+ * destroy the communicator first (a collective that will never complete would hold that wait too).  Choose the bound well above
+ * one LM iteration (milliseconds); it is a liveness guard, not a pacing device. */
 int bodyfit_set_exchange_timeout(bodyfit_problem* p, double seconds);
 typedef struct bodyfit_comm {
   int rank, size;
