@@ -303,8 +303,15 @@ int order_after_async(bodyfit_problem* p, hipStream_t own) {
   if (!p->async_pending) return BODYFIT_OK;
   if (p->async_stream != own) {                    // (same stream: ordered anyway)
     if (!p->async_event) HIP_TRY(hipEventCreateWithFlags(&p->async_event, hipEventDisableTiming));
-    HIP_TRY(hipEventRecord(p->async_event, p->async_stream));
-    HIP_TRY(hipStreamWaitEvent(own, p->async_event, 0));
+    const hipError_t er = hipEventRecord(p->async_event, p->async_stream);
+    if (er == hipErrorInvalidHandle || er == hipErrorInvalidResourceHandle || er == hipErrorContextIsDestroyed) {
+      // the caller has destroyed that stream: a stream can only be destroyed once its work is done (hipStreamDestroy waits), so
+      // there is nothing left to order behind
+      (void)hipGetLastError();
+    } else {
+      HIP_TRY(er);
+      HIP_TRY(hipStreamWaitEvent(own, p->async_event, 0));
+    }
   }
   p->async_pending = false;                        // only once the ordering is in place
   return BODYFIT_OK;
